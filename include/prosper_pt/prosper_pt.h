@@ -1,0 +1,279 @@
+/*
+ * prosper_pt/prosper_pt.h — C-ABI of the MI355X path-tracing reference pass.
+ *
+ * This library sits where prosper records `cb.traceRaysKHR(rgen, miss, hit, callable, W, H, 1)`
+ * (reference: src/render/RtReference.cpp:328-330).  prosper has no FFI for this path — the pass is
+ * a concrete C++ class (src/render/RtReference.hpp:32-60) — so the entry points below are the
+ * smallest plain-C surface that class needs: they replace, one for one,
+ *
+ *   prosper_pt_create / _destroy      RtReference::init / ~RtReference            RtReference.cpp:92-120
+ *                                     (pipeline + SBT creation -> load the gfx950 code object)
+ *   prosper_pt_upload_scene           World::updateBuffers + buildNextBlas + buildCurrentTlas
+ *                                                                                  src/scene/World.cpp:468-536,585-802
+ *                                     and the descriptor sets the pass binds       RtReference.cpp:238-274
+ *   prosper_pt_update_lights          lights ring write                            World.cpp:531-535
+ *   prosper_pt_render                 pushConstants + traceRaysKHR                 RtReference.cpp:278-330
+ *                                     + the previous/illumination ping-pong        RtReference.cpp:178-219,332-334
+ *   prosper_pt_read_hdr               the RGBA32F "rtIllumination" image           RtReference.cpp:178-187
+ *   prosper_pt_blit_rgba16f           blitImage RGBA32F -> RGBA16F                 RtReference.cpp:339-377
+ *   prosper_pt_get_counters           (new) deterministic work counters for the roofline model
+ *
+ * All entry points are `extern "C"`, take PODs / plain pointers and sizes, never throw and return
+ * PROSPER_PT_OK (0) or a negative error code; prosper_pt_last_error() returns the message of the
+ * calling thread's last failure.  A context is single-threaded (the reference makes all pass calls
+ * on the main thread, src/Allocators.hpp:9); use one context per GPU.
+ *
+ * Host pointers inside prosper_pt_scene_view are borrowed for the duration of the call only.
+ */
+#ifndef PROSPER_PT_H
+#define PROSPER_PT_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#include "shader_structs.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PROSPER_PT_ABI_VERSION 1
+
+enum
+{
+    PROSPER_PT_OK = 0,
+    PROSPER_PT_ERR_INVALID_ARGUMENT = -1,
+    PROSPER_PT_ERR_NO_DEVICE = -2,  /* no HIP device / HIP extension unusable: never falls back to CPU */
+    PROSPER_PT_ERR_HIP = -3,        /* a HIP runtime call failed */
+    PROSPER_PT_ERR_NO_SCENE = -4,   /* render before upload_scene */
+    PROSPER_PT_ERR_SCENE = -5,      /* scene view failed validation (out-of-range index/offset) */
+    PROSPER_PT_ERR_UNSUPPORTED = -6,
+};
+
+typedef struct prosper_pt_ctx prosper_pt_ctx;
+
+typedef struct prosper_pt_device_desc
+{
+    uint32_t struct_size;   /* sizeof(prosper_pt_device_desc) */
+    int32_t device_ordinal; /* HIP device index; the pass runs on this GPU only */
+    uint32_t flags;         /* PROSPER_PT_CREATE_* */
+    uint32_t reserved;
+} prosper_pt_device_desc;
+
+enum
+{
+    /* Default pipeline: wavefront kernels (raygen / extend / shade / shadow+accumulate).
+     * MEGAKERNEL selects the one-thread-per-pixel kernel (same results, kept for A/B timing). */
+    PROSPER_PT_CREATE_MEGAKERNEL = 1u << 0,
+};
+
+/* Texel formats of material textures (reference: src/scene/Texture.cpp:217-296 stores UNORM,
+ * sRGB decode happens in the shader, materials.glsl:56). */
+enum
+{
+    PROSPER_PT_FORMAT_RGBA8_UNORM = 0,
+};
+enum
+{
+    PROSPER_PT_FILTER_NEAREST = 0,
+    PROSPER_PT_FILTER_LINEAR = 1,
+};
+enum
+{
+    PROSPER_PT_WRAP_REPEAT = 0,
+    PROSPER_PT_WRAP_MIRRORED_REPEAT = 1,
+    PROSPER_PT_WRAP_CLAMP_TO_EDGE = 2,
+};
+
+/* One entry of the bindless materialTextures[] table (materials.glsl:23-24); mip 0 only, because
+ * RT stages have no derivatives and sample LOD 0. Index 0 is the "no texture" slot. */
+typedef struct prosper_pt_texture_desc
+{
+    const void *texels; /* width*height texels, row-major, tightly packed */
+    uint32_t width;
+    uint32_t height;
+    uint32_t format; /* PROSPER_PT_FORMAT_* */
+    uint32_t reserved;
+} prosper_pt_texture_desc;
+
+/* One entry of materialSamplers[] (src/scene/WorldData.cpp:681-720); index 0 = repeat/linear. */
+typedef struct prosper_pt_sampler_desc
+{
+    uint32_t magFilter; /* PROSPER_PT_FILTER_* (LOD 0 => magnification filter is the one used) */
+    uint32_t minFilter;
+    uint32_t wrapS; /* PROSPER_PT_WRAP_* */
+    uint32_t wrapT;
+} prosper_pt_sampler_desc;
+
+/* scene::MeshInfo (src/scene/Mesh.hpp:17-23), needed for the triangle count of each mesh and for
+ * the opaque flag (World.cpp:646-651 reads m_materials[info.materialIndex].alphaMode). */
+typedef struct prosper_pt_mesh_info
+{
+    uint32_t vertexCount;
+    uint32_t indexCount;
+    uint32_t meshletCount;
+    uint32_t materialIndex;
+} prosper_pt_mesh_info;
+
+/* Skybox cube: RGBA16F, mip 0, faces +X,-X,+Y,-Y,+Z,-Z, each faceSize x faceSize, row-major
+ * (reference: src/scene/Texture.cpp:589-636, sampled by textureLod(skybox, d, 0) main.rgen:251). */
+typedef struct prosper_pt_cube_desc
+{
+    const uint16_t *texels; /* 6 * faceSize * faceSize * 4 halfs; NULL = no skybox */
+    uint32_t faceSize;
+    uint32_t reserved;
+} prosper_pt_cube_desc;
+
+/* Everything the pass reads through its nine descriptor sets (RtReference.cpp:244-257). */
+typedef struct prosper_pt_scene_view
+{
+    uint32_t struct_size; /* sizeof(prosper_pt_scene_view) */
+    uint32_t reserved;
+
+    /* GEOMETRY_SET: bindless geometry buffers + per-mesh metadata (geometry.glsl:7-55) */
+    const void *const *geometryBuffers;
+    const uint64_t *geometryBufferByteSizes;
+    uint32_t geometryBufferCount;
+    uint32_t meshCount;
+    const prosper_GeometryMetadata *geometryMetadatas; /* [meshCount] */
+    const prosper_pt_mesh_info *meshInfos;             /* [meshCount] */
+
+    /* SCENE_INSTANCES_SET (instances.glsl:8-34) */
+    const prosper_DrawInstance *drawInstances; /* [drawInstanceCount] */
+    uint32_t drawInstanceCount;
+    uint32_t modelInstanceCount;
+    const prosper_ModelInstanceTransforms *modelInstanceTransforms; /* [modelInstanceCount] */
+
+    /* MATERIAL_DATAS_SET + MATERIAL_TEXTURES_SET (materials.glsl:7-24) */
+    const prosper_MaterialData *materials; /* [materialCount], index 0 = default material */
+    uint32_t materialCount;
+    uint32_t textureCount;
+    const prosper_pt_texture_desc *textures; /* [textureCount], index 0 unused by shading */
+    const prosper_pt_sampler_desc *samplers; /* [samplerCount], index 0 = default sampler */
+    uint32_t samplerCount;
+    uint32_t reserved2;
+
+    /* LIGHTS_SET (lights.glsl:6-23) */
+    const prosper_DirectionalLightParameters *directionalLight;
+    const prosper_PointLightsBuffer *pointLights;
+    const prosper_SpotLightsBuffer *spotLights;
+
+    /* SKYBOX_SET binding 0 (skybox.glsl:4) */
+    prosper_pt_cube_desc skybox;
+} prosper_pt_scene_view;
+
+/* The set of pixels one context renders.  The reference always renders the whole image
+ * (asserts renderArea.offset == 0, RtReference.cpp:327); for multi-GPU tiling the image is cut
+ * into vertical stripes `stripeWidth` pixels wide and this context renders stripes
+ * s with s % stripeCount == stripeIndex.  RNG seeds use absolute pixel coordinates
+ * (main.rgen:227-229), so any partition yields the same pixels as a whole-image render.
+ * The context's HDR buffer holds only its own pixels, rows of localWidth texels, stripes in
+ * ascending order.  NULL / {0,0,1} = whole image. */
+typedef struct prosper_pt_tile_desc
+{
+    uint32_t stripeWidth;
+    uint32_t stripeIndex;
+    uint32_t stripeCount;
+} prosper_pt_tile_desc;
+
+/* Deterministic work counters (exact integers, independent of scheduling) used to price the
+ * ALGORITHMIC bytes of a frame.  Collected only by prosper_pt_render calls made with
+ * PROSPER_PT_RENDER_COUNT_WORK; accumulate until prosper_pt_reset_counters. */
+typedef struct prosper_pt_counters
+{
+    uint64_t paths;            /* pixels rendered (one path per pixel per frame) */
+    uint64_t closestRays;      /* traceClosest calls */
+    uint64_t shadowRays;       /* shadow() calls */
+    uint64_t nodeVisits;       /* BVH node fetches, all rays */
+    uint64_t triangleTests;    /* ray/triangle tests, all rays */
+    uint64_t closestHits;      /* evaluateSurface invocations */
+    uint64_t anyHitCalls;      /* any-hit invocations (non-opaque candidates) */
+    uint64_t lightSamples;     /* sampleLight calls: sun/point */
+    uint64_t spotLightSamples; /* sampleLight calls that picked a spot light */
+    uint64_t skyLookups;       /* IBL miss lookups */
+    uint64_t pixelsWritten;    /* output texels written */
+    uint64_t historyReads;     /* output texels whose history was read */
+    uint64_t shortIndexHits;   /* of closestHits + anyHitCalls: those on u16-indexed meshes */
+    uint64_t reserved[3];
+} prosper_pt_counters;
+
+/* Sizes the roofline model needs about the acceleration structure the library built. */
+typedef struct prosper_pt_scene_stats
+{
+    uint64_t triangleCount; /* world-space triangles (instances expanded) */
+    uint64_t nodeCount;
+    uint32_t nodeBytes;     /* S_node: bytes fetched per node visit */
+    uint32_t triangleBytes; /* bytes fetched per ray/triangle test */
+    uint32_t maxDepth;
+    uint32_t reserved;
+    uint64_t deviceBytes;   /* HBM resident bytes for the scene */
+    double buildSeconds;    /* host+device time spent in prosper_pt_upload_scene building the BVH */
+} prosper_pt_scene_stats;
+
+enum
+{
+    PROSPER_PT_RENDER_COUNT_WORK = 1u << 0, /* run the instrumented kernels (slower, same pixels) */
+};
+
+const char *prosper_pt_last_error(void);
+uint32_t prosper_pt_abi_version(void);
+
+int prosper_pt_create(const prosper_pt_device_desc *desc, prosper_pt_ctx **out_ctx);
+void prosper_pt_destroy(prosper_pt_ctx *ctx);
+
+/* Copies the whole scene to HBM, flattens instances x triangles into world space from the
+ * fp16 positions (the BVH must see the decoded halfs: World.cpp:635-644) and builds the BVH. */
+int prosper_pt_upload_scene(prosper_pt_ctx *ctx, const prosper_pt_scene_view *scene);
+/* Re-uploads the three light buffers only (they are rewritten every frame: World.cpp:531-535). */
+int prosper_pt_update_lights(
+    prosper_pt_ctx *ctx, const prosper_DirectionalLightParameters *directionalLight,
+    const prosper_PointLightsBuffer *pointLights, const prosper_SpotLightsBuffer *spotLights);
+int prosper_pt_get_scene_stats(prosper_pt_ctx *ctx, prosper_pt_scene_stats *out);
+
+/* Optional: render into caller-owned device memory (localWidth*height RGBA32F texels, 16-byte
+ * aligned) instead of the context's own buffer — lets the host framework (e.g. a torch tensor
+ * that RCCL gathers) own the HDR tile.  NULL restores the internal buffer.  History is read from
+ * and written to the same buffer, like the reference's aliased previous/illumination image. */
+int prosper_pt_set_output_buffer(prosper_pt_ctx *ctx, void *device_rgba32f, size_t byte_size);
+
+/* One accumulated frame = one path per pixel (the reference's traceRaysKHR(W,H,1)).
+ * `stream` is a hipStream_t (NULL = the null stream); the call only enqueues work. */
+int prosper_pt_render(
+    prosper_pt_ctx *ctx, const prosper_ReferencePC *pc, const prosper_CameraUniforms *camera,
+    uint32_t width, uint32_t height, const prosper_pt_tile_desc *tile, uint32_t render_flags,
+    void *stream);
+
+/* Width in texels of this context's HDR rows for the last render (== width when untiled). */
+int prosper_pt_get_local_extent(prosper_pt_ctx *ctx, uint32_t *local_width, uint32_t *height);
+/* Device address of the current HDR buffer (for RCCL gathers); valid until the next render with a
+ * different extent, set_output_buffer or destroy. */
+int prosper_pt_get_hdr_device_ptr(prosper_pt_ctx *ctx, void **out_ptr, size_t *out_bytes);
+/* Synchronises `stream` and copies the HDR tile (localWidth*height RGBA32F) to host memory. */
+int prosper_pt_read_hdr(prosper_pt_ctx *ctx, float *rgba32f, size_t byte_size, void *stream);
+/* RGBA32F -> RGBA16F (round-to-nearest-even), the image later passes consume. */
+int prosper_pt_blit_rgba16f(prosper_pt_ctx *ctx, uint16_t *host_rgba16f, size_t byte_size, void *stream);
+
+int prosper_pt_get_counters(prosper_pt_ctx *ctx, prosper_pt_counters *out, void *stream);
+int prosper_pt_reset_counters(prosper_pt_ctx *ctx, void *stream);
+
+/* Average device time (ms) of the kernels launched by the last `prosper_pt_render`, measured
+ * with hipEvents on `stream`; blocks until they finish.  kernel_ms[i] follows
+ * prosper_pt_kernel_name(i). */
+#define PROSPER_PT_MAX_KERNELS 8
+int prosper_pt_get_last_render_ms(prosper_pt_ctx *ctx, float *total_ms, float kernel_ms[PROSPER_PT_MAX_KERNELS]);
+const char *prosper_pt_kernel_name(uint32_t index);
+/* Enables per-kernel hipEvent timing for subsequent renders (off by default: events add launches). */
+int prosper_pt_set_kernel_timing(prosper_pt_ctx *ctx, int enabled);
+
+/* Device self-test: evaluates device function `fn` (PROSPER_PT_FN_*) element-wise over `n`
+ * records of `in_stride` floats and writes `out_stride` floats per record.  Test-only entry that
+ * lets tests/ compare every device function with the oracle's restatement bit for bit. */
+int prosper_pt_eval_device_fn(
+    prosper_pt_ctx *ctx, uint32_t fn, const float *in, uint32_t in_stride, float *out,
+    uint32_t out_stride, uint32_t n);
+
+#ifdef __cplusplus
+}
+#endif
+
+#endif /* PROSPER_PT_H */
