@@ -1,0 +1,65 @@
+/*
+ * prosper_pt/prosper_host.h — plain-C handles onto the C++ host layer
+ * (prosper_amd/csrc/host/{camera,rt_reference}.hpp) so that non-C++ callers — the Python tests and
+ * bench.py — drive the same `scene::Camera` / `render::RtReference` code a C++ application links.
+ *
+ * Replaces, for a headless caller:
+ *   scene::Camera::{lookAt, perspective, updateBuffer}   src/scene/Camera.cpp:105-204,366-395
+ *   render::RtReference::{init, drawUi, record, recompileShaders, releasePreserved}
+ *                                                        src/render/RtReference.hpp:32-60
+ *   World::buildAccelerationStructures                   src/scene/World.cpp:538-575
+ */
+#ifndef PROSPER_HOST_H
+#define PROSPER_HOST_H
+
+#include "prosper_pt.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct prosper_host_camera prosper_host_camera;
+typedef struct prosper_host_rt_reference prosper_host_rt_reference;
+
+/* RtReference::Options (src/render/RtReference.hpp:44-50) */
+typedef struct prosper_host_record_options
+{
+    uint32_t depthOfField;
+    uint32_t ibl;
+    uint32_t colorDirty;
+    uint32_t drawType; /* prosper_DrawType */
+} prosper_host_record_options;
+
+const char *prosper_host_last_error(void);
+
+prosper_host_camera *prosper_host_camera_create(void);
+void prosper_host_camera_destroy(prosper_host_camera *camera);
+void prosper_host_camera_look_at(prosper_host_camera *camera, const float eye[3], const float target[3], const float up[3]);
+void prosper_host_camera_set_parameters(
+    prosper_host_camera *camera, float fov, float zN, float zF, float apertureDiameter, float focusDistance);
+void prosper_host_camera_update_resolution(prosper_host_camera *camera, uint32_t width, uint32_t height);
+void prosper_host_camera_update_buffer(prosper_host_camera *camera, prosper_CameraUniforms *out, float *focalLength);
+int prosper_host_camera_changed_this_frame(const prosper_host_camera *camera);
+void prosper_host_camera_end_frame(prosper_host_camera *camera);
+
+int prosper_host_rt_reference_create(int32_t deviceOrdinal, uint32_t createFlags, prosper_host_rt_reference **out);
+void prosper_host_rt_reference_destroy(prosper_host_rt_reference *pass);
+prosper_pt_ctx *prosper_host_rt_reference_context(prosper_host_rt_reference *pass);
+/* World::setSceneView + buildAccelerationStructures */
+int prosper_host_rt_reference_set_scene(prosper_host_rt_reference *pass, const prosper_pt_scene_view *view);
+void prosper_host_rt_reference_draw_ui(
+    prosper_host_rt_reference *pass, int accumulate, int clampIndirect, uint32_t rouletteStartBounce,
+    uint32_t maxBounces);
+void prosper_host_rt_reference_recompile_shaders(prosper_host_rt_reference *pass);
+void prosper_host_rt_reference_release_preserved(prosper_host_rt_reference *pass);
+/* Camera::updateBuffer + RtReference::record + end of frame; returns the ReferencePC it pushed. */
+int prosper_host_rt_reference_record(
+    prosper_host_rt_reference *pass, prosper_host_camera *camera, uint32_t width, uint32_t height,
+    const prosper_host_record_options *options, uint32_t frameCount, const prosper_pt_tile_desc *tile,
+    uint32_t renderFlags, void *stream, prosper_ReferencePC *outPushConstants);
+
+#ifdef __cplusplus
+}
+#endif
+
+#endif /* PROSPER_HOST_H */

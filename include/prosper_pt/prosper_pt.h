@@ -243,6 +243,15 @@ int prosper_pt_render(
     uint32_t width, uint32_t height, const prosper_pt_tile_desc *tile, uint32_t render_flags,
     void *stream);
 
+/* `frame_count` consecutive accumulated frames in one launch: exactly the pixels that
+ * frame_count calls of prosper_pt_render with frameIndex = (pc->frameIndex + f) % 4096 and
+ * PROSPER_PC_FLAG_SKIP_HISTORY honoured on the first of them only would produce (the running mean
+ * of main.rgen:289-297 is kept in registers between frames instead of going through HBM). */
+int prosper_pt_render_frames(
+    prosper_pt_ctx *ctx, const prosper_ReferencePC *pc, const prosper_CameraUniforms *camera,
+    uint32_t width, uint32_t height, const prosper_pt_tile_desc *tile, uint32_t frame_count,
+    uint32_t render_flags, void *stream);
+
 /* Width in texels of this context's HDR rows for the last render (== width when untiled). */
 int prosper_pt_get_local_extent(prosper_pt_ctx *ctx, uint32_t *local_width, uint32_t *height);
 /* Device address of the current HDR buffer (for RCCL gathers); valid until the next render with a
@@ -264,6 +273,27 @@ int prosper_pt_get_last_render_ms(prosper_pt_ctx *ctx, float *total_ms, float ke
 const char *prosper_pt_kernel_name(uint32_t index);
 /* Enables per-kernel hipEvent timing for subsequent renders (off by default: events add launches). */
 int prosper_pt_set_kernel_timing(prosper_pt_ctx *ctx, int enabled);
+
+enum
+{
+    PROSPER_PT_FN_SINCOS = 0,         /* in: x                                out: sin, cos */
+    PROSPER_PT_FN_POW = 1,            /* in: x, y                             out: pow */
+    PROSPER_PT_FN_SRGB_TO_LINEAR = 2, /* in: x                                out: y */
+    PROSPER_PT_FN_NORMALIZE = 3,      /* in: v3                               out: v3 */
+    PROSPER_PT_FN_UNPACK_SNORM = 4,   /* in: bits (u32 in a float)            out: n3, sign */
+    PROSPER_PT_FN_ONB = 5,            /* in: n3                               out: rows b1, b2, n */
+    PROSPER_PT_FN_COSINE_SAMPLE = 6,  /* in: n3, u2                           out: v3 */
+    PROSPER_PT_FN_VNDF_SAMPLE = 7,    /* in: Ve3, alpha, u2                   out: v3 */
+    PROSPER_PT_FN_VNDF_PDF = 8,       /* in: Ve3, Le3, alpha                  out: pdf */
+    PROSPER_PT_FN_EVAL_BRDF = 9,      /* in: l3, n3, v3, albedo3, rough, metal out: v3 */
+    PROSPER_PT_FN_OFFSET_RAY = 10,    /* in: p3, n3                           out: v3 */
+    PROSPER_PT_FN_POINT_LIGHT = 11,   /* in: pos3, radiance3, radius, surf3   out: l3, d, irr3 */
+    PROSPER_PT_FN_SPOT_LIGHT = 12,    /* in: pos3, off, rad3, scale, dir3, surf3 out: l3, d, irr3 */
+    PROSPER_PT_FN_TRIANGLE = 13,      /* in: o3, d3, v0, v1, v2, tmin, tmax   out: hit, t, bu, bv */
+    PROSPER_PT_FN_HALF = 14,          /* in: f                                out: unpack(pack(f)), bits */
+    PROSPER_PT_FN_RNG = 15,           /* in: px, py, frame (u32 bits)         out: rnd01, rnd2d01, seed */
+    PROSPER_PT_FN_COUNT = 16,
+};
 
 /* Device self-test: evaluates device function `fn` (PROSPER_PT_FN_*) element-wise over `n`
  * records of `in_stride` floats and writes `out_stride` floats per record.  Test-only entry that

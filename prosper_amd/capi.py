@@ -1,0 +1,212 @@
+"""ctypes binding of libprosper_pt.so (include/prosper_pt/prosper_pt.h, prosper_host.h).
+
+There is no Python or CPU fallback behind these calls: if the HIP library is missing, or no
+gfx950 device is visible, they raise.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+from . import structs as S
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libprosper_pt.so")
+
+
+class ProsperPtError(RuntimeError):
+    def __init__(self, code, message):
+        super().__init__("prosper_pt error %d: %s" % (code, message))
+        self.code = code
+
+
+def build(force=False):
+    """Compile the HIP library for gfx950 in-tree (prosper_amd/csrc/Makefile)."""
+    args = ["make", "-C", os.path.join(_HERE, "csrc"), "-s"]
+    if force:
+        args.append("-B")
+    subprocess.check_call(args)
+    return LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    """Loads libprosper_pt.so; raises if it has not been built (never falls back)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ProsperPtError(-2, "HIP extension %s is missing: run prosper_amd.capi.build()" % LIB_PATH)
+    L = C.CDLL(LIB_PATH)
+    vp, u32, i32 = C.c_void_p, C.c_uint32, C.c_int32
+    L.prosper_pt_last_error.restype = C.c_char_p
+    L.prosper_pt_abi_version.restype = u32
+    L.prosper_pt_create.argtypes = [C.POINTER(S.DeviceDesc), C.POINTER(vp)]
+    L.prosper_pt_destroy.argtypes = [vp]
+    L.prosper_pt_destroy.restype = None
+    L.prosper_pt_upload_scene.argtypes = [vp, C.POINTER(S.SceneView)]
+    L.prosper_pt_update_lights.argtypes = [
+        vp, C.POINTER(S.DirectionalLightParameters), C.POINTER(S.PointLightsBuffer), C.POINTER(S.SpotLightsBuffer)]
+    L.prosper_pt_get_scene_stats.argtypes = [vp, C.POINTER(S.SceneStats)]
+    L.prosper_pt_set_output_buffer.argtypes = [vp, vp, C.c_size_t]
+    L.prosper_pt_render.argtypes = [
+        vp, C.POINTER(S.ReferencePC), C.POINTER(S.CameraUniforms), u32, u32, C.POINTER(S.TileDesc), u32, vp]
+    L.prosper_pt_render_frames.argtypes = [
+        vp, C.POINTER(S.ReferencePC), C.POINTER(S.CameraUniforms), u32, u32, C.POINTER(S.TileDesc), u32, u32, vp]
+    L.prosper_pt_get_local_extent.argtypes = [vp, C.POINTER(u32), C.POINTER(u32)]
+    L.prosper_pt_get_hdr_device_ptr.argtypes = [vp, C.POINTER(vp), C.POINTER(C.c_size_t)]
+    L.prosper_pt_read_hdr.argtypes = [vp, vp, C.c_size_t, vp]
+    L.prosper_pt_blit_rgba16f.argtypes = [vp, vp, C.c_size_t, vp]
+    L.prosper_pt_get_counters.argtypes = [vp, C.POINTER(S.Counters), vp]
+    L.prosper_pt_reset_counters.argtypes = [vp, vp]
+    L.prosper_pt_get_last_render_ms.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_float)]
+    L.prosper_pt_kernel_name.argtypes = [u32]
+    L.prosper_pt_kernel_name.restype = C.c_char_p
+    L.prosper_pt_set_kernel_timing.argtypes = [vp, C.c_int]
+    L.prosper_pt_eval_device_fn.argtypes = [vp, u32, vp, u32, vp, u32, u32]
+    # host layer
+    L.prosper_host_last_error.restype = C.c_char_p
+    L.prosper_host_camera_create.restype = vp
+    L.prosper_host_camera_destroy.argtypes = [vp]
+    L.prosper_host_camera_destroy.restype = None
+    f3 = C.POINTER(C.c_float)
+    L.prosper_host_camera_look_at.argtypes = [vp, f3, f3, f3]
+    L.prosper_host_camera_look_at.restype = None
+    L.prosper_host_camera_set_parameters.argtypes = [vp] + [C.c_float] * 5
+    L.prosper_host_camera_set_parameters.restype = None
+    L.prosper_host_camera_update_resolution.argtypes = [vp, u32, u32]
+    L.prosper_host_camera_update_resolution.restype = None
+    L.prosper_host_camera_update_buffer.argtypes = [vp, C.POINTER(S.CameraUniforms), C.POINTER(C.c_float)]
+    L.prosper_host_camera_update_buffer.restype = None
+    L.prosper_host_camera_changed_this_frame.argtypes = [vp]
+    L.prosper_host_camera_end_frame.argtypes = [vp]
+    L.prosper_host_camera_end_frame.restype = None
+    L.prosper_host_rt_reference_create.argtypes = [i32, u32, C.POINTER(vp)]
+    L.prosper_host_rt_reference_destroy.argtypes = [vp]
+    L.prosper_host_rt_reference_destroy.restype = None
+    L.prosper_host_rt_reference_context.argtypes = [vp]
+    L.prosper_host_rt_reference_context.restype = vp
+    L.prosper_host_rt_reference_set_scene.argtypes = [vp, C.POINTER(S.SceneView)]
+    L.prosper_host_rt_reference_draw_ui.argtypes = [vp, C.c_int, C.c_int, u32, u32]
+    L.prosper_host_rt_reference_draw_ui.restype = None
+    L.prosper_host_rt_reference_recompile_shaders.argtypes = [vp]
+    L.prosper_host_rt_reference_recompile_shaders.restype = None
+    L.prosper_host_rt_reference_release_preserved.argtypes = [vp]
+    L.prosper_host_rt_reference_release_preserved.restype = None
+    L.prosper_host_rt_reference_record.argtypes = [
+        vp, vp, u32, u32, C.POINTER(RecordOptions), u32, C.POINTER(S.TileDesc), u32, vp, C.POINTER(S.ReferencePC)]
+    _lib = L
+    return L
+
+
+class RecordOptions(C.Structure):
+    """prosper_host_record_options == RtReference::Options (src/render/RtReference.hpp:44-50)"""
+
+    _fields_ = [("depthOfField", C.c_uint32), ("ibl", C.c_uint32), ("colorDirty", C.c_uint32),
+                ("drawType", C.c_uint32)]
+
+
+def _check(rc):
+    if rc != 0:
+        raise ProsperPtError(rc, lib().prosper_pt_last_error().decode())
+
+
+def _tile_ref(tile):
+    return C.byref(tile) if tile is not None else None
+
+
+class Context:
+    """One prosper_pt context = one GPU (prosper_pt_create .. prosper_pt_destroy)."""
+
+    def __init__(self, device=0, flags=0, _borrowed=None):
+        self._owned = _borrowed is None
+        if _borrowed is not None:
+            self._h = C.c_void_p(_borrowed)
+            return
+        desc = S.DeviceDesc(C.sizeof(S.DeviceDesc), device, flags, 0)
+        h = C.c_void_p()
+        _check(lib().prosper_pt_create(C.byref(desc), C.byref(h)))
+        self._h = h
+        self._world = None
+
+    def close(self):
+        if getattr(self, "_h", None) and self._owned:
+            lib().prosper_pt_destroy(self._h)
+        self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def upload_scene(self, world):
+        view = world.view()
+        _check(lib().prosper_pt_upload_scene(self._h, C.byref(view)))
+        self._world = world
+
+    def update_lights(self, world):
+        _check(lib().prosper_pt_update_lights(self._h, C.byref(world.directional), C.byref(world.point_lights),
+                                              C.byref(world.spot_lights)))
+
+    def scene_stats(self):
+        st = S.SceneStats()
+        _check(lib().prosper_pt_get_scene_stats(self._h, C.byref(st)))
+        return st
+
+    def set_output_buffer(self, device_ptr, byte_size):
+        _check(lib().prosper_pt_set_output_buffer(self._h, C.c_void_p(device_ptr), byte_size))
+
+    def render(self, pc, camera, width, height, tile=None, frames=1, flags=0, stream=None):
+        _check(lib().prosper_pt_render_frames(self._h, C.byref(pc), C.byref(camera), width, height, _tile_ref(tile),
+                                              frames, flags, C.c_void_p(stream)))
+
+    def local_extent(self):
+        lw, h = C.c_uint32(), C.c_uint32()
+        _check(lib().prosper_pt_get_local_extent(self._h, C.byref(lw), C.byref(h)))
+        return lw.value, h.value
+
+    def hdr_device_ptr(self):
+        p, n = C.c_void_p(), C.c_size_t()
+        _check(lib().prosper_pt_get_hdr_device_ptr(self._h, C.byref(p), C.byref(n)))
+        return p.value, n.value
+
+    def read_hdr(self, stream=None):
+        lw, h = self.local_extent()
+        out = np.empty((h, lw, 4), np.float32)
+        _check(lib().prosper_pt_read_hdr(self._h, out.ctypes.data, out.nbytes, C.c_void_p(stream)))
+        return out
+
+    def blit_rgba16f(self, stream=None):
+        lw, h = self.local_extent()
+        out = np.empty((h, lw, 4), np.float16)
+        _check(lib().prosper_pt_blit_rgba16f(self._h, out.ctypes.data, out.nbytes, C.c_void_p(stream)))
+        return out
+
+    def counters(self, stream=None):
+        c = S.Counters()
+        _check(lib().prosper_pt_get_counters(self._h, C.byref(c), C.c_void_p(stream)))
+        return c
+
+    def reset_counters(self, stream=None):
+        _check(lib().prosper_pt_reset_counters(self._h, C.c_void_p(stream)))
+
+    def set_kernel_timing(self, enabled):
+        _check(lib().prosper_pt_set_kernel_timing(self._h, 1 if enabled else 0))
+
+    def last_render_ms(self):
+        total = C.c_float()
+        per = (C.c_float * S.MAX_KERNELS)()
+        _check(lib().prosper_pt_get_last_render_ms(self._h, C.byref(total), per))
+        names = [lib().prosper_pt_kernel_name(i).decode() for i in range(S.MAX_KERNELS)]
+        return total.value, {n: per[i] for i, n in enumerate(names) if n}
+
+    def eval_device_fn(self, fn, inputs, in_stride, out_stride):
+        a = np.ascontiguousarray(inputs, dtype=np.float32).reshape(-1, in_stride)
+        out = np.zeros((a.shape[0], out_stride), np.float32)
+        _check(lib().prosper_pt_eval_device_fn(self._h, fn, a.ctypes.data, in_stride, out.ctypes.data, out_stride,
+                                               a.shape[0]))
+        return out

@@ -1,0 +1,121 @@
+// host/rt_reference.hpp — render::RtReference of the headless host layer.
+//
+// Same five-method surface as prosper's pass (reference: src/render/RtReference.hpp:32-60) with
+// the Vulkan handles replaced: `init` loads the gfx950 code object instead of compiling shaders
+// and building an RT pipeline + SBT (RtReference.cpp:104-120,405-707); `record` pushes the same
+// ReferencePC and calls prosper_pt_render where the original records cb.traceRaysKHR
+// (RtReference.cpp:161-383).  ImGui state (drawUi, RtReference.cpp:148-159) becomes UiState.
+#pragma once
+
+#include <cstdint>
+
+#include "../../../include/prosper_pt/prosper_pt.h"
+#include "camera.hpp"
+
+namespace scene
+{
+
+// src/scene/DrawType.hpp:23-26
+enum class DrawType : uint8_t
+{
+    Default, PrimitiveID, MeshletID, MeshID, MaterialID, Position, ShadingNormal, TexCoord0, Albedo, Roughness,
+    Metallic, Count
+};
+
+// What the pass needs from scene::World (src/scene/World.hpp:18-82): the flattened scene and
+// the moment its acceleration structures are (re)built (App.cpp:573-578 -> World.cpp:538-575).
+class World
+{
+  public:
+    // Borrowed pointers: the view's arrays must outlive buildAccelerationStructures().
+    void setSceneView(const prosper_pt_scene_view &view);
+    // Uploads scene + builds the BVH on `ctx` when the view changed since the last build.
+    // Throws std::runtime_error on failure.
+    void buildAccelerationStructures(prosper_pt_ctx *ctx);
+    [[nodiscard]] bool uploadedTo(const prosper_pt_ctx *ctx) const { return m_ctx == ctx && !m_dirty; }
+
+  private:
+    prosper_pt_scene_view m_view = {};
+    bool m_haveView = false;
+    bool m_dirty = true;
+    const prosper_pt_ctx *m_ctx = nullptr;
+};
+
+} // namespace scene
+
+namespace render
+{
+
+struct Rect2D
+{
+    int32_t offsetX = 0, offsetY = 0;
+    uint32_t width = 0, height = 0;
+};
+
+class RtReference
+{
+  public:
+    static constexpr uint32_t sMaxBounces = PROSPER_RT_MAX_BOUNCES;
+
+    RtReference() noexcept = default;
+    ~RtReference();
+    RtReference(const RtReference &) = delete;
+    RtReference &operator=(const RtReference &) = delete;
+
+    // Throws std::runtime_error when no gfx950 device is usable (there is no CPU fallback).
+    void init(int32_t deviceOrdinal, uint32_t createFlags = 0);
+    // The kernels are compiled ahead of time; like a successful recompile in the original this
+    // only restarts accumulation (RtReference.cpp:140-145).
+    void recompileShaders();
+
+    struct UiState
+    {
+        bool accumulate{true};
+        bool clampIndirect{true};
+        uint32_t rouletteStartBounce{3};
+        uint32_t maxBounces{sMaxBounces};
+    };
+    // What the ImGui widgets of drawUi() do: changing anything but `accumulate` dirties history.
+    void drawUi(const UiState &wanted);
+    [[nodiscard]] UiState uiState() const;
+
+    struct Options
+    {
+        bool depthOfField{false};
+        bool ibl{false};
+        bool colorDirty{false};
+        scene::DrawType drawType{scene::DrawType::Default};
+    };
+    struct Output
+    {
+        const float *illumination{nullptr}; // device pointer, RGBA32F, width*height texels
+        uint32_t width{0};
+        uint32_t height{0};
+    };
+    // `frameCount` > 1 renders that many consecutive accumulated frames in one launch.
+    [[nodiscard]] Output record(
+        void *stream, scene::World &world, const scene::Camera &cam, const Rect2D &renderArea, const Options &options,
+        uint32_t nextFrame, uint32_t frameCount = 1, const prosper_pt_tile_desc *tile = nullptr,
+        uint32_t renderFlags = 0);
+    void releasePreserved();
+
+    [[nodiscard]] prosper_pt_ctx *context() const { return m_ctx; }
+    [[nodiscard]] const prosper_ReferencePC &lastPushConstants() const { return m_lastPC; }
+
+  private:
+    bool m_initialized{false};
+    prosper_pt_ctx *m_ctx{nullptr};
+
+    bool m_accumulationDirty{true};
+    bool m_accumulate{true};
+    bool m_clampIndirect{true};
+    uint32_t m_frameIndex{0};
+    uint32_t m_rouletteStartBounce{3};
+    uint32_t m_maxBounces{sMaxBounces};
+
+    bool m_havePrevious{false};
+    uint32_t m_previousWidth{0}, m_previousHeight{0};
+    prosper_ReferencePC m_lastPC{};
+};
+
+} // namespace render

@@ -1,0 +1,671 @@
+// prosper_pt.cpp — C-ABI of the MI355X path-tracing reference pass (include/prosper_pt/prosper_pt.h).
+//
+// Host side of what prosper does around `cb.traceRaysKHR` (src/render/RtReference.cpp:161-383)
+// and of the scene/acceleration-structure upload the pass depends on
+// (src/scene/World.cpp:468-536,585-802).  There is no CPU fallback: without a usable HIP device
+// every entry point fails with PROSPER_PT_ERR_NO_DEVICE.
+#include "../../include/prosper_pt/prosper_pt.h"
+
+#include <hip/hip_runtime.h>
+
+#include <chrono>
+#include <cstdio>
+#include <cstring>
+#include <exception>
+#include <string>
+#include <vector>
+
+#include "bvh_build.hpp"
+#include "pt_kernels.hpp"
+#include "pt_scene.hpp"
+
+using namespace ppt;
+
+namespace
+{
+
+thread_local std::string g_lastError;
+
+int fail(int code, const std::string &msg)
+{
+    g_lastError = msg;
+    return code;
+}
+
+#define PPT_HIP(call)                                                                                                  \
+    do                                                                                                                 \
+    {                                                                                                                  \
+        const hipError_t e_ = (call);                                                                                  \
+        if (e_ != hipSuccess)                                                                                          \
+            return fail(PROSPER_PT_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e_));                        \
+    } while (0)
+
+struct DeviceAllocation
+{
+    void *ptr = nullptr;
+    size_t bytes = 0;
+};
+
+} // namespace
+
+struct prosper_pt_ctx
+{
+    int device = 0;
+    uint32_t flags = 0;
+    std::vector<DeviceAllocation> sceneAllocations;
+    uint64_t sceneBytes = 0;
+    bool haveScene = false;
+    DeviceScene scene = {};
+    prosper_pt_scene_stats stats = {};
+    // light buffers are re-uploaded every frame in prosper; keep their device addresses mutable
+    prosper_DirectionalLightParameters *dDirectional = nullptr;
+    prosper_PointLightsBuffer *dPointLights = nullptr;
+    prosper_SpotLightsBuffer *dSpotLights = nullptr;
+
+    float4 *hdr = nullptr; // current HDR buffer (internal or caller-owned)
+    float4 *ownedHdr = nullptr;
+    size_t ownedHdrBytes = 0;
+    void *externalHdr = nullptr;
+    size_t externalHdrBytes = 0;
+    uint32_t localWidth = 0, height = 0;
+
+    unsigned long long *dCounters = nullptr; // 16 x u64
+
+    bool kernelTiming = false;
+    hipEvent_t evStart = nullptr, evStop = nullptr;
+    bool timingValid = false;
+};
+
+namespace
+{
+
+int device_alloc(prosper_pt_ctx *ctx, size_t bytes, void **out)
+{
+    if (bytes == 0) bytes = 16;
+    void *p = nullptr;
+    PPT_HIP(hipMalloc(&p, bytes));
+    ctx->sceneAllocations.push_back({p, bytes});
+    ctx->sceneBytes += bytes;
+    *out = p;
+    return PROSPER_PT_OK;
+}
+
+int upload(prosper_pt_ctx *ctx, const void *src, size_t bytes, void **out)
+{
+    const int rc = device_alloc(ctx, bytes, out);
+    if (rc != PROSPER_PT_OK) return rc;
+    if (bytes) PPT_HIP(hipMemcpy(*out, src, bytes, hipMemcpyHostToDevice));
+    return PROSPER_PT_OK;
+}
+
+void free_scene(prosper_pt_ctx *ctx)
+{
+    for (auto &a : ctx->sceneAllocations) (void)hipFree(a.ptr);
+    ctx->sceneAllocations.clear();
+    ctx->sceneBytes = 0;
+    ctx->haveScene = false;
+    ctx->scene = DeviceScene{};
+}
+
+// Everything the kernels index with is range-checked here, so a malformed view can only fail the
+// upload, never fault the GPU.
+int validate_scene(const prosper_pt_scene_view *v)
+{
+    if (v->struct_size != sizeof(prosper_pt_scene_view))
+        return fail(PROSPER_PT_ERR_INVALID_ARGUMENT, "scene view struct_size mismatch");
+    if (v->geometryBufferCount && (!v->geometryBuffers || !v->geometryBufferByteSizes))
+        return fail(PROSPER_PT_ERR_SCENE, "geometry buffers missing");
+    if (v->meshCount && (!v->geometryMetadatas || !v->meshInfos)) return fail(PROSPER_PT_ERR_SCENE, "mesh tables missing");
+    if (v->drawInstanceCount && !v->drawInstances) return fail(PROSPER_PT_ERR_SCENE, "draw instances missing");
+    if (v->modelInstanceCount && !v->modelInstanceTransforms) return fail(PROSPER_PT_ERR_SCENE, "transforms missing");
+    if (v->materialCount == 0 || !v->materials) return fail(PROSPER_PT_ERR_SCENE, "materials missing (index 0 is required)");
+    if (v->samplerCount == 0 || !v->samplers) return fail(PROSPER_PT_ERR_SCENE, "samplers missing (index 0 is required)");
+    if (v->textureCount && !v->textures) return fail(PROSPER_PT_ERR_SCENE, "textures missing");
+    if (!v->directionalLight || !v->pointLights || !v->spotLights) return fail(PROSPER_PT_ERR_SCENE, "light buffers missing");
+    if (v->pointLights->count > PROSPER_MAX_POINT_LIGHT_COUNT || v->spotLights->count > PROSPER_MAX_SPOT_LIGHT_COUNT)
+        return fail(PROSPER_PT_ERR_SCENE, "light count exceeds 1024");
+    if (v->skybox.texels && v->skybox.faceSize == 0) return fail(PROSPER_PT_ERR_SCENE, "skybox face size is zero");
+
+    for (uint32_t i = 0; i < v->textureCount; ++i)
+    {
+        const prosper_pt_texture_desc &t = v->textures[i];
+        if (!t.texels || t.width == 0 || t.height == 0 || t.format != PROSPER_PT_FORMAT_RGBA8_UNORM)
+            return fail(PROSPER_PT_ERR_SCENE, "texture " + std::to_string(i) + " is invalid");
+    }
+    for (uint32_t i = 0; i < v->samplerCount; ++i)
+    {
+        const prosper_pt_sampler_desc &s = v->samplers[i];
+        if (s.magFilter > PROSPER_PT_FILTER_LINEAR || s.wrapS > PROSPER_PT_WRAP_CLAMP_TO_EDGE ||
+            s.wrapT > PROSPER_PT_WRAP_CLAMP_TO_EDGE)
+            return fail(PROSPER_PT_ERR_SCENE, "sampler " + std::to_string(i) + " is invalid");
+    }
+    for (uint32_t i = 0; i < v->materialCount; ++i)
+    {
+        const prosper_MaterialData &m = v->materials[i];
+        const uint32_t ts[3] = {m.baseColorTextureSampler, m.metallicRoughnessTextureSampler, m.normalTextureSampler};
+        for (uint32_t k = 0; k < 3; ++k)
+        {
+            const uint32_t tex = ts[k] & 0xFFFFFFu, smp = ts[k] >> 24;
+            if (tex > 0 && (tex >= v->textureCount || smp >= v->samplerCount))
+                return fail(PROSPER_PT_ERR_SCENE, "material " + std::to_string(i) + " references a missing texture/sampler");
+        }
+        if (m.alphaMode > PROSPER_ALPHA_MODE_BLEND) return fail(PROSPER_PT_ERR_SCENE, "material alpha mode invalid");
+    }
+    for (uint32_t i = 0; i < v->meshCount; ++i)
+    {
+        const prosper_GeometryMetadata &m = v->geometryMetadatas[i];
+        const prosper_pt_mesh_info &info = v->meshInfos[i];
+        const std::string name = "mesh " + std::to_string(i);
+        if (m.bufferIndex >= v->geometryBufferCount) return fail(PROSPER_PT_ERR_SCENE, name + ": bufferIndex out of range");
+        if (info.materialIndex >= v->materialCount) return fail(PROSPER_PT_ERR_SCENE, name + ": materialIndex out of range");
+        if (info.indexCount % 3 != 0) return fail(PROSPER_PT_ERR_SCENE, name + ": indexCount is not a multiple of 3");
+        const uint64_t words = v->geometryBufferByteSizes[m.bufferIndex] / 4;
+        if (m.indicesOffset == PROSPER_PT_ABSENT || m.positionsOffset == PROSPER_PT_ABSENT)
+            return fail(PROSPER_PT_ERR_SCENE, name + ": indices/positions are required");
+        const uint64_t indexEndWords = m.usesShortIndices == 1 ? ((uint64_t)m.indicesOffset + info.indexCount + 1) / 2
+                                                               : (uint64_t)m.indicesOffset + info.indexCount;
+        if (indexEndWords > words) return fail(PROSPER_PT_ERR_SCENE, name + ": indices run past the geometry buffer");
+        if ((uint64_t)m.positionsOffset + 2ull * info.vertexCount > words)
+            return fail(PROSPER_PT_ERR_SCENE, name + ": positions run past the geometry buffer");
+        const uint32_t attrs[3] = {m.normalsOffset, m.tangentsOffset, m.texCoord0sOffset};
+        for (uint32_t k = 0; k < 3; ++k)
+            if (attrs[k] != PROSPER_PT_ABSENT && (uint64_t)attrs[k] + info.vertexCount > words)
+                return fail(PROSPER_PT_ERR_SCENE, name + ": attribute stream runs past the geometry buffer");
+        const void *buffer = v->geometryBuffers[m.bufferIndex];
+        for (uint32_t k = 0; k < info.indexCount; ++k)
+        {
+            const uint32_t idx = m.usesShortIndices == 1 ? (uint32_t) static_cast<const uint16_t *>(buffer)[m.indicesOffset + k]
+                                                          : static_cast<const uint32_t *>(buffer)[m.indicesOffset + k];
+            if (idx >= info.vertexCount) return fail(PROSPER_PT_ERR_SCENE, name + ": vertex index out of range");
+        }
+    }
+    for (uint32_t i = 0; i < v->drawInstanceCount; ++i)
+    {
+        const prosper_DrawInstance &d = v->drawInstances[i];
+        if (d.meshIndex >= v->meshCount || d.materialIndex >= v->materialCount || d.modelInstanceIndex >= v->modelInstanceCount)
+            return fail(PROSPER_PT_ERR_SCENE, "draw instance " + std::to_string(i) + " references a missing mesh/material/transform");
+    }
+    return PROSPER_PT_OK;
+}
+
+int upload_scene_impl(prosper_pt_ctx *ctx, const prosper_pt_scene_view *v)
+{
+    DeviceScene &s = ctx->scene;
+    int rc;
+
+    // bindless geometry buffers + pointer table
+    std::vector<const void *> bufferPtrs(v->geometryBufferCount ? v->geometryBufferCount : 1, nullptr);
+    for (uint32_t i = 0; i < v->geometryBufferCount; ++i)
+    {
+        void *d = nullptr;
+        if ((rc = upload(ctx, v->geometryBuffers[i], (size_t)v->geometryBufferByteSizes[i], &d))) return rc;
+        bufferPtrs[i] = d;
+    }
+    void *d = nullptr;
+    if ((rc = upload(ctx, bufferPtrs.data(), bufferPtrs.size() * sizeof(void *), &d))) return rc;
+    s.geometryBuffers = static_cast<const void *const *>(d);
+    if ((rc = upload(ctx, v->geometryMetadatas, sizeof(prosper_GeometryMetadata) * v->meshCount, &d))) return rc;
+    s.geometryMetadatas = static_cast<const prosper_GeometryMetadata *>(d);
+    if ((rc = upload(ctx, v->drawInstances, sizeof(prosper_DrawInstance) * v->drawInstanceCount, &d))) return rc;
+    s.drawInstances = static_cast<const prosper_DrawInstance *>(d);
+    if ((rc = upload(ctx, v->modelInstanceTransforms, sizeof(prosper_ModelInstanceTransforms) * v->modelInstanceCount, &d)))
+        return rc;
+    s.modelInstanceTransforms = static_cast<const prosper_ModelInstanceTransforms *>(d);
+    if ((rc = upload(ctx, v->materials, sizeof(prosper_MaterialData) * v->materialCount, &d))) return rc;
+    s.materials = static_cast<const prosper_MaterialData *>(d);
+    if ((rc = upload(ctx, v->samplers, sizeof(prosper_pt_sampler_desc) * v->samplerCount, &d))) return rc;
+    s.samplers = static_cast<const prosper_pt_sampler_desc *>(d);
+
+    // textures: one allocation each (256-B aligned by hipMalloc) + descriptor table
+    std::vector<DeviceTexture> textures(v->textureCount ? v->textureCount : 1);
+    for (uint32_t i = 0; i < v->textureCount; ++i)
+    {
+        const prosper_pt_texture_desc &t = v->textures[i];
+        if ((rc = upload(ctx, t.texels, (size_t)t.width * t.height * 4u, &d))) return rc;
+        textures[i] = DeviceTexture{static_cast<const uint8_t *>(d), t.width, t.height};
+    }
+    if ((rc = upload(ctx, textures.data(), textures.size() * sizeof(DeviceTexture), &d))) return rc;
+    s.textures = static_cast<const DeviceTexture *>(d);
+
+    // lights
+    if ((rc = upload(ctx, v->directionalLight, sizeof(prosper_DirectionalLightParameters), &d))) return rc;
+    ctx->dDirectional = static_cast<prosper_DirectionalLightParameters *>(d);
+    if ((rc = upload(ctx, v->pointLights, sizeof(prosper_PointLightsBuffer), &d))) return rc;
+    ctx->dPointLights = static_cast<prosper_PointLightsBuffer *>(d);
+    if ((rc = upload(ctx, v->spotLights, sizeof(prosper_SpotLightsBuffer), &d))) return rc;
+    ctx->dSpotLights = static_cast<prosper_SpotLightsBuffer *>(d);
+    s.directionalLight = ctx->dDirectional;
+    s.pointLights = ctx->dPointLights;
+    s.spotLights = ctx->dSpotLights;
+    s.pointLightCount = v->pointLights->count;
+    s.spotLightCount = v->spotLights->count;
+
+    // skybox
+    s.skybox = nullptr;
+    s.skyboxFaceSize = 0;
+    if (v->skybox.texels)
+    {
+        const size_t bytes = 6ull * v->skybox.faceSize * v->skybox.faceSize * 4u * sizeof(uint16_t);
+        if ((rc = upload(ctx, v->skybox.texels, bytes, &d))) return rc;
+        s.skybox = static_cast<const uint16_t *>(d);
+        s.skyboxFaceSize = v->skybox.faceSize;
+    }
+
+    // ---- acceleration structure (replaces buildNextBlas/buildCurrentTlas, World.cpp:585-802) ----
+    const auto t0 = std::chrono::steady_clock::now();
+    std::vector<uint32_t> triOffsets(v->drawInstanceCount + 1, 0);
+    std::vector<uint32_t> diFlags(v->drawInstanceCount ? v->drawInstanceCount : 1, 0);
+    uint64_t total = 0;
+    for (uint32_t i = 0; i < v->drawInstanceCount; ++i)
+    {
+        const prosper_pt_mesh_info &info = v->meshInfos[v->drawInstances[i].meshIndex];
+        triOffsets[i] = (uint32_t)total;
+        total += info.indexCount / 3;
+        // World.cpp:646-651: eOpaque iff the mesh's material is AlphaMode_Opaque
+        diFlags[i] = v->materials[info.materialIndex].alphaMode == PROSPER_ALPHA_MODE_OPAQUE ? kTriFlagOpaque : 0u;
+    }
+    triOffsets[v->drawInstanceCount] = (uint32_t)total;
+    if (total >= (1ull << 28)) return fail(PROSPER_PT_ERR_UNSUPPORTED, "more than 2^28 triangles after instancing");
+
+    WorldTriangle *dFlat = nullptr;
+    uint32_t *dOffsets = nullptr, *dFlags = nullptr, *dPerm = nullptr;
+    const size_t triBytes = sizeof(WorldTriangle) * (size_t)(total ? total : 1);
+    PPT_HIP(hipMalloc((void **)&dFlat, triBytes));
+    auto cleanupTemp = [&]() {
+        (void)hipFree(dFlat);
+        (void)hipFree(dOffsets);
+        (void)hipFree(dFlags);
+        (void)hipFree(dPerm);
+    };
+    hipError_t e;
+    if ((e = hipMalloc((void **)&dOffsets, triOffsets.size() * 4)) != hipSuccess ||
+        (e = hipMalloc((void **)&dFlags, diFlags.size() * 4)) != hipSuccess ||
+        (e = hipMemcpy(dOffsets, triOffsets.data(), triOffsets.size() * 4, hipMemcpyHostToDevice)) != hipSuccess ||
+        (e = hipMemcpy(dFlags, diFlags.data(), diFlags.size() * 4, hipMemcpyHostToDevice)) != hipSuccess)
+    {
+        cleanupTemp();
+        return fail(PROSPER_PT_ERR_HIP, std::string("scene upload: ") + hipGetErrorString(e));
+    }
+    launch_flatten_triangles(s, dOffsets, v->drawInstanceCount, dFlags, dFlat, (uint32_t)total, nullptr);
+    std::vector<WorldTriangle> flat((size_t)total);
+    if ((e = hipGetLastError()) != hipSuccess ||
+        (total && (e = hipMemcpy(flat.data(), dFlat, sizeof(WorldTriangle) * (size_t)total, hipMemcpyDeviceToHost)) != hipSuccess) ||
+        (e = hipDeviceSynchronize()) != hipSuccess)
+    {
+        cleanupTemp();
+        return fail(PROSPER_PT_ERR_HIP, std::string("flatten_triangles: ") + hipGetErrorString(e));
+    }
+
+    BvhBuildResult bvh;
+    try
+    {
+        bvh = build_bvh(flat.data(), total);
+    }
+    catch (const std::exception &ex)
+    {
+        cleanupTemp();
+        return fail(PROSPER_PT_ERR_UNSUPPORTED, std::string("BVH build failed: ") + ex.what());
+    }
+
+    if ((rc = upload(ctx, bvh.nodes.data(), bvh.nodes.size() * sizeof(BvhNode), &d)))
+    {
+        cleanupTemp();
+        return rc;
+    }
+    s.nodes = static_cast<const BvhNode *>(d);
+    void *dTris = nullptr;
+    if ((rc = device_alloc(ctx, triBytes, &dTris)))
+    {
+        cleanupTemp();
+        return rc;
+    }
+    if ((e = hipMemset(dTris, 0, triBytes)) != hipSuccess ||
+        (e = hipMalloc((void **)&dPerm, (bvh.permutation.size() ? bvh.permutation.size() : 1) * 4)) != hipSuccess ||
+        (total && (e = hipMemcpy(dPerm, bvh.permutation.data(), bvh.permutation.size() * 4, hipMemcpyHostToDevice)) != hipSuccess))
+    {
+        cleanupTemp();
+        return fail(PROSPER_PT_ERR_HIP, std::string("BVH upload: ") + hipGetErrorString(e));
+    }
+    launch_permute_triangles(dFlat, dPerm, static_cast<WorldTriangle *>(dTris), (uint32_t)total, nullptr);
+    if ((e = hipGetLastError()) != hipSuccess || (e = hipDeviceSynchronize()) != hipSuccess)
+    {
+        cleanupTemp();
+        return fail(PROSPER_PT_ERR_HIP, std::string("permute_triangles: ") + hipGetErrorString(e));
+    }
+    cleanupTemp();
+    s.triangles = static_cast<const WorldTriangle *>(dTris);
+
+    ctx->stats = prosper_pt_scene_stats{};
+    ctx->stats.triangleCount = total;
+    ctx->stats.nodeCount = bvh.nodes.size();
+    ctx->stats.nodeBytes = sizeof(BvhNode);
+    ctx->stats.triangleBytes = sizeof(WorldTriangle);
+    ctx->stats.maxDepth = bvh.maxDepth;
+    ctx->stats.deviceBytes = ctx->sceneBytes;
+    ctx->stats.buildSeconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    return PROSPER_PT_OK;
+}
+
+uint32_t compute_local_width(uint32_t width, const prosper_pt_tile_desc *tile)
+{
+    if (!tile || tile->stripeCount <= 1 || tile->stripeWidth == 0) return width;
+    uint32_t n = 0;
+    for (uint32_t x = 0; x < width; x += tile->stripeWidth)
+    {
+        if ((x / tile->stripeWidth) % tile->stripeCount == tile->stripeIndex)
+            n += (x + tile->stripeWidth <= width) ? tile->stripeWidth : (width - x);
+    }
+    return n;
+}
+
+} // namespace
+
+extern "C" {
+
+const char *prosper_pt_last_error(void) { return g_lastError.c_str(); }
+uint32_t prosper_pt_abi_version(void) { return PROSPER_PT_ABI_VERSION; }
+
+int prosper_pt_create(const prosper_pt_device_desc *desc, prosper_pt_ctx **out_ctx)
+{
+    if (!desc || !out_ctx || desc->struct_size != sizeof(prosper_pt_device_desc))
+        return fail(PROSPER_PT_ERR_INVALID_ARGUMENT, "prosper_pt_create: bad descriptor");
+    *out_ctx = nullptr;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0)
+        return fail(PROSPER_PT_ERR_NO_DEVICE, "no HIP device is visible (this pass has no CPU fallback)");
+    if (desc->device_ordinal < 0 || desc->device_ordinal >= count)
+        return fail(PROSPER_PT_ERR_NO_DEVICE, "device ordinal out of range");
+    PPT_HIP(hipSetDevice(desc->device_ordinal));
+    hipDeviceProp_t prop;
+    PPT_HIP(hipGetDeviceProperties(&prop, desc->device_ordinal));
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(PROSPER_PT_ERR_NO_DEVICE, std::string("device is ") + prop.gcnArchName + ", this library carries gfx950 code only");
+    prosper_pt_ctx *ctx = new (std::nothrow) prosper_pt_ctx();
+    if (!ctx) return fail(PROSPER_PT_ERR_INVALID_ARGUMENT, "out of host memory");
+    ctx->device = desc->device_ordinal;
+    ctx->flags = desc->flags;
+    if (hipMalloc((void **)&ctx->dCounters, 16 * sizeof(unsigned long long)) != hipSuccess ||
+        hipMemset(ctx->dCounters, 0, 16 * sizeof(unsigned long long)) != hipSuccess ||
+        hipEventCreate(&ctx->evStart) != hipSuccess || hipEventCreate(&ctx->evStop) != hipSuccess)
+    {
+        prosper_pt_destroy(ctx);
+        return fail(PROSPER_PT_ERR_HIP, "context allocation failed");
+    }
+    *out_ctx = ctx;
+    return PROSPER_PT_OK;
+}
+
+void prosper_pt_destroy(prosper_pt_ctx *ctx)
+{
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    (void)hipDeviceSynchronize();
+    free_scene(ctx);
+    if (ctx->ownedHdr) (void)hipFree(ctx->ownedHdr);
+    if (ctx->dCounters) (void)hipFree(ctx->dCounters);
+    if (ctx->evStart) (void)hipEventDestroy(ctx->evStart);
+    if (ctx->evStop) (void)hipEventDestroy(ctx->evStop);
+    delete ctx;
+}
+
+int prosper_pt_upload_scene(prosper_pt_ctx *ctx, const prosper_pt_scene_view *scene)
+{
+    if (!ctx || !scene) return fail(PROSPER_PT_ERR_INVALID_ARGUMENT, "prosper_pt_upload_scene: null argument");
+    int rc = validate_scene(scene);
+    if (rc != PROSPER_PT_OK) return rc;
+    PPT_HIP(hipSetDevice(ctx->device));
+    PPT_HIP(hipDeviceSynchronize());
+    free_scene(ctx);
+    rc = upload_scene_impl(ctx, scene);
+    if (rc != PROSPER_PT_OK)
+    {
+        free_scene(ctx);
+        return rc;
+    }
+    ctx->haveScene = true;
+    return PROSPER_PT_OK;
+}
+
+int prosper_pt_update_lights(
+    prosper_pt_ctx *ctx, const prosper_DirectionalLightParameters *directionalLight,
+    const prosper_PointLightsBuffer *pointLights, const prosper_SpotLightsBuffer *spotLights)
+{
+    if (!ctx || !directionalLight || !pointLights || !spotLights)
+        return fail(PROSPER_PT_ERR_INVALID_ARGUMENT, "prosper_pt_update_lights: null argument");
+    if (!ctx->haveScene) return fail(PROSPER_PT_ERR_NO_SCENE, "no scene uploaded");
+    if (pointLights->count > PROSPER_MAX_POINT_LIGHT_COUNT || spotLights->count > PROSPER_MAX_SPOT_LIGHT_COUNT)
+        return fail(PROSPER_PT_ERR_SCENE, "light count exceeds 1024");
+    PPT_HIP(hipSetDevice(ctx->device));
+    PPT_HIP(hipDeviceSynchronize());
+    PPT_HIP(hipMemcpy(ctx->dDirectional, directionalLight, sizeof(*directionalLight), hipMemcpyHostToDevice));
+    PPT_HIP(hipMemcpy(ctx->dPointLights, pointLights, sizeof(*pointLights), hipMemcpyHostToDevice));
+    PPT_HIP(hipMemcpy(ctx->dSpotLights, spotLights, sizeof(*spotLights), hipMemcpyHostToDevice));
+    ctx->scene.pointLightCount = pointLights->count;
+    ctx->scene.spotLightCount = spotLights->count;
+    return PROSPER_PT_OK;
+}
+
+int prosper_pt_get_scene_stats(prosper_pt_ctx *ctx, prosper_pt_scene_stats *out)
+{
+    if (!ctx || !out) return fail(PROSPER_PT_ERR_INVALID_ARGUMENT, "prosper_pt_get_scene_stats: null argument");
+    if (!ctx->haveScene) return fail(PROSPER_PT_ERR_NO_SCENE, "no scene uploaded");
+    *out = ctx->stats;
+    return PROSPER_PT_OK;
+}
+
+int prosper_pt_set_output_buffer(prosper_pt_ctx *ctx, void *device_rgba32f, size_t byte_size)
+{
+    if (!ctx) return fail(PROSPER_PT_ERR_INVALID_ARGUMENT, "prosper_pt_set_output_buffer: null context");
+    if (device_rgba32f && (reinterpret_cast<uintptr_t>(device_rgba32f) & 15u))
+        return fail(PROSPER_PT_ERR_INVALID_ARGUMENT, "output buffer must be 16-byte aligned");
+    ctx->externalHdr = device_rgba32f;
+    ctx->externalHdrBytes = device_rgba32f ? byte_size : 0;
+    return PROSPER_PT_OK;
+}
+
+int prosper_pt_render_frames(
+    prosper_pt_ctx *ctx, const prosper_ReferencePC *pc, const prosper_CameraUniforms *camera, uint32_t width,
+    uint32_t height, const prosper_pt_tile_desc *tile, uint32_t frame_count, uint32_t render_flags, void *stream)
+{
+    if (!ctx || !pc || !camera) return fail(PROSPER_PT_ERR_INVALID_ARGUMENT, "prosper_pt_render: null argument");
+    if (!ctx->haveScene) return fail(PROSPER_PT_ERR_NO_SCENE, "prosper_pt_render called before prosper_pt_upload_scene");
+    if (width == 0 || height == 0 || frame_count == 0)
+        return fail(PROSPER_PT_ERR_INVALID_ARGUMENT, "prosper_pt_render: empty extent or frame count");
+    if (pc->drawType >= PROSPER_DRAW_TYPE_COUNT) return fail(PROSPER_PT_ERR_INVALID_ARGUMENT, "drawType out of range");
+    const bool tiled = tile && tile->stripeCount > 1 && tile->stripeWidth > 0;
+    if (tiled && tile->stripeIndex >= tile->stripeCount)
+        return fail(PROSPER_PT_ERR_INVALID_ARGUMENT, "tile stripeIndex >= stripeCount");
+    PPT_HIP(hipSetDevice(ctx->device));
+    hipStream_t s = static_cast<hipStream_t>(stream);
+
+    const uint32_t localWidth = compute_local_width(width, tile);
+    const size_t bytes = (size_t)localWidth * height * sizeof(float4);
+    if (ctx->externalHdr)
+    {
+        if (ctx->externalHdrBytes < bytes) return fail(PROSPER_PT_ERR_INVALID_ARGUMENT, "caller-owned output buffer is too small");
+        ctx->hdr = static_cast<float4 *>(ctx->externalHdr);
+    }
+    else
+    {
+        if (ctx->ownedHdrBytes < bytes || !ctx->ownedHdr)
+        {
+            PPT_HIP(hipStreamSynchronize(s));
+            if (ctx->ownedHdr) PPT_HIP(hipFree(ctx->ownedHdr));
+            ctx->ownedHdr = nullptr;
+            PPT_HIP(hipMalloc((void **)&ctx->ownedHdr, bytes ? bytes : 16));
+            PPT_HIP(hipMemset(ctx->ownedHdr, 0, bytes ? bytes : 16));
+            ctx->ownedHdrBytes = bytes;
+        }
+        ctx->hdr = ctx->ownedHdr;
+    }
+    ctx->localWidth = localWidth;
+    ctx->height = height;
+
+    RenderParams p = {};
+    p.pc = *pc;
+    // rt/ray.glsl:21-35 and scene/camera.glsl:46-51 read these parts of CameraUniforms
+    p.eye[0] = camera->eye.x;
+    p.eye[1] = camera->eye.y;
+    p.eye[2] = camera->eye.z;
+    const prosper_mat4 &w2c = camera->worldToCamera;
+    p.right[0] = w2c.col[0].x; p.right[1] = w2c.col[1].x; p.right[2] = w2c.col[2].x;
+    p.up[0] = w2c.col[0].y; p.up[1] = w2c.col[1].y; p.up[2] = w2c.col[2].y;
+    p.fwd[0] = -w2c.col[0].z; p.fwd[1] = -w2c.col[1].z; p.fwd[2] = -w2c.col[2].z;
+    p.c2c00 = camera->cameraToClip.col[0].x;
+    p.c2c11 = camera->cameraToClip.col[1].y;
+    std::memcpy(p.cameraToWorld, &camera->cameraToWorld, 64);
+    p.width = width;
+    p.height = height;
+    p.stripeWidth = tiled ? tile->stripeWidth : 0;
+    p.stripeIndex = tiled ? tile->stripeIndex : 0;
+    p.stripeCount = tiled ? tile->stripeCount : 1;
+    p.localWidth = localWidth;
+    p.frameCount = frame_count;
+
+    if (localWidth == 0) return PROSPER_PT_OK;
+    const bool countWork = (render_flags & PROSPER_PT_RENDER_COUNT_WORK) != 0;
+    if (ctx->kernelTiming) PPT_HIP(hipEventRecord(ctx->evStart, s));
+    launch_render_megakernel(ctx->scene, p, ctx->hdr, ctx->dCounters, countWork, s);
+    PPT_HIP(hipGetLastError());
+    if (ctx->kernelTiming)
+    {
+        PPT_HIP(hipEventRecord(ctx->evStop, s));
+        ctx->timingValid = true;
+    }
+    return PROSPER_PT_OK;
+}
+
+int prosper_pt_render(
+    prosper_pt_ctx *ctx, const prosper_ReferencePC *pc, const prosper_CameraUniforms *camera, uint32_t width,
+    uint32_t height, const prosper_pt_tile_desc *tile, uint32_t render_flags, void *stream)
+{
+    return prosper_pt_render_frames(ctx, pc, camera, width, height, tile, 1, render_flags, stream);
+}
+
+int prosper_pt_get_local_extent(prosper_pt_ctx *ctx, uint32_t *local_width, uint32_t *height)
+{
+    if (!ctx || !local_width || !height) return fail(PROSPER_PT_ERR_INVALID_ARGUMENT, "prosper_pt_get_local_extent: null argument");
+    *local_width = ctx->localWidth;
+    *height = ctx->height;
+    return PROSPER_PT_OK;
+}
+
+int prosper_pt_get_hdr_device_ptr(prosper_pt_ctx *ctx, void **out_ptr, size_t *out_bytes)
+{
+    if (!ctx || !out_ptr) return fail(PROSPER_PT_ERR_INVALID_ARGUMENT, "prosper_pt_get_hdr_device_ptr: null argument");
+    if (!ctx->hdr) return fail(PROSPER_PT_ERR_NO_SCENE, "nothing has been rendered yet");
+    *out_ptr = ctx->hdr;
+    if (out_bytes) *out_bytes = (size_t)ctx->localWidth * ctx->height * sizeof(float4);
+    return PROSPER_PT_OK;
+}
+
+int prosper_pt_read_hdr(prosper_pt_ctx *ctx, float *rgba32f, size_t byte_size, void *stream)
+{
+    if (!ctx || !rgba32f) return fail(PROSPER_PT_ERR_INVALID_ARGUMENT, "prosper_pt_read_hdr: null argument");
+    if (!ctx->hdr) return fail(PROSPER_PT_ERR_NO_SCENE, "nothing has been rendered yet");
+    const size_t bytes = (size_t)ctx->localWidth * ctx->height * sizeof(float4);
+    if (byte_size < bytes) return fail(PROSPER_PT_ERR_INVALID_ARGUMENT, "prosper_pt_read_hdr: destination too small");
+    PPT_HIP(hipSetDevice(ctx->device));
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    PPT_HIP(hipMemcpyAsync(rgba32f, ctx->hdr, bytes, hipMemcpyDeviceToHost, s));
+    PPT_HIP(hipStreamSynchronize(s));
+    return PROSPER_PT_OK;
+}
+
+int prosper_pt_blit_rgba16f(prosper_pt_ctx *ctx, uint16_t *host_rgba16f, size_t byte_size, void *stream)
+{
+    if (!ctx || !host_rgba16f) return fail(PROSPER_PT_ERR_INVALID_ARGUMENT, "prosper_pt_blit_rgba16f: null argument");
+    if (!ctx->hdr) return fail(PROSPER_PT_ERR_NO_SCENE, "nothing has been rendered yet");
+    const uint32_t count = ctx->localWidth * ctx->height;
+    if (byte_size < (size_t)count * 8u) return fail(PROSPER_PT_ERR_INVALID_ARGUMENT, "prosper_pt_blit_rgba16f: destination too small");
+    PPT_HIP(hipSetDevice(ctx->device));
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    void *tmp = nullptr;
+    PPT_HIP(hipMalloc(&tmp, (size_t)count * 8u + 16));
+    launch_blit_rgba16f(ctx->hdr, tmp, count, s);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipMemcpyAsync(host_rgba16f, tmp, (size_t)count * 8u, hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    (void)hipFree(tmp);
+    if (e != hipSuccess) return fail(PROSPER_PT_ERR_HIP, std::string("blit: ") + hipGetErrorString(e));
+    return PROSPER_PT_OK;
+}
+
+int prosper_pt_get_counters(prosper_pt_ctx *ctx, prosper_pt_counters *out, void *stream)
+{
+    if (!ctx || !out) return fail(PROSPER_PT_ERR_INVALID_ARGUMENT, "prosper_pt_get_counters: null argument");
+    PPT_HIP(hipSetDevice(ctx->device));
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    unsigned long long host[16] = {};
+    PPT_HIP(hipMemcpyAsync(host, ctx->dCounters, sizeof(host), hipMemcpyDeviceToHost, s));
+    PPT_HIP(hipStreamSynchronize(s));
+    static_assert(sizeof(prosper_pt_counters) == 16 * sizeof(uint64_t), "counter layout");
+    std::memcpy(out, host, sizeof(*out));
+    return PROSPER_PT_OK;
+}
+
+int prosper_pt_reset_counters(prosper_pt_ctx *ctx, void *stream)
+{
+    if (!ctx) return fail(PROSPER_PT_ERR_INVALID_ARGUMENT, "prosper_pt_reset_counters: null context");
+    PPT_HIP(hipSetDevice(ctx->device));
+    PPT_HIP(hipMemsetAsync(ctx->dCounters, 0, 16 * sizeof(unsigned long long), static_cast<hipStream_t>(stream)));
+    return PROSPER_PT_OK;
+}
+
+int prosper_pt_set_kernel_timing(prosper_pt_ctx *ctx, int enabled)
+{
+    if (!ctx) return fail(PROSPER_PT_ERR_INVALID_ARGUMENT, "prosper_pt_set_kernel_timing: null context");
+    ctx->kernelTiming = enabled != 0;
+    ctx->timingValid = false;
+    return PROSPER_PT_OK;
+}
+
+const char *prosper_pt_kernel_name(uint32_t index)
+{
+    static const char *names[PROSPER_PT_MAX_KERNELS] = {"render_megakernel", "", "", "", "", "", "", ""};
+    return index < PROSPER_PT_MAX_KERNELS ? names[index] : "";
+}
+
+int prosper_pt_get_last_render_ms(prosper_pt_ctx *ctx, float *total_ms, float kernel_ms[PROSPER_PT_MAX_KERNELS])
+{
+    if (!ctx || !total_ms) return fail(PROSPER_PT_ERR_INVALID_ARGUMENT, "prosper_pt_get_last_render_ms: null argument");
+    if (!ctx->kernelTiming || !ctx->timingValid)
+        return fail(PROSPER_PT_ERR_INVALID_ARGUMENT, "kernel timing is not enabled or nothing was rendered since enabling it");
+    PPT_HIP(hipSetDevice(ctx->device));
+    PPT_HIP(hipEventSynchronize(ctx->evStop));
+    float ms = 0.0f;
+    PPT_HIP(hipEventElapsedTime(&ms, ctx->evStart, ctx->evStop));
+    *total_ms = ms;
+    if (kernel_ms)
+    {
+        for (int i = 0; i < PROSPER_PT_MAX_KERNELS; ++i) kernel_ms[i] = 0.0f;
+        kernel_ms[0] = ms;
+    }
+    return PROSPER_PT_OK;
+}
+
+int prosper_pt_eval_device_fn(
+    prosper_pt_ctx *ctx, uint32_t fn, const float *in, uint32_t in_stride, float *out, uint32_t out_stride, uint32_t n)
+{
+    if (!ctx || !in || !out || fn >= PROSPER_PT_FN_COUNT || in_stride == 0 || out_stride == 0)
+        return fail(PROSPER_PT_ERR_INVALID_ARGUMENT, "prosper_pt_eval_device_fn: bad argument");
+    PPT_HIP(hipSetDevice(ctx->device));
+    float *dIn = nullptr, *dOut = nullptr;
+    const size_t inBytes = (size_t)n * in_stride * 4, outBytes = (size_t)n * out_stride * 4;
+    PPT_HIP(hipMalloc((void **)&dIn, inBytes + 16));
+    hipError_t e = hipMalloc((void **)&dOut, outBytes + 16);
+    if (e == hipSuccess) e = hipMemcpy(dIn, in, inBytes, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemset(dOut, 0, outBytes + 16);
+    if (e == hipSuccess)
+    {
+        launch_eval_fn(fn, dIn, in_stride, dOut, out_stride, n, nullptr);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpy(out, dOut, outBytes, hipMemcpyDeviceToHost);
+    (void)hipFree(dIn);
+    (void)hipFree(dOut);
+    if (e != hipSuccess) return fail(PROSPER_PT_ERR_HIP, std::string("eval_device_fn: ") + hipGetErrorString(e));
+    return PROSPER_PT_OK;
+}
+
+} // extern "C"

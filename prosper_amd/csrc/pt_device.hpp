@@ -1,0 +1,1044 @@
+// pt_device.hpp — device functions of the HIP path tracer (gfx950), restating prosper's RT
+// reference shaders.  Citations are file:line under /root/reference/res/shader/ unless noted.
+#pragma once
+
+#include "pt_math.hpp"
+#include "pt_scene.hpp"
+
+namespace ppt
+{
+
+#define PPT_D __device__ __forceinline__
+
+constexpr uint32_t kMissIndex = 0xFFFFFFFFu; // rt/reference/main.rgen:47
+
+// Work counters of one lane (SURVEY §8d byte model).  Only the COUNT=true kernel variants touch
+// them; the timed variants compile every increment away.
+struct LaneCounters
+{
+    uint32_t closestRays, shadowRays, nodeVisits, triangleTests, closestHits, anyHitCalls, lightSamples,
+        spotLightSamples, skyLookups, shortIndexHits, paths, pixelsWritten, historyReads;
+};
+
+// ------------------------------------------------------------------------------------------
+// F8 RNG — common/random.glsl
+// ------------------------------------------------------------------------------------------
+
+// random.glsl:7-12
+PPT_D uint32_t pcg(uint32_t v)
+{
+    const uint32_t state = v * 747796405u + 2891336453u;
+    const uint32_t word = ((state >> ((state >> 28) + 4u)) ^ state) * 277803737u;
+    return (word >> 22) ^ word;
+}
+
+struct Rng
+{
+    uint32_t x, y, z;
+    // random.glsl:17-28
+    PPT_D void step()
+    {
+        x = x * 1664525u + 1013904223u;
+        y = y * 1664525u + 1013904223u;
+        z = z * 1664525u + 1013904223u;
+        x += y * z;
+        y += z * x;
+        z += x * y;
+        x ^= x >> 16;
+        y ^= y >> 16;
+        z ^= z >> 16;
+        x += y * z;
+        y += z * x;
+        z += x * y;
+    }
+    // random.glsl:42: float(0xFFFFFFFFu) rounds to 2^32
+    static PPT_D float to01(uint32_t u) { return (float)u / 4294967296.0f; }
+    // random.glsl:50-63
+    PPT_D float rnd01()
+    {
+        step();
+        return to01(x);
+    }
+    PPT_D f2 rnd2d01()
+    {
+        step();
+        return f2{to01(x), to01(y)};
+    }
+};
+
+// random.glsl:30-40
+PPT_D f3 uint_to_color(uint32_t v)
+{
+    const uint32_t xr = pcg(v);
+    return f3{(float)((xr >> 20) & 0x3FFu) / 1023.0f, (float)((xr >> 10) & 0x3FFu) / 1023.0f,
+              (float)(xr & 0x3FFu) / 1023.0f};
+}
+
+// ------------------------------------------------------------------------------------------
+// F10 bindless fetch + decode — scene/geometry.glsl
+// ------------------------------------------------------------------------------------------
+
+struct Vertex
+{
+    f3 position;
+    f3 normal;
+    f4 tangent;
+    f2 uv;
+};
+
+PPT_D const uint32_t *geo_u32(const DeviceScene &s, uint32_t buffer)
+{
+    return static_cast<const uint32_t *>(s.geometryBuffers[buffer]);
+}
+
+// geometry.glsl:51-59
+PPT_D uint32_t load_index(const DeviceScene &s, const prosper_GeometryMetadata &m, uint32_t index)
+{
+    if (m.usesShortIndices == 1)
+        return (uint32_t) static_cast<const uint16_t *>(s.geometryBuffers[m.bufferIndex])[m.indicesOffset + index];
+    return geo_u32(s, m.bufferIndex)[m.indicesOffset + index];
+}
+
+// geometry.glsl:71-80
+PPT_D f2 load_r16g16(const DeviceScene &s, uint32_t buffer, uint32_t offset, uint32_t index)
+{
+    if (offset == PROSPER_PT_ABSENT) return f2{0.0f, 0.0f};
+    const uint32_t packed = geo_u32(s, buffer)[offset + index];
+    return f2{half_to_float(packed & 0xFFFFu), half_to_float(packed >> 16)};
+}
+
+// geometry.glsl:82-93
+PPT_D f3 load_r16g16b16a16(const DeviceScene &s, uint32_t buffer, uint32_t offset, uint32_t index)
+{
+    if (offset == PROSPER_PT_ABSENT) return f3{0.0f, 0.0f, 0.0f};
+    const uint2 p = *reinterpret_cast<const uint2 *>(geo_u32(s, buffer) + offset + index * 2);
+    return f3{half_to_float(p.x & 0xFFFFu), half_to_float(p.x >> 16), half_to_float(p.y & 0xFFFFu)};
+}
+
+// geometry.glsl:95-103
+PPT_D f3 unpack_snorm_r10g10b10(uint32_t packed)
+{
+    const int32_t sx = (int32_t)(packed << 22) >> 22;
+    const int32_t sy = (int32_t)(packed << 12) >> 22;
+    const int32_t sz = (int32_t)(packed << 2) >> 22;
+    return normalize(
+        f3{fmax_((float)sx / 511.0f, -1.0f), fmax_((float)sy / 511.0f, -1.0f), fmax_((float)sz / 511.0f, -1.0f)});
+}
+
+// geometry.glsl:220-244
+PPT_D Vertex load_vertex_through_index_buffer(const DeviceScene &s, const prosper_GeometryMetadata &m, uint32_t index)
+{
+    const uint32_t vi = load_index(s, m, index);
+    Vertex v;
+    v.position = load_r16g16b16a16(s, m.bufferIndex, m.positionsOffset, vi);
+    // geometry.glsl:105-114
+    v.normal = m.normalsOffset == PROSPER_PT_ABSENT
+                   ? f3{0.0f, 0.0f, 0.0f}
+                   : unpack_snorm_r10g10b10(geo_u32(s, m.bufferIndex)[m.normalsOffset + vi]);
+    // geometry.glsl:116-127
+    if (m.tangentsOffset == PROSPER_PT_ABSENT)
+        v.tangent = f4{0.0f, 0.0f, 0.0f, 0.0f};
+    else
+    {
+        const uint32_t packed = geo_u32(s, m.bufferIndex)[m.tangentsOffset + vi];
+        const f3 t = unpack_snorm_r10g10b10(packed);
+        v.tangent = f4{t.x, t.y, t.z, (float)((int32_t)packed >> 30)};
+    }
+    v.uv = load_r16g16(s, m.bufferIndex, m.texCoord0sOffset, vi);
+    return v;
+}
+
+// geometry.glsl:258-270
+PPT_D float bary1(float v0, float v1, float v2, float a, float b, float c) { return (v0 * a + v1 * b) + v2 * c; }
+
+// geometry.glsl:271-286
+PPT_D Vertex interpolate(const Vertex &v0, const Vertex &v1, const Vertex &v2, f2 bc)
+{
+    const float a = (1.0f - bc.x) - bc.y;
+    const float b = bc.x;
+    const float c = bc.y;
+    Vertex r;
+    r.position = f3{bary1(v0.position.x, v1.position.x, v2.position.x, a, b, c),
+                    bary1(v0.position.y, v1.position.y, v2.position.y, a, b, c),
+                    bary1(v0.position.z, v1.position.z, v2.position.z, a, b, c)};
+    r.normal = f3{bary1(v0.normal.x, v1.normal.x, v2.normal.x, a, b, c),
+                  bary1(v0.normal.y, v1.normal.y, v2.normal.y, a, b, c),
+                  bary1(v0.normal.z, v1.normal.z, v2.normal.z, a, b, c)};
+    r.tangent = f4{bary1(v0.tangent.x, v1.tangent.x, v2.tangent.x, a, b, c),
+                   bary1(v0.tangent.y, v1.tangent.y, v2.tangent.y, a, b, c),
+                   bary1(v0.tangent.z, v1.tangent.z, v2.tangent.z, a, b, c),
+                   bary1(v0.tangent.w, v1.tangent.w, v2.tangent.w, a, b, c)};
+    r.uv = f2{bary1(v0.uv.x, v1.uv.x, v2.uv.x, a, b, c), bary1(v0.uv.y, v1.uv.y, v2.uv.y, a, b, c)};
+    return r;
+}
+
+// ------------------------------------------------------------------------------------------
+// F11 object -> world — scene/instances.glsl:36-53
+// ------------------------------------------------------------------------------------------
+
+// vec4(p,1) * mat3x4
+PPT_D f3 mul_point_mat3x4(f3 p, const prosper_mat3x4 &m)
+{
+    return f3{((p.x * m.col[0].x + p.y * m.col[0].y) + p.z * m.col[0].z) + m.col[0].w,
+              ((p.x * m.col[1].x + p.y * m.col[1].y) + p.z * m.col[1].z) + m.col[1].w,
+              ((p.x * m.col[2].x + p.y * m.col[2].y) + p.z * m.col[2].z) + m.col[2].w};
+}
+// v * mat3(m)
+PPT_D f3 mul_vec_mat3(f3 v, const prosper_mat3x4 &m)
+{
+    return f3{(v.x * m.col[0].x + v.y * m.col[0].y) + v.z * m.col[0].z,
+              (v.x * m.col[1].x + v.y * m.col[1].y) + v.z * m.col[1].z,
+              (v.x * m.col[2].x + v.y * m.col[2].y) + v.z * m.col[2].z};
+}
+
+PPT_D Vertex transform(const Vertex &v, const prosper_ModelInstanceTransforms &t)
+{
+    Vertex r;
+    r.position = mul_point_mat3x4(v.position, t.modelToWorld);
+    r.normal = normalize(mul_vec_mat3(v.normal, t.normalToWorld));
+    if (v.tangent.w != 0.0f)
+    {
+        const f3 tt = normalize(mul_vec_mat3(f3{v.tangent.x, v.tangent.y, v.tangent.z}, t.modelToWorld));
+        r.tangent = f4{tt.x, tt.y, tt.z, v.tangent.w};
+    }
+    else
+        r.tangent = v.tangent;
+    r.uv = v.uv;
+    return r;
+}
+
+// ------------------------------------------------------------------------------------------
+// Texture sampling (LOD 0; DESIGN.md "Texture contract")
+// ------------------------------------------------------------------------------------------
+
+PPT_D int32_t wrap_coord(int32_t i, int32_t size, uint32_t mode)
+{
+    if (mode == PROSPER_PT_WRAP_REPEAT)
+    {
+        const int32_t m = i % size;
+        return m < 0 ? m + size : m;
+    }
+    if (mode == PROSPER_PT_WRAP_MIRRORED_REPEAT)
+    {
+        const int32_t period = 2 * size;
+        int32_t m = i % period;
+        if (m < 0) m += period;
+        return m < size ? m : period - 1 - m;
+    }
+    return i < 0 ? 0 : (i >= size ? size - 1 : i);
+}
+
+PPT_D f4 fetch_rgba8(const DeviceTexture &t, int32_t i, int32_t j)
+{
+    const uint32_t p = reinterpret_cast<const uint32_t *>(t.texels)[(size_t)j * t.width + (size_t)i];
+    return f4{(float)(p & 0xFFu) / 255.0f, (float)((p >> 8) & 0xFFu) / 255.0f, (float)((p >> 16) & 0xFFu) / 255.0f,
+              (float)(p >> 24) / 255.0f};
+}
+
+PPT_D f4 sample_texture(const DeviceScene &s, uint32_t tex, uint32_t smp, f2 uv)
+{
+    const DeviceTexture t = s.textures[tex];
+    const prosper_pt_sampler_desc sd = s.samplers[smp];
+    const int32_t w = (int32_t)t.width;
+    const int32_t h = (int32_t)t.height;
+    if (sd.magFilter == PROSPER_PT_FILTER_NEAREST)
+    {
+        const int32_t i = wrap_coord(f2i(__builtin_floorf(uv.x * (float)w)), w, sd.wrapS);
+        const int32_t j = wrap_coord(f2i(__builtin_floorf(uv.y * (float)h)), h, sd.wrapT);
+        return fetch_rgba8(t, i, j);
+    }
+    const float u = uv.x * (float)w - 0.5f;
+    const float v = uv.y * (float)h - 0.5f;
+    const float fu = __builtin_floorf(u);
+    const float fv = __builtin_floorf(v);
+    const float a = u - fu;
+    const float b = v - fv;
+    const int32_t i0 = wrap_coord(f2i(fu), w, sd.wrapS);
+    const int32_t i1 = wrap_coord(f2i(fu) + 1, w, sd.wrapS);
+    const int32_t j0 = wrap_coord(f2i(fv), h, sd.wrapT);
+    const int32_t j1 = wrap_coord(f2i(fv) + 1, h, sd.wrapT);
+    const f4 t00 = fetch_rgba8(t, i0, j0);
+    const f4 t10 = fetch_rgba8(t, i1, j0);
+    const f4 t01 = fetch_rgba8(t, i0, j1);
+    const f4 t11 = fetch_rgba8(t, i1, j1);
+    const float w00 = (1.0f - a) * (1.0f - b);
+    const float w10 = a * (1.0f - b);
+    const float w01 = (1.0f - a) * b;
+    const float w11 = a * b;
+    return f4{((w00 * t00.x + w10 * t10.x) + w01 * t01.x) + w11 * t11.x,
+              ((w00 * t00.y + w10 * t10.y) + w01 * t01.y) + w11 * t11.y,
+              ((w00 * t00.z + w10 * t10.z) + w01 * t01.z) + w11 * t11.z,
+              ((w00 * t00.w + w10 * t10.w) + w01 * t01.w) + w11 * t11.w};
+}
+
+// Cube face selection per Vulkan 1.3 §16.5.4 (faces +X,-X,+Y,-Y,+Z,-Z)
+PPT_D void cube_face_coords(f3 d, uint32_t &face, float &sc, float &tc, float &ma)
+{
+    const float ax = fabs_(d.x), ay = fabs_(d.y), az = fabs_(d.z);
+    if (az >= ax && az >= ay)
+    {
+        face = d.z < 0.0f ? 5u : 4u;
+        sc = d.z < 0.0f ? -d.x : d.x;
+        tc = -d.y;
+        ma = az;
+    }
+    else if (ay >= ax)
+    {
+        face = d.y < 0.0f ? 3u : 2u;
+        sc = d.x;
+        tc = d.y < 0.0f ? -d.z : d.z;
+        ma = ay;
+    }
+    else
+    {
+        face = d.x < 0.0f ? 1u : 0u;
+        sc = d.x < 0.0f ? d.z : -d.z;
+        tc = -d.y;
+        ma = ax;
+    }
+}
+
+PPT_D f3 cube_face_dir(uint32_t face, float sc, float tc)
+{
+    switch (face)
+    {
+    case 0: return f3{1.0f, -tc, -sc};
+    case 1: return f3{-1.0f, -tc, sc};
+    case 2: return f3{sc, 1.0f, tc};
+    case 3: return f3{sc, -1.0f, -tc};
+    case 4: return f3{sc, -tc, 1.0f};
+    default: return f3{-sc, -tc, -1.0f};
+    }
+}
+
+PPT_D f3 fetch_cube_rgb(const DeviceScene &s, uint32_t face, int32_t i, int32_t j)
+{
+    const int32_t n = (int32_t)s.skyboxFaceSize;
+    if (i < 0 || j < 0 || i >= n || j >= n)
+    {
+        // seamless edge: re-project the centre of the out-of-face texel onto the neighbouring face
+        const float sc = (2.0f * ((float)i + 0.5f)) / (float)n - 1.0f;
+        const float tc = (2.0f * ((float)j + 0.5f)) / (float)n - 1.0f;
+        const f3 d = cube_face_dir(face, sc, tc);
+        float sc2, tc2, ma2;
+        cube_face_coords(d, face, sc2, tc2, ma2);
+        const float ss = 0.5f * (sc2 / ma2) + 0.5f;
+        const float tt = 0.5f * (tc2 / ma2) + 0.5f;
+        i = f2i(__builtin_floorf(ss * (float)n));
+        j = f2i(__builtin_floorf(tt * (float)n));
+        i = i < 0 ? 0 : (i >= n ? n - 1 : i);
+        j = j < 0 ? 0 : (j >= n ? n - 1 : j);
+    }
+    const uint2 p = *reinterpret_cast<const uint2 *>(s.skybox + 4u * (((size_t)face * n + (size_t)j) * n + (size_t)i));
+    return f3{half_to_float(p.x & 0xFFFFu), half_to_float(p.x >> 16), half_to_float(p.y & 0xFFFFu)};
+}
+
+// F18: textureLod(skybox, d, 0).rgb — rt/reference/main.rgen:251
+PPT_D f3 sample_skybox(const DeviceScene &s, f3 d)
+{
+    if (s.skybox == nullptr) return f3{0.0f, 0.0f, 0.0f};
+    const int32_t n = (int32_t)s.skyboxFaceSize;
+    uint32_t face;
+    float sc, tc, ma;
+    cube_face_coords(d, face, sc, tc, ma);
+    const float ss = 0.5f * (sc / ma) + 0.5f;
+    const float tt = 0.5f * (tc / ma) + 0.5f;
+    const float u = ss * (float)n - 0.5f;
+    const float v = tt * (float)n - 0.5f;
+    const float fu = __builtin_floorf(u);
+    const float fv = __builtin_floorf(v);
+    const float a = u - fu;
+    const float b = v - fv;
+    const int32_t i0 = f2i(fu);
+    const int32_t j0 = f2i(fv);
+    const f3 t00 = fetch_cube_rgb(s, face, i0, j0);
+    const f3 t10 = fetch_cube_rgb(s, face, i0 + 1, j0);
+    const f3 t01 = fetch_cube_rgb(s, face, i0, j0 + 1);
+    const f3 t11 = fetch_cube_rgb(s, face, i0 + 1, j0 + 1);
+    const float w00 = (1.0f - a) * (1.0f - b);
+    const float w10 = a * (1.0f - b);
+    const float w01 = (1.0f - a) * b;
+    const float w11 = a * b;
+    return f3{((w00 * t00.x + w10 * t10.x) + w01 * t01.x) + w11 * t11.x,
+              ((w00 * t00.y + w10 * t10.y) + w01 * t01.y) + w11 * t11.y,
+              ((w00 * t00.z + w10 * t10.z) + w01 * t01.z) + w11 * t11.z};
+}
+
+// ------------------------------------------------------------------------------------------
+// F12 materials — scene/materials.glsl
+// ------------------------------------------------------------------------------------------
+
+struct Material
+{
+    f3 albedo;
+    f3 normal;
+    float roughness;
+    float metallic;
+    float alpha;
+};
+
+// materials.glsl:26-29
+PPT_D float srgb_to_linear(float x) { return x <= 0.04045f ? x / 12.92f : pow_((x + 0.055f) / 1.055f, 2.4f); }
+
+// materials.glsl:47-119
+PPT_D Material sample_material(const DeviceScene &s, uint32_t index, f2 uv)
+{
+    const prosper_MaterialData data = s.materials[index];
+    Material ret;
+    ret.albedo = f3{0.0f, 0.0f, 0.0f};
+    ret.normal = f3{0.0f, 0.0f, 0.0f};
+    ret.roughness = 0.0f;
+    ret.metallic = 0.0f;
+
+    f4 base = f4{1.0f, 1.0f, 1.0f, 1.0f};
+    const uint32_t baseTex = data.baseColorTextureSampler & 0xFFFFFFu;
+    if (baseTex > 0)
+    {
+        const f4 t = sample_texture(s, baseTex, data.baseColorTextureSampler >> 24, uv);
+        base = f4{srgb_to_linear(t.x), srgb_to_linear(t.y), srgb_to_linear(t.z), t.w};
+    }
+    base.x *= data.baseColorFactor.x;
+    base.y *= data.baseColorFactor.y;
+    base.z *= data.baseColorFactor.z;
+    base.w *= data.baseColorFactor.w;
+
+    if (data.alphaMode == PROSPER_ALPHA_MODE_BLEND)
+        ret.alpha = base.w;
+    else
+    {
+        if (data.alphaMode == PROSPER_ALPHA_MODE_MASK && base.w < data.alphaCutoff)
+        {
+            ret.alpha = 0.0f;
+            return ret;
+        }
+        ret.alpha = -1.0f;
+    }
+    ret.albedo = f3{base.x, base.y, base.z};
+
+    const uint32_t mrTex = data.metallicRoughnessTextureSampler & 0xFFFFFFu;
+    if (mrTex > 0)
+    {
+        const f4 mr = sample_texture(s, mrTex, data.metallicRoughnessTextureSampler >> 24, uv);
+        ret.roughness = mr.y * data.roughnessFactor;
+        ret.metallic = mr.z * data.metallicFactor;
+    }
+    else
+    {
+        ret.roughness = data.roughnessFactor;
+        ret.metallic = data.metallicFactor;
+    }
+    ret.roughness = fmax_(ret.roughness, 0.05f);
+
+    const uint32_t nTex = data.normalTextureSampler & 0xFFFFFFu;
+    if (nTex > 0)
+    {
+        const f4 tn = sample_texture(s, nTex, data.normalTextureSampler >> 24, uv);
+        ret.normal = f3{tn.x * 2.0f - 1.0f, tn.y * 2.0f - 1.0f, tn.z * 2.0f - 1.0f};
+    }
+    else
+        ret.normal = f3{-2.0f, -2.0f, -2.0f};
+    return ret;
+}
+
+// materials.glsl:121-147
+PPT_D float sample_alpha(const DeviceScene &s, uint32_t index, f2 uv)
+{
+    const prosper_MaterialData data = s.materials[index];
+    float linearAlpha = 1.0f;
+    const uint32_t baseTex = data.baseColorTextureSampler & 0xFFFFFFu;
+    if (baseTex > 0) linearAlpha = srgb_to_linear(sample_texture(s, baseTex, data.baseColorTextureSampler >> 24, uv).w);
+    linearAlpha *= data.baseColorFactor.w;
+    if (data.alphaMode == PROSPER_ALPHA_MODE_BLEND) return linearAlpha;
+    if (data.alphaMode == PROSPER_ALPHA_MODE_MASK && linearAlpha < data.alphaCutoff) return 0.0f;
+    return -1.0f;
+}
+
+// ------------------------------------------------------------------------------------------
+// F15 BRDF — brdf.glsl
+// ------------------------------------------------------------------------------------------
+
+struct Surface
+{
+    f3 positionWS;
+    f3 normalWS;
+    f3 invViewRayWS;
+    f2 uv;
+    float NoV;
+    Material material;
+};
+
+// brdf.glsl:12-19
+PPT_D float trowbridge_reitz(float NoH, float alpha)
+{
+    const float a2 = alpha * alpha;
+    const float denom = (NoH * NoH) * (a2 - 1.0f) + 1.0f;
+    return a2 / ((kPi * denom) * denom);
+}
+// brdf.glsl:21-24
+PPT_D f3 schlick_fresnel(float VoH, f3 f0)
+{
+    const float p = pow5(1.0f - VoH);
+    return f3{f0.x + (1.0f - f0.x) * p, f0.y + (1.0f - f0.y) * p, f0.z + (1.0f - f0.z) * p};
+}
+// brdf.glsl:35-43
+PPT_D float schlick_trowbridge_reitz(float NoL, float NoV, float alpha)
+{
+    float k = alpha * 0.5f;
+    k = fmax_(k, 0.0001f);
+    const float gl = NoL / (NoL * (1.0f - k) + k);
+    const float gv = NoV / (NoV * (1.0f - k) + k);
+    return gl * gv;
+}
+// brdf.glsl:46-58
+PPT_D f3 cook_torrance_brdf(float NoL, float NoV, float NoH, float VoH, f3 f0, float roughness)
+{
+    const float alpha = roughness * roughness;
+    const float D = trowbridge_reitz(NoH, alpha);
+    const f3 F = schlick_fresnel(VoH, f0);
+    const float G = schlick_trowbridge_reitz(NoL, NoV, alpha);
+    const float denom = (4.0f * NoL) * NoV + 0.0001f;
+    return ((F * D) * G) / denom;
+}
+// brdf.glsl:60-64
+PPT_D f3 fresnel_zero(const Surface &sf)
+{
+    const float m = sf.material.metallic;
+    return f3{mix(0.04f, sf.material.albedo.x, m), mix(0.04f, sf.material.albedo.y, m),
+              mix(0.04f, sf.material.albedo.z, m)};
+}
+// brdf.glsl:9
+PPT_D f3 lambert_brdf(f3 c) { return c / kPi; }
+
+// brdf.glsl:67-87
+PPT_D f3 eval_brdf_times_nol(f3 l, const Surface &sf)
+{
+    const f3 h = normalize(sf.invViewRayWS + l);
+    const float NoL = saturate(dot(sf.normalWS, l));
+    const float NoH = saturate(dot(sf.normalWS, h));
+    const float VoH = saturate(dot(sf.invViewRayWS, h));
+    const f3 f0 = fresnel_zero(sf);
+    const float m = sf.material.metallic;
+    const f3 cdiff = f3{mix(sf.material.albedo.x * 0.96f, 0.0f, m), mix(sf.material.albedo.y * 0.96f, 0.0f, m),
+                        mix(sf.material.albedo.z * 0.96f, 0.0f, m)};
+    return (lambert_brdf(cdiff) + cook_torrance_brdf(NoL, sf.NoV, NoH, VoH, f0, sf.material.roughness)) * NoL;
+}
+
+// ------------------------------------------------------------------------------------------
+// F17 sampling — common/sampling.glsl
+// ------------------------------------------------------------------------------------------
+
+// sampling.glsl:18-33
+PPT_D f3 cosine_sample_hemisphere(f3 n, f2 u)
+{
+    float a = 1.0f - 2.0f * u.x;
+    a *= 0.99999f;
+    float b = sqrt_(1.0f - a * a);
+    b *= 0.99999f;
+    const float phi = kTwoPi * u.y;
+    float sn, cs;
+    sincos_(phi, sn, cs);
+    return normalize(f3{n.x + b * cs, n.y + b * sn, n.z + a});
+}
+
+// sampling.glsl:37-47 (rows b1, b2, n)
+struct Onb
+{
+    f3 b1, b2, n;
+    PPT_D f3 to_local(f3 v) const { return f3{dot(b1, v), dot(b2, v), dot(n, v)}; }
+    PPT_D f3 to_world(f3 v) const
+    {
+        return f3{(b1.x * v.x + b2.x * v.y) + n.x * v.z, (b1.y * v.x + b2.y * v.y) + n.y * v.z,
+                  (b1.z * v.x + b2.z * v.y) + n.z * v.z};
+    }
+};
+PPT_D Onb orthonormal_basis(f3 n)
+{
+    const float s = sign_(n.z);
+    const float a = -1.0f / (s + n.z);
+    const float b = (n.x * n.y) * a;
+    Onb o;
+    o.b1 = f3{1.0f + ((s * n.x) * n.x) * a, s * b, (-s) * n.x};
+    o.b2 = f3{b, s + (n.y * n.y) * a, -n.y};
+    o.n = n;
+    return o;
+}
+
+// sampling.glsl:53-79
+PPT_D f3 sample_visible_trowbridge_reitz(f3 Ve, float alpha, f2 Us)
+{
+    const f3 Vh = normalize(f3{alpha * Ve.x, alpha * Ve.y, Ve.z});
+    const float lensq = Vh.x * Vh.x + Vh.y * Vh.y;
+    f3 T1;
+    if (lensq > 0.0f)
+    {
+        const float inv = 1.0f / sqrt_(lensq);
+        T1 = f3{-Vh.y * inv, Vh.x * inv, 0.0f * inv};
+    }
+    else
+        T1 = f3{1.0f, 0.0f, 0.0f};
+    const f3 T2 = cross(Vh, T1);
+    const float r = sqrt_(Us.x);
+    const float phi = kTwoPi * Us.y;
+    float sn, cs;
+    sincos_(phi, sn, cs);
+    const float t1 = r * cs;
+    float t2 = r * sn;
+    const float s = 0.5f * (1.0f + Vh.z);
+    t2 = (1.0f - s) * sqrt_(1.0f - t1 * t1) + s * t2;
+    const float k = sqrt_(fmax_(0.0f, (1.0f - t1 * t1) - t2 * t2));
+    const f3 Nh = ((T1 * t1) + (T2 * t2)) + (Vh * k);
+    const f3 Ne = normalize(f3{alpha * Nh.x, alpha * Nh.y, fmax_(0.0f, Nh.z)});
+    return reflect(-Ve, Ne);
+}
+
+// sampling.glsl:81-93
+PPT_D float visible_trowbridge_reitz_pdf(f3 Ve, f3 Le, float alpha)
+{
+    const f3 N = f3{0.0f, 0.0f, 1.0f};
+    const f3 Ne = normalize(Ve + Le);
+    const float NoV = saturate(dot(N, Ve));
+    const float NoL = saturate(dot(N, Le));
+    const float NoH = saturate(dot(N, Ne));
+    const float VNDF = ((schlick_trowbridge_reitz(NoL, NoV, alpha) * NoV) * trowbridge_reitz(NoH, alpha)) / Ve.z;
+    return VNDF / (4.0f * NoV);
+}
+
+// ------------------------------------------------------------------------------------------
+// F14 lights — scene/lighting.glsl
+// ------------------------------------------------------------------------------------------
+
+// lighting.glsl:15-37
+PPT_D void eval_point_light(const prosper_PointLight &light, f3 surfacePos, f3 &l, float &d, f3 &irradiance)
+{
+    const f3 pos = f3{light.position.x, light.position.y, light.position.z};
+    const f3 radiance = f3{light.radianceAndRadius.x, light.radianceAndRadius.y, light.radianceAndRadius.z};
+    const float radius = light.radianceAndRadius.w;
+    const f3 toLight = pos - surfacePos;
+    const float d2 = dot(toLight, toLight);
+    d = sqrt_(d2);
+    l = toLight / d;
+    const float dPerR = d / radius;
+    const float dPerR2 = dPerR * dPerR;
+    const float dPerR4 = dPerR2 * dPerR2;
+    const float att = fmax_(fmin_(1.0f - dPerR4, 1.0f), 0.0f);
+    irradiance = (radiance * att) / d2;
+}
+
+// lighting.glsl:39-56
+PPT_D void eval_spot_light(const prosper_SpotLight &light, f3 surfacePos, f3 &l, float &d, f3 &irradiance)
+{
+    const f3 pos = f3{light.positionAndAngleOffset.x, light.positionAndAngleOffset.y, light.positionAndAngleOffset.z};
+    const f3 toLight = pos - surfacePos;
+    const float d2 = dot(toLight, toLight);
+    d = sqrt_(d2);
+    l = toLight / d;
+    const f3 negDir = f3{-light.direction.x, -light.direction.y, -light.direction.z};
+    const float cd = dot(negDir, l);
+    float att = saturate(cd * light.radianceAndAngleScale.w + light.positionAndAngleOffset.w);
+    att *= att;
+    const f3 rad = f3{light.radianceAndAngleScale.x, light.radianceAndAngleScale.y, light.radianceAndAngleScale.z};
+    irradiance = (rad * att) / d2;
+}
+
+// lighting.glsl:58-89; returns true when a spot light was picked
+PPT_D bool sample_light(const DeviceScene &s, f3 surfacePos, uint32_t lightIndex, f3 &l, float &d, f3 &irradiance)
+{
+    if (lightIndex == 0)
+    {
+        const prosper_DirectionalLightParameters sun = *s.directionalLight;
+        l = -normalize(f3{sun.direction.x, sun.direction.y, sun.direction.z});
+        d = 100.0f;
+        irradiance = f3{sun.irradiance.x, sun.irradiance.y, sun.irradiance.z};
+        return false;
+    }
+    lightIndex -= 1;
+    if (lightIndex < s.pointLightCount)
+    {
+        eval_point_light(s.pointLights->lights[lightIndex], surfacePos, l, d, irradiance);
+        return false;
+    }
+    lightIndex -= s.pointLightCount;
+    if (lightIndex < s.spotLightCount)
+    {
+        eval_spot_light(s.spotLights->lights[lightIndex], surfacePos, l, d, irradiance);
+        return true;
+    }
+    l = f3{0.0f, 1.0f, 0.0f};
+    d = 1.0f;
+    irradiance = f3{0.0f, 0.0f, 0.0f};
+    return false;
+}
+
+// ------------------------------------------------------------------------------------------
+// F6/F7 rays — rt/ray.glsl
+// ------------------------------------------------------------------------------------------
+
+struct Ray
+{
+    f3 o, d;
+    float tMin, tMax;
+};
+
+// ray.glsl:15-43
+PPT_D Ray pinhole_camera_ray(const RenderParams &p, f2 uv)
+{
+    const float ndx = uv.x * 2.0f - 1.0f;
+    const float ndy = uv.y * 2.0f - 1.0f;
+    Ray ray;
+    ray.o = f3{p.eye[0], p.eye[1], p.eye[2]};
+    ray.tMin = 0.0f;
+    ray.tMax = kInf;
+    const float aspect = p.c2c11 / p.c2c00;
+    const float tanHalfFovY = 1.0f / p.c2c11;
+    const f3 right = f3{p.right[0], p.right[1], p.right[2]};
+    const f3 up = f3{p.up[0], p.up[1], p.up[2]};
+    const f3 fwd = f3{p.fwd[0], p.fwd[1], p.fwd[2]};
+    const f3 tx = ((right * ndx) * tanHalfFovY) * aspect;
+    const f3 ty = (up * ndy) * tanHalfFovY;
+    ray.d = normalize((tx + ty) + fwd);
+    return ray;
+}
+
+// ray.glsl:46-78
+PPT_D Ray thin_lens_camera_ray(const RenderParams &p, f2 uv, f2 lensOffset)
+{
+    const Ray pin = pinhole_camera_ray(p, uv);
+    const float theta = (lensOffset.x * 2.0f) * kPi;
+    const float radius = lensOffset.y;
+    float sn, cs;
+    sincos_(theta, sn, cs);
+    const float u = cs * sqrt_(radius);
+    const float v = sn * sqrt_(radius);
+    const f3 fwd = f3{p.fwd[0], p.fwd[1], p.fwd[2]};
+    const float k = p.pc.focusDistance / dot(pin.d, fwd);
+    const f3 focusPoint = pin.o + pin.d * k;
+    const float fStop = p.pc.focalLength / p.pc.apertureDiameter;
+    const float coc = p.pc.focalLength / (2.0f * fStop);
+    const f3 lensPos = (f3{1.0f, 0.0f, 0.0f} * (u * coc)) + (f3{0.0f, 1.0f, 0.0f} * (v * coc));
+    const float *m = p.cameraToWorld; // column-major
+    Ray ray;
+    ray.o = f3{((m[0] * lensPos.x + m[4] * lensPos.y) + m[8] * lensPos.z) + m[12],
+               ((m[1] * lensPos.x + m[5] * lensPos.y) + m[9] * lensPos.z) + m[13],
+               ((m[2] * lensPos.x + m[6] * lensPos.y) + m[10] * lensPos.z) + m[14]};
+    ray.d = normalize(focusPoint - ray.o);
+    ray.tMin = 0.0f;
+    ray.tMax = kInf;
+    return ray;
+}
+
+// ray.glsl:83-103
+PPT_D float offset_component(float p, float n)
+{
+    const int32_t ofI = f2i(256.0f * n);
+    const uint32_t moved = f2u(p) + (uint32_t)((p < 0.0f) ? -ofI : ofI);
+    return fabs_(p) < (1.0f / 32.0f) ? p + (1.0f / 65536.0f) * n : u2f(moved);
+}
+PPT_D f3 offset_ray(f3 p, f3 n)
+{
+    return f3{offset_component(p.x, n.x), offset_component(p.y, n.y), offset_component(p.z, n.z)};
+}
+
+// ------------------------------------------------------------------------------------------
+// F2-F5 traversal.  prosper leaves this to the Vulkan driver (World.cpp:740,798;
+// main.rgen:57,73); the hit contract of this build is in DESIGN.md: world-space triangles from
+// the decoded fp16 positions, scalar-triple-product edge functions (watertight on shared edges),
+// no culling, tMin < t < tMax, closest = smallest t with ties to the smaller (instance,
+// primitive), any-hit (rt/scene.rahit:18-39) on non-opaque geometry.
+// ------------------------------------------------------------------------------------------
+
+PPT_D bool intersect_triangle(f3 o, f3 d, f3 v0, f3 v1, f3 v2, float tMin, float tMax, float &t, float &bu, float &bv)
+{
+    const f3 A = v0 - o;
+    const f3 B = v1 - o;
+    const f3 C = v2 - o;
+    const float U = dot(d, cross(C, B));
+    const float V = dot(d, cross(A, C));
+    const float W = dot(d, cross(B, A));
+    if ((U < 0.0f || V < 0.0f || W < 0.0f) && (U > 0.0f || V > 0.0f || W > 0.0f)) return false;
+    const float det = (U + V) + W;
+    if (!(det != 0.0f)) return false;
+    const f3 N = cross(v1 - v0, v2 - v0);
+    const float tt = dot(A, N) / dot(d, N);
+    if (!(tt > tMin && tt < tMax)) return false;
+    t = tt;
+    bu = V / det;
+    bv = W / det;
+    return true;
+}
+
+struct Hit
+{
+    uint32_t drawInstance;
+    uint32_t primitive;
+    f2 bary;
+    float t;
+};
+
+// rt/scene.rahit:18-39; true = accept the candidate
+template <bool COUNT>
+PPT_D bool any_hit(
+    const DeviceScene &s, uint32_t drawInstance, uint32_t primitive, f2 bary, uint32_t randomSeed, LaneCounters &cnt)
+{
+    const prosper_DrawInstance inst = s.drawInstances[drawInstance];
+    const prosper_GeometryMetadata m = s.geometryMetadatas[inst.meshIndex];
+    // geometry.glsl:246-256
+    const f2 uv0 = load_r16g16(s, m.bufferIndex, m.texCoord0sOffset, load_index(s, m, primitive * 3 + 0));
+    const f2 uv1 = load_r16g16(s, m.bufferIndex, m.texCoord0sOffset, load_index(s, m, primitive * 3 + 1));
+    const f2 uv2 = load_r16g16(s, m.bufferIndex, m.texCoord0sOffset, load_index(s, m, primitive * 3 + 2));
+    const float a = (1.0f - bary.x) - bary.y;
+    const f2 uv = f2{bary1(uv0.x, uv1.x, uv2.x, a, bary.x, bary.y), bary1(uv0.y, uv1.y, uv2.y, a, bary.x, bary.y)};
+    if constexpr (COUNT)
+    {
+        cnt.anyHitCalls++;
+        cnt.shortIndexHits += m.usesShortIndices == 1 ? 1u : 0u;
+    }
+    const float alpha = sample_alpha(s, inst.materialIndex, uv);
+    if (alpha == 0.0f) return false;
+    if (alpha > 0.0f)
+    {
+        const float u = (float)pcg(randomSeed) / 4294967296.0f;
+        if (u > alpha) return false;
+    }
+    return true;
+}
+
+PPT_D float safe_rcp_dir(float d)
+{
+    return 1.0f / (fabs_(d) < 1e-30f ? (d < 0.0f ? -1e-30f : 1e-30f) : d);
+}
+
+// Conservative slab test of one child box; returns entry distance or +inf on a miss.  The boxes
+// are padded by the builder so a triangle the edge-function test accepts is never culled.
+PPT_D float box_entry(const float lo[3], const float hi[3], f3 o, f3 invd, float tMin, float tMax)
+{
+    float t0 = (lo[0] - o.x) * invd.x, t1 = (hi[0] - o.x) * invd.x;
+    float tn = fminf(t0, t1), tf = fmaxf(t0, t1);
+    t0 = (lo[1] - o.y) * invd.y;
+    t1 = (hi[1] - o.y) * invd.y;
+    tn = fmaxf(tn, fminf(t0, t1));
+    tf = fminf(tf, fmaxf(t0, t1));
+    t0 = (lo[2] - o.z) * invd.z;
+    t1 = (hi[2] - o.z) * invd.z;
+    tn = fmaxf(tn, fminf(t0, t1));
+    tf = fminf(tf, fmaxf(t0, t1));
+    const bool hit = tn <= tf * 1.0000004f && tf >= tMin && tn <= tMax;
+    return hit ? tn : kInf;
+}
+
+// Shared driver of traceClosest (ANY = false, main.rgen:62-81) and shadow (ANY = true,
+// main.rgen:49-60).  `stack` points at this lane's column of the workgroup's LDS stack
+// (entry e lives at stack[e * 64]).  Returns true on a hit (ANY: occluded).
+template <bool ANY, bool COUNT>
+PPT_D bool trace(
+    const DeviceScene &s, f3 o, f3 d, float tMin, float tMaxIn, uint32_t seed, int32_t *stack, Hit &hit,
+    LaneCounters &cnt)
+{
+    hit.drawInstance = kMissIndex;
+    hit.primitive = kMissIndex;
+    hit.bary = f2{0.0f, 0.0f};
+    hit.t = tMaxIn;
+    const f3 invd = f3{safe_rcp_dir(d.x), safe_rcp_dir(d.y), safe_rcp_dir(d.z)};
+
+    int32_t sp = 0;
+    int32_t node = 0; // root is always an inner node
+    while (true)
+    {
+        if (node >= 0)
+        {
+            const BvhNode n = s.nodes[node];
+            if constexpr (COUNT) cnt.nodeVisits++;
+            const float e0 = box_entry(n.lo0, n.hi0, o, invd, tMin, hit.t);
+            const float e1 = box_entry(n.lo1, n.hi1, o, invd, tMin, hit.t);
+            const bool h0 = e0 < kInf;
+            const bool h1 = e1 < kInf;
+            if (h0 && h1)
+            {
+                const bool firstIs0 = e0 <= e1;
+                stack[sp * 64] = firstIs0 ? n.child1 : n.child0;
+                ++sp;
+                node = firstIs0 ? n.child0 : n.child1;
+                continue;
+            }
+            if (h0 || h1)
+            {
+                node = h0 ? n.child0 : n.child1;
+                continue;
+            }
+        }
+        else
+        {
+            const uint32_t ref = (uint32_t)~node;
+            const uint32_t first = ref >> 3;
+            const uint32_t count = (ref & 7u) + 1u;
+            for (uint32_t i = 0; i < count; ++i)
+            {
+                const float4 *tp = reinterpret_cast<const float4 *>(s.triangles + first + i);
+                const float4 a = tp[0], b = tp[1], c = tp[2];
+                if constexpr (COUNT) cnt.triangleTests++;
+                float t, bu, bv;
+                if (!intersect_triangle(
+                        o, d, f3{a.x, a.y, a.z}, f3{b.x, b.y, b.z}, f3{c.x, c.y, c.z}, tMin, tMaxIn, t, bu, bv))
+                    continue;
+                const uint32_t di = __builtin_bit_cast(uint32_t, a.w);
+                const uint32_t prim = __builtin_bit_cast(uint32_t, b.w);
+                const uint32_t flags = __builtin_bit_cast(uint32_t, c.w);
+                if (!ANY && hit.drawInstance != kMissIndex)
+                {
+                    if (t > hit.t) continue;
+                    if (t == hit.t && !(di < hit.drawInstance || (di == hit.drawInstance && prim < hit.primitive)))
+                        continue;
+                }
+                if (!(flags & kTriFlagOpaque) && !any_hit<COUNT>(s, di, prim, f2{bu, bv}, seed, cnt)) continue;
+                hit.drawInstance = di;
+                hit.primitive = prim;
+                hit.bary = f2{bu, bv};
+                hit.t = t;
+                if (ANY) return true;
+            }
+        }
+        if (sp == 0) break;
+        --sp;
+        node = stack[sp * 64];
+    }
+    return hit.drawInstance != kMissIndex;
+}
+
+// ------------------------------------------------------------------------------------------
+// F9 hit -> shading frame — rt/reference/main.rgen:146-179, :37-45
+// ------------------------------------------------------------------------------------------
+
+PPT_D f3 mapped_normal(f3 tsn, f3 normal, f3 tangent, float sgn)
+{
+    const f3 vB = cross(normal, tangent) * sgn;
+    return normalize(((tangent * tsn.x) + (vB * tsn.y)) + (normal * tsn.z));
+}
+
+template <bool COUNT>
+PPT_D Surface evaluate_surface(const DeviceScene &s, f3 rayDir, const Hit &hit, LaneCounters &cnt)
+{
+    const prosper_DrawInstance inst = s.drawInstances[hit.drawInstance];
+    const prosper_GeometryMetadata m = s.geometryMetadatas[inst.meshIndex];
+    const Vertex v0 = load_vertex_through_index_buffer(s, m, hit.primitive * 3 + 0);
+    const Vertex v1 = load_vertex_through_index_buffer(s, m, hit.primitive * 3 + 1);
+    const Vertex v2 = load_vertex_through_index_buffer(s, m, hit.primitive * 3 + 2);
+    const Vertex vi = interpolate(v0, v1, v2, hit.bary);
+    const Vertex v = transform(vi, s.modelInstanceTransforms[inst.modelInstanceIndex]);
+    if constexpr (COUNT)
+    {
+        cnt.closestHits++;
+        cnt.shortIndexHits += m.usesShortIndices == 1 ? 1u : 0u;
+    }
+    Surface sf;
+    sf.positionWS = v.position;
+    sf.invViewRayWS = -rayDir;
+    sf.uv = v.uv;
+    sf.material = sample_material(s, inst.materialIndex, v.uv);
+    if (sf.material.normal.x != -2.0f && v.tangent.w != 0.0f)
+        sf.normalWS = mapped_normal(sf.material.normal, v.normal, f3{v.tangent.x, v.tangent.y, v.tangent.z}, v.tangent.w);
+    else
+        sf.normalWS = normalize(v.normal);
+    sf.NoV = saturate(dot(sf.normalWS, sf.invViewRayWS));
+    return sf;
+}
+
+// main.rgen:181-193 + debug.glsl:17-38
+PPT_D f3 debug_color(const DeviceScene &s, uint32_t drawType, const Hit &hit, const Surface &sf)
+{
+    const prosper_DrawInstance inst = s.drawInstances[hit.drawInstance];
+    switch (drawType)
+    {
+    case PROSPER_DRAW_TYPE_PRIMITIVE_ID: return uint_to_color(hit.primitive);
+    case PROSPER_DRAW_TYPE_MESH_ID: return uint_to_color(inst.meshIndex);
+    case PROSPER_DRAW_TYPE_MATERIAL_ID: return uint_to_color(inst.materialIndex);
+    case PROSPER_DRAW_TYPE_POSITION: return sf.positionWS;
+    case PROSPER_DRAW_TYPE_TEXCOORD0: return f3{sf.uv.x, sf.uv.y, 0.0f};
+    case PROSPER_DRAW_TYPE_ALBEDO: return sf.material.albedo;
+    case PROSPER_DRAW_TYPE_SHADING_NORMAL:
+        return f3{sf.normalWS.x * 0.5f + 0.5f, sf.normalWS.y * 0.5f + 0.5f, sf.normalWS.z * 0.5f + 0.5f};
+    case PROSPER_DRAW_TYPE_ROUGHNESS: return f3{sf.material.roughness, sf.material.roughness, sf.material.roughness};
+    case PROSPER_DRAW_TYPE_METALLIC: return f3{sf.material.metallic, sf.material.metallic, sf.material.metallic};
+    default: return f3{1.0f, 0.0f, 1.0f};
+    }
+}
+
+// main.rgen:83-88
+PPT_D void add_bounce(uint32_t flags, f3 &acc, f3 color, uint32_t bounce)
+{
+    if (bounce > 0 && (flags & PROSPER_PC_FLAG_CLAMP_INDIRECT))
+        color = f3{clamp_(color.x, 0.0f, 2.0f), clamp_(color.y, 0.0f, 2.0f), clamp_(color.z, 0.0f, 2.0f)};
+    acc = acc + color;
+}
+
+// main.rgen:90-144
+PPT_D void importance_sample_bounce(const Surface &sf, Rng &rng, f3 &throughput, f3 &rd)
+{
+    const bool specularOnly = sf.material.metallic > 0.999f;
+    const float specularWeight = specularOnly ? 1.0f : 0.5f;
+    const float diffuseWeight = 1.0f - specularWeight;
+    const Onb basis = orthonormal_basis(sf.normalWS);
+    const f3 vInBasis = basis.to_local(sf.invViewRayWS);
+    const float alpha = sf.material.roughness * sf.material.roughness;
+    const bool pickDiffuse = rng.rnd01() < diffuseWeight;
+    const f2 u = rng.rnd2d01();
+    f3 brdf;
+    float NoL;
+    float pdf;
+    if (pickDiffuse)
+    {
+        rd = cosine_sample_hemisphere(sf.normalWS, u);
+        NoL = saturate(dot(sf.normalWS, rd));
+        brdf = lambert_brdf(sf.material.albedo);
+        pdf = NoL / kPi; // sampling.glsl:35
+        pdf *= diffuseWeight;
+    }
+    else
+    {
+        rd = sample_visible_trowbridge_reitz(vInBasis, alpha, u);
+        rd = basis.to_world(rd);
+        NoL = saturate(dot(sf.normalWS, rd));
+        const f3 h = normalize(sf.invViewRayWS + rd);
+        const float NoH = saturate(dot(sf.normalWS, h));
+        const float VoH = saturate(dot(sf.invViewRayWS, h));
+        brdf = cook_torrance_brdf(NoL, sf.NoV, NoH, VoH, fresnel_zero(sf), sf.material.roughness);
+        pdf = visible_trowbridge_reitz_pdf(vInBasis, basis.to_local(rd), alpha);
+        pdf *= specularWeight;
+    }
+    const f3 w = (brdf * NoL) / pdf;
+    throughput = f3{throughput.x * fmax_(w.x, 0.0f), throughput.y * fmax_(w.y, 0.0f), throughput.z * fmax_(w.z, 0.0f)};
+}
+
+// First half of evaluateDirectLighting (main.rgen:195-214): pick a light, evaluate it.  Returns
+// true when a shadow ray towards `l` of length `d` must be traced; `contribution` is then
+// throughput * irradiance * lightCount * BRDF (everything but the visibility term).
+template <bool COUNT>
+PPT_D bool prepare_direct_lighting(
+    const DeviceScene &s, const Surface &sf, f3 throughput, Rng &rng, f3 &l, float &d, f3 &irradiance,
+    LaneCounters &cnt)
+{
+    if (sf.material.alpha == 0.0f) return false;
+    const uint32_t lightCount = 1u + s.pointLightCount + s.spotLightCount;
+    uint32_t lightIndex = f2uint(rng.rnd01() * (float)lightCount);
+    if (lightIndex > lightCount - 1u) lightIndex = lightCount - 1u;
+    const bool spot = sample_light(s, sf.positionWS, lightIndex, l, d, irradiance);
+    if constexpr (COUNT)
+    {
+        if (spot)
+            cnt.spotLightSamples++;
+        else
+            cnt.lightSamples++;
+    }
+    (void)spot;
+    (void)throughput;
+    return dot(l, sf.normalWS) > 0.0f;
+}
+
+// Second half (main.rgen:216-222): apply visibility, the uniform-pick weight and the BRDF.
+PPT_D f3 finish_direct_lighting(const DeviceScene &s, const Surface &sf, f3 throughput, f3 l, f3 irradiance, float visibility)
+{
+    const uint32_t lightCount = 1u + s.pointLightCount + s.spotLightCount;
+    irradiance = irradiance * visibility;
+    irradiance = irradiance * (float)lightCount;
+    return (throughput * irradiance) * eval_brdf_times_nol(l, sf);
+}
+
+} // namespace ppt

@@ -1,0 +1,417 @@
+// pt_kernels.hip — gfx950 kernels of the path-tracing reference pass.
+//
+//   flatten_triangles   upload: bindless fp16 geometry x instance transforms -> world triangles
+//   permute_triangles   upload: reorder world triangles into BVH leaf order
+//   render_megakernel   one lane per pixel runs whole paths (rt/reference/main.rgen:225-299)
+//   blit_rgba16f        RGBA32F -> RGBA16F (src/render/RtReference.cpp:339-377)
+//   eval_fn             device self-test entry (prosper_pt_eval_device_fn)
+#include "pt_kernels.hpp"
+
+#include "pt_device.hpp"
+
+namespace ppt
+{
+
+// ------------------------------------------------------------------------------------------
+// upload kernels
+// ------------------------------------------------------------------------------------------
+
+__global__ void flatten_triangles_kernel(
+    DeviceScene s, const uint32_t *__restrict__ triOffsets, uint32_t drawInstanceCount,
+    const uint32_t *__restrict__ drawInstanceFlags, WorldTriangle *__restrict__ out, uint32_t total)
+{
+    const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= total) return;
+    // find the draw instance whose triangle range holds g
+    uint32_t lo = 0, hi = drawInstanceCount;
+    while (hi - lo > 1)
+    {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (triOffsets[mid] <= g)
+            lo = mid;
+        else
+            hi = mid;
+    }
+    const uint32_t di = lo;
+    const uint32_t prim = g - triOffsets[di];
+    const prosper_DrawInstance inst = s.drawInstances[di];
+    const prosper_GeometryMetadata m = s.geometryMetadatas[inst.meshIndex];
+    const prosper_mat3x4 modelToWorld = s.modelInstanceTransforms[inst.modelInstanceIndex].modelToWorld;
+    const uint32_t i0 = load_index(s, m, prim * 3 + 0);
+    const uint32_t i1 = load_index(s, m, prim * 3 + 1);
+    const uint32_t i2 = load_index(s, m, prim * 3 + 2);
+    const f3 v0 = mul_point_mat3x4(load_r16g16b16a16(s, m.bufferIndex, m.positionsOffset, i0), modelToWorld);
+    const f3 v1 = mul_point_mat3x4(load_r16g16b16a16(s, m.bufferIndex, m.positionsOffset, i1), modelToWorld);
+    const f3 v2 = mul_point_mat3x4(load_r16g16b16a16(s, m.bufferIndex, m.positionsOffset, i2), modelToWorld);
+    WorldTriangle t;
+    t.v0[0] = v0.x; t.v0[1] = v0.y; t.v0[2] = v0.z;
+    t.v1[0] = v1.x; t.v1[1] = v1.y; t.v1[2] = v1.z;
+    t.v2[0] = v2.x; t.v2[1] = v2.y; t.v2[2] = v2.z;
+    t.drawInstance = di;
+    t.primitive = prim;
+    t.flags = drawInstanceFlags[di];
+    out[g] = t;
+}
+
+__global__ void permute_triangles_kernel(
+    const WorldTriangle *__restrict__ in, const uint32_t *__restrict__ permutation, WorldTriangle *__restrict__ out,
+    uint32_t total)
+{
+    const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= total) return;
+    const float4 *src = reinterpret_cast<const float4 *>(in + permutation[g]);
+    float4 *dst = reinterpret_cast<float4 *>(out + g);
+    dst[0] = src[0];
+    dst[1] = src[1];
+    dst[2] = src[2];
+}
+
+void launch_flatten_triangles(
+    const DeviceScene &s, const uint32_t *triOffsets, uint32_t drawInstanceCount, const uint32_t *drawInstanceFlags,
+    WorldTriangle *out, uint32_t total, hipStream_t stream)
+{
+    if (total == 0) return;
+    hipLaunchKernelGGL(
+        flatten_triangles_kernel, dim3((total + 255) / 256), dim3(256), 0, stream, s, triOffsets, drawInstanceCount,
+        drawInstanceFlags, out, total);
+}
+
+void launch_permute_triangles(
+    const WorldTriangle *in, const uint32_t *permutation, WorldTriangle *out, uint32_t total, hipStream_t stream)
+{
+    if (total == 0) return;
+    hipLaunchKernelGGL(
+        permute_triangles_kernel, dim3((total + 255) / 256), dim3(256), 0, stream, in, permutation, out, total);
+}
+
+// ------------------------------------------------------------------------------------------
+// path tracing
+// ------------------------------------------------------------------------------------------
+
+// One path: rt/reference/main.rgen:225-283.
+template <bool COUNT>
+__device__ f3 trace_path(
+    const DeviceScene &s, const RenderParams &p, uint32_t px, uint32_t py, uint32_t frameIndex, int32_t *stack,
+    LaneCounters &cnt)
+{
+    Rng rng{px, py, frameIndex};
+    const f2 j = rng.rnd2d01();
+    const f2 uv = f2{((float)px + j.x) / (float)p.width, ((float)py + j.y) / (float)p.height};
+
+    f3 color = f3{0.0f, 0.0f, 0.0f};
+    f3 throughput = f3{1.0f, 1.0f, 1.0f};
+    uint32_t bounce = 0;
+    Ray ray;
+    if (p.pc.flags & PROSPER_PC_FLAG_DEPTH_OF_FIELD)
+    {
+        const f2 lens = rng.rnd2d01();
+        ray = thin_lens_camera_ray(p, uv, lens);
+    }
+    else
+        ray = pinhole_camera_ray(p, uv);
+    if constexpr (COUNT) cnt.paths++;
+
+    while (bounce < PROSPER_RT_MAX_BOUNCES)
+    {
+        if (bounce >= p.pc.maxBounces) break;
+        // traceClosest: main.rgen:62-81
+        Hit hit;
+        if constexpr (COUNT) cnt.closestRays++;
+        const bool found = trace<false, COUNT>(s, ray.o, ray.d, ray.tMin, ray.tMax, pcg(rng.x ^ rng.z), stack, hit, cnt);
+        if (!found)
+        {
+            if (p.pc.flags & PROSPER_PC_FLAG_IBL)
+            {
+                if constexpr (COUNT) cnt.skyLookups++;
+                add_bounce(p.pc.flags, color, throughput * sample_skybox(s, ray.d), bounce);
+            }
+            break;
+        }
+        const Surface sf = evaluate_surface<COUNT>(s, ray.d, hit, cnt);
+        if (p.pc.drawType != PROSPER_DRAW_TYPE_DEFAULT && p.pc.drawType != PROSPER_DRAW_TYPE_MESHLET_ID)
+        {
+            color = debug_color(s, p.pc.drawType, hit, sf);
+            break;
+        }
+        // evaluateDirectLighting: main.rgen:195-223
+        {
+            f3 l, irradiance;
+            float d;
+            f3 direct = f3{0.0f, 0.0f, 0.0f};
+            if (prepare_direct_lighting<COUNT>(s, sf, throughput, rng, l, d, irradiance, cnt))
+            {
+                // shadow(): main.rgen:49-60
+                Hit sh;
+                if constexpr (COUNT) cnt.shadowRays++;
+                const bool occluded = trace<true, COUNT>(s, sf.positionWS, l, 0.1f, d, pcg(rng.x ^ rng.y), stack, sh, cnt);
+                direct = finish_direct_lighting(s, sf, throughput, l, irradiance, occluded ? 0.0f : 1.0f);
+            }
+            add_bounce(p.pc.flags, color, direct, bounce);
+        }
+        f3 rd;
+        importance_sample_bounce(sf, rng, throughput, rd);
+        if (bounce > p.pc.rouletteStartBounce)
+        {
+            if (rng.rnd01() < fmax_(0.05f, 1.0f - max3(throughput))) break;
+        }
+        ray.o = offset_ray(sf.positionWS, sf.normalWS);
+        ray.d = rd;
+        ray.tMin = 0.0f;
+        ray.tMax = kInf;
+        bounce++;
+    }
+    return color;
+}
+
+__device__ __forceinline__ uint32_t wave_sum(uint32_t v)
+{
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+template <bool COUNT>
+__device__ void flush_counters(const LaneCounters &c, unsigned long long *counters)
+{
+    if constexpr (COUNT)
+    {
+        // order = prosper_pt_counters fields
+        const uint32_t vals[13] = {c.paths, c.closestRays, c.shadowRays, c.nodeVisits, c.triangleTests, c.closestHits,
+                                   c.anyHitCalls, c.lightSamples, c.spotLightSamples, c.skyLookups, c.pixelsWritten,
+                                   c.historyReads, c.shortIndexHits};
+        for (int i = 0; i < 13; ++i)
+        {
+            const uint32_t sum = wave_sum(vals[i]);
+            if ((threadIdx.x & 63) == 0 && sum) atomicAdd(&counters[i], (unsigned long long)sum);
+        }
+    }
+}
+
+// Local pixel column -> absolute image column for the stripe partition (prosper_pt_tile_desc).
+__device__ __forceinline__ uint32_t local_to_global_x(const RenderParams &p, uint32_t lx)
+{
+    if (p.stripeWidth == 0) return lx;
+    const uint32_t ls = lx / p.stripeWidth;
+    return (ls * p.stripeCount + p.stripeIndex) * p.stripeWidth + (lx % p.stripeWidth);
+}
+
+// One lane per pixel; a wave covers an 8x8 pixel tile, a 256-thread workgroup a 16x16 tile.
+// Workgroups are dealt round-robin over the 8 XCDs (b and b+8 share an XCD's L2), so the block id
+// is remapped to give each XCD a contiguous band of tiles (speed only, never correctness).
+template <bool COUNT>
+__global__ __launch_bounds__(256) void render_megakernel(
+    DeviceScene s, RenderParams p, float4 *__restrict__ hdr, unsigned long long *__restrict__ counters)
+{
+    __shared__ int32_t ldsStack[kTraversalStackDepth * 256];
+
+    const uint32_t tilesX = (p.localWidth + 15u) / 16u;
+    const uint32_t tilesY = (p.height + 15u) / 16u;
+    const uint32_t numTiles = tilesX * tilesY;
+    const uint32_t perXcd = (numTiles + 7u) / 8u;
+    const uint32_t tile = (blockIdx.x % 8u) * perXcd + (blockIdx.x / 8u);
+    if (tile >= numTiles) return;
+
+    const uint32_t wave = threadIdx.x >> 6;
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t lx = (tile % tilesX) * 16u + (wave & 1u) * 8u + (lane & 7u);
+    const uint32_t py = (tile / tilesX) * 16u + (wave >> 1) * 8u + (lane >> 3);
+    int32_t *stack = ldsStack + wave * (kTraversalStackDepth * 64u) + lane;
+
+    LaneCounters cnt = {};
+    if (lx < p.localWidth && py < p.height)
+    {
+        const uint32_t px = local_to_global_x(p, lx);
+        float4 *texel = hdr + (size_t)py * p.localWidth + lx;
+        float4 history = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        for (uint32_t f = 0; f < p.frameCount; ++f)
+        {
+            const uint32_t frameIndex = (p.pc.frameIndex + f) % PROSPER_RT_FRAME_PERIOD;
+            const f3 color = trace_path<COUNT>(s, p, px, py, frameIndex, stack, cnt);
+            // main.rgen:285-298; skipHistory only applies to the first frame of a batch.  Frames
+            // after the first find their history in registers (an fp32 store + load is lossless).
+            const bool skip = (f == 0 && (p.pc.flags & PROSPER_PC_FLAG_SKIP_HISTORY)) ||
+                              !(p.pc.flags & PROSPER_PC_FLAG_ACCUMULATE);
+            if (skip)
+                history = make_float4(color.x, color.y, color.z, 1.0f);
+            else
+            {
+                if (f == 0) history = *texel;
+                if constexpr (COUNT) cnt.historyReads++;
+                const float hc = history.w + 1.0f;
+                history = make_float4(
+                    history.x + (color.x - history.x) / hc, history.y + (color.y - history.y) / hc,
+                    history.z + (color.z - history.z) / hc, hc);
+            }
+            if constexpr (COUNT) cnt.pixelsWritten++;
+        }
+        *texel = history;
+    }
+    flush_counters<COUNT>(cnt, counters);
+}
+
+void launch_render_megakernel(
+    const DeviceScene &s, const RenderParams &p, float4 *hdr, unsigned long long *counters, bool countWork,
+    hipStream_t stream)
+{
+    const uint32_t tilesX = (p.localWidth + 15u) / 16u;
+    const uint32_t tilesY = (p.height + 15u) / 16u;
+    const uint32_t numTiles = tilesX * tilesY;
+    if (numTiles == 0) return;
+    const uint32_t perXcd = (numTiles + 7u) / 8u;
+    const dim3 grid(perXcd * 8u), block(256);
+    if (countWork)
+        hipLaunchKernelGGL(render_megakernel<true>, grid, block, 0, stream, s, p, hdr, counters);
+    else
+        hipLaunchKernelGGL(render_megakernel<false>, grid, block, 0, stream, s, p, hdr, counters);
+}
+
+// ------------------------------------------------------------------------------------------
+// RGBA32F -> RGBA16F
+// ------------------------------------------------------------------------------------------
+
+__global__ void blit_rgba16f_kernel(const float4 *__restrict__ in, uint2 *__restrict__ out, uint32_t count)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    const float4 v = in[i];
+    out[i] = make_uint2(float_to_half(v.x) | (float_to_half(v.y) << 16), float_to_half(v.z) | (float_to_half(v.w) << 16));
+}
+
+void launch_blit_rgba16f(const float4 *in, void *out, uint32_t count, hipStream_t stream)
+{
+    if (count == 0) return;
+    hipLaunchKernelGGL(
+        blit_rgba16f_kernel, dim3((count + 255) / 256), dim3(256), 0, stream, in, static_cast<uint2 *>(out), count);
+}
+
+// ------------------------------------------------------------------------------------------
+// device self-test
+// ------------------------------------------------------------------------------------------
+
+__global__ void eval_fn_kernel(
+    uint32_t fn, const float *__restrict__ in, uint32_t inStride, float *__restrict__ out, uint32_t outStride, uint32_t n)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float *a = in + (size_t)i * inStride;
+    float *o = out + (size_t)i * outStride;
+    switch (fn)
+    {
+    case PROSPER_PT_FN_SINCOS: sincos_(a[0], o[0], o[1]); break;
+    case PROSPER_PT_FN_POW: o[0] = pow_(a[0], a[1]); break;
+    case PROSPER_PT_FN_SRGB_TO_LINEAR: o[0] = srgb_to_linear(a[0]); break;
+    case PROSPER_PT_FN_NORMALIZE:
+    {
+        const f3 r = normalize(f3{a[0], a[1], a[2]});
+        o[0] = r.x; o[1] = r.y; o[2] = r.z;
+        break;
+    }
+    case PROSPER_PT_FN_UNPACK_SNORM:
+    {
+        const uint32_t bits = f2u(a[0]);
+        const f3 r = unpack_snorm_r10g10b10(bits);
+        o[0] = r.x; o[1] = r.y; o[2] = r.z;
+        o[3] = (float)((int32_t)bits >> 30);
+        break;
+    }
+    case PROSPER_PT_FN_ONB:
+    {
+        const Onb b = orthonormal_basis(f3{a[0], a[1], a[2]});
+        o[0] = b.b1.x; o[1] = b.b1.y; o[2] = b.b1.z;
+        o[3] = b.b2.x; o[4] = b.b2.y; o[5] = b.b2.z;
+        o[6] = b.n.x; o[7] = b.n.y; o[8] = b.n.z;
+        break;
+    }
+    case PROSPER_PT_FN_COSINE_SAMPLE:
+    {
+        const f3 r = cosine_sample_hemisphere(f3{a[0], a[1], a[2]}, f2{a[3], a[4]});
+        o[0] = r.x; o[1] = r.y; o[2] = r.z;
+        break;
+    }
+    case PROSPER_PT_FN_VNDF_SAMPLE:
+    {
+        const f3 r = sample_visible_trowbridge_reitz(f3{a[0], a[1], a[2]}, a[3], f2{a[4], a[5]});
+        o[0] = r.x; o[1] = r.y; o[2] = r.z;
+        break;
+    }
+    case PROSPER_PT_FN_VNDF_PDF:
+        o[0] = visible_trowbridge_reitz_pdf(f3{a[0], a[1], a[2]}, f3{a[3], a[4], a[5]}, a[6]);
+        break;
+    case PROSPER_PT_FN_EVAL_BRDF:
+    {
+        Surface sf = {};
+        sf.normalWS = f3{a[3], a[4], a[5]};
+        sf.invViewRayWS = f3{a[6], a[7], a[8]};
+        sf.material.albedo = f3{a[9], a[10], a[11]};
+        sf.material.roughness = a[12];
+        sf.material.metallic = a[13];
+        sf.NoV = saturate(dot(sf.normalWS, sf.invViewRayWS));
+        const f3 r = eval_brdf_times_nol(f3{a[0], a[1], a[2]}, sf);
+        o[0] = r.x; o[1] = r.y; o[2] = r.z;
+        break;
+    }
+    case PROSPER_PT_FN_OFFSET_RAY:
+    {
+        const f3 r = offset_ray(f3{a[0], a[1], a[2]}, f3{a[3], a[4], a[5]});
+        o[0] = r.x; o[1] = r.y; o[2] = r.z;
+        break;
+    }
+    case PROSPER_PT_FN_POINT_LIGHT:
+    {
+        prosper_PointLight L;
+        L.position = prosper_vec4{a[0], a[1], a[2], 0.0f};
+        L.radianceAndRadius = prosper_vec4{a[3], a[4], a[5], a[6]};
+        f3 l, irr;
+        float d;
+        eval_point_light(L, f3{a[7], a[8], a[9]}, l, d, irr);
+        o[0] = l.x; o[1] = l.y; o[2] = l.z; o[3] = d; o[4] = irr.x; o[5] = irr.y; o[6] = irr.z;
+        break;
+    }
+    case PROSPER_PT_FN_SPOT_LIGHT:
+    {
+        prosper_SpotLight L;
+        L.positionAndAngleOffset = prosper_vec4{a[0], a[1], a[2], a[3]};
+        L.radianceAndAngleScale = prosper_vec4{a[4], a[5], a[6], a[7]};
+        L.direction = prosper_vec4{a[8], a[9], a[10], 0.0f};
+        f3 l, irr;
+        float d;
+        eval_spot_light(L, f3{a[11], a[12], a[13]}, l, d, irr);
+        o[0] = l.x; o[1] = l.y; o[2] = l.z; o[3] = d; o[4] = irr.x; o[5] = irr.y; o[6] = irr.z;
+        break;
+    }
+    case PROSPER_PT_FN_TRIANGLE:
+    {
+        float t = 0.0f, bu = 0.0f, bv = 0.0f;
+        const bool hit = intersect_triangle(
+            f3{a[0], a[1], a[2]}, f3{a[3], a[4], a[5]}, f3{a[6], a[7], a[8]}, f3{a[9], a[10], a[11]},
+            f3{a[12], a[13], a[14]}, a[15], a[16], t, bu, bv);
+        o[0] = hit ? 1.0f : 0.0f; o[1] = hit ? t : 0.0f; o[2] = hit ? bu : 0.0f; o[3] = hit ? bv : 0.0f;
+        break;
+    }
+    case PROSPER_PT_FN_HALF:
+    {
+        const uint32_t h = float_to_half(a[0]);
+        o[0] = half_to_float(h);
+        o[1] = u2f(h);
+        break;
+    }
+    case PROSPER_PT_FN_RNG:
+    {
+        Rng r{f2u(a[0]), f2u(a[1]), f2u(a[2])};
+        o[0] = r.rnd01();
+        const f2 u = r.rnd2d01();
+        o[1] = u.x; o[2] = u.y;
+        o[3] = u2f(pcg(r.x ^ r.z));
+        break;
+    }
+    default: break;
+    }
+}
+
+void launch_eval_fn(
+    uint32_t fn, const float *in, uint32_t inStride, float *out, uint32_t outStride, uint32_t n, hipStream_t stream)
+{
+    if (n == 0) return;
+    hipLaunchKernelGGL(eval_fn_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, fn, in, inStride, out, outStride, n);
+}
+
+} // namespace ppt

@@ -1,0 +1,100 @@
+// pt_scene.hpp — HBM-resident scene layout of the HIP path tracer.
+//
+// What the RT pass reads through prosper's descriptor sets (src/render/RtReference.cpp:244-257)
+// lives here as plain device pointers; the acceleration structure the Vulkan driver would own
+// (src/scene/World.cpp:585-802) is this build's own flattened BVH (DESIGN.md "BVH").
+#pragma once
+
+#include <stdint.h>
+
+#include "../../include/prosper_pt/prosper_pt.h"
+
+namespace ppt
+{
+
+// BVH2 node, 64 B = one aligned 64-B fetch (4 x dwordx4 per lane).  A child reference >= 0 is
+// an inner node index; < 0 is a leaf: ~ref = (firstTriangle << 3) | (triangleCount - 1).
+// An unused child has a NaN box, which fails every comparison of the slab test.
+struct alignas(64) BvhNode
+{
+    float lo0[3];
+    float hi0[3];
+    float lo1[3];
+    float hi1[3];
+    int32_t child0;
+    int32_t child1;
+    uint32_t pad[2];
+};
+static_assert(sizeof(BvhNode) == 64, "BVH node is 64 B");
+
+constexpr uint32_t kMaxLeafTriangles = 4;
+constexpr uint32_t kTraversalStackDepth = 32; // LDS entries per lane; the builder caps depth
+
+// World-space triangle, 48 B = 3 x dwordx4, stored in BVH leaf order.  Vertices are the fp16
+// positions of the bindless geometry buffers (reference: src/scene/Mesh.hpp:11-12) decoded and
+// multiplied by the instance's modelToWorld on the GPU at upload (kernel flatten_triangles).
+struct alignas(16) WorldTriangle
+{
+    float v0[3];
+    uint32_t drawInstance;
+    float v1[3];
+    uint32_t primitive;
+    float v2[3];
+    uint32_t flags; // bit 0: opaque geometry (World.cpp:646-651)
+};
+static_assert(sizeof(WorldTriangle) == 48, "world triangle is 48 B");
+constexpr uint32_t kTriFlagOpaque = 1u;
+
+struct DeviceTexture
+{
+    const uint8_t *texels;
+    uint32_t width;
+    uint32_t height;
+};
+
+// Everything a kernel needs about the scene; passed by value as a kernel argument so every
+// pointer arrives in SGPRs.
+struct DeviceScene
+{
+    const BvhNode *nodes;
+    const WorldTriangle *triangles;
+    const void *const *geometryBuffers; // device array of device pointers
+    const prosper_GeometryMetadata *geometryMetadatas;
+    const prosper_DrawInstance *drawInstances;
+    const prosper_ModelInstanceTransforms *modelInstanceTransforms;
+    const prosper_MaterialData *materials;
+    const DeviceTexture *textures;
+    const prosper_pt_sampler_desc *samplers;
+    const prosper_DirectionalLightParameters *directionalLight;
+    const prosper_PointLightsBuffer *pointLights;
+    const prosper_SpotLightsBuffer *spotLights;
+    const uint16_t *skybox; // RGBA16F, 6 faces
+    uint32_t skyboxFaceSize;
+    uint32_t pointLightCount; // snapshot of pointLights->count at upload (kept in SGPRs)
+    uint32_t spotLightCount;
+    uint32_t pad;
+};
+
+// Per-launch constants: push constants, the camera terms the path reads, extent and tile.
+struct RenderParams
+{
+    prosper_ReferencePC pc;
+    // rt/ray.glsl:21-35,72 read only these parts of CameraUniforms
+    float eye[3];
+    float right[3];
+    float up[3];
+    float fwd[3];
+    float c2c00;
+    float c2c11;
+    float cameraToWorld[16];
+    uint32_t width;
+    uint32_t height;
+    uint32_t stripeWidth; // 0 = untiled
+    uint32_t stripeIndex;
+    uint32_t stripeCount;
+    uint32_t localWidth;
+    uint32_t frameCount; // consecutive accumulated frames rendered by this launch
+    uint32_t pad;
+};
+
+} // namespace ppt

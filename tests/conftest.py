@@ -1,0 +1,54 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    from oracle import binding
+    binding.lib()
+    return binding
+
+
+@pytest.fixture(scope="session")
+def gpu_ctx():
+    """One prosper_pt context on cuda:0 for the whole session (loads libprosper_pt.so; no fallback)."""
+    from prosper_amd import capi
+    ctx = capi.Context(device=0)
+    yield ctx
+    ctx.close()
+
+
+@pytest.fixture(scope="session")
+def cornell_world():
+    from prosper_amd import scenes
+    return scenes.cornell(with_skybox=True)
+
+
+def default_pc(structs, focal_length, frame_index=1, max_bounces=4, draw_type=0, ibl=False, dof=False,
+               skip_history=True, accumulate=True, clamp=True, roulette=3):
+    flags = 0
+    flags |= structs.PC_FLAG_SKIP_HISTORY if skip_history else 0
+    flags |= structs.PC_FLAG_ACCUMULATE if accumulate else 0
+    flags |= structs.PC_FLAG_IBL if ibl else 0
+    flags |= structs.PC_FLAG_DEPTH_OF_FIELD if dof else 0
+    flags |= structs.PC_FLAG_CLAMP_INDIRECT if clamp else 0
+    return structs.ReferencePC(draw_type, flags, frame_index, 1e-5, 1.0, focal_length, roulette, max_bounces)
+
+
+def same_bits(a, b):
+    """Bitwise equality of float32 arrays, with NaN == NaN regardless of payload."""
+    a = np.ascontiguousarray(a, np.float32)
+    b = np.ascontiguousarray(b, np.float32)
+    eq = a.view(np.uint32) == b.view(np.uint32)
+    return eq | (np.isnan(a) & np.isnan(b))
