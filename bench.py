@@ -1,0 +1,248 @@
+#!/usr/bin/env python3
+"""bench.py — Mpaths/s and HDR frames/s of the path-tracing reference pass on MI355X.
+
+A step = one pass of the hot path over one batch: the 1920x1080 S-cornell frame accumulated to
+8 spp with maxBounces 4 (BASELINE.json configs[1]), inputs resident in HBM.  With
+N > 1 GPUs the image is cut into interleaved 16-pixel stripes, one stripe set per rank, and the
+per-rank RGBA32F tiles are gathered to rank 0 over RCCL inside the timed region (strong scaling:
+the total work is fixed).
+
+    python bench.py --gpus 1 --steps 20 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+from prosper_amd import capi, scenes, structs as S  # noqa: E402
+from prosper_amd.rt_reference import Camera  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md, chip-level parameters)
+STRIPE_WIDTH = 16
+
+CONFIGS = {
+    # name: (scene builder, width, height, spp, maxBounces, ibl)
+    "c2": ("S-cornell 1920x1080 8spp maxBounces 4", lambda: scenes.cornell(), 1920, 1080, 8, 4, False),
+    "c3": ("S-sponza-class 1920x1080 8spp maxBounces 4 IBL", lambda: scenes.sponza_class(), 1920, 1080, 8, 4, True),
+    "c4": ("S-sponza-class + 1024 lights + foliage 1920x1080 8spp maxBounces 4 IBL",
+           lambda: scenes.sponza_class(lights=True, foliage=True), 1920, 1080, 8, 4, True),
+    "c1": ("S-cornell 256x256 1spp maxBounces 1", lambda: scenes.cornell(), 256, 256, 1, 1, False),
+}
+
+
+def algorithmic_bytes(c, stats):
+    """B_alg of SURVEY §8d from the deterministic work counters of one launch."""
+    tri_long = c["triangleTests"] - c["shortIndexTriangleTests"]
+    hits = c["closestHits"] + c["anyHitCalls"]
+    short_share = (c["shortIndexHits"] / hits) if hits else 0.0
+    chit = c["closestHits"] * (314.0 * short_share + 320.0 * (1.0 - short_share))
+    ahit = c["anyHitCalls"] * (138.0 * short_share + 144.0 * (1.0 - short_share))
+    return (c["nodeVisits"] * float(stats.nodeBytes) + c["shortIndexTriangleTests"] * 30.0 + tri_long * 36.0 + chit +
+            ahit + c["lightSamples"] * 36.0 + c["spotLightSamples"] * 52.0 + c["skyLookups"] * 32.0 +
+            c["pixelsWritten"] * 16.0 + c["historyReads"] * 16.0)
+
+
+def make_pc(focal, frame_index, max_bounces, ibl, skip_history):
+    flags = S.PC_FLAG_ACCUMULATE | S.PC_FLAG_CLAMP_INDIRECT
+    if ibl:
+        flags |= S.PC_FLAG_IBL
+    if skip_history:
+        flags |= S.PC_FLAG_SKIP_HISTORY
+    return S.ReferencePC(0, flags, frame_index, 1e-5, 1.0, focal, 3, max_bounces)
+
+
+def cpu_baseline(world, cam, focal, width, height, spp, max_bounces, ibl, budget_s=15.0):
+    """The oracle (a scalar port) timed on this box's host cores on a bounded sample."""
+    from oracle import binding as oracle
+    osc = oracle.OracleScene(world, brute_force=False)
+    cores = os.cpu_count() or 1
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        pass
+    img = None
+    frames = 0
+    t0 = time.perf_counter()
+    while frames < spp:
+        pc = make_pc(focal, frames + 1, max_bounces, ibl, frames == 0)
+        img, _ = osc.render(pc, cam, width, height, history=img, threads=cores)
+        frames += 1
+        elapsed = time.perf_counter() - t0
+        if elapsed + elapsed / frames > budget_s:
+            break
+    elapsed = time.perf_counter() - t0
+    osc.close()
+    return {
+        "value": width * height * frames / elapsed / 1e6,
+        "unit": "Mpaths/s",
+        "cores": cores,
+        "kind": "port",
+        "sample": "%d of %d spp of the same %dx%d frame (%.1f s, OpenMP over rows)" % (frames, spp, width, height, elapsed),
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--config", default="c2", choices=sorted(CONFIGS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--megakernel", action="store_true", help="use the one-lane-per-pixel kernel (A/B)")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world_size = int(os.environ.get("WORLD_SIZE", "1"))
+    if world_size != args.gpus:
+        if world_size == 1 and args.gpus > 1:
+            raise SystemExit("--gpus %d needs torch.distributed.run with --nproc-per-node %d" % (args.gpus, args.gpus))
+        raise SystemExit("WORLD_SIZE %d != --gpus %d" % (world_size, args.gpus))
+    torch.cuda.set_device(local_rank)
+    if world_size > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world_size, device_id=torch.device("cuda", local_rank))
+
+    workload, builder, width, height, spp, max_bounces, ibl = CONFIGS[args.config]
+    if (width // STRIPE_WIDTH) % world_size != 0:
+        raise SystemExit("%d stripes do not divide over %d ranks" % (width // STRIPE_WIDTH, world_size))
+    world = builder()
+
+    camera = Camera.from_world(world, width, height)
+    cam, focal = camera.update_buffer()
+
+    ctx = capi.Context(device=local_rank, flags=S.CREATE_MEGAKERNEL if args.megakernel else 0)
+    ctx.upload_scene(world)
+    stats = ctx.scene_stats()
+    tile = S.TileDesc(STRIPE_WIDTH, rank, world_size) if world_size > 1 else None
+    local_w = width // world_size
+    hdr = torch.zeros((height, local_w, 4), dtype=torch.float32, device="cuda")
+    ctx.set_output_buffer(hdr.data_ptr(), hdr.numel() * 4)
+    stream = torch.cuda.current_stream().cuda_stream
+    gathered = [torch.empty_like(hdr) for _ in range(world_size)] if (world_size > 1 and rank == 0) else None
+    full = None
+
+    def step():
+        nonlocal full
+        pc = make_pc(focal, 1, max_bounces, ibl, True)
+        ctx.render(pc, cam, width, height, tile=tile, frames=spp, stream=stream)
+        if world_size > 1:
+            dist.gather(hdr, gathered, dst=0)
+            if rank == 0:
+                k = width // STRIPE_WIDTH // world_size
+                parts = [g.view(height, k, STRIPE_WIDTH, 4) for g in gathered]
+                full = torch.stack(parts, dim=2).reshape(height, width, 4)
+        else:
+            full = hdr
+
+    # deterministic work counters of one launch (outside the timed region)
+    ctx.reset_counters(stream)
+    pc = make_pc(focal, 1, max_bounces, ibl, True)
+    ctx.render(pc, cam, width, height, tile=tile, frames=spp, flags=S.RENDER_COUNT_WORK, stream=stream)
+    counters = ctx.counters(stream).as_dict()
+    bytes_per_launch = algorithmic_bytes(counters, stats)
+
+    for _ in range(args.warmup):
+        step()
+
+    def barrier():
+        if world_size > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    starts = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
+    stops = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        # kernel-only time: events on the stream the render kernels are launched on
+        pc = make_pc(focal, 1, max_bounces, ibl, True)
+        starts[i].record()
+        ctx.render(pc, cam, width, height, tile=tile, frames=spp, stream=stream)
+        stops[i].record()
+        if world_size > 1:
+            dist.gather(hdr, gathered, dst=0)
+            if rank == 0:
+                k = width // STRIPE_WIDTH // world_size
+                parts = [g.view(height, k, STRIPE_WIDTH, 4) for g in gathered]
+                full = torch.stack(parts, dim=2).reshape(height, width, 4)
+        else:
+            full = hdr
+    barrier()
+    elapsed = time.perf_counter() - t0
+    kernel_ms = sum(s.elapsed_time(e) for s, e in zip(starts, stops)) / max(1, args.steps)
+
+    t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+    if world_size > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+
+    if rank == 0:
+        paths_per_step = width * height * spp
+        ms_per_step = elapsed * 1e3 / args.steps
+        achieved = bytes_per_launch / (kernel_ms * 1e-3) / 1e9
+        result = {
+            "metric": "Mpaths/s",
+            "value": paths_per_step * args.steps / elapsed / 1e6,
+            "unit": "Mpaths/s",
+            "n_gpus": world_size,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": ms_per_step,
+            "frames_per_s": 1e3 / ms_per_step,
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": workload,
+                "width": width,
+                "height": height,
+                "spp": spp,
+                "max_bounces": max_bounces,
+                "triangles": int(stats.triangleCount),
+                "bvh_nodes": int(stats.nodeCount),
+                "parallelism": "image stripes x%d%s" % (world_size, " + RCCL gather" if world_size > 1 else ""),
+                "pipeline": "megakernel" if args.megakernel else "default",
+            },
+            "roofline": {
+                "bound": "hbm",
+                "kernel": "render (rank 0 tile)",
+                "achieved": achieved,
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS,
+                "traffic": None,
+                "algorithmic_bytes_per_launch": bytes_per_launch,
+                "kernel_ms": kernel_ms,
+                "bytes_per_path": bytes_per_launch / max(1, counters["paths"]),
+            },
+            "counters": counters,
+            "mean_radiance": float(full[..., :3].mean().item()),
+        }
+        if world_size == 1 and not args.no_cpu_baseline:
+            result["cpu_baseline"] = cpu_baseline(world, cam, focal, width, height, spp, max_bounces, ibl)
+            result["gpu_over_cpu"] = result["value"] / result["cpu_baseline"]["value"]
+        print(json.dumps(result))
+
+    ctx.set_output_buffer(0, 0)
+    ctx.close()
+    if world_size > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

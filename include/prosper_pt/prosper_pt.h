@@ -194,7 +194,8 @@ typedef struct prosper_pt_counters
     uint64_t pixelsWritten;    /* output texels written */
     uint64_t historyReads;     /* output texels whose history was read */
     uint64_t shortIndexHits;   /* of closestHits + anyHitCalls: those on u16-indexed meshes */
-    uint64_t reserved[3];
+    uint64_t shortIndexTriangleTests; /* of triangleTests: those on u16-indexed meshes */
+    uint64_t reserved[2];
 } prosper_pt_counters;
 
 /* Sizes the roofline model needs about the acceleration structure the library built. */

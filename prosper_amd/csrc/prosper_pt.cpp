@@ -263,6 +263,7 @@ int upload_scene_impl(prosper_pt_ctx *ctx, const prosper_pt_scene_view *v)
         total += info.indexCount / 3;
         // World.cpp:646-651: eOpaque iff the mesh's material is AlphaMode_Opaque
         diFlags[i] = v->materials[info.materialIndex].alphaMode == PROSPER_ALPHA_MODE_OPAQUE ? kTriFlagOpaque : 0u;
+        if (v->geometryMetadatas[v->drawInstances[i].meshIndex].usesShortIndices == 1) diFlags[i] |= kTriFlagShortIndices;
     }
     triOffsets[v->drawInstanceCount] = (uint32_t)total;
     if (total >= (1ull << 28)) return fail(PROSPER_PT_ERR_UNSUPPORTED, "more than 2^28 triangles after instancing");

@@ -17,7 +17,7 @@ constexpr uint32_t kMissIndex = 0xFFFFFFFFu; // rt/reference/main.rgen:47
 struct LaneCounters
 {
     uint32_t closestRays, shadowRays, nodeVisits, triangleTests, closestHits, anyHitCalls, lightSamples,
-        spotLightSamples, skyLookups, shortIndexHits, paths, pixelsWritten, historyReads;
+        spotLightSamples, skyLookups, shortIndexHits, paths, pixelsWritten, historyReads, shortIndexTriangleTests;
 };
 
 // ------------------------------------------------------------------------------------------
@@ -874,7 +874,11 @@ PPT_D bool trace(
             {
                 const float4 *tp = reinterpret_cast<const float4 *>(s.triangles + first + i);
                 const float4 a = tp[0], b = tp[1], c = tp[2];
-                if constexpr (COUNT) cnt.triangleTests++;
+                if constexpr (COUNT)
+                {
+                    cnt.triangleTests++;
+                    cnt.shortIndexTriangleTests += (__builtin_bit_cast(uint32_t, c.w) & kTriFlagShortIndices) ? 1u : 0u;
+                }
                 float t, bu, bv;
                 if (!intersect_triangle(
                         o, d, f3{a.x, a.y, a.z}, f3{b.x, b.y, b.z}, f3{c.x, c.y, c.z}, tMin, tMaxIn, t, bu, bv))

@@ -40,10 +40,11 @@ struct alignas(16) WorldTriangle
     float v1[3];
     uint32_t primitive;
     float v2[3];
-    uint32_t flags; // bit 0: opaque geometry (World.cpp:646-651)
+    uint32_t flags; // bit 0: opaque geometry (World.cpp:646-651); bit 1: u16-indexed mesh
 };
 static_assert(sizeof(WorldTriangle) == 48, "world triangle is 48 B");
 constexpr uint32_t kTriFlagOpaque = 1u;
+constexpr uint32_t kTriFlagShortIndices = 2u; // the mesh is u16-indexed (only the byte model cares)
 
 struct DeviceTexture
 {

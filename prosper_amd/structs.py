@@ -239,7 +239,8 @@ class Counters(C.Structure):
         ("pixelsWritten", C.c_uint64),
         ("historyReads", C.c_uint64),
         ("shortIndexHits", C.c_uint64),
-        ("reserved", C.c_uint64 * 3),
+        ("shortIndexTriangleTests", C.c_uint64),
+        ("reserved", C.c_uint64 * 2),
     ]
 
     def as_dict(self):
