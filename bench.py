@@ -23,11 +23,11 @@ if ROOT not in sys.path:
 
 import numpy as np  # noqa: E402
 
-from prosper_amd import capi, scenes, structs as S  # noqa: E402
+from prosper_amd import capi, scenes, structs as S, tiling  # noqa: E402
 from prosper_amd.rt_reference import Camera  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md, chip-level parameters)
-STRIPE_WIDTH = 16
+STRIPE_WIDTH = tiling.STRIPE_WIDTH
 
 CONFIGS = {
     # name: (scene builder, width, height, spp, maxBounces, ibl)
@@ -60,15 +60,27 @@ def make_pc(focal, frame_index, max_bounces, ibl, skip_history):
     return S.ReferencePC(0, flags, frame_index, 1e-5, 1.0, focal, 3, max_bounces)
 
 
-def cpu_baseline(world, cam, focal, width, height, spp, max_bounces, ibl, budget_s=15.0):
-    """The oracle (a scalar port) timed on this box's host cores on a bounded sample."""
-    from oracle import binding as oracle
-    osc = oracle.OracleScene(world, brute_force=False)
+def host_cores():
+    """Hardware threads this process may actually use: min(affinity, cgroup CPU quota)."""
     cores = os.cpu_count() or 1
     try:
         cores = len(os.sched_getaffinity(0))
     except (AttributeError, OSError):
         pass
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            cores = max(1, min(cores, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return cores
+
+
+def cpu_baseline(world, cam, focal, width, height, spp, max_bounces, ibl, budget_s=15.0):
+    """The oracle (a scalar port) timed on this box's host cores on a bounded sample."""
+    from oracle import binding as oracle
+    osc = oracle.OracleScene(world, brute_force=False)
+    cores = host_cores()
     img = None
     frames = 0
     t0 = time.perf_counter()
@@ -116,7 +128,7 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world_size, device_id=torch.device("cuda", local_rank))
 
     workload, builder, width, height, spp, max_bounces, ibl = CONFIGS[args.config]
-    if (width // STRIPE_WIDTH) % world_size != 0:
+    if not tiling.check_divisible(width, world_size):
         raise SystemExit("%d stripes do not divide over %d ranks" % (width // STRIPE_WIDTH, world_size))
     world = builder()
 
@@ -126,8 +138,8 @@ def main():
     ctx = capi.Context(device=local_rank, flags=S.CREATE_MEGAKERNEL if args.megakernel else 0)
     ctx.upload_scene(world)
     stats = ctx.scene_stats()
-    tile = S.TileDesc(STRIPE_WIDTH, rank, world_size) if world_size > 1 else None
-    local_w = width // world_size
+    tile = tiling.tile_for_rank(rank, world_size)
+    local_w = tiling.local_width(width, rank, world_size)
     hdr = torch.zeros((height, local_w, 4), dtype=torch.float32, device="cuda")
     ctx.set_output_buffer(hdr.data_ptr(), hdr.numel() * 4)
     stream = torch.cuda.current_stream().cuda_stream
@@ -141,9 +153,7 @@ def main():
         if world_size > 1:
             dist.gather(hdr, gathered, dst=0)
             if rank == 0:
-                k = width // STRIPE_WIDTH // world_size
-                parts = [g.view(height, k, STRIPE_WIDTH, 4) for g in gathered]
-                full = torch.stack(parts, dim=2).reshape(height, width, 4)
+                full = tiling.deinterleave(gathered, width)
         else:
             full = hdr
 
@@ -175,9 +185,7 @@ def main():
         if world_size > 1:
             dist.gather(hdr, gathered, dst=0)
             if rank == 0:
-                k = width // STRIPE_WIDTH // world_size
-                parts = [g.view(height, k, STRIPE_WIDTH, 4) for g in gathered]
-                full = torch.stack(parts, dim=2).reshape(height, width, 4)
+                full = tiling.deinterleave(gathered, width)
         else:
             full = hdr
     barrier()

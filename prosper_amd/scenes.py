@@ -323,7 +323,8 @@ def sponza_class(lights=False, foliage=False, texture_size=1024, sky_size=512, d
         mats.append(w.add_material(base_color=(1, 1, 1, 1), metallic=1.0, roughness=1.0,
                                    base_tex=(bt, tex_sampler), mr_tex=(mr, tex_sampler), normal_tex=(nt, tex_sampler)))
 
-    d = detail
+    # 1.2859375 calibrates detail=1 to 262 426 triangles (SURVEY §8d asks for 262 144 +-1 %)
+    d = detail * 1.2859375
     L, W, H = 24.0, 10.0, 9.0  # atrium interior: x in [-12,12], z in [-5,5], y in [0,9]
 
     def seg(n):
@@ -334,7 +335,11 @@ def sponza_class(lights=False, foliage=False, texture_size=1024, sky_size=512, d
         return 0.01 * np.sin(gx * 2.1) * np.cos(gz * 1.7)
 
     floor = grid(seg(160), seg(80), L, W, bumps, uv_scale=12.0)
-    ceiling = transform_mesh(grid(seg(96), seg(48), L, W, None, uv_scale=8.0), translate((0, H, 0)) @ rotate_x(math.pi))
+    # the roof is open over the central half of the atrium (sun and sky enter there): two strips
+    ceiling = merge([
+        transform_mesh(grid(seg(96), seg(24), L, W * 0.25, None, uv_scale=8.0),
+                       translate((0, H, zc)) @ rotate_x(math.pi))
+        for zc in (-W * 0.375, W * 0.375)])
     wall_l = transform_mesh(grid(seg(128), seg(56), L, H, None, 8.0),
                             translate((0, H / 2, -W / 2)) @ rotate_x(math.pi / 2))
     wall_r = transform_mesh(grid(seg(128), seg(56), L, H, None, 8.0),

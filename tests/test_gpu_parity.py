@@ -176,3 +176,237 @@ def test_counters_match_oracle(gpu_ctx, oracle, cornell_world):
                 "pixelsWritten", "historyReads"):
         assert got[key] == want[key], key
     assert got["nodeVisits"] > 0 and got["triangleTests"] > 0
+
+
+# ---------------------------------------------------------------------------------------------
+# committed goldens, larger scenes, tiles, host class, full-size properties
+# ---------------------------------------------------------------------------------------------
+
+import importlib.util
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def test_gpu_reproduces_committed_goldens(gpu_ctx, cornell_world):
+    """tests/golden/cornell_48.npz (every DrawType + Default radiance), bit for bit."""
+    spec = importlib.util.spec_from_file_location("make_images", os.path.join(HERE, "golden", "make_images.py"))
+    make_images = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(make_images)
+    golden = np.load(os.path.join(HERE, "golden", "cornell_48.npz"))
+    cam = S.CameraUniforms.from_buffer_copy(golden["camera"].tobytes())
+    gpu_ctx.upload_scene(cornell_world)
+
+    def render(pc, hist):
+        # history lives in the context's HDR buffer: frames are rendered in golden order
+        gpu_ctx.render(pc, cam, 48, 48)
+        return gpu_ctx.read_hdr()
+
+    images = make_images.render_all(render)
+    for name, img in images.items():
+        assert same_bits(img, golden[name]).all(), name
+
+
+@pytest.fixture(scope="module")
+def sponza_small():
+    from prosper_amd import scenes
+    return scenes.sponza_class(lights=True, foliage=True, texture_size=64, sky_size=32, detail=0.25)
+
+
+@pytest.mark.parametrize("draw_type", ["PrimitiveID", "ShadingNormal", "Albedo", "Roughness", "TexCoord0"])
+def test_sponza_class_debug_draw_types_bit_exact(gpu_ctx, oracle, sponza_small, draw_type):
+    """Instancing, u16+u32 indices, two geometry buffers, textures, normal maps, alpha foliage."""
+    w, h = 240, 136
+    cam, fl = _camera(oracle, sponza_small, w, h)
+    pc = default_pc(S, fl, draw_type=S.DrawType[draw_type], max_bounces=1)
+    gpu_ctx.upload_scene(sponza_small)
+    gpu_ctx.render(pc, cam, w, h)
+    got = gpu_ctx.read_hdr()
+    want, _ = oracle.OracleScene(sponza_small).render(pc, cam, w, h)
+    ok = same_bits(got, want).all(axis=2)
+    assert ok.all(), "%s: %d of %d pixels differ" % (draw_type, (~ok).sum(), ok.size)
+
+
+def test_sponza_class_radiance_bit_exact(gpu_ctx, oracle, sponza_small):
+    """C4-style: 1024 punctual lights + sun + IBL + stochastic foliage, 3 accumulated frames."""
+    w, h = 240, 136
+    cam, fl = _camera(oracle, sponza_small, w, h)
+    gpu_ctx.upload_scene(sponza_small)
+    st = gpu_ctx.scene_stats()
+    assert st.triangleCount == sponza_small.triangle_count() and st.maxDepth <= 32
+    osc = oracle.OracleScene(sponza_small)
+    want = None
+    for frame in (1, 2, 3):
+        pc = default_pc(S, fl, frame_index=frame, max_bounces=4, ibl=True, skip_history=(frame == 1))
+        gpu_ctx.render(pc, cam, w, h)
+        want, _ = osc.render(pc, cam, w, h, history=want)
+    got = gpu_ctx.read_hdr()
+    ok = same_bits(got, want).all(axis=2)
+    assert ok.all(), "%d of %d pixels differ; max abs diff %g" % ((~ok).sum(), ok.size, np.nanmax(np.abs(got - want)))
+
+
+def test_traversal_semantics_on_gpu(gpu_ctx, oracle):
+    """The tiny-scene cases of test_oracle_traversal.py seen through whole renders."""
+    from prosper_amd import scenes
+    world = scenes.tiny_triangles()
+    w = h = 64
+    cam, fl = _camera(oracle, world, w, h)
+    gpu_ctx.upload_scene(world)
+    osc = oracle.OracleScene(world, brute_force=True)
+    for frame in (1, 7, 4095, 0):  # frameIndex wraps mod 4096 (RtReference.cpp:170)
+        pc = default_pc(S, fl, frame_index=frame, draw_type=S.DrawType["MeshID"], max_bounces=1)
+        gpu_ctx.render(pc, cam, w, h)
+        want, _ = osc.render(pc, cam, w, h)
+        assert same_bits(gpu_ctx.read_hdr(), want).all()
+
+
+def test_stripe_tiles_equal_whole_image(gpu_ctx, oracle, cornell_world):
+    """prosper_pt_tile_desc: the union of the ranks' tiles is the single-GPU image, bit for bit."""
+    from prosper_amd import tiling
+    w, h = 256, 72
+    cam, fl = _camera(oracle, cornell_world, w, h)
+    pc = default_pc(S, fl, max_bounces=3, ibl=True)
+    gpu_ctx.upload_scene(cornell_world)
+    gpu_ctx.render(pc, cam, w, h, frames=2)
+    whole = gpu_ctx.read_hdr()
+    for world_size in (2, 4, 8):
+        tiles = []
+        for r in range(world_size):
+            gpu_ctx.render(pc, cam, w, h, tile=tiling.tile_for_rank(r, world_size), frames=2)
+            t = gpu_ctx.read_hdr()
+            assert t.shape == (h, w // world_size, 4)
+            tiles.append(t)
+        assert same_bits(tiling.deinterleave(tiles, w), whole).all(), world_size
+
+
+def test_rgba16f_blit_rounds_to_nearest_even(gpu_ctx, oracle, cornell_world):
+    w, h = 64, 64
+    cam, fl = _camera(oracle, cornell_world, w, h)
+    gpu_ctx.upload_scene(cornell_world)
+    gpu_ctx.render(default_pc(S, fl), cam, w, h)
+    f32 = gpu_ctx.read_hdr()
+    f16 = gpu_ctx.blit_rgba16f()
+    assert (f16.view(np.uint16) == f32.astype(np.float16).view(np.uint16)).all()
+
+
+def test_rt_reference_host_class_semantics(oracle, cornell_world):
+    """render::RtReference (C++ host): frame index, history dirtiness, drawUi, releasePreserved —
+    RtReference.cpp:148-159,170,189-216,278-298,385-391."""
+    from prosper_amd.rt_reference import Camera, RtReference
+    w, h = 96, 64
+    rt = RtReference()
+    rt.init(0)
+    rt.set_world(cornell_world)
+    cam = Camera.from_world(cornell_world, w, h)
+    rt.draw_ui(maxBounces=4)
+    pcs = [rt.record(cam, w, h) for _ in range(3)]
+    assert [p.frameIndex for p in pcs] == [1, 2, 3]                    # pre-incremented: first frame is 1
+    assert [p.flags & 1 for p in pcs] == [1, 0, 0]                     # skipHistory on the first frame only
+    assert all(p.flags & 2 and p.flags & 16 for p in pcs)              # accumulate + clampIndirect defaults
+    assert pcs[0].maxBounces == 4 and pcs[0].rouletteStartBounce == 3
+    got = rt.context.read_hdr()
+    assert (got[..., 3] == 3.0).all()
+    # the same three frames straight through the C-ABI + oracle
+    cu, fl = cam.update_buffer()
+    osc = oracle.OracleScene(cornell_world, brute_force=True)
+    want = None
+    for p in pcs:
+        want, _ = osc.render(p, cu, w, h, history=want)
+    assert same_bits(got, want).all()
+    # drawUi: changing anything but `accumulate` restarts history
+    rt.draw_ui(maxBounces=4, accumulate=True)
+    assert rt.record(cam, w, h).flags & 1 == 0
+    rt.draw_ui(maxBounces=4, clampIndirect=False)
+    p = rt.record(cam, w, h)
+    assert p.flags & 1 == 1 and p.flags & 16 == 0 and p.frameIndex == 5
+    # camera move, colorDirty, extent change, recompile and releasePreserved all skip history
+    cam.look_at((0.0, 1.0, 3.0), (0.0, 1.0, 0.0))
+    assert rt.record(cam, w, h).flags & 1 == 1
+    assert rt.record(cam, w, h).flags & 1 == 0
+    assert rt.record(cam, w, h, RtReference.Options(colorDirty=True)).flags & 1 == 1
+    assert rt.record(cam, w + 16, h).flags & 1 == 1
+    assert rt.record(cam, w + 16, h).flags & 1 == 0
+    rt.recompile_shaders()
+    assert rt.record(cam, w + 16, h).flags & 1 == 1
+    rt.release_preserved()
+    assert rt.record(cam, w + 16, h).flags & 1 == 1
+    # a batch of frames advances the frame index by its length
+    before = rt.record(cam, w + 16, h).frameIndex
+    after = rt.record(cam, w + 16, h, frame_count=4)
+    assert after.frameIndex == before + 1
+    assert rt.record(cam, w + 16, h).frameIndex == before + 5
+    # options reach the push constants (RtReference.cpp:278-298)
+    p = rt.record(cam, w + 16, h, RtReference.Options(depthOfField=True, ibl=True, drawType="Albedo"))
+    assert p.drawType == 8 and p.flags & 4 and p.flags & 8
+    rt.close()
+
+
+def test_error_paths_through_the_c_abi(gpu_ctx, oracle, cornell_world):
+    import ctypes as C
+    from prosper_amd import capi, world as W
+    lib = capi.lib()
+    fresh = capi.Context(device=0)
+    cam, fl = _camera(oracle, cornell_world, 32, 32)
+    pc = default_pc(S, fl)
+    with pytest.raises(capi.ProsperPtError) as e:
+        fresh.render(pc, cam, 32, 32)
+    assert e.value.code == -4  # PROSPER_PT_ERR_NO_SCENE
+    # a draw instance pointing past the mesh table is rejected by validation, not by a GPU fault
+    bad = W.World()
+    m = bad.add_material()
+    from prosper_amd import scenes
+    b = scenes.box()
+    mesh = bad.add_mesh(b[0], b[4], m)
+    bad.add_instance(bad.add_model([(mesh + 5, m)]))
+    with pytest.raises(capi.ProsperPtError) as e:
+        fresh.upload_scene(bad)
+    assert e.value.code == -5 and "draw instance" in str(e.value)
+    with pytest.raises(capi.ProsperPtError):
+        fresh.render(S.ReferencePC(99, 0, 1, 0, 0, 0, 0, 1), cam, 32, 32)
+    # empty scene renders (every ray misses)
+    empty = W.World()
+    fresh.upload_scene(empty)
+    fresh.render(default_pc(S, fl), cam, 32, 32)
+    img = fresh.read_hdr()
+    assert (img[..., :3] == 0).all() and (img[..., 3] == 1).all()
+    fresh.close()
+
+
+def test_full_size_c2_properties(gpu_ctx, oracle, cornell_world):
+    """BASELINE C2 size (1920x1080, 8 spp, 4 bounces): properties that do not need the oracle to
+    trace 16.6 M paths — frame batching, determinism, counter identities — plus an exact check of a
+    sampled set of rows against the oracle."""
+    w, h, spp = 1920, 1080, 8
+    cam, fl = _camera(oracle, cornell_world, w, h)
+    gpu_ctx.upload_scene(cornell_world)
+    pc = default_pc(S, fl, max_bounces=4)
+    gpu_ctx.reset_counters()
+    gpu_ctx.render(pc, cam, w, h, frames=spp, flags=S.RENDER_COUNT_WORK)
+    a = gpu_ctx.read_hdr()
+    c = gpu_ctx.counters().as_dict()
+    assert c["paths"] == w * h * spp and c["pixelsWritten"] == w * h * spp and c["historyReads"] == w * h * (spp - 1)
+    assert c["closestRays"] >= c["paths"] and c["closestHits"] <= c["closestRays"]
+    assert c["shadowRays"] <= c["closestHits"] and c["lightSamples"] + c["spotLightSamples"] <= c["closestHits"]
+    gpu_ctx.render(pc, cam, w, h, frames=spp)
+    b = gpu_ctx.read_hdr()
+    assert same_bits(a, b).all()                       # run-to-run determinism, counting kernel == timed kernel
+    assert np.isfinite(b).all() and (b[..., 3] == spp).all()
+    # two half batches == one batch (history through HBM vs registers)
+    gpu_ctx.render(pc, cam, w, h, frames=3)
+    pc2 = default_pc(S, fl, frame_index=4, max_bounces=4, skip_history=False)
+    gpu_ctx.render(pc2, cam, w, h, frames=5)
+    assert same_bits(gpu_ctx.read_hdr(), b).all()
+    # exact oracle check on a 1920x24 band in the middle of the image (rendered as its own frames:
+    # seeds are absolute pixel coordinates, so compare rows of a reduced-height oracle run is not
+    # possible; instead compare full-width rows via a 2-frame render of the same extent)
+    osc = oracle.OracleScene(cornell_world, brute_force=True)
+    want = None
+    for frame in (1, 2):
+        p = default_pc(S, fl, frame_index=frame, max_bounces=4, skip_history=(frame == 1))
+        gpu_ctx.render(p, cam, w, h)
+    got2 = gpu_ctx.read_hdr()
+    # oracle renders the whole 1920x1080 twice in a few seconds with all cores
+    for frame in (1, 2):
+        p = default_pc(S, fl, frame_index=frame, max_bounces=4, skip_history=(frame == 1))
+        want, _ = osc.render(p, cam, w, h, history=want)
+    assert same_bits(got2, want).all()
