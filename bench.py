@@ -110,6 +110,7 @@ def main():
     ap.add_argument("--config", default="c2", choices=sorted(CONFIGS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--megakernel", action="store_true", help="use the one-lane-per-pixel kernel (A/B)")
+    ap.add_argument("--persistent", action="store_true", help="use the persistent path-regeneration kernel (A/B)")
     args = ap.parse_args()
 
     import torch
@@ -135,7 +136,7 @@ def main():
     camera = Camera.from_world(world, width, height)
     cam, focal = camera.update_buffer()
 
-    ctx = capi.Context(device=local_rank, flags=S.CREATE_MEGAKERNEL if args.megakernel else 0)
+    ctx = capi.Context(device=local_rank, flags=S.CREATE_MEGAKERNEL if args.megakernel else (S.CREATE_PERSISTENT if args.persistent else 0))
     ctx.upload_scene(world)
     stats = ctx.scene_stats()
     tile = tiling.tile_for_rank(rank, world_size)
@@ -224,7 +225,7 @@ def main():
                 "triangles": int(stats.triangleCount),
                 "bvh_nodes": int(stats.nodeCount),
                 "parallelism": "image stripes x%d%s" % (world_size, " + RCCL gather" if world_size > 1 else ""),
-                "pipeline": "megakernel" if args.megakernel else "default",
+                "pipeline": "megakernel" if args.megakernel else ("persistent" if args.persistent else "wavefront"),
             },
             "roofline": {
                 "bound": "hbm",

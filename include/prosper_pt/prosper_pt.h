@@ -62,9 +62,12 @@ typedef struct prosper_pt_device_desc
 
 enum
 {
-    /* Default pipeline: wavefront kernels (raygen / extend / shade / shadow+accumulate).
-     * MEGAKERNEL selects the one-thread-per-pixel kernel (same results, kept for A/B timing). */
+    /* Default pipeline: wavefront stage kernels (generate+extend / shade / shadow / extend /
+     * accumulate) with per-wave ballot compaction.  The two alternatives produce the same pixels
+     * and are kept for A/B timing: MEGAKERNEL = one lane per pixel runs whole paths,
+     * PERSISTENT = resident waves that regenerate finished paths from a global counter. */
     PROSPER_PT_CREATE_MEGAKERNEL = 1u << 0,
+    PROSPER_PT_CREATE_PERSISTENT = 1u << 1,
 };
 
 /* Texel formats of material textures (reference: src/scene/Texture.cpp:217-296 stores UNORM,

@@ -70,6 +70,11 @@ struct prosper_pt_ctx
     uint32_t localWidth = 0, height = 0;
 
     unsigned long long *dCounters = nullptr; // 16 x u64
+    uint32_t *dWorkCounter = nullptr;        // work-distribution counter of the persistent kernel
+    // wavefront workspace (one allocation, carved into the WavefrontBuffers arrays)
+    void *wfBlock = nullptr;
+    size_t wfBytes = 0;
+    uint64_t wfSlots = 0;
 
     bool kernelTiming = false;
     hipEvent_t evStart = nullptr, evStop = nullptr;
@@ -347,6 +352,73 @@ int upload_scene_impl(prosper_pt_ctx *ctx, const prosper_pt_scene_view *v)
     return PROSPER_PT_OK;
 }
 
+// Sizes and carves the wavefront workspace for `frames` x (tilesX*tilesY*64) path slots.
+int ensure_wavefront_workspace(
+    prosper_pt_ctx *ctx, uint32_t tilesX, uint32_t tilesY, uint32_t frames, hipStream_t stream, WavefrontBuffers *out)
+{
+    const uint64_t pixelsPadded = (uint64_t)tilesX * tilesY * 64u;
+    const uint64_t slots = pixelsPadded * frames;
+    // one segment per wave; aim for ~16k waves so every CU has many segments to balance over
+    uint64_t segLen = ((slots / 16384u) + 63u) / 64u * 64u;
+    if (segLen < 256u) segLen = 256u;
+    if (segLen > 2048u) segLen = 2048u;
+    const uint64_t nSeg = (slots + segLen - 1u) / segLen;
+    const uint64_t padded = nSeg * segLen;
+    // per slot: 8 x 16 B ping-pong state, hit 16 + idx 4, shadow 48, colour 16; + 3 counters per segment
+    const size_t bytes = (size_t)padded * (8u * 16u + 16u + 4u + 48u + 16u) + (size_t)nSeg * 12u + 4096u;
+    if (bytes > ctx->wfBytes)
+    {
+        PPT_HIP(hipStreamSynchronize(stream));
+        if (ctx->wfBlock) PPT_HIP(hipFree(ctx->wfBlock));
+        ctx->wfBlock = nullptr;
+        ctx->wfBytes = 0;
+        PPT_HIP(hipMalloc(&ctx->wfBlock, bytes));
+        ctx->wfBytes = bytes;
+    }
+    uint8_t *cursor = static_cast<uint8_t *>(ctx->wfBlock);
+    auto carve = [&](size_t n) {
+        void *r = cursor;
+        cursor += (n + 255u) & ~(size_t)255u;
+        return r;
+    };
+    WavefrontBuffers w = {};
+    for (int k = 0; k < 2; ++k)
+    {
+        w.rayA[k] = static_cast<float4 *>(carve(padded * 16u));
+        w.rayB[k] = static_cast<float4 *>(carve(padded * 16u));
+        w.pathT[k] = static_cast<float4 *>(carve(padded * 16u));
+        w.pathR[k] = static_cast<uint4 *>(carve(padded * 16u));
+    }
+    w.hit = static_cast<uint4 *>(carve(padded * 16u));
+    w.hitIdx = static_cast<uint32_t *>(carve(padded * 4u));
+    w.shA = static_cast<float4 *>(carve(padded * 16u));
+    w.shB = static_cast<float4 *>(carve(padded * 16u));
+    w.shC = static_cast<float4 *>(carve(padded * 16u));
+    w.color = static_cast<float4 *>(carve(padded * 16u));
+    w.segRays = static_cast<uint32_t *>(carve(nSeg * 4u));
+    w.segHits = static_cast<uint32_t *>(carve(nSeg * 4u));
+    w.segShadow = static_cast<uint32_t *>(carve(nSeg * 4u));
+    w.segLen = (uint32_t)segLen;
+    w.nSeg = (uint32_t)nSeg;
+    w.pixelsPadded = (uint32_t)pixelsPadded;
+    w.tilesX = tilesX;
+    w.tilesY = tilesY;
+    if ((size_t)(cursor - static_cast<uint8_t *>(ctx->wfBlock)) > ctx->wfBytes + 0u)
+    {
+        // carve() rounds every array up to 256 B: re-allocate with the exact carved size
+        const size_t need = (size_t)(cursor - static_cast<uint8_t *>(ctx->wfBlock));
+        PPT_HIP(hipStreamSynchronize(stream));
+        PPT_HIP(hipFree(ctx->wfBlock));
+        ctx->wfBlock = nullptr;
+        ctx->wfBytes = 0;
+        PPT_HIP(hipMalloc(&ctx->wfBlock, need));
+        ctx->wfBytes = need;
+        return ensure_wavefront_workspace(ctx, tilesX, tilesY, frames, stream, out);
+    }
+    *out = w;
+    return PROSPER_PT_OK;
+}
+
 uint32_t compute_local_width(uint32_t width, const prosper_pt_tile_desc *tile)
 {
     if (!tile || tile->stripeCount <= 1 || tile->stripeWidth == 0) return width;
@@ -387,6 +459,7 @@ int prosper_pt_create(const prosper_pt_device_desc *desc, prosper_pt_ctx **out_c
     ctx->flags = desc->flags;
     if (hipMalloc((void **)&ctx->dCounters, 16 * sizeof(unsigned long long)) != hipSuccess ||
         hipMemset(ctx->dCounters, 0, 16 * sizeof(unsigned long long)) != hipSuccess ||
+        hipMalloc((void **)&ctx->dWorkCounter, 64) != hipSuccess ||
         hipEventCreate(&ctx->evStart) != hipSuccess || hipEventCreate(&ctx->evStop) != hipSuccess)
     {
         prosper_pt_destroy(ctx);
@@ -404,6 +477,8 @@ void prosper_pt_destroy(prosper_pt_ctx *ctx)
     free_scene(ctx);
     if (ctx->ownedHdr) (void)hipFree(ctx->ownedHdr);
     if (ctx->dCounters) (void)hipFree(ctx->dCounters);
+    if (ctx->dWorkCounter) (void)hipFree(ctx->dWorkCounter);
+    if (ctx->wfBlock) (void)hipFree(ctx->wfBlock);
     if (ctx->evStart) (void)hipEventDestroy(ctx->evStart);
     if (ctx->evStop) (void)hipEventDestroy(ctx->evStop);
     delete ctx;
@@ -526,7 +601,33 @@ int prosper_pt_render_frames(
     if (localWidth == 0) return PROSPER_PT_OK;
     const bool countWork = (render_flags & PROSPER_PT_RENDER_COUNT_WORK) != 0;
     if (ctx->kernelTiming) PPT_HIP(hipEventRecord(ctx->evStart, s));
-    launch_render_megakernel(ctx->scene, p, ctx->hdr, ctx->dCounters, countWork, s);
+    if (ctx->flags & PROSPER_PT_CREATE_MEGAKERNEL)
+        launch_render_megakernel(ctx->scene, p, ctx->hdr, ctx->dCounters, countWork, s);
+    else if (ctx->flags & PROSPER_PT_CREATE_PERSISTENT)
+        launch_render_persistent(ctx->scene, p, ctx->hdr, ctx->dCounters, ctx->dWorkCounter, countWork, s);
+    else
+    {
+        // wavefront: all frames of the batch are in flight together, in chunks that keep the
+        // workspace under kMaxWavefrontSlots path slots
+        const uint32_t tilesX = (localWidth + 7u) / 8u, tilesY = (height + 7u) / 8u;
+        const uint64_t pixelsPadded = (uint64_t)tilesX * tilesY * 64u;
+        constexpr uint64_t kMaxWavefrontSlots = 64ull << 20;
+        if (pixelsPadded > kMaxWavefrontSlots) return fail(PROSPER_PT_ERR_UNSUPPORTED, "image too large for the wavefront workspace");
+        uint32_t framesPerChunk = (uint32_t)(kMaxWavefrontSlots / pixelsPadded);
+        if (framesPerChunk > frame_count) framesPerChunk = frame_count;
+        for (uint32_t f0 = 0; f0 < frame_count; f0 += framesPerChunk)
+        {
+            const uint32_t frames = (frame_count - f0 < framesPerChunk) ? frame_count - f0 : framesPerChunk;
+            WavefrontBuffers w = {};
+            const int rc = ensure_wavefront_workspace(ctx, tilesX, tilesY, frames, s, &w);
+            if (rc != PROSPER_PT_OK) return rc;
+            RenderParams pp = p;
+            pp.frameCount = frames;
+            pp.pc.frameIndex = (p.pc.frameIndex + f0) % PROSPER_RT_FRAME_PERIOD;
+            if (f0 > 0) pp.pc.flags &= ~(uint32_t)PROSPER_PC_FLAG_SKIP_HISTORY;
+            launch_render_wavefront(ctx->scene, pp, ctx->hdr, ctx->dCounters, w, countWork, s);
+        }
+    }
     PPT_HIP(hipGetLastError());
     if (ctx->kernelTiming)
     {
@@ -623,7 +724,7 @@ int prosper_pt_set_kernel_timing(prosper_pt_ctx *ctx, int enabled)
 
 const char *prosper_pt_kernel_name(uint32_t index)
 {
-    static const char *names[PROSPER_PT_MAX_KERNELS] = {"render_megakernel", "", "", "", "", "", "", ""};
+    static const char *names[PROSPER_PT_MAX_KERNELS] = {"render", "", "", "", "", "", "", ""};
     return index < PROSPER_PT_MAX_KERNELS ? names[index] : "";
 }
 

@@ -1037,12 +1037,17 @@ PPT_D bool prepare_direct_lighting(
 }
 
 // Second half (main.rgen:216-222): apply visibility, the uniform-pick weight and the BRDF.
-PPT_D f3 finish_direct_lighting(const DeviceScene &s, const Surface &sf, f3 throughput, f3 l, f3 irradiance, float visibility)
+// `brdfTimesNoL` = evalBRDFTimesNoL(l, surface).
+PPT_D f3 direct_lighting_value(const DeviceScene &s, f3 throughput, f3 irradiance, f3 brdfTimesNoL, float visibility)
 {
     const uint32_t lightCount = 1u + s.pointLightCount + s.spotLightCount;
     irradiance = irradiance * visibility;
     irradiance = irradiance * (float)lightCount;
-    return (throughput * irradiance) * eval_brdf_times_nol(l, sf);
+    return (throughput * irradiance) * brdfTimesNoL;
+}
+PPT_D f3 finish_direct_lighting(const DeviceScene &s, const Surface &sf, f3 throughput, f3 l, f3 irradiance, float visibility)
+{
+    return direct_lighting_value(s, throughput, irradiance, eval_brdf_times_nol(l, sf), visibility);
 }
 
 } // namespace ppt

@@ -8,6 +8,7 @@
 #include "pt_kernels.hpp"
 
 #include "pt_device.hpp"
+#include "pt_render_common.hpp"
 
 namespace ppt
 {
@@ -163,37 +164,6 @@ __device__ f3 trace_path(
     return color;
 }
 
-__device__ __forceinline__ uint32_t wave_sum(uint32_t v)
-{
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-    return v;
-}
-
-template <bool COUNT>
-__device__ void flush_counters(const LaneCounters &c, unsigned long long *counters)
-{
-    if constexpr (COUNT)
-    {
-        // order = prosper_pt_counters fields
-        const uint32_t vals[14] = {c.paths, c.closestRays, c.shadowRays, c.nodeVisits, c.triangleTests, c.closestHits,
-                                   c.anyHitCalls, c.lightSamples, c.spotLightSamples, c.skyLookups, c.pixelsWritten,
-                                   c.historyReads, c.shortIndexHits, c.shortIndexTriangleTests};
-        for (int i = 0; i < 14; ++i)
-        {
-            const uint32_t sum = wave_sum(vals[i]);
-            if ((threadIdx.x & 63) == 0 && sum) atomicAdd(&counters[i], (unsigned long long)sum);
-        }
-    }
-}
-
-// Local pixel column -> absolute image column for the stripe partition (prosper_pt_tile_desc).
-__device__ __forceinline__ uint32_t local_to_global_x(const RenderParams &p, uint32_t lx)
-{
-    if (p.stripeWidth == 0) return lx;
-    const uint32_t ls = lx / p.stripeWidth;
-    return (ls * p.stripeCount + p.stripeIndex) * p.stripeWidth + (lx % p.stripeWidth);
-}
-
 // One lane per pixel; a wave covers an 8x8 pixel tile, a 256-thread workgroup a 16x16 tile.
 // Workgroups are dealt round-robin over the 8 XCDs (b and b+8 share an XCD's L2), so the block id
 // is remapped to give each XCD a contiguous band of tiles (speed only, never correctness).
@@ -262,6 +232,202 @@ void launch_render_megakernel(
         hipLaunchKernelGGL(render_megakernel<true>, grid, block, 0, stream, s, p, hdr, counters);
     else
         hipLaunchKernelGGL(render_megakernel<false>, grid, block, 0, stream, s, p, hdr, counters);
+}
+
+// ------------------------------------------------------------------------------------------
+// Persistent waves with path regeneration.
+//
+// One lane per pixel wastes half the machine on this path: paths end after 1..maxBounces bounces
+// (miss, roulette), so within a wave the set of live lanes shrinks every bounce.  Here a fixed set
+// of resident waves pulls pixels from one global counter; every loop iteration runs ONE bounce for
+// all live lanes (all lanes traverse together, then shade together), and a lane whose path ended
+// starts its pixel's next accumulated frame - or claims the next pixel with a wave-aggregated
+// atomic (ballot + popcount, one atomic per wave) - before the next iteration.  A pixel's frames
+// stay on one lane in order, so the running mean of main.rgen:289-297 is evaluated exactly as by
+// frame-at-a-time rendering (same bits), with the history in registers.
+// Work order: 8x8-pixel tiles in row-major tile order, so a wave's first claim is one coherent tile.
+// ------------------------------------------------------------------------------------------
+
+// One iteration of the while loop of main.rgen:241-283 for one lane; returns true when the path
+// has ended (its radiance is then in st.color).
+template <bool COUNT>
+__device__ __forceinline__ bool path_bounce(
+    const DeviceScene &s, const RenderParams &p, PathState &st, int32_t *stack, LaneCounters &cnt)
+{
+    Hit hit;
+    if constexpr (COUNT) cnt.closestRays++;
+    const bool found = trace<false, COUNT>(s, st.o, st.d, 0.0f, kInf, pcg(st.rng.x ^ st.rng.z), stack, hit, cnt);
+    if (!found)
+    {
+        if (p.pc.flags & PROSPER_PC_FLAG_IBL)
+        {
+            if constexpr (COUNT) cnt.skyLookups++;
+            add_bounce(p.pc.flags, st.color, st.throughput * sample_skybox(s, st.d), st.bounce);
+        }
+        return true;
+    }
+    const Surface sf = evaluate_surface<COUNT>(s, st.d, hit, cnt);
+    if (p.pc.drawType != PROSPER_DRAW_TYPE_DEFAULT && p.pc.drawType != PROSPER_DRAW_TYPE_MESHLET_ID)
+    {
+        st.color = debug_color(s, p.pc.drawType, hit, sf);
+        return true;
+    }
+    {
+        f3 l, irradiance;
+        float d;
+        f3 direct = f3{0.0f, 0.0f, 0.0f};
+        if (prepare_direct_lighting<COUNT>(s, sf, st.throughput, st.rng, l, d, irradiance, cnt))
+        {
+            Hit sh;
+            if constexpr (COUNT) cnt.shadowRays++;
+            const bool occluded =
+                trace<true, COUNT>(s, sf.positionWS, l, 0.1f, d, pcg(st.rng.x ^ st.rng.y), stack, sh, cnt);
+            direct = finish_direct_lighting(s, sf, st.throughput, l, irradiance, occluded ? 0.0f : 1.0f);
+        }
+        add_bounce(p.pc.flags, st.color, direct, st.bounce);
+    }
+    f3 rd;
+    importance_sample_bounce(sf, st.rng, st.throughput, rd);
+    if (st.bounce > p.pc.rouletteStartBounce)
+    {
+        if (st.rng.rnd01() < fmax_(0.05f, 1.0f - max3(st.throughput))) return true;
+    }
+    st.o = offset_ray(sf.positionWS, sf.normalWS);
+    st.d = rd;
+    st.bounce++;
+    // the loop conditions of main.rgen:241-244, evaluated now instead of next iteration
+    return st.bounce >= PROSPER_RT_MAX_BOUNCES || st.bounce >= p.pc.maxBounces;
+}
+
+template <bool COUNT>
+__global__ __launch_bounds__(256) void render_persistent(
+    DeviceScene s, RenderParams p, float4 *__restrict__ hdr, unsigned long long *__restrict__ counters,
+    uint32_t *__restrict__ workCounter)
+{
+    __shared__ int32_t ldsStack[kTraversalStackDepth * 256];
+    const uint32_t wave = threadIdx.x >> 6;
+    const uint32_t lane = threadIdx.x & 63u;
+    int32_t *stack = ldsStack + wave * (kTraversalStackDepth * 64u) + lane;
+
+    const uint32_t tilesX = (p.localWidth + 7u) / 8u;
+    const uint32_t tilesY = (p.height + 7u) / 8u;
+    const uint32_t totalWork = tilesX * tilesY * 64u;
+    const bool zeroBounces = p.pc.maxBounces == 0;
+
+    LaneCounters cnt = {};
+    PathState st = {};
+    float4 history = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    uint32_t lx = 0, py = 0, px = 0;
+    uint32_t frame = 0;    // accumulated frames finished for the current pixel
+    bool havePixel = false; // lane owns a pixel
+    bool active = false;    // lane has a path in flight
+    bool done = false;      // work counter exhausted
+
+    while (true)
+    {
+        if (!active && !done)
+        {
+            if (havePixel && frame >= p.frameCount)
+            {
+                hdr[(size_t)py * p.localWidth + lx] = history;
+                havePixel = false;
+            }
+            if (!havePixel)
+            {
+                // wave-aggregated claim of the next work items
+                const unsigned long long need = __ballot(1);
+                const uint32_t leader = (uint32_t)__builtin_ctzll(need);
+                uint32_t base = 0;
+                if (lane == leader) base = atomicAdd(workCounter, (uint32_t)__builtin_popcountll(need));
+                base = __shfl(base, leader, 64);
+                const uint32_t idx = base + (uint32_t)__builtin_popcountll(need & ((1ull << lane) - 1ull));
+                if (idx >= totalWork)
+                    done = true;
+                else
+                {
+                    const uint32_t tile = idx >> 6, inTile = idx & 63u;
+                    lx = (tile % tilesX) * 8u + (inTile & 7u);
+                    py = (tile / tilesX) * 8u + (inTile >> 3);
+                    if (lx < p.localWidth && py < p.height)
+                    {
+                        px = local_to_global_x(p, lx);
+                        havePixel = true;
+                        frame = 0;
+                    }
+                }
+            }
+            if (havePixel)
+            {
+                start_path<COUNT>(p, px, py, (p.pc.frameIndex + frame) % PROSPER_RT_FRAME_PERIOD, st, cnt);
+                active = true;
+            }
+        }
+        if (__ballot(active) == 0ull)
+        {
+            if (__ballot(!done) == 0ull) break;
+            continue;
+        }
+        if (active)
+        {
+            const bool ended = zeroBounces ? true : path_bounce<COUNT>(s, p, st, stack, cnt);
+            if (ended)
+            {
+                // main.rgen:285-298; skipHistory applies to the first frame of a batch only
+                const bool skip = (frame == 0 && (p.pc.flags & PROSPER_PC_FLAG_SKIP_HISTORY)) ||
+                                  !(p.pc.flags & PROSPER_PC_FLAG_ACCUMULATE);
+                if (skip)
+                    history = make_float4(st.color.x, st.color.y, st.color.z, 1.0f);
+                else
+                {
+                    if (frame == 0) history = hdr[(size_t)py * p.localWidth + lx];
+                    if constexpr (COUNT) cnt.historyReads++;
+                    const float hc = history.w + 1.0f;
+                    history = make_float4(
+                        history.x + (st.color.x - history.x) / hc, history.y + (st.color.y - history.y) / hc,
+                        history.z + (st.color.z - history.z) / hc, hc);
+                }
+                if constexpr (COUNT) cnt.pixelsWritten++;
+                frame++;
+                active = false;
+            }
+        }
+    }
+    flush_counters<COUNT>(cnt, counters);
+}
+
+uint32_t persistent_grid_blocks()
+{
+    static uint32_t cached = 0;
+    if (cached) return cached;
+    int perCu = 0, dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess ||
+        hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCu, render_persistent<false>, 256, 0) != hipSuccess || perCu < 1)
+    {
+        perCu = 2;
+        prop.multiProcessorCount = 256;
+    }
+    cached = (uint32_t)perCu * (uint32_t)prop.multiProcessorCount;
+    return cached;
+}
+
+void launch_render_persistent(
+    const DeviceScene &s, const RenderParams &p, float4 *hdr, unsigned long long *counters, uint32_t *workCounter,
+    bool countWork, hipStream_t stream)
+{
+    const uint32_t tilesX = (p.localWidth + 7u) / 8u;
+    const uint32_t tilesY = (p.height + 7u) / 8u;
+    const uint32_t waves = tilesX * tilesY;
+    if (waves == 0) return;
+    (void)hipMemsetAsync(workCounter, 0, sizeof(uint32_t), stream);
+    uint32_t blocks = persistent_grid_blocks();
+    const uint32_t needed = (waves + 3u) / 4u;
+    if (blocks > needed) blocks = needed;
+    const dim3 grid(blocks), block(256);
+    if (countWork)
+        hipLaunchKernelGGL(render_persistent<true>, grid, block, 0, stream, s, p, hdr, counters, workCounter);
+    else
+        hipLaunchKernelGGL(render_persistent<false>, grid, block, 0, stream, s, p, hdr, counters, workCounter);
 }
 
 // ------------------------------------------------------------------------------------------

@@ -5,6 +5,7 @@
 // (src/scene/World.cpp:585-802) is this build's own flattened BVH (DESIGN.md "BVH").
 #pragma once
 
+#include <hip/hip_runtime.h>
 #include <stdint.h>
 
 #include "../../include/prosper_pt/prosper_pt.h"
@@ -95,6 +96,33 @@ struct RenderParams
     uint32_t stripeCount;
     uint32_t localWidth;
     uint32_t frameCount; // consecutive accumulated frames rendered by this launch
+    uint32_t pad;
+};
+
+// Workspace of the wavefront pipeline (pt_wavefront.hip).  Paths live in fixed-length SEGMENTS of
+// `segLen` slots, one segment per wave; every stage compacts its survivors to the front of the
+// wave's own segment with ballot/popcount, so there is no global queue counter and no atomic.
+// slot = frame * pixelsPadded + tile * 64 + laneInTile identifies the (pixel, accumulated frame).
+struct WavefrontBuffers
+{
+    float4 *rayA[2];  // (origin.xyz, closest-ray seed)        ping-pong by bounce parity
+    float4 *rayB[2];  // (direction.xyz, -)
+    float4 *pathT[2]; // (throughput.rgb, slot)
+    uint4 *pathR[2];  // (rng state x,y,z, -)
+    uint4 *hit;       // (drawInstance, primitive, bary.u, bary.v), compacted per segment
+    uint32_t *hitIdx; // in-segment index of the ray each compacted hit came from
+    float4 *shA;      // shadow rays: (origin.xyz, seed)
+    float4 *shB;      // (direction.xyz, distance)
+    float4 *shC;      // (unoccluded contribution.rgb, slot | nanMask << 28)
+    float4 *color;    // per slot: radiance of that path so far
+    uint32_t *segRays;   // [nSeg] live rays in rayA/B[cur]
+    uint32_t *segHits;   // [nSeg]
+    uint32_t *segShadow; // [nSeg]
+    uint32_t segLen;
+    uint32_t nSeg;
+    uint32_t pixelsPadded; // tilesX * tilesY * 64
+    uint32_t tilesX;
+    uint32_t tilesY;
     uint32_t pad;
 };
 

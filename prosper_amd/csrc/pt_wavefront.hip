@@ -1,0 +1,454 @@
+// pt_wavefront.hip — wavefront formulation of the path-tracing reference pass (gfx950).
+//
+// The megakernel of rt/reference/main.rgen:225-299 runs at ~25 % lane utilisation on 64-wide
+// waves (measured: SQ_THREAD_CYCLES_VALU / SQ_INSTS_VALU, profiles/): lanes whose ray missed sit
+// through the shading of the others, only the lanes that drew a front-facing light traverse the
+// shadow ray, and every traversal loop runs as long as its slowest lane.  Here the loop body is cut
+// into stage kernels and each stage only ever sees live work:
+//
+//   generate_extend   camera rays (ray.glsl:15-78) + first traceClosest, sky on a miss
+//   shade             evaluateSurface + evaluateDirectLighting (without visibility) +
+//                     importanceSampleBounce + roulette (main.rgen:146-223,90-144,269-276)
+//   shadow            shadow() any-hit traversal (main.rgen:49-60), adds the direct term
+//   extend            traceClosest of the next bounce (main.rgen:62-81), sky on a miss
+//   accumulate        running mean over the batch's frames + history (main.rgen:285-298)
+//
+// Scheduling is per WAVE: a wave owns one fixed segment of path slots (WavefrontBuffers) through
+// all bounces and compacts survivors to the front of its segment with __ballot + popcount.  No
+// global queue, no atomics, fully coalesced 16-byte-per-lane state traffic, and the memory layout
+// (hence every sum) is identical from run to run.  Results are bit-identical to the megakernel:
+// every path keeps its own RNG stream and its contributions are added in the reference's order
+// (direct of bounce b, then sky of bounce b+1).
+#include "pt_kernels.hpp"
+
+#include "pt_device.hpp"
+#include "pt_render_common.hpp"
+
+namespace ppt
+{
+
+namespace
+{
+
+constexpr uint32_t kSlotMask = 0x0FFFFFFFu;
+
+struct SegmentId
+{
+    uint32_t seg;
+    uint32_t base;
+    bool valid;
+};
+
+// Workgroup -> 4 consecutive segments; block ids are remapped so that each XCD (blocks b, b+8, ...)
+// works on one contiguous range of segments, i.e. one band of the image (speed only).
+__device__ __forceinline__ SegmentId my_segment(const WavefrontBuffers &w)
+{
+    const uint32_t groups = (w.nSeg + 3u) / 4u;
+    const uint32_t perXcd = (groups + 7u) / 8u;
+    const uint32_t group = (blockIdx.x % 8u) * perXcd + (blockIdx.x / 8u);
+    const uint32_t seg = group * 4u + (threadIdx.x >> 6);
+    SegmentId id;
+    id.seg = seg;
+    id.base = seg * w.segLen;
+    id.valid = group < groups && seg < w.nSeg;
+    return id;
+}
+
+__device__ __forceinline__ uint32_t lane_id() { return threadIdx.x & 63u; }
+
+// Exclusive rank of this lane among the lanes whose predicate is set, and the total.
+__device__ __forceinline__ uint32_t wave_rank(bool pred, uint32_t &total)
+{
+    const unsigned long long m = __ballot(pred);
+    total = (uint32_t)__builtin_popcountll(m);
+    return (uint32_t)__builtin_popcountll(m & ((1ull << lane_id()) - 1ull));
+}
+
+__device__ __forceinline__ f3 xyz(float4 v) { return f3{v.x, v.y, v.z}; }
+__device__ __forceinline__ uint32_t asu(float f) { return __builtin_bit_cast(uint32_t, f); }
+__device__ __forceinline__ float asf(uint32_t u) { return __builtin_bit_cast(float, u); }
+
+struct SlotPixel
+{
+    uint32_t lx, py, frame;
+    bool valid;
+};
+__device__ __forceinline__ SlotPixel decode_slot(const WavefrontBuffers &w, const RenderParams &p, uint32_t slot)
+{
+    SlotPixel r;
+    r.frame = slot / w.pixelsPadded;
+    const uint32_t rem = slot - r.frame * w.pixelsPadded;
+    const uint32_t tile = rem >> 6, inTile = rem & 63u;
+    const uint32_t ty = tile / w.tilesX;
+    r.lx = (tile - ty * w.tilesX) * 8u + (inTile & 7u);
+    r.py = ty * 8u + (inTile >> 3);
+    r.valid = r.frame < p.frameCount && r.lx < p.localWidth && r.py < p.height;
+    return r;
+}
+
+// addBounce (main.rgen:83-88) into the path's radiance slot
+__device__ __forceinline__ void add_to_slot(float4 *color, uint32_t slot, uint32_t flags, f3 value, uint32_t bounce)
+{
+    float4 c = color[slot];
+    f3 acc = f3{c.x, c.y, c.z};
+    add_bounce(flags, acc, value, bounce);
+    color[slot] = make_float4(acc.x, acc.y, acc.z, 0.0f);
+}
+
+} // namespace
+
+// ------------------------------------------------------------------------------------------
+// generate + first extend
+// ------------------------------------------------------------------------------------------
+
+template <bool COUNT>
+__global__ __launch_bounds__(256) void wf_generate_extend(
+    DeviceScene s, RenderParams p, WavefrontBuffers w, unsigned long long *__restrict__ counters)
+{
+    __shared__ int32_t ldsStack[kTraversalStackDepth * 256];
+    const SegmentId id = my_segment(w);
+    if (!id.valid) return;
+    const uint32_t lane = lane_id();
+    int32_t *stack = ldsStack + (threadIdx.x >> 6) * (kTraversalStackDepth * 64u) + lane;
+    const bool traceRays = p.pc.maxBounces > 0;
+
+    LaneCounters cnt = {};
+    uint32_t nHit = 0;
+    for (uint32_t k0 = 0; k0 < w.segLen; k0 += 64u)
+    {
+        const uint32_t k = k0 + lane;
+        const uint32_t slot = id.base + k;
+        const SlotPixel sp = decode_slot(w, p, slot);
+        bool found = false;
+        Hit hit;
+        if (sp.valid)
+        {
+            const uint32_t px = local_to_global_x(p, sp.lx);
+            PathState st;
+            start_path<COUNT>(p, px, sp.py, (p.pc.frameIndex + sp.frame) % PROSPER_RT_FRAME_PERIOD, st, cnt);
+            f3 color = f3{0.0f, 0.0f, 0.0f};
+            if (traceRays)
+            {
+                if constexpr (COUNT) cnt.closestRays++;
+                found = trace<false, COUNT>(s, st.o, st.d, 0.0f, kInf, pcg(st.rng.x ^ st.rng.z), stack, hit, cnt);
+                if (!found && (p.pc.flags & PROSPER_PC_FLAG_IBL))
+                {
+                    if constexpr (COUNT) cnt.skyLookups++;
+                    add_bounce(p.pc.flags, color, st.throughput * sample_skybox(s, st.d), 0u);
+                }
+            }
+            w.color[slot] = make_float4(color.x, color.y, color.z, 0.0f);
+            if (found)
+            {
+                w.rayB[0][slot] = make_float4(st.d.x, st.d.y, st.d.z, 0.0f);
+                w.pathT[0][slot] = make_float4(1.0f, 1.0f, 1.0f, asf(slot));
+                w.pathR[0][slot] = make_uint4(st.rng.x, st.rng.y, st.rng.z, 0u);
+            }
+        }
+        uint32_t total;
+        const uint32_t pos = nHit + wave_rank(found, total);
+        if (found)
+        {
+            w.hit[id.base + pos] =
+                make_uint4(hit.drawInstance, hit.primitive, asu(hit.bary.x), asu(hit.bary.y));
+            w.hitIdx[id.base + pos] = k;
+        }
+        nHit += total;
+    }
+    if (lane == 0) w.segHits[id.seg] = nHit;
+    flush_counters<COUNT>(cnt, counters);
+}
+
+// ------------------------------------------------------------------------------------------
+// extend: traceClosest of bounce >= 1
+// ------------------------------------------------------------------------------------------
+
+template <bool COUNT>
+__global__ __launch_bounds__(256) void wf_extend(
+    DeviceScene s, RenderParams p, WavefrontBuffers w, uint32_t bounce, uint32_t cur,
+    unsigned long long *__restrict__ counters)
+{
+    __shared__ int32_t ldsStack[kTraversalStackDepth * 256];
+    const SegmentId id = my_segment(w);
+    if (!id.valid) return;
+    const uint32_t lane = lane_id();
+    int32_t *stack = ldsStack + (threadIdx.x >> 6) * (kTraversalStackDepth * 64u) + lane;
+    const float4 *__restrict__ rayA = w.rayA[cur];
+    const float4 *__restrict__ rayB = w.rayB[cur];
+
+    LaneCounters cnt = {};
+    const uint32_t n = w.segRays[id.seg];
+    uint32_t nHit = 0;
+    for (uint32_t i0 = 0; i0 < n; i0 += 64u)
+    {
+        const uint32_t i = i0 + lane;
+        bool found = false;
+        Hit hit;
+        if (i < n)
+        {
+            const float4 a = rayA[id.base + i];
+            const float4 b = rayB[id.base + i];
+            if constexpr (COUNT) cnt.closestRays++;
+            found = trace<false, COUNT>(s, xyz(a), xyz(b), 0.0f, kInf, asu(a.w), stack, hit, cnt);
+            if (!found && (p.pc.flags & PROSPER_PC_FLAG_IBL))
+            {
+                if constexpr (COUNT) cnt.skyLookups++;
+                const float4 t = w.pathT[cur][id.base + i];
+                add_to_slot(w.color, asu(t.w) & kSlotMask, p.pc.flags, xyz(t) * sample_skybox(s, xyz(b)), bounce);
+            }
+        }
+        uint32_t total;
+        const uint32_t pos = nHit + wave_rank(found, total);
+        if (found)
+        {
+            w.hit[id.base + pos] =
+                make_uint4(hit.drawInstance, hit.primitive, asu(hit.bary.x), asu(hit.bary.y));
+            w.hitIdx[id.base + pos] = i;
+        }
+        nHit += total;
+    }
+    if (lane == 0) w.segHits[id.seg] = nHit;
+    flush_counters<COUNT>(cnt, counters);
+}
+
+// ------------------------------------------------------------------------------------------
+// shade
+// ------------------------------------------------------------------------------------------
+
+template <bool COUNT>
+__global__ __launch_bounds__(256) void wf_shade(
+    DeviceScene s, RenderParams p, WavefrontBuffers w, uint32_t bounce, uint32_t cur, uint32_t lastBounce,
+    unsigned long long *__restrict__ counters)
+{
+    const SegmentId id = my_segment(w);
+    if (!id.valid) return;
+    const uint32_t lane = lane_id();
+    const uint32_t nxt = cur ^ 1u;
+    const bool debugDraw =
+        p.pc.drawType != PROSPER_DRAW_TYPE_DEFAULT && p.pc.drawType != PROSPER_DRAW_TYPE_MESHLET_ID;
+
+    LaneCounters cnt = {};
+    const uint32_t n = w.segHits[id.seg];
+    uint32_t nShadow = 0, nNext = 0;
+    for (uint32_t j0 = 0; j0 < n; j0 += 64u)
+    {
+        const uint32_t j = j0 + lane;
+        bool wantShadow = false, wantNext = false;
+        // shadow-ray record
+        f3 shP = {}, shL = {}, shC1 = {};
+        float shDist = 0.0f;
+        uint32_t shSeed = 0, nanMask = 0;
+        // next-ray record
+        f3 nO = {}, nD = {}, nT = {};
+        Rng rng = {};
+        uint32_t slot = 0;
+        if (j < n)
+        {
+            const uint32_t i = w.hitIdx[id.base + j];
+            const uint4 h = w.hit[id.base + j];
+            const float4 b = w.rayB[cur][id.base + i];
+            const float4 t = w.pathT[cur][id.base + i];
+            const uint4 r = w.pathR[cur][id.base + i];
+            slot = asu(t.w) & kSlotMask;
+            rng = Rng{r.x, r.y, r.z};
+            const f3 throughput = xyz(t);
+            Hit hit;
+            hit.drawInstance = h.x;
+            hit.primitive = h.y;
+            hit.bary = f2{asf(h.z), asf(h.w)};
+            hit.t = 0.0f;
+            const Surface sf = evaluate_surface<COUNT>(s, xyz(b), hit, cnt);
+            if (debugDraw)
+            {
+                const f3 c = debug_color(s, p.pc.drawType, hit, sf);
+                w.color[slot] = make_float4(c.x, c.y, c.z, 0.0f); // `color =`, not `+=` (main.rgen:262)
+            }
+            else
+            {
+                f3 l, irradiance;
+                float d;
+                if (prepare_direct_lighting<COUNT>(s, sf, throughput, rng, l, d, irradiance, cnt))
+                {
+                    wantShadow = true;
+                    if constexpr (COUNT) cnt.shadowRays++;
+                    shSeed = pcg(rng.x ^ rng.y);
+                    shP = sf.positionWS;
+                    shL = l;
+                    shDist = d;
+                    const f3 brdf = eval_brdf_times_nol(l, sf);
+                    shC1 = direct_lighting_value(s, throughput, irradiance, brdf, 1.0f);
+                    // what the reference adds when the light is occluded is (t * (irr*0*n)) * brdf:
+                    // +-0 unless a factor is non-finite; remember which channels come out NaN
+                    const f3 c0 = direct_lighting_value(s, throughput, irradiance, brdf, 0.0f);
+                    nanMask = (c0.x != c0.x ? 1u : 0u) | (c0.y != c0.y ? 2u : 0u) | (c0.z != c0.z ? 4u : 0u);
+                }
+                if (!lastBounce)
+                {
+                    f3 rd;
+                    f3 tp = throughput;
+                    importance_sample_bounce(sf, rng, tp, rd);
+                    bool alive = true;
+                    if (bounce > p.pc.rouletteStartBounce)
+                        alive = !(rng.rnd01() < fmax_(0.05f, 1.0f - max3(tp)));
+                    if (alive)
+                    {
+                        wantNext = true;
+                        nO = offset_ray(sf.positionWS, sf.normalWS);
+                        nD = rd;
+                        nT = tp;
+                    }
+                }
+            }
+        }
+        uint32_t total;
+        uint32_t pos = nShadow + wave_rank(wantShadow, total);
+        if (wantShadow)
+        {
+            w.shA[id.base + pos] = make_float4(shP.x, shP.y, shP.z, asf(shSeed));
+            w.shB[id.base + pos] = make_float4(shL.x, shL.y, shL.z, shDist);
+            w.shC[id.base + pos] = make_float4(shC1.x, shC1.y, shC1.z, asf(slot | (nanMask << 28)));
+        }
+        nShadow += total;
+        pos = nNext + wave_rank(wantNext, total);
+        if (wantNext)
+        {
+            w.rayA[nxt][id.base + pos] = make_float4(nO.x, nO.y, nO.z, asf(pcg(rng.x ^ rng.z)));
+            w.rayB[nxt][id.base + pos] = make_float4(nD.x, nD.y, nD.z, 0.0f);
+            w.pathT[nxt][id.base + pos] = make_float4(nT.x, nT.y, nT.z, asf(slot));
+            w.pathR[nxt][id.base + pos] = make_uint4(rng.x, rng.y, rng.z, 0u);
+        }
+        nNext += total;
+    }
+    if (lane == 0)
+    {
+        w.segShadow[id.seg] = nShadow;
+        w.segRays[id.seg] = nNext;
+    }
+    flush_counters<COUNT>(cnt, counters);
+}
+
+// ------------------------------------------------------------------------------------------
+// shadow
+// ------------------------------------------------------------------------------------------
+
+template <bool COUNT>
+__global__ __launch_bounds__(256) void wf_shadow(
+    DeviceScene s, RenderParams p, WavefrontBuffers w, uint32_t bounce, unsigned long long *__restrict__ counters)
+{
+    __shared__ int32_t ldsStack[kTraversalStackDepth * 256];
+    const SegmentId id = my_segment(w);
+    if (!id.valid) return;
+    const uint32_t lane = lane_id();
+    int32_t *stack = ldsStack + (threadIdx.x >> 6) * (kTraversalStackDepth * 64u) + lane;
+
+    LaneCounters cnt = {};
+    const uint32_t n = w.segShadow[id.seg];
+    for (uint32_t k0 = 0; k0 < n; k0 += 64u)
+    {
+        const uint32_t k = k0 + lane;
+        if (k < n)
+        {
+            const float4 a = w.shA[id.base + k];
+            const float4 b = w.shB[id.base + k];
+            Hit sh;
+            const bool occluded = trace<true, COUNT>(s, xyz(a), xyz(b), 0.1f, b.w, asu(a.w), stack, sh, cnt);
+            const float4 c = w.shC[id.base + k];
+            const uint32_t packed = asu(c.w);
+            const uint32_t nanMask = packed >> 28;
+            if (!occluded || nanMask)
+            {
+                f3 v = xyz(c);
+                if (occluded)
+                {
+                    const float nan = __builtin_nanf("");
+                    v = f3{(nanMask & 1u) ? nan : 0.0f, (nanMask & 2u) ? nan : 0.0f, (nanMask & 4u) ? nan : 0.0f};
+                }
+                add_to_slot(w.color, packed & kSlotMask, p.pc.flags, v, bounce);
+            }
+        }
+    }
+    flush_counters<COUNT>(cnt, counters);
+}
+
+// ------------------------------------------------------------------------------------------
+// accumulate: main.rgen:285-298 over the frames of the batch, in order
+// ------------------------------------------------------------------------------------------
+
+template <bool COUNT>
+__global__ __launch_bounds__(256) void wf_accumulate(
+    RenderParams p, WavefrontBuffers w, float4 *__restrict__ hdr, unsigned long long *__restrict__ counters)
+{
+    const uint32_t rem = blockIdx.x * blockDim.x + threadIdx.x;
+    LaneCounters cnt = {};
+    if (rem < w.pixelsPadded)
+    {
+        const SlotPixel sp = decode_slot(w, p, rem);
+        if (sp.valid)
+        {
+            float4 *texel = hdr + (size_t)sp.py * p.localWidth + sp.lx;
+            float4 history = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            for (uint32_t f = 0; f < p.frameCount; ++f)
+            {
+                const float4 c = w.color[(size_t)f * w.pixelsPadded + rem];
+                const bool skip = (f == 0 && (p.pc.flags & PROSPER_PC_FLAG_SKIP_HISTORY)) ||
+                                  !(p.pc.flags & PROSPER_PC_FLAG_ACCUMULATE);
+                if (skip)
+                    history = make_float4(c.x, c.y, c.z, 1.0f);
+                else
+                {
+                    if (f == 0) history = *texel;
+                    if constexpr (COUNT) cnt.historyReads++;
+                    const float hc = history.w + 1.0f;
+                    history = make_float4(
+                        history.x + (c.x - history.x) / hc, history.y + (c.y - history.y) / hc,
+                        history.z + (c.z - history.z) / hc, hc);
+                }
+                if constexpr (COUNT) cnt.pixelsWritten++;
+            }
+            *texel = history;
+        }
+    }
+    flush_counters<COUNT>(cnt, counters);
+}
+
+// ------------------------------------------------------------------------------------------
+// host-side sequencing
+// ------------------------------------------------------------------------------------------
+
+template <bool COUNT>
+static void enqueue_wavefront(
+    const DeviceScene &s, const RenderParams &p, float4 *hdr, unsigned long long *counters, const WavefrontBuffers &w,
+    hipStream_t stream)
+{
+    const uint32_t groups = (w.nSeg + 3u) / 4u;
+    const dim3 grid(((groups + 7u) / 8u) * 8u), block(256);
+    uint32_t bounces = p.pc.maxBounces < PROSPER_RT_MAX_BOUNCES ? p.pc.maxBounces : PROSPER_RT_MAX_BOUNCES;
+    const bool debugDraw =
+        p.pc.drawType != PROSPER_DRAW_TYPE_DEFAULT && p.pc.drawType != PROSPER_DRAW_TYPE_MESHLET_ID;
+    if (debugDraw && bounces > 1) bounces = 1; // every hit ends its path in the first shade
+
+    hipLaunchKernelGGL(wf_generate_extend<COUNT>, grid, block, 0, stream, s, p, w, counters);
+    for (uint32_t b = 0; b < bounces; ++b)
+    {
+        const uint32_t cur = b & 1u;
+        const uint32_t last = (b + 1u == bounces) ? 1u : 0u;
+        hipLaunchKernelGGL(wf_shade<COUNT>, grid, block, 0, stream, s, p, w, b, cur, last, counters);
+        if (!debugDraw) hipLaunchKernelGGL(wf_shadow<COUNT>, grid, block, 0, stream, s, p, w, b, counters);
+        if (!last) hipLaunchKernelGGL(wf_extend<COUNT>, grid, block, 0, stream, s, p, w, b + 1u, cur ^ 1u, counters);
+    }
+    hipLaunchKernelGGL(
+        wf_accumulate<COUNT>, dim3((w.pixelsPadded + 255u) / 256u), block, 0, stream, p, w, hdr, counters);
+}
+
+void launch_render_wavefront(
+    const DeviceScene &s, const RenderParams &p, float4 *hdr, unsigned long long *counters, const WavefrontBuffers &w,
+    bool countWork, hipStream_t stream)
+{
+    if (w.nSeg == 0) return;
+    if (countWork)
+        enqueue_wavefront<true>(s, p, hdr, counters, w, stream);
+    else
+        enqueue_wavefront<false>(s, p, hdr, counters, w, stream);
+}
+
+} // namespace ppt

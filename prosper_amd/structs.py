@@ -152,6 +152,7 @@ FILTER_NEAREST, FILTER_LINEAR = 0, 1
 WRAP_REPEAT, WRAP_MIRRORED_REPEAT, WRAP_CLAMP_TO_EDGE = 0, 1, 2
 
 CREATE_MEGAKERNEL = 1 << 0
+CREATE_PERSISTENT = 1 << 1
 RENDER_COUNT_WORK = 1 << 0
 MAX_KERNELS = 8
 

@@ -410,3 +410,33 @@ def test_full_size_c2_properties(gpu_ctx, oracle, cornell_world):
         p = default_pc(S, fl, frame_index=frame, max_bounces=4, skip_history=(frame == 1))
         want, _ = osc.render(p, cam, w, h, history=want)
     assert same_bits(got2, want).all()
+
+
+def test_all_pipelines_produce_identical_pixels(gpu_ctx, oracle, cornell_world):
+    """Default wavefront pipeline, PROSPER_PT_CREATE_PERSISTENT and PROSPER_PT_CREATE_MEGAKERNEL are
+    the same function of (pixel, frame): identical images, identical counters, all equal to the oracle."""
+    from prosper_amd import capi
+    w, h = 200, 120  # not a multiple of the 8x8 / 16x16 tiles: exercises partial tiles
+    cam, fl = _camera(oracle, cornell_world, w, h)
+    others = [capi.Context(device=0, flags=S.CREATE_MEGAKERNEL), capi.Context(device=0, flags=S.CREATE_PERSISTENT)]
+    images, counts = [], []
+    for ctx in [gpu_ctx] + others:
+        ctx.upload_scene(cornell_world)
+        ctx.reset_counters()
+        ctx.render(default_pc(S, fl, max_bounces=5, ibl=True, roulette=1), cam, w, h, frames=3, flags=S.RENDER_COUNT_WORK)
+        images.append(ctx.read_hdr())
+        counts.append(ctx.counters().as_dict())
+    for ctx in others:
+        ctx.close()
+    assert same_bits(images[0], images[1]).all() and same_bits(images[0], images[2]).all()
+    assert counts[0] == counts[1] == counts[2]
+    osc = oracle.OracleScene(cornell_world, brute_force=True)
+    want = None
+    for f in (1, 2, 3):
+        want, _ = osc.render(default_pc(S, fl, frame_index=f, max_bounces=5, ibl=True, roulette=1, skip_history=(f == 1)),
+                             cam, w, h, history=want)
+    assert same_bits(images[0], want).all()
+    # maxBounces = 0 never traces: black image, count 1
+    gpu_ctx.render(default_pc(S, fl, max_bounces=0), cam, w, h)
+    z = gpu_ctx.read_hdr()
+    assert (z[..., :3] == 0).all() and (z[..., 3] == 1).all()
