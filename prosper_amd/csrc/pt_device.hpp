@@ -780,19 +780,34 @@ PPT_D bool any_hit(
     const DeviceScene &s, uint32_t drawInstance, uint32_t primitive, f2 bary, uint32_t randomSeed, LaneCounters &cnt)
 {
     const prosper_DrawInstance inst = s.drawInstances[drawInstance];
-    const prosper_GeometryMetadata m = s.geometryMetadatas[inst.meshIndex];
-    // geometry.glsl:246-256
-    const f2 uv0 = load_r16g16(s, m.bufferIndex, m.texCoord0sOffset, load_index(s, m, primitive * 3 + 0));
-    const f2 uv1 = load_r16g16(s, m.bufferIndex, m.texCoord0sOffset, load_index(s, m, primitive * 3 + 1));
-    const f2 uv2 = load_r16g16(s, m.bufferIndex, m.texCoord0sOffset, load_index(s, m, primitive * 3 + 2));
-    const float a = (1.0f - bary.x) - bary.y;
-    const f2 uv = f2{bary1(uv0.x, uv1.x, uv2.x, a, bary.x, bary.y), bary1(uv0.y, uv1.y, uv2.y, a, bary.x, bary.y)};
-    if constexpr (COUNT)
+    const prosper_MaterialData data = s.materials[inst.materialIndex];
+    // materials.glsl:121-147 (sampleAlpha); the uv fetch of scene.rahit:23-27 only matters when the
+    // material has a base-colour texture, so untextured materials skip the geometry loads
+    float linearAlpha = 1.0f;
+    const uint32_t baseTex = data.baseColorTextureSampler & 0xFFFFFFu;
+    if constexpr (COUNT) cnt.anyHitCalls++;
+    if (baseTex > 0 || COUNT)
     {
-        cnt.anyHitCalls++;
-        cnt.shortIndexHits += m.usesShortIndices == 1 ? 1u : 0u;
+        const prosper_GeometryMetadata m = s.geometryMetadatas[inst.meshIndex];
+        if constexpr (COUNT) cnt.shortIndexHits += m.usesShortIndices == 1 ? 1u : 0u;
+        if (baseTex > 0)
+        {
+            // geometry.glsl:246-256
+            const f2 uv0 = load_r16g16(s, m.bufferIndex, m.texCoord0sOffset, load_index(s, m, primitive * 3 + 0));
+            const f2 uv1 = load_r16g16(s, m.bufferIndex, m.texCoord0sOffset, load_index(s, m, primitive * 3 + 1));
+            const f2 uv2 = load_r16g16(s, m.bufferIndex, m.texCoord0sOffset, load_index(s, m, primitive * 3 + 2));
+            const float a = (1.0f - bary.x) - bary.y;
+            const f2 uv =
+                f2{bary1(uv0.x, uv1.x, uv2.x, a, bary.x, bary.y), bary1(uv0.y, uv1.y, uv2.y, a, bary.x, bary.y)};
+            linearAlpha = srgb_to_linear(sample_texture(s, baseTex, data.baseColorTextureSampler >> 24, uv).w);
+        }
     }
-    const float alpha = sample_alpha(s, inst.materialIndex, uv);
+    linearAlpha *= data.baseColorFactor.w;
+    float alpha = -1.0f;
+    if (data.alphaMode == PROSPER_ALPHA_MODE_BLEND)
+        alpha = linearAlpha;
+    else if (data.alphaMode == PROSPER_ALPHA_MODE_MASK && linearAlpha < data.alphaCutoff)
+        alpha = 0.0f;
     if (alpha == 0.0f) return false;
     if (alpha > 0.0f)
     {
@@ -839,11 +854,15 @@ PPT_D bool trace(
     hit.t = tMaxIn;
     const f3 invd = f3{safe_rcp_dir(d.x), safe_rcp_dir(d.y), safe_rcp_dir(d.z)};
 
+    // while-while traversal: all lanes first descend inner nodes until every live lane holds a leaf
+    // (lanes that already do wait), then all lanes intersect their leaf's triangles.  Under
+    // divergence this keeps the (long) triangle code out of the node loop and vice versa.
     int32_t sp = 0;
     int32_t node = 0; // root is always an inner node
-    while (true)
+    bool alive = true;
+    while (alive)
     {
-        if (node >= 0)
+        while (alive && node >= 0)
         {
             const BvhNode n = s.nodes[node];
             if constexpr (COUNT) cnt.nodeVisits++;
@@ -857,15 +876,18 @@ PPT_D bool trace(
                 stack[sp * 64] = firstIs0 ? n.child1 : n.child0;
                 ++sp;
                 node = firstIs0 ? n.child0 : n.child1;
-                continue;
             }
-            if (h0 || h1)
-            {
+            else if (h0 || h1)
                 node = h0 ? n.child0 : n.child1;
-                continue;
+            else if (sp == 0)
+                alive = false;
+            else
+            {
+                --sp;
+                node = stack[sp * 64];
             }
         }
-        else
+        if (!alive) break;
         {
             const uint32_t ref = (uint32_t)~node;
             const uint32_t first = ref >> 3;
