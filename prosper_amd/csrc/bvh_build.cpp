@@ -250,14 +250,15 @@ struct Emitter
 BvhBuildResult build_bvh(const WorldTriangle *triangles, uint64_t count)
 {
     BvhBuildResult out;
-    // An unused child slot gets a NaN box: every comparison of the slab test is then false, so
-    // it can never be entered (an inverted +inf/-inf box would pass a min/max slab test).
-    const float nan = std::numeric_limits<float>::quiet_NaN();
+    // An unused child slot gets the box lo = hi = +inf: both slab tests (pt_device.hpp box_entry,
+    // pt_trace_stream.hpp box_entry_fma) then report an entry distance of +inf at best, which the
+    // traversal treats as a miss.  (A NaN box would slip through min/max, an inverted box passes.)
+    const float inf = std::numeric_limits<float>::infinity();
     auto empty_child = [&](float lo[3], float hi[3]) {
         for (int k = 0; k < 3; ++k)
         {
-            lo[k] = nan;
-            hi[k] = nan;
+            lo[k] = inf;
+            hi[k] = inf;
         }
     };
     if (count >= (1ull << 28)) throw std::runtime_error("too many triangles for the leaf reference encoding");

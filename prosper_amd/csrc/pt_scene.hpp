@@ -15,7 +15,7 @@ namespace ppt
 
 // BVH2 node, 64 B = one aligned 64-B fetch (4 x dwordx4 per lane).  A child reference >= 0 is
 // an inner node index; < 0 is a leaf: ~ref = (firstTriangle << 3) | (triangleCount - 1).
-// An unused child has a NaN box, which fails every comparison of the slab test.
+// An unused child has the box lo = hi = +inf, which no ray can enter (see bvh_build.cpp).
 struct alignas(64) BvhNode
 {
     float lo0[3];

@@ -1,0 +1,264 @@
+// pt_trace_stream.hpp — wave-scheduled BVH traversal over a stream of rays (gfx950).
+//
+// A 64-lane wave that traces 64 incoherent rays in lockstep runs at ~25 % lane utilisation
+// (measured, profiles/): the node loop lasts as long as its slowest lane, the (long) triangle code
+// runs for the few lanes sitting in a leaf, the (longer) any-hit code for the odd lane on alpha
+// geometry.  Here a wave owns a STREAM of n rays and every lane is a small state machine:
+//
+//     idle -> node* -> tri* -> (any-hit)? -> ... -> finished -> (commit, refill) -> node ...
+//
+// Each scheduling step the wave takes a ballot of the lane states and runs ONE phase — the one most
+// lanes are waiting for — so node steps, triangle tests and any-hit evaluations each execute with a
+// well-filled wave, and a lane whose ray is done is refilled from the stream instead of idling until
+// the slowest lane of its batch finishes.  Hit selection is unchanged (DESIGN.md "hit contract":
+// it is defined by arithmetic, not by traversal order), so results equal trace<>() bit for bit.
+#pragma once
+
+#include "pt_device.hpp"
+
+namespace ppt
+{
+
+enum : uint32_t
+{
+    kLaneIdle = 0,
+    kLaneNode = 1,
+    kLaneTri = 2,
+    kLaneAny = 3,
+    kLaneFinished = 4,
+};
+
+struct StreamRay
+{
+    f3 o, d;
+    float tMin, tMax;
+    uint32_t seed;
+};
+
+// Slab test in fma form: t = lo*invd + (-o*invd).  Conservative together with the builder's box
+// padding (rounding of o*invd is ~1 ulp of the coordinate, the padding is >= 8 ulp + 1e-5 extent).
+PPT_D float box_entry_fma(const float lo[3], const float hi[3], f3 invd, f3 oid, float tMin, float tMax)
+{
+    float t0 = __builtin_fmaf(lo[0], invd.x, oid.x), t1 = __builtin_fmaf(hi[0], invd.x, oid.x);
+    float tn = fminf(t0, t1), tf = fmaxf(t0, t1);
+    t0 = __builtin_fmaf(lo[1], invd.y, oid.y);
+    t1 = __builtin_fmaf(hi[1], invd.y, oid.y);
+    tn = fmaxf(tn, fminf(t0, t1));
+    tf = fminf(tf, fmaxf(t0, t1));
+    t0 = __builtin_fmaf(lo[2], invd.z, oid.z);
+    t1 = __builtin_fmaf(hi[2], invd.z, oid.z);
+    tn = fmaxf(tn, fminf(t0, t1));
+    tf = fminf(tf, fmaxf(t0, t1));
+    const bool hit = fmaxf(tn, tMin) <= fminf(tf * 1.0000004f, tMax);
+    return hit ? tn : kInf;
+}
+
+// fetch(i) -> StreamRay for stream position i (called by the lanes that take a new ray);
+// commit(pred, i, found, hit, dir) is called by ALL lanes in converged code; lanes with pred set
+// hand over the result of ray i with direction dir (so commit may compact with ballots).
+template <bool ANY, bool COUNT, class Fetch, class Commit>
+PPT_D void trace_stream(
+    const DeviceScene &s, uint32_t n, int32_t *stack, LaneCounters &cnt, Fetch &&fetch, Commit &&commit)
+{
+    const uint32_t lane = threadIdx.x & 63u;
+    const unsigned long long below = (1ull << lane) - 1ull;
+
+    uint32_t next = 0; // wave-uniform: next stream position to hand out
+    uint32_t state = kLaneIdle;
+    uint32_t ray = 0;
+    f3 o = {}, d = {}, invd = {}, oid = {};
+    float tMin = 0.0f, tMaxIn = 0.0f;
+    uint32_t seed = 0;
+    int32_t node = 0, sp = 0;
+    uint32_t triFirst = 0, triCount = 0;
+    Hit hit = {};
+    // candidate waiting for its any-hit evaluation
+    uint32_t cDi = 0, cPrim = 0;
+    float cT = 0.0f, cBu = 0.0f, cBv = 0.0f;
+
+    // after a leaf is exhausted or a node misses: pop the next entry or finish
+    auto pop = [&]() {
+        if (sp == 0)
+            state = kLaneFinished;
+        else
+        {
+            --sp;
+            node = stack[sp * 64];
+            if (node >= 0)
+                state = kLaneNode;
+            else
+            {
+                const uint32_t ref = (uint32_t)~node;
+                triFirst = ref >> 3;
+                triCount = (ref & 7u) + 1u;
+                state = kLaneTri;
+            }
+        }
+    };
+    auto accept = [&](uint32_t di, uint32_t prim, float t, float bu, float bv) {
+        hit.drawInstance = di;
+        hit.primitive = prim;
+        hit.bary = f2{bu, bv};
+        hit.t = t;
+        if (ANY) state = kLaneFinished;
+    };
+
+    while (true)
+    {
+        const uint32_t nNode = (uint32_t)__builtin_popcountll(__ballot(state == kLaneNode));
+        const uint32_t nTri = (uint32_t)__builtin_popcountll(__ballot(state == kLaneTri));
+        const uint32_t nAny = (uint32_t)__builtin_popcountll(__ballot(state == kLaneAny));
+        const unsigned long long mFin = __ballot(state == kLaneFinished);
+        const uint32_t nFin = (uint32_t)__builtin_popcountll(mFin);
+        const uint32_t nIdle = 64u - nNode - nTri - nAny - nFin;
+        const bool raysLeft = next < n;
+        const uint32_t nRefill = nFin + (raysLeft ? nIdle : 0u);
+        const uint32_t nWork = nNode + nTri + nAny;
+        if (nWork == 0 && nRefill == 0) break;
+
+        // phase with the most lanes waiting; refill also runs when nothing else can
+        uint32_t best = nNode, pick = kLaneNode;
+        if (nTri > best)
+        {
+            best = nTri;
+            pick = kLaneTri;
+        }
+        if (nAny > best)
+        {
+            best = nAny;
+            pick = kLaneAny;
+        }
+        if (nRefill > best || nWork == 0) pick = kLaneFinished;
+
+        // A phase keeps stepping while it stays (by estimate) the phase most lanes wait for:
+        // lanes that leave it are assumed to join the runner-up, so continue while
+        // 2 * stillInPhase > runnerUp + startedInPhase.  Saves the full five-ballot census per step.
+        if (pick == kLaneNode)
+        {
+            const uint32_t other = nTri > nAny ? (nTri > nRefill ? nTri : nRefill) : (nAny > nRefill ? nAny : nRefill);
+            uint32_t c = nNode;
+            do
+            {
+                if (state == kLaneNode)
+                {
+                    const BvhNode nd = s.nodes[node];
+                    if constexpr (COUNT) cnt.nodeVisits++;
+                    const float e0 = box_entry_fma(nd.lo0, nd.hi0, invd, oid, tMin, hit.t);
+                    const float e1 = box_entry_fma(nd.lo1, nd.hi1, invd, oid, tMin, hit.t);
+                    const bool h0 = e0 < kInf;
+                    const bool h1 = e1 < kInf;
+                    if (h0 || h1)
+                    {
+                        const bool firstIs0 = h0 && (!h1 || e0 <= e1);
+                        if (h0 && h1)
+                        {
+                            stack[sp * 64] = firstIs0 ? nd.child1 : nd.child0;
+                            ++sp;
+                        }
+                        node = firstIs0 ? nd.child0 : nd.child1;
+                        if (node < 0)
+                        {
+                            const uint32_t ref = (uint32_t)~node;
+                            triFirst = ref >> 3;
+                            triCount = (ref & 7u) + 1u;
+                            state = kLaneTri;
+                        }
+                    }
+                    else
+                        pop();
+                }
+                c = (uint32_t)__builtin_popcountll(__ballot(state == kLaneNode));
+            } while (2u * c > other + nNode);
+        }
+        else if (pick == kLaneTri)
+        {
+            const uint32_t other = nNode > nAny ? (nNode > nRefill ? nNode : nRefill) : (nAny > nRefill ? nAny : nRefill);
+            uint32_t c = nTri;
+            do
+            {
+                if (state == kLaneTri)
+                {
+                    const float4 *tp = reinterpret_cast<const float4 *>(s.triangles + triFirst);
+                    const float4 a = tp[0], b = tp[1], c4 = tp[2];
+                    ++triFirst;
+                    --triCount;
+                    if constexpr (COUNT)
+                    {
+                        cnt.triangleTests++;
+                        cnt.shortIndexTriangleTests +=
+                            (__builtin_bit_cast(uint32_t, c4.w) & kTriFlagShortIndices) ? 1u : 0u;
+                    }
+                    float t, bu, bv;
+                    bool candidate = intersect_triangle(
+                        o, d, f3{a.x, a.y, a.z}, f3{b.x, b.y, b.z}, f3{c4.x, c4.y, c4.z}, tMin, tMaxIn, t, bu, bv);
+                    const uint32_t di = __builtin_bit_cast(uint32_t, a.w);
+                    const uint32_t prim = __builtin_bit_cast(uint32_t, b.w);
+                    const uint32_t flags = __builtin_bit_cast(uint32_t, c4.w);
+                    if (candidate && !ANY && hit.drawInstance != kMissIndex)
+                    {
+                        if (t > hit.t) candidate = false;
+                        if (t == hit.t && !(di < hit.drawInstance || (di == hit.drawInstance && prim < hit.primitive)))
+                            candidate = false;
+                    }
+                    if (candidate)
+                    {
+                        if (flags & kTriFlagOpaque)
+                            accept(di, prim, t, bu, bv);
+                        else
+                        {
+                            cDi = di;
+                            cPrim = prim;
+                            cT = t;
+                            cBu = bu;
+                            cBv = bv;
+                            state = kLaneAny;
+                        }
+                    }
+                    if (state == kLaneTri && triCount == 0) pop();
+                }
+                c = (uint32_t)__builtin_popcountll(__ballot(state == kLaneTri));
+            } while (2u * c > other + nTri);
+        }
+        else if (pick == kLaneAny)
+        {
+            if (state == kLaneAny)
+            {
+                state = kLaneTri;
+                if (any_hit<COUNT>(s, cDi, cPrim, f2{cBu, cBv}, seed, cnt)) accept(cDi, cPrim, cT, cBu, cBv);
+                if (state == kLaneTri && triCount == 0) pop();
+            }
+        }
+        else
+        {
+            // hand finished rays over (converged call), then refill finished + idle lanes
+            commit(state == kLaneFinished, ray, hit.drawInstance != kMissIndex, hit, d);
+            if (state == kLaneFinished) state = kLaneIdle;
+            const unsigned long long mIdle = __ballot(state == kLaneIdle);
+            const uint32_t rank = (uint32_t)__builtin_popcountll(mIdle & below);
+            const uint32_t idx = next + rank;
+            if (state == kLaneIdle && idx < n)
+            {
+                ray = idx;
+                const StreamRay r = fetch(idx);
+                o = r.o;
+                d = r.d;
+                tMin = r.tMin;
+                tMaxIn = r.tMax;
+                seed = r.seed;
+                invd = f3{safe_rcp_dir(d.x), safe_rcp_dir(d.y), safe_rcp_dir(d.z)};
+                oid = f3{-(o.x * invd.x), -(o.y * invd.y), -(o.z * invd.z)};
+                hit.drawInstance = kMissIndex;
+                hit.primitive = kMissIndex;
+                hit.bary = f2{0.0f, 0.0f};
+                hit.t = tMaxIn;
+                sp = 0;
+                node = 0; // the root is always an inner node
+                state = kLaneNode;
+            }
+            const uint32_t handed = (uint32_t)__builtin_popcountll(mIdle);
+            next = (n - next < handed) ? n : next + handed;
+        }
+    }
+}
+
+} // namespace ppt
