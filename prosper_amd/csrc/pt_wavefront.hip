@@ -21,9 +21,18 @@
 // (direct of bounce b, then sky of bounce b+1).
 #include "pt_kernels.hpp"
 
+#include <cstdlib>
+
 #include "pt_device.hpp"
 #include "pt_render_common.hpp"
 #include "pt_trace_stream.hpp"
+
+// Register budgets (measured on C2/C3, profiles/r01_occupancy_ab.txt): the traversal kernels run
+// best at 6 waves/SIMD (<= 80 VGPRs, a few spilled dwords), the shade kernel at 4.  The LDS stack
+// is sized to the BVH depth (16/24/32 entries x 64 lanes x 4 B per wave); at 32 entries the LDS
+// caps a CU at 20 waves, so that variant is allocated for 5 waves/SIMD.
+#define PPT_SHADE_WPE 4
+#define PPT_TRAV_WPE(stack) ((stack) <= 24 ? 6 : 5)
 
 namespace ppt
 {
@@ -102,15 +111,15 @@ __device__ __forceinline__ void add_to_slot(float4 *color, uint32_t slot, uint32
 // generate + first extend
 // ------------------------------------------------------------------------------------------
 
-template <bool COUNT>
+template <bool COUNT, int STACK>
 __global__ __launch_bounds__(256) void wf_generate_extend(
     DeviceScene s, RenderParams p, WavefrontBuffers w, unsigned long long *__restrict__ counters)
 {
-    __shared__ int32_t ldsStack[kTraversalStackDepth * 256];
+    __shared__ int32_t ldsStack[STACK * 256];
     const SegmentId id = my_segment(w);
     if (!id.valid) return;
     const uint32_t lane = lane_id();
-    int32_t *stack = ldsStack + (threadIdx.x >> 6) * (kTraversalStackDepth * 64u) + lane;
+    int32_t *stack = ldsStack + (threadIdx.x >> 6) * (STACK * 64u) + lane;
     const bool traceRays = p.pc.maxBounces > 0;
 
     LaneCounters cnt = {};
@@ -201,16 +210,16 @@ __global__ __launch_bounds__(256) void wf_generate_extend(
 // extend: traceClosest of bounce >= 1
 // ------------------------------------------------------------------------------------------
 
-template <bool COUNT>
-__global__ __launch_bounds__(256) void wf_extend(
+template <bool COUNT, int STACK>
+__global__ __launch_bounds__(256, PPT_TRAV_WPE(STACK)) void wf_extend(
     DeviceScene s, RenderParams p, WavefrontBuffers w, uint32_t bounce, uint32_t cur,
     unsigned long long *__restrict__ counters)
 {
-    __shared__ int32_t ldsStack[kTraversalStackDepth * 256];
+    __shared__ int32_t ldsStack[STACK * 256];
     const SegmentId id = my_segment(w);
     if (!id.valid) return;
     const uint32_t lane = lane_id();
-    int32_t *stack = ldsStack + (threadIdx.x >> 6) * (kTraversalStackDepth * 64u) + lane;
+    int32_t *stack = ldsStack + (threadIdx.x >> 6) * (STACK * 64u) + lane;
     const float4 *__restrict__ rayA = w.rayA[cur];
     const float4 *__restrict__ rayB = w.rayB[cur];
 
@@ -256,7 +265,7 @@ __global__ __launch_bounds__(256) void wf_extend(
 // ------------------------------------------------------------------------------------------
 
 template <bool COUNT>
-__global__ __launch_bounds__(256) void wf_shade(
+__global__ __launch_bounds__(256, PPT_SHADE_WPE) void wf_shade(
     DeviceScene s, RenderParams p, WavefrontBuffers w, uint32_t bounce, uint32_t cur, uint32_t lastBounce,
     unsigned long long *__restrict__ counters)
 {
@@ -371,15 +380,15 @@ __global__ __launch_bounds__(256) void wf_shade(
 // shadow
 // ------------------------------------------------------------------------------------------
 
-template <bool COUNT>
-__global__ __launch_bounds__(256) void wf_shadow(
+template <bool COUNT, int STACK>
+__global__ __launch_bounds__(256, PPT_TRAV_WPE(STACK)) void wf_shadow(
     DeviceScene s, RenderParams p, WavefrontBuffers w, uint32_t bounce, unsigned long long *__restrict__ counters)
 {
-    __shared__ int32_t ldsStack[kTraversalStackDepth * 256];
+    __shared__ int32_t ldsStack[STACK * 256];
     const SegmentId id = my_segment(w);
     if (!id.valid) return;
     const uint32_t lane = lane_id();
-    int32_t *stack = ldsStack + (threadIdx.x >> 6) * (kTraversalStackDepth * 64u) + lane;
+    int32_t *stack = ldsStack + (threadIdx.x >> 6) * (STACK * 64u) + lane;
 
     LaneCounters cnt = {};
     const uint32_t n = w.segShadow[id.seg];
@@ -461,7 +470,7 @@ __global__ __launch_bounds__(256) void wf_accumulate(
 // host-side sequencing
 // ------------------------------------------------------------------------------------------
 
-template <bool COUNT>
+template <bool COUNT, int STACK>
 static void enqueue_wavefront(
     const DeviceScene &s, const RenderParams &p, float4 *hdr, unsigned long long *counters, const WavefrontBuffers &w,
     hipStream_t stream)
@@ -473,28 +482,50 @@ static void enqueue_wavefront(
         p.pc.drawType != PROSPER_DRAW_TYPE_DEFAULT && p.pc.drawType != PROSPER_DRAW_TYPE_MESHLET_ID;
     if (debugDraw && bounces > 1) bounces = 1; // every hit ends its path in the first shade
 
-    hipLaunchKernelGGL(wf_generate_extend<COUNT>, grid, block, 0, stream, s, p, w, counters);
+    hipLaunchKernelGGL((wf_generate_extend<COUNT, STACK>), grid, block, 0, stream, s, p, w, counters);
     for (uint32_t b = 0; b < bounces; ++b)
     {
         const uint32_t cur = b & 1u;
         const uint32_t last = (b + 1u == bounces) ? 1u : 0u;
         hipLaunchKernelGGL(wf_shade<COUNT>, grid, block, 0, stream, s, p, w, b, cur, last, counters);
-        if (!debugDraw) hipLaunchKernelGGL(wf_shadow<COUNT>, grid, block, 0, stream, s, p, w, b, counters);
-        if (!last) hipLaunchKernelGGL(wf_extend<COUNT>, grid, block, 0, stream, s, p, w, b + 1u, cur ^ 1u, counters);
+        if (!debugDraw) hipLaunchKernelGGL((wf_shadow<COUNT, STACK>), grid, block, 0, stream, s, p, w, b, counters);
+        if (!last)
+            hipLaunchKernelGGL((wf_extend<COUNT, STACK>), grid, block, 0, stream, s, p, w, b + 1u, cur ^ 1u, counters);
     }
     hipLaunchKernelGGL(
         wf_accumulate<COUNT>, dim3((w.pixelsPadded + 255u) / 256u), block, 0, stream, p, w, hdr, counters);
 }
 
+template <bool COUNT>
+static void enqueue_for_depth(
+    const DeviceScene &s, const RenderParams &p, float4 *hdr, unsigned long long *counters, const WavefrontBuffers &w,
+    uint32_t bvhDepth, hipStream_t stream)
+{
+    // smallest LDS stack that holds the deepest root-to-leaf path (the builder caps it at 32)
+    if (bvhDepth <= 16)
+        enqueue_wavefront<COUNT, 16>(s, p, hdr, counters, w, stream);
+    else if (bvhDepth <= 24)
+        enqueue_wavefront<COUNT, 24>(s, p, hdr, counters, w, stream);
+    else
+        enqueue_wavefront<COUNT, 32>(s, p, hdr, counters, w, stream);
+}
+
 void launch_render_wavefront(
     const DeviceScene &s, const RenderParams &p, float4 *hdr, unsigned long long *counters, const WavefrontBuffers &w,
-    bool countWork, hipStream_t stream)
+    uint32_t bvhDepth, bool countWork, hipStream_t stream)
 {
     if (w.nSeg == 0) return;
+    static_assert(kTraversalStackDepth == 32, "stack variants assume the builder's depth cap");
+    // test hook: PROSPER_PT_DEBUG_STACK=24|32 forces a deeper stack variant than the BVH needs
+    if (const char *forced = std::getenv("PROSPER_PT_DEBUG_STACK"))
+    {
+        const uint32_t v = (uint32_t)std::atoi(forced);
+        if (v > bvhDepth && v <= kTraversalStackDepth) bvhDepth = v;
+    }
     if (countWork)
-        enqueue_wavefront<true>(s, p, hdr, counters, w, stream);
+        enqueue_for_depth<true>(s, p, hdr, counters, w, bvhDepth, stream);
     else
-        enqueue_wavefront<false>(s, p, hdr, counters, w, stream);
+        enqueue_for_depth<false>(s, p, hdr, counters, w, bvhDepth, stream);
 }
 
 } // namespace ppt

@@ -445,3 +445,20 @@ def test_all_pipelines_produce_identical_pixels(gpu_ctx, oracle, cornell_world):
     gpu_ctx.render(default_pc(S, fl, max_bounces=0), cam, w, h)
     z = gpu_ctx.read_hdr()
     assert (z[..., :3] == 0).all() and (z[..., 3] == 1).all()
+
+
+def test_lds_stack_variants_agree(gpu_ctx, oracle, sponza_small, monkeypatch):
+    """The traversal kernels are instantiated for 16/24/32-entry LDS stacks and picked by BVH depth;
+    forcing the deeper variants must not change a pixel."""
+    w, h = 160, 96
+    cam, fl = _camera(oracle, sponza_small, w, h)
+    pc = default_pc(S, fl, max_bounces=3, ibl=True)
+    gpu_ctx.upload_scene(sponza_small)
+    assert gpu_ctx.scene_stats().maxDepth <= 32
+    gpu_ctx.render(pc, cam, w, h, frames=2)
+    base = gpu_ctx.read_hdr()
+    for forced in ("24", "32"):
+        monkeypatch.setenv("PROSPER_PT_DEBUG_STACK", forced)
+        gpu_ctx.render(pc, cam, w, h, frames=2)
+        assert same_bits(gpu_ctx.read_hdr(), base).all(), forced
+    monkeypatch.delenv("PROSPER_PT_DEBUG_STACK")
