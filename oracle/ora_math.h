@@ -9,8 +9,10 @@
  *   - every operation is IEEE-754 binary32, round-to-nearest-even, denormals kept, NO contraction
  *     (build with -ffp-contract=off); fmaf() is used only where written out below;
  *   - a/b and sqrtf are the correctly rounded operations;
- *   - dot(a,b) = (a.x*b.x + a.y*b.y) + a.z*b.z, evaluated left to right;
- *   - normalize(v) = v * (1 / sqrtf(dot(v,v)));
+ *   - dot(a,b) = fmaf(a.z,b.z, fmaf(a.y,b.y, a.x*b.x)); cross is NOT fused (a.y*b.z - a.z*b.y with
+ *     both products rounded) so that cross(a,b) == -cross(b,a) exactly;
+ *   - normalize(v) = v * (1 / sqrtf(dot(v,v))); vector / scalar = vector * (1 / scalar);
+ *   - division by a constant (255, 511, 1023, 12.92, 1.055, PI) multiplies by the fp32 reciprocal;
  *   - sin/cos/exp2/log2/pow are the fixed polynomial kernels in this file (a few ulp, far inside
  *     Vulkan's precision bounds for GLSL.std.450 Sin/Cos/Pow);
  *   - min/max follow IEEE minNum/maxNum (a NaN operand loses), as GPU hardware does; GLSL leaves
@@ -31,6 +33,7 @@ typedef struct ora_v4 { float x, y, z, w; } ora_v4;
 
 /* math.glsl:4 — `#define PI 3.14159265`, rounded to binary32 when used in float expressions */
 #define ORA_PI 3.14159265f
+#define ORA_INV_PI (1.0f / 3.14159265f)
 
 static inline uint32_t ora_f2u(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
 static inline float ora_u2f(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
@@ -77,9 +80,14 @@ static inline ora_v3 ora_add(ora_v3 a, ora_v3 b) { return ora_v3_make(a.x + b.x,
 static inline ora_v3 ora_sub(ora_v3 a, ora_v3 b) { return ora_v3_make(a.x - b.x, a.y - b.y, a.z - b.z); }
 static inline ora_v3 ora_mul(ora_v3 a, ora_v3 b) { return ora_v3_make(a.x * b.x, a.y * b.y, a.z * b.z); }
 static inline ora_v3 ora_scale(ora_v3 a, float s) { return ora_v3_make(a.x * s, a.y * s, a.z * s); }
-static inline ora_v3 ora_divs(ora_v3 a, float s) { return ora_v3_make(a.x / s, a.y / s, a.z / s); }
+/* vector / scalar = vector * (1 / scalar): one division, three multiplications */
+static inline ora_v3 ora_divs(ora_v3 a, float s)
+{
+    const float inv = 1.0f / s;
+    return ora_v3_make(a.x * inv, a.y * inv, a.z * inv);
+}
 static inline ora_v3 ora_neg(ora_v3 a) { return ora_v3_make(-a.x, -a.y, -a.z); }
-static inline float ora_dot(ora_v3 a, ora_v3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
+static inline float ora_dot(ora_v3 a, ora_v3 b) { return fmaf(a.z, b.z, fmaf(a.y, b.y, a.x * b.x)); }
 static inline ora_v3 ora_cross(ora_v3 a, ora_v3 b)
 {
     return ora_v3_make(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
@@ -91,12 +99,12 @@ static inline ora_v3 ora_normalize(ora_v3 a)
     return ora_scale(a, inv);
 }
 /* GLSL mix(a, b, t) = a*(1-t) + b*t */
-static inline float ora_mix(float a, float b, float t) { return a * (1.0f - t) + b * t; }
+static inline float ora_mix(float a, float b, float t) { return fmaf(b, t, a * (1.0f - t)); }
 /* GLSL reflect(I, N) = I - 2*dot(N,I)*N */
 static inline ora_v3 ora_reflect(ora_v3 i, ora_v3 n)
 {
     const float k = 2.0f * ora_dot(n, i);
-    return ora_sub(i, ora_scale(n, k));
+    return ora_v3_make(fmaf(-k, n.x, i.x), fmaf(-k, n.y, i.y), fmaf(-k, n.z, i.z));
 }
 /* math.glsl:8 */
 static inline float ora_max3(ora_v3 v) { return ora_max(ora_max(v.x, v.y), v.z); }

@@ -74,7 +74,8 @@ static ora_v3 uint_to_color(uint32_t x)
     const uint32_t r = (xr >> 20) & 0x3FFu;
     const uint32_t g = (xr >> 10) & 0x3FFu;
     const uint32_t b = xr & 0x3FFu;
-    return ora_v3_make((float)r / 1023.0f, (float)g / 1023.0f, (float)b / 1023.0f);
+    const float k = 1.0f / 1023.0f;
+    return ora_v3_make((float)r * k, (float)g * k, (float)b * k);
 }
 
 /* ------------------------------------------------------------------------------------------
@@ -160,9 +161,9 @@ static ora_v3 unpack_snorm_r10g10b10(uint32_t packed)
     const int32_t sx = (int32_t)(packed << 22) >> 22;
     const int32_t sy = (int32_t)(packed << 12) >> 22;
     const int32_t sz = (int32_t)(packed << 2) >> 22;
-    const ora_v3 v = ora_v3_make(
-        ora_max((float)sx / 511.0f, -1.0f), ora_max((float)sy / 511.0f, -1.0f),
-        ora_max((float)sz / 511.0f, -1.0f));
+    const float k = 1.0f / 511.0f;
+    const ora_v3 v =
+        ora_v3_make(ora_max((float)sx * k, -1.0f), ora_max((float)sy * k, -1.0f), ora_max((float)sz * k, -1.0f));
     return ora_normalize(v);
 }
 
@@ -211,7 +212,7 @@ static ora_v2 load_uv(const ora_scene *s, uint32_t meshIndex, uint32_t index)
 /* geometry.glsl:258-270: v0*a + v1*b + v2*c */
 static inline float bary1(float v0, float v1, float v2, float a, float b, float c)
 {
-    return (v0 * a + v1 * b) + v2 * c;
+    return fmaf(v2, c, fmaf(v1, b, v0 * a));
 }
 
 /* geometry.glsl:271-295 */
@@ -246,17 +247,17 @@ static ora_vertex interpolate_vertex(const ora_vertex *v0, const ora_vertex *v1,
 static inline ora_v3 mul_point_mat3x4(ora_v3 p, const prosper_mat3x4 *m)
 {
     return ora_v3_make(
-        ((p.x * m->col[0].x + p.y * m->col[0].y) + p.z * m->col[0].z) + m->col[0].w,
-        ((p.x * m->col[1].x + p.y * m->col[1].y) + p.z * m->col[1].z) + m->col[1].w,
-        ((p.x * m->col[2].x + p.y * m->col[2].y) + p.z * m->col[2].z) + m->col[2].w);
+        fmaf(p.z, m->col[0].z, fmaf(p.y, m->col[0].y, fmaf(p.x, m->col[0].x, m->col[0].w))),
+        fmaf(p.z, m->col[1].z, fmaf(p.y, m->col[1].y, fmaf(p.x, m->col[1].x, m->col[1].w))),
+        fmaf(p.z, m->col[2].z, fmaf(p.y, m->col[2].y, fmaf(p.x, m->col[2].x, m->col[2].w))));
 }
 /* v * mat3(m): component i = dot(v, column i .xyz) */
 static inline ora_v3 mul_vec_mat3(ora_v3 v, const prosper_mat3x4 *m)
 {
     return ora_v3_make(
-        (v.x * m->col[0].x + v.y * m->col[0].y) + v.z * m->col[0].z,
-        (v.x * m->col[1].x + v.y * m->col[1].y) + v.z * m->col[1].z,
-        (v.x * m->col[2].x + v.y * m->col[2].y) + v.z * m->col[2].z);
+        fmaf(v.z, m->col[0].z, fmaf(v.y, m->col[0].y, v.x * m->col[0].x)),
+        fmaf(v.z, m->col[1].z, fmaf(v.y, m->col[1].y, v.x * m->col[1].x)),
+        fmaf(v.z, m->col[2].z, fmaf(v.y, m->col[2].y, v.x * m->col[2].x)));
 }
 
 static ora_vertex transform_vertex(const ora_vertex *v, const prosper_ModelInstanceTransforms *t)
@@ -303,7 +304,8 @@ static inline int32_t wrap_coord(int32_t i, int32_t size, uint32_t mode)
 static inline ora_v4 fetch_rgba8(const prosper_pt_texture_desc *t, int32_t i, int32_t j)
 {
     const uint8_t *p = (const uint8_t *)t->texels + 4u * ((size_t)j * t->width + (size_t)i);
-    ora_v4 r = {(float)p[0] / 255.0f, (float)p[1] / 255.0f, (float)p[2] / 255.0f, (float)p[3] / 255.0f};
+    const float k = 1.0f / 255.0f;
+    ora_v4 r = {(float)p[0] * k, (float)p[1] * k, (float)p[2] * k, (float)p[3] * k};
     return r;
 }
 
@@ -320,8 +322,8 @@ static ora_v4 sample_texture(const ora_scene *s, uint32_t tex, uint32_t smp, ora
         const int32_t j = wrap_coord(ora_f2i(floorf(uv.y * (float)h)), h, sd->wrapT);
         return fetch_rgba8(t, i, j);
     }
-    const float u = uv.x * (float)w - 0.5f;
-    const float v = uv.y * (float)h - 0.5f;
+    const float u = fmaf(uv.x, (float)w, -0.5f);
+    const float v = fmaf(uv.y, (float)h, -0.5f);
     const float fu = floorf(u);
     const float fv = floorf(v);
     const float a = u - fu;
@@ -339,10 +341,10 @@ static ora_v4 sample_texture(const ora_scene *s, uint32_t tex, uint32_t smp, ora
     const float w01 = (1.0f - a) * b;
     const float w11 = a * b;
     ora_v4 r;
-    r.x = ((w00 * t00.x + w10 * t10.x) + w01 * t01.x) + w11 * t11.x;
-    r.y = ((w00 * t00.y + w10 * t10.y) + w01 * t01.y) + w11 * t11.y;
-    r.z = ((w00 * t00.z + w10 * t10.z) + w01 * t01.z) + w11 * t11.z;
-    r.w = ((w00 * t00.w + w10 * t10.w) + w01 * t01.w) + w11 * t11.w;
+    r.x = fmaf(w11, t11.x, fmaf(w01, t01.x, fmaf(w10, t10.x, w00 * t00.x)));
+    r.y = fmaf(w11, t11.y, fmaf(w01, t01.y, fmaf(w10, t10.y, w00 * t00.y)));
+    r.z = fmaf(w11, t11.z, fmaf(w01, t01.z, fmaf(w10, t10.z, w00 * t00.z)));
+    r.w = fmaf(w11, t11.w, fmaf(w01, t01.w, fmaf(w10, t10.w, w00 * t00.w)));
     return r;
 }
 
@@ -396,13 +398,15 @@ static inline ora_v3 fetch_cube_rgb(const ora_scene *s, uint32_t face, int32_t i
     {
         /* Seamless edge: re-project the centre of the out-of-face texel onto the cube and take
          * the texel it lands in on the neighbouring face. */
-        const float sc = (2.0f * ((float)i + 0.5f)) / (float)n - 1.0f;
-        const float tc = (2.0f * ((float)j + 0.5f)) / (float)n - 1.0f;
+        const float invN = 1.0f / (float)n;
+        const float sc = fmaf(2.0f * ((float)i + 0.5f), invN, -1.0f);
+        const float tc = fmaf(2.0f * ((float)j + 0.5f), invN, -1.0f);
         const ora_v3 d = cube_face_dir(face, sc, tc);
         float sc2, tc2, ma2;
         cube_face_coords(d, &face, &sc2, &tc2, &ma2);
-        const float ss = 0.5f * (sc2 / ma2) + 0.5f;
-        const float tt = 0.5f * (tc2 / ma2) + 0.5f;
+        const float inv2 = 1.0f / ma2;
+        const float ss = fmaf(0.5f, sc2 * inv2, 0.5f);
+        const float tt = fmaf(0.5f, tc2 * inv2, 0.5f);
         i = ora_f2i(floorf(ss * (float)n));
         j = ora_f2i(floorf(tt * (float)n));
         i = i < 0 ? 0 : (i >= n ? n - 1 : i);
@@ -420,10 +424,11 @@ static ora_v3 sample_skybox(const ora_scene *s, ora_v3 d)
     uint32_t face;
     float sc, tc, ma;
     cube_face_coords(d, &face, &sc, &tc, &ma);
-    const float ss = 0.5f * (sc / ma) + 0.5f;
-    const float tt = 0.5f * (tc / ma) + 0.5f;
-    const float u = ss * (float)n - 0.5f;
-    const float v = tt * (float)n - 0.5f;
+    const float invMa = 1.0f / ma;
+    const float ss = fmaf(0.5f, sc * invMa, 0.5f);
+    const float tt = fmaf(0.5f, tc * invMa, 0.5f);
+    const float u = fmaf(ss, (float)n, -0.5f);
+    const float v = fmaf(tt, (float)n, -0.5f);
     const float fu = floorf(u);
     const float fv = floorf(v);
     const float a = u - fu;
@@ -439,9 +444,9 @@ static ora_v3 sample_skybox(const ora_scene *s, ora_v3 d)
     const float w01 = (1.0f - a) * b;
     const float w11 = a * b;
     return ora_v3_make(
-        ((w00 * t00.x + w10 * t10.x) + w01 * t01.x) + w11 * t11.x,
-        ((w00 * t00.y + w10 * t10.y) + w01 * t01.y) + w11 * t11.y,
-        ((w00 * t00.z + w10 * t10.z) + w01 * t01.z) + w11 * t11.z);
+        fmaf(w11, t11.x, fmaf(w01, t01.x, fmaf(w10, t10.x, w00 * t00.x))),
+        fmaf(w11, t11.y, fmaf(w01, t01.y, fmaf(w10, t10.y, w00 * t00.y))),
+        fmaf(w11, t11.z, fmaf(w01, t01.z, fmaf(w10, t10.z, w00 * t00.z))));
 }
 
 /* ------------------------------------------------------------------------------------------
@@ -460,7 +465,7 @@ typedef struct ora_material
 /* materials.glsl:26-29 */
 static inline float srgb_to_linear(float x)
 {
-    return x <= 0.04045f ? x / 12.92f : ora_pow((x + 0.055f) / 1.055f, 2.4f);
+    return x <= 0.04045f ? x * (1.0f / 12.92f) : ora_pow((x + 0.055f) * (1.0f / 1.055f), 2.4f);
 }
 
 /* materials.glsl:47-119 */
@@ -526,7 +531,7 @@ static ora_material sample_material(const ora_scene *s, uint32_t index, ora_v2 u
     if (nTex > 0)
     {
         const ora_v4 tn = sample_texture(s, nTex, nSmp, uv);
-        ret.normal = ora_v3_make(tn.x * 2.0f - 1.0f, tn.y * 2.0f - 1.0f, tn.z * 2.0f - 1.0f);
+        ret.normal = ora_v3_make(fmaf(tn.x, 2.0f, -1.0f), fmaf(tn.y, 2.0f, -1.0f), fmaf(tn.z, 2.0f, -1.0f));
     }
     else
         ret.normal = ora_v3_make(-2.0f, -2.0f, -2.0f);
@@ -568,22 +573,22 @@ typedef struct ora_surface
 static inline float trowbridge_reitz(float NoH, float alpha)
 {
     const float a2 = alpha * alpha;
-    const float denom = (NoH * NoH) * (a2 - 1.0f) + 1.0f;
+    const float denom = fmaf(NoH * NoH, a2 - 1.0f, 1.0f);
     return a2 / ((ORA_PI * denom) * denom);
 }
 /* brdf.glsl:21-24 */
 static inline ora_v3 schlick_fresnel(float VoH, ora_v3 f0)
 {
     const float p = ora_pow5(1.0f - VoH);
-    return ora_v3_make(f0.x + (1.0f - f0.x) * p, f0.y + (1.0f - f0.y) * p, f0.z + (1.0f - f0.z) * p);
+    return ora_v3_make(fmaf(1.0f - f0.x, p, f0.x), fmaf(1.0f - f0.y, p, f0.y), fmaf(1.0f - f0.z, p, f0.z));
 }
 /* brdf.glsl:35-43 */
 static inline float schlick_trowbridge_reitz(float NoL, float NoV, float alpha)
 {
     float k = alpha * 0.5f;
     k = ora_max(k, 0.0001f);
-    const float gl = NoL / (NoL * (1.0f - k) + k);
-    const float gv = NoV / (NoV * (1.0f - k) + k);
+    const float gl = NoL / fmaf(NoL, 1.0f - k, k);
+    const float gv = NoV / fmaf(NoV, 1.0f - k, k);
     return gl * gv;
 }
 /* brdf.glsl:46-58 */
@@ -593,7 +598,7 @@ static ora_v3 cook_torrance_brdf(float NoL, float NoV, float NoH, float VoH, ora
     const float D = trowbridge_reitz(NoH, alpha);
     const ora_v3 F = schlick_fresnel(VoH, f0);
     const float G = schlick_trowbridge_reitz(NoL, NoV, alpha);
-    const float denom = (4.0f * NoL) * NoV + 0.0001f;
+    const float denom = fmaf(4.0f * NoL, NoV, 0.0001f);
     return ora_divs(ora_scale(ora_scale(F, D), G), denom);
 }
 /* brdf.glsl:60-64 */
@@ -605,7 +610,7 @@ static inline ora_v3 fresnel_zero(const ora_surface *sf)
         ora_mix(0.04f, sf->material.albedo.z, m));
 }
 /* brdf.glsl:9 */
-static inline ora_v3 lambert_brdf(ora_v3 c) { return ora_divs(c, ORA_PI); }
+static inline ora_v3 lambert_brdf(ora_v3 c) { return ora_scale(c, ORA_INV_PI); }
 
 /* brdf.glsl:67-87 */
 static ora_v3 eval_brdf_times_nol(ora_v3 l, const ora_surface *sf)
@@ -632,17 +637,14 @@ static ora_v3 eval_brdf_times_nol(ora_v3 l, const ora_surface *sf)
 /* sampling.glsl:18-33 */
 static ora_v3 cosine_sample_hemisphere(ora_v3 n, ora_v2 u)
 {
-    float a = 1.0f - 2.0f * u.x;
+    float a = fmaf(-2.0f, u.x, 1.0f);
     a *= 0.99999f;
-    float b = sqrtf(1.0f - a * a);
+    float b = sqrtf(fmaf(-a, a, 1.0f));
     b *= 0.99999f;
     const float phi = (2.0f * ORA_PI) * u.y;
     float sn, cs;
     ora_sincos(phi, &sn, &cs);
-    const float x = b * cs;
-    const float y = b * sn;
-    const float z = a;
-    return ora_normalize(ora_v3_make(n.x + x, n.y + y, n.z + z));
+    return ora_normalize(ora_v3_make(fmaf(b, cs, n.x), fmaf(b, sn, n.y), n.z + a));
 }
 
 /* sampling.glsl:37-47: rows of the returned matrix are b1, b2, n */
@@ -653,8 +655,8 @@ static ora_onb orthonormal_basis(ora_v3 n)
     const float a = -1.0f / (s + n.z);
     const float b = (n.x * n.y) * a;
     ora_onb o;
-    o.b1 = ora_v3_make(1.0f + ((s * n.x) * n.x) * a, s * b, (-s) * n.x);
-    o.b2 = ora_v3_make(b, s + (n.y * n.y) * a, -n.y);
+    o.b1 = ora_v3_make(fmaf((s * n.x) * n.x, a, 1.0f), s * b, (-s) * n.x);
+    o.b2 = ora_v3_make(b, fmaf(n.y * n.y, a, s), -n.y);
     o.n = n;
     return o;
 }
@@ -667,15 +669,15 @@ static inline ora_v3 onb_to_local(const ora_onb *o, ora_v3 v)
 static inline ora_v3 onb_to_world(const ora_onb *o, ora_v3 v)
 {
     return ora_v3_make(
-        (o->b1.x * v.x + o->b2.x * v.y) + o->n.x * v.z, (o->b1.y * v.x + o->b2.y * v.y) + o->n.y * v.z,
-        (o->b1.z * v.x + o->b2.z * v.y) + o->n.z * v.z);
+        fmaf(o->n.x, v.z, fmaf(o->b2.x, v.y, o->b1.x * v.x)), fmaf(o->n.y, v.z, fmaf(o->b2.y, v.y, o->b1.y * v.x)),
+        fmaf(o->n.z, v.z, fmaf(o->b2.z, v.y, o->b1.z * v.x)));
 }
 
 /* sampling.glsl:53-79 */
 static ora_v3 sample_visible_trowbridge_reitz(ora_v3 Ve, float alpha, ora_v2 Us)
 {
     const ora_v3 Vh = ora_normalize(ora_v3_make(alpha * Ve.x, alpha * Ve.y, Ve.z));
-    const float lensq = Vh.x * Vh.x + Vh.y * Vh.y;
+    const float lensq = fmaf(Vh.y, Vh.y, Vh.x * Vh.x);
     ora_v3 T1;
     if (lensq > 0.0f)
     {
@@ -692,9 +694,12 @@ static ora_v3 sample_visible_trowbridge_reitz(ora_v3 Ve, float alpha, ora_v2 Us)
     const float t1 = r * cs;
     float t2 = r * sn;
     const float s = 0.5f * (1.0f + Vh.z);
-    t2 = (1.0f - s) * sqrtf(1.0f - t1 * t1) + s * t2;
-    const float k = sqrtf(ora_max(0.0f, (1.0f - t1 * t1) - t2 * t2));
-    const ora_v3 Nh = ora_add(ora_add(ora_scale(T1, t1), ora_scale(T2, t2)), ora_scale(Vh, k));
+    const float c1 = fmaf(-t1, t1, 1.0f);
+    t2 = fmaf(s, t2, (1.0f - s) * sqrtf(c1));
+    const float k = sqrtf(ora_max(0.0f, fmaf(-t2, t2, c1)));
+    const ora_v3 Nh = ora_v3_make(
+        fmaf(Vh.x, k, fmaf(T2.x, t2, T1.x * t1)), fmaf(Vh.y, k, fmaf(T2.y, t2, T1.y * t1)),
+        fmaf(Vh.z, k, fmaf(T2.z, t2, T1.z * t1)));
     const ora_v3 Ne = ora_normalize(ora_v3_make(alpha * Nh.x, alpha * Nh.y, ora_max(0.0f, Nh.z)));
     return ora_reflect(ora_neg(Ve), Ne);
 }
@@ -746,7 +751,7 @@ static void eval_spot_light(
     *l = ora_divs(toLight, *d);
     const ora_v3 negDir = ora_v3_make(-light->direction.x, -light->direction.y, -light->direction.z);
     const float cd = ora_dot(negDir, *l);
-    float att = ora_saturate(cd * light->radianceAndAngleScale.w + light->positionAndAngleOffset.w);
+    float att = ora_saturate(fmaf(cd, light->radianceAndAngleScale.w, light->positionAndAngleOffset.w));
     att *= att;
     const ora_v3 rad = ora_v3_make(
         light->radianceAndAngleScale.x, light->radianceAndAngleScale.y, light->radianceAndAngleScale.z);
@@ -802,8 +807,8 @@ static inline ora_v3 camera_world_fwd(const prosper_CameraUniforms *c)
 /* ray.glsl:15-43 */
 static ora_ray pinhole_camera_ray(const prosper_CameraUniforms *c, ora_v2 uv)
 {
-    const float ndx = uv.x * 2.0f - 1.0f;
-    const float ndy = uv.y * 2.0f - 1.0f;
+    const float ndx = fmaf(uv.x, 2.0f, -1.0f);
+    const float ndy = fmaf(uv.y, 2.0f, -1.0f);
     ora_ray ray;
     ray.o = ora_v3_make(c->eye.x, c->eye.y, c->eye.z);
     ray.tMin = 0.0f;
@@ -832,7 +837,7 @@ static ora_ray thin_lens_camera_ray(
     const float u = cs * sqrtf(radius);
     const float v = sn * sqrtf(radius);
     const float k = focusDistance / ora_dot(pin.d, camera_world_fwd(c));
-    const ora_v3 focusPoint = ora_add(pin.o, ora_scale(pin.d, k));
+    const ora_v3 focusPoint = ora_v3_make(fmaf(pin.d.x, k, pin.o.x), fmaf(pin.d.y, k, pin.o.y), fmaf(pin.d.z, k, pin.o.z));
     const float fStop = focalLength / apertureDiameter;
     const float coc = focalLength / (2.0f * fStop);
     const ora_v3 lensPos = ora_add(
@@ -841,9 +846,9 @@ static ora_ray thin_lens_camera_ray(
     const prosper_mat4 *m = &c->cameraToWorld;
     ora_ray ray;
     ray.o = ora_v3_make(
-        ((m->col[0].x * lensPos.x + m->col[1].x * lensPos.y) + m->col[2].x * lensPos.z) + m->col[3].x,
-        ((m->col[0].y * lensPos.x + m->col[1].y * lensPos.y) + m->col[2].y * lensPos.z) + m->col[3].y,
-        ((m->col[0].z * lensPos.x + m->col[1].z * lensPos.y) + m->col[2].z * lensPos.z) + m->col[3].z);
+        fmaf(m->col[2].x, lensPos.z, fmaf(m->col[1].x, lensPos.y, fmaf(m->col[0].x, lensPos.x, m->col[3].x))),
+        fmaf(m->col[2].y, lensPos.z, fmaf(m->col[1].y, lensPos.y, fmaf(m->col[0].y, lensPos.x, m->col[3].y))),
+        fmaf(m->col[2].z, lensPos.z, fmaf(m->col[1].z, lensPos.y, fmaf(m->col[0].z, lensPos.x, m->col[3].z))));
     ray.d = ora_normalize(ora_sub(focusPoint, ray.o));
     ray.tMin = 0.0f;
     ray.tMax = INFINITY;
@@ -860,7 +865,7 @@ static inline float offset_component(float p, float n)
     const int32_t bits = (int32_t)ora_f2u(p);
     const uint32_t moved = (uint32_t)bits + (uint32_t)((p < 0.0f) ? -ofI : ofI);
     const float pI = ora_u2f(moved);
-    return ora_abs(p) < origin ? p + float_scale * n : pI;
+    return ora_abs(p) < origin ? fmaf(float_scale, n, p) : pI;
 }
 static ora_v3 offset_ray(ora_v3 p, ora_v3 n)
 {
@@ -890,12 +895,15 @@ static int intersect_triangle(
     if ((U < 0.0f || V < 0.0f || W < 0.0f) && (U > 0.0f || V > 0.0f || W > 0.0f)) return 0;
     const float det = (U + V) + W;
     if (!(det != 0.0f)) return 0; /* zero or NaN */
+    /* det = U + V + W equals -dot(d, N) in exact arithmetic (N = (v1-v0) x (v2-v0)), so one
+     * reciprocal serves the distance and both barycentrics */
     const ora_v3 N = ora_cross(ora_sub(v1, v0), ora_sub(v2, v0));
-    const float tt = ora_dot(A, N) / ora_dot(d, N);
+    const float inv = 1.0f / det;
+    const float tt = -ora_dot(A, N) * inv;
     if (!(tt > tMin && tt < tMax)) return 0;
     *t = tt;
-    *bu = V / det;
-    *bv = W / det;
+    *bu = V * inv;
+    *bv = W * inv;
     return 1;
 }
 
@@ -1249,7 +1257,7 @@ static void importance_sample_bounce(ora_path_ctx *c, const ora_surface *sf, ora
         *rd = cosine_sample_hemisphere(sf->normalWS, rnd2d01(&c->rng));
         NoL = ora_saturate(ora_dot(sf->normalWS, *rd));
         brdf = lambert_brdf(sf->material.albedo);
-        pdf = NoL / ORA_PI; /* sampling.glsl:35 */
+        pdf = NoL * ORA_INV_PI; /* sampling.glsl:35 */
         pdf *= diffuseWeight;
     }
     else
@@ -1312,7 +1320,7 @@ static ora_v3 debug_color(const ora_scene *s, uint32_t drawType, const ora_hit *
     case PROSPER_DRAW_TYPE_TEXCOORD0: return ora_v3_make(sf->uv.x, sf->uv.y, 0.0f);
     case PROSPER_DRAW_TYPE_ALBEDO: return sf->material.albedo;
     case PROSPER_DRAW_TYPE_SHADING_NORMAL:
-        return ora_v3_make(sf->normalWS.x * 0.5f + 0.5f, sf->normalWS.y * 0.5f + 0.5f, sf->normalWS.z * 0.5f + 0.5f);
+        return ora_v3_make(fmaf(sf->normalWS.x, 0.5f, 0.5f), fmaf(sf->normalWS.y, 0.5f, 0.5f), fmaf(sf->normalWS.z, 0.5f, 0.5f));
     case PROSPER_DRAW_TYPE_ROUGHNESS: return ora_v3_make(sf->material.roughness, sf->material.roughness, sf->material.roughness);
     case PROSPER_DRAW_TYPE_METALLIC: return ora_v3_make(sf->material.metallic, sf->material.metallic, sf->material.metallic);
     default: return ora_v3_make(1.0f, 0.0f, 1.0f);
@@ -1459,9 +1467,10 @@ void ora_render(
                 else
                 {
                     const float hc = out[3] + 1.0f;
-                    out[0] = out[0] + (color.x - out[0]) / hc;
-                    out[1] = out[1] + (color.y - out[1]) / hc;
-                    out[2] = out[2] + (color.z - out[2]) / hc;
+                    const float inv = 1.0f / hc;
+                    out[0] = fmaf(color.x - out[0], inv, out[0]);
+                    out[1] = fmaf(color.y - out[1], inv, out[1]);
+                    out[2] = fmaf(color.z - out[2], inv, out[2]);
                     out[3] = hc;
                     local.historyReads++;
                 }

@@ -70,8 +70,8 @@ struct Rng
 PPT_D f3 uint_to_color(uint32_t v)
 {
     const uint32_t xr = pcg(v);
-    return f3{(float)((xr >> 20) & 0x3FFu) / 1023.0f, (float)((xr >> 10) & 0x3FFu) / 1023.0f,
-              (float)(xr & 0x3FFu) / 1023.0f};
+    const float k = 1.0f / 1023.0f;
+    return f3{(float)((xr >> 20) & 0x3FFu) * k, (float)((xr >> 10) & 0x3FFu) * k, (float)(xr & 0x3FFu) * k};
 }
 
 // ------------------------------------------------------------------------------------------
@@ -121,8 +121,8 @@ PPT_D f3 unpack_snorm_r10g10b10(uint32_t packed)
     const int32_t sx = (int32_t)(packed << 22) >> 22;
     const int32_t sy = (int32_t)(packed << 12) >> 22;
     const int32_t sz = (int32_t)(packed << 2) >> 22;
-    return normalize(
-        f3{fmax_((float)sx / 511.0f, -1.0f), fmax_((float)sy / 511.0f, -1.0f), fmax_((float)sz / 511.0f, -1.0f)});
+    const float k = 1.0f / 511.0f;
+    return normalize(f3{fmax_((float)sx * k, -1.0f), fmax_((float)sy * k, -1.0f), fmax_((float)sz * k, -1.0f)});
 }
 
 // geometry.glsl:220-244
@@ -149,7 +149,10 @@ PPT_D Vertex load_vertex_through_index_buffer(const DeviceScene &s, const prospe
 }
 
 // geometry.glsl:258-270
-PPT_D float bary1(float v0, float v1, float v2, float a, float b, float c) { return (v0 * a + v1 * b) + v2 * c; }
+PPT_D float bary1(float v0, float v1, float v2, float a, float b, float c)
+{
+    return __builtin_fmaf(v2, c, __builtin_fmaf(v1, b, v0 * a));
+}
 
 // geometry.glsl:271-286
 PPT_D Vertex interpolate(const Vertex &v0, const Vertex &v1, const Vertex &v2, f2 bc)
@@ -179,16 +182,16 @@ PPT_D Vertex interpolate(const Vertex &v0, const Vertex &v1, const Vertex &v2, f
 // vec4(p,1) * mat3x4
 PPT_D f3 mul_point_mat3x4(f3 p, const prosper_mat3x4 &m)
 {
-    return f3{((p.x * m.col[0].x + p.y * m.col[0].y) + p.z * m.col[0].z) + m.col[0].w,
-              ((p.x * m.col[1].x + p.y * m.col[1].y) + p.z * m.col[1].z) + m.col[1].w,
-              ((p.x * m.col[2].x + p.y * m.col[2].y) + p.z * m.col[2].z) + m.col[2].w};
+    return f3{__builtin_fmaf(p.z, m.col[0].z, __builtin_fmaf(p.y, m.col[0].y, __builtin_fmaf(p.x, m.col[0].x, m.col[0].w))),
+              __builtin_fmaf(p.z, m.col[1].z, __builtin_fmaf(p.y, m.col[1].y, __builtin_fmaf(p.x, m.col[1].x, m.col[1].w))),
+              __builtin_fmaf(p.z, m.col[2].z, __builtin_fmaf(p.y, m.col[2].y, __builtin_fmaf(p.x, m.col[2].x, m.col[2].w)))};
 }
 // v * mat3(m)
 PPT_D f3 mul_vec_mat3(f3 v, const prosper_mat3x4 &m)
 {
-    return f3{(v.x * m.col[0].x + v.y * m.col[0].y) + v.z * m.col[0].z,
-              (v.x * m.col[1].x + v.y * m.col[1].y) + v.z * m.col[1].z,
-              (v.x * m.col[2].x + v.y * m.col[2].y) + v.z * m.col[2].z};
+    return f3{__builtin_fmaf(v.z, m.col[0].z, __builtin_fmaf(v.y, m.col[0].y, v.x * m.col[0].x)),
+              __builtin_fmaf(v.z, m.col[1].z, __builtin_fmaf(v.y, m.col[1].y, v.x * m.col[1].x)),
+              __builtin_fmaf(v.z, m.col[2].z, __builtin_fmaf(v.y, m.col[2].y, v.x * m.col[2].x))};
 }
 
 PPT_D Vertex transform(const Vertex &v, const prosper_ModelInstanceTransforms &t)
@@ -231,8 +234,8 @@ PPT_D int32_t wrap_coord(int32_t i, int32_t size, uint32_t mode)
 PPT_D f4 fetch_rgba8(const DeviceTexture &t, int32_t i, int32_t j)
 {
     const uint32_t p = reinterpret_cast<const uint32_t *>(t.texels)[(size_t)j * t.width + (size_t)i];
-    return f4{(float)(p & 0xFFu) / 255.0f, (float)((p >> 8) & 0xFFu) / 255.0f, (float)((p >> 16) & 0xFFu) / 255.0f,
-              (float)(p >> 24) / 255.0f};
+    const float k = 1.0f / 255.0f;
+    return f4{(float)(p & 0xFFu) * k, (float)((p >> 8) & 0xFFu) * k, (float)((p >> 16) & 0xFFu) * k, (float)(p >> 24) * k};
 }
 
 PPT_D f4 sample_texture(const DeviceScene &s, uint32_t tex, uint32_t smp, f2 uv)
@@ -247,8 +250,8 @@ PPT_D f4 sample_texture(const DeviceScene &s, uint32_t tex, uint32_t smp, f2 uv)
         const int32_t j = wrap_coord(f2i(__builtin_floorf(uv.y * (float)h)), h, sd.wrapT);
         return fetch_rgba8(t, i, j);
     }
-    const float u = uv.x * (float)w - 0.5f;
-    const float v = uv.y * (float)h - 0.5f;
+    const float u = __builtin_fmaf(uv.x, (float)w, -0.5f);
+    const float v = __builtin_fmaf(uv.y, (float)h, -0.5f);
     const float fu = __builtin_floorf(u);
     const float fv = __builtin_floorf(v);
     const float a = u - fu;
@@ -265,10 +268,10 @@ PPT_D f4 sample_texture(const DeviceScene &s, uint32_t tex, uint32_t smp, f2 uv)
     const float w10 = a * (1.0f - b);
     const float w01 = (1.0f - a) * b;
     const float w11 = a * b;
-    return f4{((w00 * t00.x + w10 * t10.x) + w01 * t01.x) + w11 * t11.x,
-              ((w00 * t00.y + w10 * t10.y) + w01 * t01.y) + w11 * t11.y,
-              ((w00 * t00.z + w10 * t10.z) + w01 * t01.z) + w11 * t11.z,
-              ((w00 * t00.w + w10 * t10.w) + w01 * t01.w) + w11 * t11.w};
+    return f4{__builtin_fmaf(w11, t11.x, __builtin_fmaf(w01, t01.x, __builtin_fmaf(w10, t10.x, w00 * t00.x))),
+              __builtin_fmaf(w11, t11.y, __builtin_fmaf(w01, t01.y, __builtin_fmaf(w10, t10.y, w00 * t00.y))),
+              __builtin_fmaf(w11, t11.z, __builtin_fmaf(w01, t01.z, __builtin_fmaf(w10, t10.z, w00 * t00.z))),
+              __builtin_fmaf(w11, t11.w, __builtin_fmaf(w01, t01.w, __builtin_fmaf(w10, t10.w, w00 * t00.w)))};
 }
 
 // Cube face selection per Vulkan 1.3 §16.5.4 (faces +X,-X,+Y,-Y,+Z,-Z)
@@ -317,13 +320,15 @@ PPT_D f3 fetch_cube_rgb(const DeviceScene &s, uint32_t face, int32_t i, int32_t 
     if (i < 0 || j < 0 || i >= n || j >= n)
     {
         // seamless edge: re-project the centre of the out-of-face texel onto the neighbouring face
-        const float sc = (2.0f * ((float)i + 0.5f)) / (float)n - 1.0f;
-        const float tc = (2.0f * ((float)j + 0.5f)) / (float)n - 1.0f;
+        const float invN = 1.0f / (float)n;
+        const float sc = __builtin_fmaf(2.0f * ((float)i + 0.5f), invN, -1.0f);
+        const float tc = __builtin_fmaf(2.0f * ((float)j + 0.5f), invN, -1.0f);
         const f3 d = cube_face_dir(face, sc, tc);
         float sc2, tc2, ma2;
         cube_face_coords(d, face, sc2, tc2, ma2);
-        const float ss = 0.5f * (sc2 / ma2) + 0.5f;
-        const float tt = 0.5f * (tc2 / ma2) + 0.5f;
+        const float inv2 = 1.0f / ma2;
+        const float ss = __builtin_fmaf(0.5f, sc2 * inv2, 0.5f);
+        const float tt = __builtin_fmaf(0.5f, tc2 * inv2, 0.5f);
         i = f2i(__builtin_floorf(ss * (float)n));
         j = f2i(__builtin_floorf(tt * (float)n));
         i = i < 0 ? 0 : (i >= n ? n - 1 : i);
@@ -341,10 +346,11 @@ PPT_D f3 sample_skybox(const DeviceScene &s, f3 d)
     uint32_t face;
     float sc, tc, ma;
     cube_face_coords(d, face, sc, tc, ma);
-    const float ss = 0.5f * (sc / ma) + 0.5f;
-    const float tt = 0.5f * (tc / ma) + 0.5f;
-    const float u = ss * (float)n - 0.5f;
-    const float v = tt * (float)n - 0.5f;
+    const float invMa = 1.0f / ma;
+    const float ss = __builtin_fmaf(0.5f, sc * invMa, 0.5f);
+    const float tt = __builtin_fmaf(0.5f, tc * invMa, 0.5f);
+    const float u = __builtin_fmaf(ss, (float)n, -0.5f);
+    const float v = __builtin_fmaf(tt, (float)n, -0.5f);
     const float fu = __builtin_floorf(u);
     const float fv = __builtin_floorf(v);
     const float a = u - fu;
@@ -359,9 +365,9 @@ PPT_D f3 sample_skybox(const DeviceScene &s, f3 d)
     const float w10 = a * (1.0f - b);
     const float w01 = (1.0f - a) * b;
     const float w11 = a * b;
-    return f3{((w00 * t00.x + w10 * t10.x) + w01 * t01.x) + w11 * t11.x,
-              ((w00 * t00.y + w10 * t10.y) + w01 * t01.y) + w11 * t11.y,
-              ((w00 * t00.z + w10 * t10.z) + w01 * t01.z) + w11 * t11.z};
+    return f3{__builtin_fmaf(w11, t11.x, __builtin_fmaf(w01, t01.x, __builtin_fmaf(w10, t10.x, w00 * t00.x))),
+              __builtin_fmaf(w11, t11.y, __builtin_fmaf(w01, t01.y, __builtin_fmaf(w10, t10.y, w00 * t00.y))),
+              __builtin_fmaf(w11, t11.z, __builtin_fmaf(w01, t01.z, __builtin_fmaf(w10, t10.z, w00 * t00.z)))};
 }
 
 // ------------------------------------------------------------------------------------------
@@ -378,7 +384,10 @@ struct Material
 };
 
 // materials.glsl:26-29
-PPT_D float srgb_to_linear(float x) { return x <= 0.04045f ? x / 12.92f : pow_((x + 0.055f) / 1.055f, 2.4f); }
+PPT_D float srgb_to_linear(float x)
+{
+    return x <= 0.04045f ? x * (1.0f / 12.92f) : pow_((x + 0.055f) * (1.0f / 1.055f), 2.4f);
+}
 
 // materials.glsl:47-119
 PPT_D Material sample_material(const DeviceScene &s, uint32_t index, f2 uv)
@@ -433,7 +442,7 @@ PPT_D Material sample_material(const DeviceScene &s, uint32_t index, f2 uv)
     if (nTex > 0)
     {
         const f4 tn = sample_texture(s, nTex, data.normalTextureSampler >> 24, uv);
-        ret.normal = f3{tn.x * 2.0f - 1.0f, tn.y * 2.0f - 1.0f, tn.z * 2.0f - 1.0f};
+        ret.normal = f3{__builtin_fmaf(tn.x, 2.0f, -1.0f), __builtin_fmaf(tn.y, 2.0f, -1.0f), __builtin_fmaf(tn.z, 2.0f, -1.0f)};
     }
     else
         ret.normal = f3{-2.0f, -2.0f, -2.0f};
@@ -471,22 +480,22 @@ struct Surface
 PPT_D float trowbridge_reitz(float NoH, float alpha)
 {
     const float a2 = alpha * alpha;
-    const float denom = (NoH * NoH) * (a2 - 1.0f) + 1.0f;
+    const float denom = __builtin_fmaf(NoH * NoH, a2 - 1.0f, 1.0f);
     return a2 / ((kPi * denom) * denom);
 }
 // brdf.glsl:21-24
 PPT_D f3 schlick_fresnel(float VoH, f3 f0)
 {
     const float p = pow5(1.0f - VoH);
-    return f3{f0.x + (1.0f - f0.x) * p, f0.y + (1.0f - f0.y) * p, f0.z + (1.0f - f0.z) * p};
+    return f3{__builtin_fmaf(1.0f - f0.x, p, f0.x), __builtin_fmaf(1.0f - f0.y, p, f0.y), __builtin_fmaf(1.0f - f0.z, p, f0.z)};
 }
 // brdf.glsl:35-43
 PPT_D float schlick_trowbridge_reitz(float NoL, float NoV, float alpha)
 {
     float k = alpha * 0.5f;
     k = fmax_(k, 0.0001f);
-    const float gl = NoL / (NoL * (1.0f - k) + k);
-    const float gv = NoV / (NoV * (1.0f - k) + k);
+    const float gl = NoL / __builtin_fmaf(NoL, 1.0f - k, k);
+    const float gv = NoV / __builtin_fmaf(NoV, 1.0f - k, k);
     return gl * gv;
 }
 // brdf.glsl:46-58
@@ -496,7 +505,7 @@ PPT_D f3 cook_torrance_brdf(float NoL, float NoV, float NoH, float VoH, f3 f0, f
     const float D = trowbridge_reitz(NoH, alpha);
     const f3 F = schlick_fresnel(VoH, f0);
     const float G = schlick_trowbridge_reitz(NoL, NoV, alpha);
-    const float denom = (4.0f * NoL) * NoV + 0.0001f;
+    const float denom = __builtin_fmaf(4.0f * NoL, NoV, 0.0001f);
     return ((F * D) * G) / denom;
 }
 // brdf.glsl:60-64
@@ -507,7 +516,7 @@ PPT_D f3 fresnel_zero(const Surface &sf)
               mix(0.04f, sf.material.albedo.z, m)};
 }
 // brdf.glsl:9
-PPT_D f3 lambert_brdf(f3 c) { return c / kPi; }
+PPT_D f3 lambert_brdf(f3 c) { return c * kInvPi; }
 
 // brdf.glsl:67-87
 PPT_D f3 eval_brdf_times_nol(f3 l, const Surface &sf)
@@ -530,14 +539,14 @@ PPT_D f3 eval_brdf_times_nol(f3 l, const Surface &sf)
 // sampling.glsl:18-33
 PPT_D f3 cosine_sample_hemisphere(f3 n, f2 u)
 {
-    float a = 1.0f - 2.0f * u.x;
+    float a = __builtin_fmaf(-2.0f, u.x, 1.0f);
     a *= 0.99999f;
-    float b = sqrt_(1.0f - a * a);
+    float b = sqrt_(__builtin_fmaf(-a, a, 1.0f));
     b *= 0.99999f;
     const float phi = kTwoPi * u.y;
     float sn, cs;
     sincos_(phi, sn, cs);
-    return normalize(f3{n.x + b * cs, n.y + b * sn, n.z + a});
+    return normalize(f3{__builtin_fmaf(b, cs, n.x), __builtin_fmaf(b, sn, n.y), n.z + a});
 }
 
 // sampling.glsl:37-47 (rows b1, b2, n)
@@ -547,8 +556,9 @@ struct Onb
     PPT_D f3 to_local(f3 v) const { return f3{dot(b1, v), dot(b2, v), dot(n, v)}; }
     PPT_D f3 to_world(f3 v) const
     {
-        return f3{(b1.x * v.x + b2.x * v.y) + n.x * v.z, (b1.y * v.x + b2.y * v.y) + n.y * v.z,
-                  (b1.z * v.x + b2.z * v.y) + n.z * v.z};
+        return f3{__builtin_fmaf(n.x, v.z, __builtin_fmaf(b2.x, v.y, b1.x * v.x)),
+                  __builtin_fmaf(n.y, v.z, __builtin_fmaf(b2.y, v.y, b1.y * v.x)),
+                  __builtin_fmaf(n.z, v.z, __builtin_fmaf(b2.z, v.y, b1.z * v.x))};
     }
 };
 PPT_D Onb orthonormal_basis(f3 n)
@@ -557,8 +567,8 @@ PPT_D Onb orthonormal_basis(f3 n)
     const float a = -1.0f / (s + n.z);
     const float b = (n.x * n.y) * a;
     Onb o;
-    o.b1 = f3{1.0f + ((s * n.x) * n.x) * a, s * b, (-s) * n.x};
-    o.b2 = f3{b, s + (n.y * n.y) * a, -n.y};
+    o.b1 = f3{__builtin_fmaf((s * n.x) * n.x, a, 1.0f), s * b, (-s) * n.x};
+    o.b2 = f3{b, __builtin_fmaf(n.y * n.y, a, s), -n.y};
     o.n = n;
     return o;
 }
@@ -567,7 +577,7 @@ PPT_D Onb orthonormal_basis(f3 n)
 PPT_D f3 sample_visible_trowbridge_reitz(f3 Ve, float alpha, f2 Us)
 {
     const f3 Vh = normalize(f3{alpha * Ve.x, alpha * Ve.y, Ve.z});
-    const float lensq = Vh.x * Vh.x + Vh.y * Vh.y;
+    const float lensq = __builtin_fmaf(Vh.y, Vh.y, Vh.x * Vh.x);
     f3 T1;
     if (lensq > 0.0f)
     {
@@ -584,9 +594,12 @@ PPT_D f3 sample_visible_trowbridge_reitz(f3 Ve, float alpha, f2 Us)
     const float t1 = r * cs;
     float t2 = r * sn;
     const float s = 0.5f * (1.0f + Vh.z);
-    t2 = (1.0f - s) * sqrt_(1.0f - t1 * t1) + s * t2;
-    const float k = sqrt_(fmax_(0.0f, (1.0f - t1 * t1) - t2 * t2));
-    const f3 Nh = ((T1 * t1) + (T2 * t2)) + (Vh * k);
+    const float c1 = __builtin_fmaf(-t1, t1, 1.0f);
+    t2 = __builtin_fmaf(s, t2, (1.0f - s) * sqrt_(c1));
+    const float k = sqrt_(fmax_(0.0f, __builtin_fmaf(-t2, t2, c1)));
+    const f3 Nh = f3{__builtin_fmaf(Vh.x, k, __builtin_fmaf(T2.x, t2, T1.x * t1)),
+                     __builtin_fmaf(Vh.y, k, __builtin_fmaf(T2.y, t2, T1.y * t1)),
+                     __builtin_fmaf(Vh.z, k, __builtin_fmaf(T2.z, t2, T1.z * t1))};
     const f3 Ne = normalize(f3{alpha * Nh.x, alpha * Nh.y, fmax_(0.0f, Nh.z)});
     return reflect(-Ve, Ne);
 }
@@ -634,7 +647,7 @@ PPT_D void eval_spot_light(const prosper_SpotLight &light, f3 surfacePos, f3 &l,
     l = toLight / d;
     const f3 negDir = f3{-light.direction.x, -light.direction.y, -light.direction.z};
     const float cd = dot(negDir, l);
-    float att = saturate(cd * light.radianceAndAngleScale.w + light.positionAndAngleOffset.w);
+    float att = saturate(__builtin_fmaf(cd, light.radianceAndAngleScale.w, light.positionAndAngleOffset.w));
     att *= att;
     const f3 rad = f3{light.radianceAndAngleScale.x, light.radianceAndAngleScale.y, light.radianceAndAngleScale.z};
     irradiance = (rad * att) / d2;
@@ -682,8 +695,8 @@ struct Ray
 // ray.glsl:15-43
 PPT_D Ray pinhole_camera_ray(const RenderParams &p, f2 uv)
 {
-    const float ndx = uv.x * 2.0f - 1.0f;
-    const float ndy = uv.y * 2.0f - 1.0f;
+    const float ndx = __builtin_fmaf(uv.x, 2.0f, -1.0f);
+    const float ndy = __builtin_fmaf(uv.y, 2.0f, -1.0f);
     Ray ray;
     ray.o = f3{p.eye[0], p.eye[1], p.eye[2]};
     ray.tMin = 0.0f;
@@ -711,15 +724,15 @@ PPT_D Ray thin_lens_camera_ray(const RenderParams &p, f2 uv, f2 lensOffset)
     const float v = sn * sqrt_(radius);
     const f3 fwd = f3{p.fwd[0], p.fwd[1], p.fwd[2]};
     const float k = p.pc.focusDistance / dot(pin.d, fwd);
-    const f3 focusPoint = pin.o + pin.d * k;
+    const f3 focusPoint = f3{__builtin_fmaf(pin.d.x, k, pin.o.x), __builtin_fmaf(pin.d.y, k, pin.o.y), __builtin_fmaf(pin.d.z, k, pin.o.z)};
     const float fStop = p.pc.focalLength / p.pc.apertureDiameter;
     const float coc = p.pc.focalLength / (2.0f * fStop);
     const f3 lensPos = (f3{1.0f, 0.0f, 0.0f} * (u * coc)) + (f3{0.0f, 1.0f, 0.0f} * (v * coc));
     const float *m = p.cameraToWorld; // column-major
     Ray ray;
-    ray.o = f3{((m[0] * lensPos.x + m[4] * lensPos.y) + m[8] * lensPos.z) + m[12],
-               ((m[1] * lensPos.x + m[5] * lensPos.y) + m[9] * lensPos.z) + m[13],
-               ((m[2] * lensPos.x + m[6] * lensPos.y) + m[10] * lensPos.z) + m[14]};
+    ray.o = f3{__builtin_fmaf(m[8], lensPos.z, __builtin_fmaf(m[4], lensPos.y, __builtin_fmaf(m[0], lensPos.x, m[12]))),
+               __builtin_fmaf(m[9], lensPos.z, __builtin_fmaf(m[5], lensPos.y, __builtin_fmaf(m[1], lensPos.x, m[13]))),
+               __builtin_fmaf(m[10], lensPos.z, __builtin_fmaf(m[6], lensPos.y, __builtin_fmaf(m[2], lensPos.x, m[14])))};
     ray.d = normalize(focusPoint - ray.o);
     ray.tMin = 0.0f;
     ray.tMax = kInf;
@@ -731,7 +744,7 @@ PPT_D float offset_component(float p, float n)
 {
     const int32_t ofI = f2i(256.0f * n);
     const uint32_t moved = f2u(p) + (uint32_t)((p < 0.0f) ? -ofI : ofI);
-    return fabs_(p) < (1.0f / 32.0f) ? p + (1.0f / 65536.0f) * n : u2f(moved);
+    return fabs_(p) < (1.0f / 32.0f) ? __builtin_fmaf(1.0f / 65536.0f, n, p) : u2f(moved);
 }
 PPT_D f3 offset_ray(f3 p, f3 n)
 {
@@ -757,12 +770,15 @@ PPT_D bool intersect_triangle(f3 o, f3 d, f3 v0, f3 v1, f3 v2, float tMin, float
     if ((U < 0.0f || V < 0.0f || W < 0.0f) && (U > 0.0f || V > 0.0f || W > 0.0f)) return false;
     const float det = (U + V) + W;
     if (!(det != 0.0f)) return false;
+    // det = U + V + W equals -dot(d, N) in exact arithmetic, so one reciprocal serves t and both
+    // barycentrics (DESIGN.md "hit contract")
     const f3 N = cross(v1 - v0, v2 - v0);
-    const float tt = dot(A, N) / dot(d, N);
+    const float inv = 1.0f / det;
+    const float tt = -dot(A, N) * inv;
     if (!(tt > tMin && tt < tMax)) return false;
     t = tt;
-    bu = V / det;
-    bv = W / det;
+    bu = V * inv;
+    bv = W * inv;
     return true;
 }
 
@@ -980,7 +996,7 @@ PPT_D f3 debug_color(const DeviceScene &s, uint32_t drawType, const Hit &hit, co
     case PROSPER_DRAW_TYPE_TEXCOORD0: return f3{sf.uv.x, sf.uv.y, 0.0f};
     case PROSPER_DRAW_TYPE_ALBEDO: return sf.material.albedo;
     case PROSPER_DRAW_TYPE_SHADING_NORMAL:
-        return f3{sf.normalWS.x * 0.5f + 0.5f, sf.normalWS.y * 0.5f + 0.5f, sf.normalWS.z * 0.5f + 0.5f};
+        return f3{__builtin_fmaf(sf.normalWS.x, 0.5f, 0.5f), __builtin_fmaf(sf.normalWS.y, 0.5f, 0.5f), __builtin_fmaf(sf.normalWS.z, 0.5f, 0.5f)};
     case PROSPER_DRAW_TYPE_ROUGHNESS: return f3{sf.material.roughness, sf.material.roughness, sf.material.roughness};
     case PROSPER_DRAW_TYPE_METALLIC: return f3{sf.material.metallic, sf.material.metallic, sf.material.metallic};
     default: return f3{1.0f, 0.0f, 1.0f};
@@ -1014,7 +1030,7 @@ PPT_D void importance_sample_bounce(const Surface &sf, Rng &rng, f3 &throughput,
         rd = cosine_sample_hemisphere(sf.normalWS, u);
         NoL = saturate(dot(sf.normalWS, rd));
         brdf = lambert_brdf(sf.material.albedo);
-        pdf = NoL / kPi; // sampling.glsl:35
+        pdf = NoL * kInvPi; // sampling.glsl:35
         pdf *= diffuseWeight;
     }
     else

@@ -207,9 +207,10 @@ __global__ __launch_bounds__(256) void render_megakernel(
                 if (f == 0) history = *texel;
                 if constexpr (COUNT) cnt.historyReads++;
                 const float hc = history.w + 1.0f;
+                const float invHc = 1.0f / hc;
                 history = make_float4(
-                    history.x + (color.x - history.x) / hc, history.y + (color.y - history.y) / hc,
-                    history.z + (color.z - history.z) / hc, hc);
+                    __builtin_fmaf(color.x - history.x, invHc, history.x), __builtin_fmaf(color.y - history.y, invHc, history.y),
+                    __builtin_fmaf(color.z - history.z, invHc, history.z), hc);
             }
             if constexpr (COUNT) cnt.pixelsWritten++;
         }
@@ -382,9 +383,10 @@ __global__ __launch_bounds__(256) void render_persistent(
                     if (frame == 0) history = hdr[(size_t)py * p.localWidth + lx];
                     if constexpr (COUNT) cnt.historyReads++;
                     const float hc = history.w + 1.0f;
-                    history = make_float4(
-                        history.x + (st.color.x - history.x) / hc, history.y + (st.color.y - history.y) / hc,
-                        history.z + (st.color.z - history.z) / hc, hc);
+                const float invHc = 1.0f / hc;
+                history = make_float4(
+                    __builtin_fmaf(st.color.x - history.x, invHc, history.x), __builtin_fmaf(st.color.y - history.y, invHc, history.y),
+                    __builtin_fmaf(st.color.z - history.z, invHc, history.z), hc);
                 }
                 if constexpr (COUNT) cnt.pixelsWritten++;
                 frame++;

@@ -6,7 +6,9 @@
 //   * IEEE binary32, round-to-nearest-even, denormals kept, no contraction (-ffp-contract=off);
 //     fmaf only where written;
 //   * a/b and sqrt are correctly rounded (hipcc default -fhip-fp32-correctly-rounded-divide-sqrt);
-//   * dot(a,b) = (a.x*b.x + a.y*b.y) + a.z*b.z; normalize(v) = v * (1/sqrt(dot(v,v)));
+//   * dot(a,b) = fma(a.z,b.z, fma(a.y,b.y, a.x*b.x)); cross is NOT fused (exact antisymmetry);
+//     normalize(v) = v * (1/sqrt(dot(v,v))); vector / scalar = vector * (1 / scalar); division by a
+//     constant multiplies by its fp32 reciprocal;
 //   * sin/cos/exp2/log2 are the fixed polynomial kernels below (no v_sin_f32/v_exp_f32, whose
 //     results are not reproducible off-GPU);
 //   * min/max are IEEE minNum/maxNum (a NaN operand loses).
@@ -26,6 +28,7 @@ struct f3 { float x, y, z; };
 struct f4 { float x, y, z, w; };
 
 constexpr float kPi = 3.14159265f; // math.glsl:4
+constexpr float kInvPi = 1.0f / 3.14159265f;
 constexpr float kTwoPi = 6.2831853f; // the GLSL front end folds (2.0 * PI)
 constexpr float kInf = __builtin_huge_valf();
 
@@ -71,9 +74,14 @@ PPT_HD f3 operator+(f3 a, f3 b) { return f3{a.x + b.x, a.y + b.y, a.z + b.z}; }
 PPT_HD f3 operator-(f3 a, f3 b) { return f3{a.x - b.x, a.y - b.y, a.z - b.z}; }
 PPT_HD f3 operator*(f3 a, f3 b) { return f3{a.x * b.x, a.y * b.y, a.z * b.z}; }
 PPT_HD f3 operator*(f3 a, float s) { return f3{a.x * s, a.y * s, a.z * s}; }
-PPT_HD f3 operator/(f3 a, float s) { return f3{a.x / s, a.y / s, a.z / s}; }
+// vector / scalar = vector * (1 / scalar): one division, three multiplications
+PPT_HD f3 operator/(f3 a, float s)
+{
+    const float inv = 1.0f / s;
+    return f3{a.x * inv, a.y * inv, a.z * inv};
+}
 PPT_HD f3 operator-(f3 a) { return f3{-a.x, -a.y, -a.z}; }
-PPT_HD float dot(f3 a, f3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
+PPT_HD float dot(f3 a, f3 b) { return __builtin_fmaf(a.z, b.z, __builtin_fmaf(a.y, b.y, a.x * b.x)); }
 PPT_HD f3 cross(f3 a, f3 b)
 {
     return f3{a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x};
@@ -85,11 +93,11 @@ PPT_HD f3 normalize(f3 a)
     const float inv = 1.0f / sqrt_(dot(a, a));
     return a * inv;
 }
-PPT_HD float mix(float a, float b, float t) { return a * (1.0f - t) + b * t; }
+PPT_HD float mix(float a, float b, float t) { return __builtin_fmaf(b, t, a * (1.0f - t)); }
 PPT_HD f3 reflect(f3 i, f3 n)
 {
     const float k = 2.0f * dot(n, i);
-    return i - n * k;
+    return f3{__builtin_fmaf(-k, n.x, i.x), __builtin_fmaf(-k, n.y, i.y), __builtin_fmaf(-k, n.z, i.z)};
 }
 PPT_HD float max3(f3 v) { return fmax_(fmax_(v.x, v.y), v.z); }
 

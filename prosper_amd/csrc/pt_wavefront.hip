@@ -32,7 +32,15 @@
 // is sized to the BVH depth (16/24/32 entries x 64 lanes x 4 B per wave); at 32 entries the LDS
 // caps a CU at 20 waves, so that variant is allocated for 5 waves/SIMD.
 #define PPT_SHADE_WPE 4
+#ifndef PPT_GEN_WPE
+#define PPT_GEN_WPE 4
+#endif
+#ifndef PPT_SHADOW_WPE
+#define PPT_SHADOW_WPE(stack) 5
+#endif
+#ifndef PPT_TRAV_WPE
 #define PPT_TRAV_WPE(stack) ((stack) <= 24 ? 6 : 5)
+#endif
 
 namespace ppt
 {
@@ -112,7 +120,7 @@ __device__ __forceinline__ void add_to_slot(float4 *color, uint32_t slot, uint32
 // ------------------------------------------------------------------------------------------
 
 template <bool COUNT, int STACK>
-__global__ __launch_bounds__(256) void wf_generate_extend(
+__global__ __launch_bounds__(256, PPT_GEN_WPE) void wf_generate_extend(
     DeviceScene s, RenderParams p, WavefrontBuffers w, unsigned long long *__restrict__ counters)
 {
     __shared__ int32_t ldsStack[STACK * 256];
@@ -381,7 +389,7 @@ __global__ __launch_bounds__(256, PPT_SHADE_WPE) void wf_shade(
 // ------------------------------------------------------------------------------------------
 
 template <bool COUNT, int STACK>
-__global__ __launch_bounds__(256, PPT_TRAV_WPE(STACK)) void wf_shadow(
+__global__ __launch_bounds__(256, PPT_SHADOW_WPE(STACK)) void wf_shadow(
     DeviceScene s, RenderParams p, WavefrontBuffers w, uint32_t bounce, unsigned long long *__restrict__ counters)
 {
     __shared__ int32_t ldsStack[STACK * 256];
@@ -454,9 +462,10 @@ __global__ __launch_bounds__(256) void wf_accumulate(
                     if (f == 0) history = *texel;
                     if constexpr (COUNT) cnt.historyReads++;
                     const float hc = history.w + 1.0f;
-                    history = make_float4(
-                        history.x + (c.x - history.x) / hc, history.y + (c.y - history.y) / hc,
-                        history.z + (c.z - history.z) / hc, hc);
+                const float invHc = 1.0f / hc;
+                history = make_float4(
+                    __builtin_fmaf(c.x - history.x, invHc, history.x), __builtin_fmaf(c.y - history.y, invHc, history.y),
+                    __builtin_fmaf(c.z - history.z, invHc, history.z), hc);
                 }
                 if constexpr (COUNT) cnt.pixelsWritten++;
             }
