@@ -9,6 +9,7 @@
 #include <hip/hip_runtime.h>
 
 #include <chrono>
+#include <cstdlib>
 #include <cstdio>
 #include <cstring>
 #include <exception>
@@ -358,10 +359,16 @@ int ensure_wavefront_workspace(
 {
     const uint64_t pixelsPadded = (uint64_t)tilesX * tilesY * 64u;
     const uint64_t slots = pixelsPadded * frames;
-    // one segment per wave; aim for ~16k waves so every CU has many segments to balance over
-    uint64_t segLen = ((slots / 16384u) + 63u) / 64u * 64u;
+    // one segment per wave; ~32k waves give each CU several rounds of segments to balance over
+    // (measured sweep, profiles/r01_seglen_sweep.txt: 512 slots is the optimum at 16.6 M slots)
+    uint64_t segLen = ((slots / 32768u) + 63u) / 64u * 64u;
     if (segLen < 256u) segLen = 256u;
-    if (segLen > 2048u) segLen = 2048u;
+    if (segLen > 1024u) segLen = 1024u;
+    if (const char *forced = std::getenv("PROSPER_PT_DEBUG_SEGLEN")) // tuning/test hook
+    {
+        const uint64_t v = (uint64_t)std::atoll(forced);
+        if (v >= 64u && v <= 8192u && v % 64u == 0u) segLen = v;
+    }
     const uint64_t nSeg = (slots + segLen - 1u) / segLen;
     const uint64_t padded = nSeg * segLen;
     // per slot: 8 x 16 B ping-pong state, hit 16 + idx 4, shadow 48, colour 16; + 3 counters per segment
