@@ -35,11 +35,8 @@
 #ifndef PPT_GEN_WPE
 #define PPT_GEN_WPE 4
 #endif
-#ifndef PPT_SHADOW_WPE
-#define PPT_SHADOW_WPE(stack) 5
-#endif
-#ifndef PPT_TRAV_WPE
-#define PPT_TRAV_WPE(stack) ((stack) <= 24 ? 6 : 5)
+#ifndef PPT_TRACE_WPE
+#define PPT_TRACE_WPE(stack) 5
 #endif
 
 namespace ppt
@@ -218,20 +215,14 @@ __global__ __launch_bounds__(256, PPT_GEN_WPE) void wf_generate_extend(
 // extend: traceClosest of bounce >= 1
 // ------------------------------------------------------------------------------------------
 
-template <bool COUNT, int STACK>
-__global__ __launch_bounds__(256, PPT_TRAV_WPE(STACK)) void wf_extend(
-    DeviceScene s, RenderParams p, WavefrontBuffers w, uint32_t bounce, uint32_t cur,
-    unsigned long long *__restrict__ counters)
+// One wave's extend work: traces the live rays of its segment (buffer set `cur`), compacts the hits.
+template <bool COUNT>
+__device__ __forceinline__ void extend_segment(
+    const DeviceScene &s, const RenderParams &p, const WavefrontBuffers &w, const SegmentId &id, uint32_t bounce,
+    uint32_t cur, int32_t *stack, LaneCounters &cnt)
 {
-    __shared__ int32_t ldsStack[STACK * 256];
-    const SegmentId id = my_segment(w);
-    if (!id.valid) return;
-    const uint32_t lane = lane_id();
-    int32_t *stack = ldsStack + (threadIdx.x >> 6) * (STACK * 64u) + lane;
     const float4 *__restrict__ rayA = w.rayA[cur];
     const float4 *__restrict__ rayB = w.rayB[cur];
-
-    LaneCounters cnt = {};
     const uint32_t n = w.segRays[id.seg];
     uint32_t nHit = 0;
     auto fetch = [&](uint32_t i) {
@@ -264,8 +255,7 @@ __global__ __launch_bounds__(256, PPT_TRAV_WPE(STACK)) void wf_extend(
         nHit += total;
     };
     trace_stream<false, COUNT>(s, n, stack, cnt, fetch, commit);
-    if (lane == 0) w.segHits[id.seg] = nHit;
-    flush_counters<COUNT>(cnt, counters);
+    if (lane_id() == 0) w.segHits[id.seg] = nHit;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -388,17 +378,13 @@ __global__ __launch_bounds__(256, PPT_SHADE_WPE) void wf_shade(
 // shadow
 // ------------------------------------------------------------------------------------------
 
-template <bool COUNT, int STACK>
-__global__ __launch_bounds__(256, PPT_SHADOW_WPE(STACK)) void wf_shadow(
-    DeviceScene s, RenderParams p, WavefrontBuffers w, uint32_t bounce, unsigned long long *__restrict__ counters)
+// One wave's shadow work: shadow() for the shadow rays shade queued in its segment; adds the direct
+// term of bounce `bounce` where the light is visible.
+template <bool COUNT>
+__device__ __forceinline__ void shadow_segment(
+    const DeviceScene &s, const RenderParams &p, const WavefrontBuffers &w, const SegmentId &id, uint32_t bounce,
+    int32_t *stack, LaneCounters &cnt)
 {
-    __shared__ int32_t ldsStack[STACK * 256];
-    const SegmentId id = my_segment(w);
-    if (!id.valid) return;
-    const uint32_t lane = lane_id();
-    int32_t *stack = ldsStack + (threadIdx.x >> 6) * (STACK * 64u) + lane;
-
-    LaneCounters cnt = {};
     const uint32_t n = w.segShadow[id.seg];
     auto fetch = [&](uint32_t k) {
         const float4 a = w.shA[id.base + k];
@@ -430,6 +416,31 @@ __global__ __launch_bounds__(256, PPT_SHADOW_WPE(STACK)) void wf_shadow(
         }
     };
     trace_stream<true, COUNT>(s, n, stack, cnt, fetch, commit);
+}
+
+// Shadow rays of bounce `bounce` and (unless it was the last bounce) the closest-hit rays of bounce
+// `bounce + 1` in ONE launch: both belong to the same wave-owned segment, neither depends on the
+// other, and one launch has one tail instead of two.  The reference adds the direct term of bounce b
+// before the sky term of bounce b + 1 (main.rgen:266 then :252); both may touch the same radiance
+// slot from different lanes of this wave, hence shadow first, a fence, then extend.
+template <bool COUNT, int STACK>
+__global__ __launch_bounds__(256, PPT_TRACE_WPE(STACK)) void wf_trace(
+    DeviceScene s, RenderParams p, WavefrontBuffers w, uint32_t bounce, uint32_t nextCur, uint32_t doExtend,
+    unsigned long long *__restrict__ counters)
+{
+    __shared__ int32_t ldsStack[STACK * 256];
+    const SegmentId id = my_segment(w);
+    if (!id.valid) return;
+    int32_t *stack = ldsStack + (threadIdx.x >> 6) * (STACK * 64u) + lane_id();
+    LaneCounters cnt = {};
+    shadow_segment<COUNT>(s, p, w, id, bounce, stack, cnt);
+    if (doExtend)
+    {
+        // same wave, same CU: a workgroup-scope fence (s_waitcnt vmcnt(0)) orders the shadow phase's
+        // radiance stores before the extend phase's loads; the vector L1 is write-through
+        __threadfence_block();
+        extend_segment<COUNT>(s, p, w, id, bounce + 1u, nextCur, stack, cnt);
+    }
     flush_counters<COUNT>(cnt, counters);
 }
 
@@ -497,9 +508,9 @@ static void enqueue_wavefront(
         const uint32_t cur = b & 1u;
         const uint32_t last = (b + 1u == bounces) ? 1u : 0u;
         hipLaunchKernelGGL(wf_shade<COUNT>, grid, block, 0, stream, s, p, w, b, cur, last, counters);
-        if (!debugDraw) hipLaunchKernelGGL((wf_shadow<COUNT, STACK>), grid, block, 0, stream, s, p, w, b, counters);
-        if (!last)
-            hipLaunchKernelGGL((wf_extend<COUNT, STACK>), grid, block, 0, stream, s, p, w, b + 1u, cur ^ 1u, counters);
+        if (!debugDraw)
+            hipLaunchKernelGGL(
+                (wf_trace<COUNT, STACK>), grid, block, 0, stream, s, p, w, b, cur ^ 1u, last ? 0u : 1u, counters);
     }
     hipLaunchKernelGGL(
         wf_accumulate<COUNT>, dim3((w.pixelsPadded + 255u) / 256u), block, 0, stream, p, w, hdr, counters);
