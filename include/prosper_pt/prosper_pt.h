@@ -267,13 +267,19 @@ int prosper_pt_read_hdr(prosper_pt_ctx *ctx, float *rgba32f, size_t byte_size, v
 int prosper_pt_blit_rgba16f(prosper_pt_ctx *ctx, uint16_t *host_rgba16f, size_t byte_size, void *stream);
 
 int prosper_pt_get_counters(prosper_pt_ctx *ctx, prosper_pt_counters *out, void *stream);
+/* The same counters for one kernel stage (index as in prosper_pt_kernel_name): lets the roofline
+ * of a single kernel be priced from the work that kernel did. */
+int prosper_pt_get_stage_counters(prosper_pt_ctx *ctx, uint32_t stage, prosper_pt_counters *out, void *stream);
 int prosper_pt_reset_counters(prosper_pt_ctx *ctx, void *stream);
 
-/* Average device time (ms) of the kernels launched by the last `prosper_pt_render`, measured
- * with hipEvents on `stream`; blocks until they finish.  kernel_ms[i] follows
- * prosper_pt_kernel_name(i). */
+/* Device time (ms) of the kernels launched by the last `prosper_pt_render(_frames)`, measured with
+ * hipEvents on the launch stream; blocks until they finish.  kernel_ms[i] is the SUM over the
+ * kernel_launches[i] launches of stage i, named by prosper_pt_kernel_name(i). */
 #define PROSPER_PT_MAX_KERNELS 8
 int prosper_pt_get_last_render_ms(prosper_pt_ctx *ctx, float *total_ms, float kernel_ms[PROSPER_PT_MAX_KERNELS]);
+int prosper_pt_get_last_render_timing(
+    prosper_pt_ctx *ctx, float *total_ms, float kernel_ms[PROSPER_PT_MAX_KERNELS],
+    uint32_t kernel_launches[PROSPER_PT_MAX_KERNELS]);
 const char *prosper_pt_kernel_name(uint32_t index);
 /* Enables per-kernel hipEvent timing for subsequent renders (off by default: events add launches). */
 int prosper_pt_set_kernel_timing(prosper_pt_ctx *ctx, int enabled);

@@ -62,6 +62,8 @@ def lib():
     L.prosper_pt_blit_rgba16f.argtypes = [vp, vp, C.c_size_t, vp]
     L.prosper_pt_get_counters.argtypes = [vp, C.POINTER(S.Counters), vp]
     L.prosper_pt_reset_counters.argtypes = [vp, vp]
+    L.prosper_pt_get_stage_counters.argtypes = [vp, u32, C.POINTER(S.Counters), vp]
+    L.prosper_pt_get_last_render_timing.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(u32)]
     L.prosper_pt_get_last_render_ms.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_float)]
     L.prosper_pt_kernel_name.argtypes = [u32]
     L.prosper_pt_kernel_name.restype = C.c_char_p
@@ -190,6 +192,20 @@ class Context:
         c = S.Counters()
         _check(lib().prosper_pt_get_counters(self._h, C.byref(c), C.c_void_p(stream)))
         return c
+
+    def stage_counters(self, stage, stream=None):
+        c = S.Counters()
+        _check(lib().prosper_pt_get_stage_counters(self._h, stage, C.byref(c), C.c_void_p(stream)))
+        return c
+
+    def last_render_timing(self):
+        """-> (total_ms, {kernel name: (sum_ms, launches)}) of the last render, from hipEvents."""
+        total = C.c_float()
+        per = (C.c_float * S.MAX_KERNELS)()
+        launches = (C.c_uint32 * S.MAX_KERNELS)()
+        _check(lib().prosper_pt_get_last_render_timing(self._h, C.byref(total), per, launches))
+        names = [lib().prosper_pt_kernel_name(i).decode() for i in range(S.MAX_KERNELS)]
+        return total.value, {n: (per[i], launches[i]) for i, n in enumerate(names) if n}
 
     def reset_counters(self, stream=None):
         _check(lib().prosper_pt_reset_counters(self._h, C.c_void_p(stream)))

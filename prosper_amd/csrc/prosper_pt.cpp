@@ -70,7 +70,7 @@ struct prosper_pt_ctx
     size_t externalHdrBytes = 0;
     uint32_t localWidth = 0, height = 0;
 
-    unsigned long long *dCounters = nullptr; // 16 x u64
+    unsigned long long *dCounters = nullptr; // kStageCount x 16 u64: one block of work counters per kernel stage
     uint32_t *dWorkCounter = nullptr;        // work-distribution counter of the persistent kernel
     // wavefront workspace (one allocation, carved into the WavefrontBuffers arrays)
     void *wfBlock = nullptr;
@@ -78,7 +78,10 @@ struct prosper_pt_ctx
     uint64_t wfSlots = 0;
 
     bool kernelTiming = false;
-    hipEvent_t evStart = nullptr, evStop = nullptr;
+    static constexpr uint32_t kMaxTimedLaunches = 96;
+    hipEvent_t events[kMaxTimedLaunches + 1] = {};
+    uint32_t eventStage[kMaxTimedLaunches] = {};
+    uint32_t timedLaunches = 0;
     bool timingValid = false;
 };
 
@@ -464,10 +467,11 @@ int prosper_pt_create(const prosper_pt_device_desc *desc, prosper_pt_ctx **out_c
     if (!ctx) return fail(PROSPER_PT_ERR_INVALID_ARGUMENT, "out of host memory");
     ctx->device = desc->device_ordinal;
     ctx->flags = desc->flags;
-    if (hipMalloc((void **)&ctx->dCounters, 16 * sizeof(unsigned long long)) != hipSuccess ||
-        hipMemset(ctx->dCounters, 0, 16 * sizeof(unsigned long long)) != hipSuccess ||
-        hipMalloc((void **)&ctx->dWorkCounter, 64) != hipSuccess ||
-        hipEventCreate(&ctx->evStart) != hipSuccess || hipEventCreate(&ctx->evStop) != hipSuccess)
+    bool eventsOk = true;
+    for (auto &e : ctx->events) eventsOk = eventsOk && hipEventCreate(&e) == hipSuccess;
+    if (!eventsOk || hipMalloc((void **)&ctx->dCounters, kStageCount * 16 * sizeof(unsigned long long)) != hipSuccess ||
+        hipMemset(ctx->dCounters, 0, kStageCount * 16 * sizeof(unsigned long long)) != hipSuccess ||
+        hipMalloc((void **)&ctx->dWorkCounter, 64) != hipSuccess)
     {
         prosper_pt_destroy(ctx);
         return fail(PROSPER_PT_ERR_HIP, "context allocation failed");
@@ -486,8 +490,8 @@ void prosper_pt_destroy(prosper_pt_ctx *ctx)
     if (ctx->dCounters) (void)hipFree(ctx->dCounters);
     if (ctx->dWorkCounter) (void)hipFree(ctx->dWorkCounter);
     if (ctx->wfBlock) (void)hipFree(ctx->wfBlock);
-    if (ctx->evStart) (void)hipEventDestroy(ctx->evStart);
-    if (ctx->evStop) (void)hipEventDestroy(ctx->evStop);
+    for (auto &e : ctx->events)
+        if (e) (void)hipEventDestroy(e);
     delete ctx;
 }
 
@@ -607,11 +611,21 @@ int prosper_pt_render_frames(
 
     if (localWidth == 0) return PROSPER_PT_OK;
     const bool countWork = (render_flags & PROSPER_PT_RENDER_COUNT_WORK) != 0;
-    if (ctx->kernelTiming) PPT_HIP(hipEventRecord(ctx->evStart, s));
+    LaunchTimer timer;
+    timer.events = ctx->events;
+    timer.stage = ctx->eventStage;
+    timer.capacity = prosper_pt_ctx::kMaxTimedLaunches;
+    LaunchTimer *tp = ctx->kernelTiming ? &timer : nullptr;
     if (ctx->flags & PROSPER_PT_CREATE_MEGAKERNEL)
+    {
+        if (tp) tp->mark(kStageGenerate, s);
         launch_render_megakernel(ctx->scene, p, ctx->hdr, ctx->dCounters, countWork, s);
+    }
     else if (ctx->flags & PROSPER_PT_CREATE_PERSISTENT)
+    {
+        if (tp) tp->mark(kStageGenerate, s);
         launch_render_persistent(ctx->scene, p, ctx->hdr, ctx->dCounters, ctx->dWorkCounter, countWork, s);
+    }
     else
     {
         // wavefront: all frames of the batch are in flight together, in chunks that keep the
@@ -632,13 +646,14 @@ int prosper_pt_render_frames(
             pp.frameCount = frames;
             pp.pc.frameIndex = (p.pc.frameIndex + f0) % PROSPER_RT_FRAME_PERIOD;
             if (f0 > 0) pp.pc.flags &= ~(uint32_t)PROSPER_PC_FLAG_SKIP_HISTORY;
-            launch_render_wavefront(ctx->scene, pp, ctx->hdr, ctx->dCounters, w, ctx->stats.maxDepth, countWork, s);
+            launch_render_wavefront(ctx->scene, pp, ctx->hdr, ctx->dCounters, w, ctx->stats.maxDepth, countWork, tp, s);
         }
     }
     PPT_HIP(hipGetLastError());
-    if (ctx->kernelTiming)
+    if (tp)
     {
-        PPT_HIP(hipEventRecord(ctx->evStop, s));
+        tp->close(s);
+        ctx->timedLaunches = tp->count;
         ctx->timingValid = true;
     }
     return PROSPER_PT_OK;
@@ -700,16 +715,37 @@ int prosper_pt_blit_rgba16f(prosper_pt_ctx *ctx, uint16_t *host_rgba16f, size_t 
     return PROSPER_PT_OK;
 }
 
+static int read_stage_counters(prosper_pt_ctx *ctx, unsigned long long host[kStageCount * 16], void *stream)
+{
+    PPT_HIP(hipSetDevice(ctx->device));
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    PPT_HIP(hipMemcpyAsync(host, ctx->dCounters, kStageCount * 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+    PPT_HIP(hipStreamSynchronize(s));
+    return PROSPER_PT_OK;
+}
+
 int prosper_pt_get_counters(prosper_pt_ctx *ctx, prosper_pt_counters *out, void *stream)
 {
     if (!ctx || !out) return fail(PROSPER_PT_ERR_INVALID_ARGUMENT, "prosper_pt_get_counters: null argument");
-    PPT_HIP(hipSetDevice(ctx->device));
-    hipStream_t s = static_cast<hipStream_t>(stream);
-    unsigned long long host[16] = {};
-    PPT_HIP(hipMemcpyAsync(host, ctx->dCounters, sizeof(host), hipMemcpyDeviceToHost, s));
-    PPT_HIP(hipStreamSynchronize(s));
+    unsigned long long host[kStageCount * 16] = {};
+    const int rc = read_stage_counters(ctx, host, stream);
+    if (rc != PROSPER_PT_OK) return rc;
     static_assert(sizeof(prosper_pt_counters) == 16 * sizeof(uint64_t), "counter layout");
-    std::memcpy(out, host, sizeof(*out));
+    unsigned long long sum[16] = {};
+    for (uint32_t st = 0; st < kStageCount; ++st)
+        for (uint32_t i = 0; i < 16; ++i) sum[i] += host[st * 16 + i];
+    std::memcpy(out, sum, sizeof(*out));
+    return PROSPER_PT_OK;
+}
+
+int prosper_pt_get_stage_counters(prosper_pt_ctx *ctx, uint32_t stage, prosper_pt_counters *out, void *stream)
+{
+    if (!ctx || !out || stage >= kStageCount)
+        return fail(PROSPER_PT_ERR_INVALID_ARGUMENT, "prosper_pt_get_stage_counters: bad argument");
+    unsigned long long host[kStageCount * 16] = {};
+    const int rc = read_stage_counters(ctx, host, stream);
+    if (rc != PROSPER_PT_OK) return rc;
+    std::memcpy(out, host + stage * 16, sizeof(*out));
     return PROSPER_PT_OK;
 }
 
@@ -717,7 +753,8 @@ int prosper_pt_reset_counters(prosper_pt_ctx *ctx, void *stream)
 {
     if (!ctx) return fail(PROSPER_PT_ERR_INVALID_ARGUMENT, "prosper_pt_reset_counters: null context");
     PPT_HIP(hipSetDevice(ctx->device));
-    PPT_HIP(hipMemsetAsync(ctx->dCounters, 0, 16 * sizeof(unsigned long long), static_cast<hipStream_t>(stream)));
+    PPT_HIP(hipMemsetAsync(
+        ctx->dCounters, 0, kStageCount * 16 * sizeof(unsigned long long), static_cast<hipStream_t>(stream)));
     return PROSPER_PT_OK;
 }
 
@@ -731,24 +768,41 @@ int prosper_pt_set_kernel_timing(prosper_pt_ctx *ctx, int enabled)
 
 const char *prosper_pt_kernel_name(uint32_t index)
 {
-    static const char *names[PROSPER_PT_MAX_KERNELS] = {"render", "", "", "", "", "", "", ""};
+    static const char *names[PROSPER_PT_MAX_KERNELS] = {"wf_generate_extend", "wf_shade", "wf_trace", "wf_accumulate",
+                                                        "",                   "",         "",         ""};
     return index < PROSPER_PT_MAX_KERNELS ? names[index] : "";
 }
 
 int prosper_pt_get_last_render_ms(prosper_pt_ctx *ctx, float *total_ms, float kernel_ms[PROSPER_PT_MAX_KERNELS])
 {
-    if (!ctx || !total_ms) return fail(PROSPER_PT_ERR_INVALID_ARGUMENT, "prosper_pt_get_last_render_ms: null argument");
+    return prosper_pt_get_last_render_timing(ctx, total_ms, kernel_ms, nullptr);
+}
+
+int prosper_pt_get_last_render_timing(
+    prosper_pt_ctx *ctx, float *total_ms, float kernel_ms[PROSPER_PT_MAX_KERNELS],
+    uint32_t kernel_launches[PROSPER_PT_MAX_KERNELS])
+{
+    if (!ctx || !total_ms) return fail(PROSPER_PT_ERR_INVALID_ARGUMENT, "prosper_pt_get_last_render_timing: null argument");
     if (!ctx->kernelTiming || !ctx->timingValid)
         return fail(PROSPER_PT_ERR_INVALID_ARGUMENT, "kernel timing is not enabled or nothing was rendered since enabling it");
     PPT_HIP(hipSetDevice(ctx->device));
-    PPT_HIP(hipEventSynchronize(ctx->evStop));
-    float ms = 0.0f;
-    PPT_HIP(hipEventElapsedTime(&ms, ctx->evStart, ctx->evStop));
-    *total_ms = ms;
-    if (kernel_ms)
+    PPT_HIP(hipEventSynchronize(ctx->events[ctx->timedLaunches]));
+    float perStage[PROSPER_PT_MAX_KERNELS] = {};
+    uint32_t launches[PROSPER_PT_MAX_KERNELS] = {};
+    float total = 0.0f;
+    for (uint32_t i = 0; i < ctx->timedLaunches; ++i)
     {
-        for (int i = 0; i < PROSPER_PT_MAX_KERNELS; ++i) kernel_ms[i] = 0.0f;
-        kernel_ms[0] = ms;
+        float ms = 0.0f;
+        PPT_HIP(hipEventElapsedTime(&ms, ctx->events[i], ctx->events[i + 1]));
+        perStage[ctx->eventStage[i]] += ms;
+        launches[ctx->eventStage[i]] += 1;
+        total += ms;
+    }
+    *total_ms = total;
+    for (int i = 0; i < PROSPER_PT_MAX_KERNELS; ++i)
+    {
+        if (kernel_ms) kernel_ms[i] = perStage[i];
+        if (kernel_launches) kernel_launches[i] = launches[i];
     }
     return PROSPER_PT_OK;
 }

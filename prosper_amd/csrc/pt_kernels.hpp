@@ -8,6 +8,39 @@
 namespace ppt
 {
 
+// Stage index of a render kernel: selects its block of 16 work counters and its timing bucket.
+enum : uint32_t
+{
+    kStageGenerate = 0, // wf_generate_extend, or the single kernel of the megakernel/persistent pipelines
+    kStageShade = 1,
+    kStageTrace = 2,
+    kStageAccumulate = 3,
+    kStageCount = 4,
+};
+
+// Optional per-launch hipEvent timestamps (prosper_pt_set_kernel_timing): one event before every
+// launch, one after the last; interval i belongs to stage[i].
+struct LaunchTimer
+{
+    hipEvent_t *events = nullptr;
+    uint32_t *stage = nullptr;
+    uint32_t count = 0; // intervals recorded so far (events used = count + 1 once closed)
+    uint32_t capacity = 0;
+    void mark(uint32_t st, hipStream_t stream)
+    {
+        if (events && count < capacity)
+        {
+            (void)hipEventRecord(events[count], stream);
+            stage[count] = st;
+            ++count;
+        }
+    }
+    void close(hipStream_t stream)
+    {
+        if (events) (void)hipEventRecord(events[count], stream);
+    }
+};
+
 void launch_flatten_triangles(
     const DeviceScene &s, const uint32_t *triOffsets, uint32_t drawInstanceCount, const uint32_t *drawInstanceFlags,
     WorldTriangle *out, uint32_t total, hipStream_t stream);
@@ -21,7 +54,7 @@ void launch_render_persistent(
     bool countWork, hipStream_t stream);
 void launch_render_wavefront(
     const DeviceScene &s, const RenderParams &p, float4 *hdr, unsigned long long *counters, const WavefrontBuffers &w,
-    uint32_t bvhDepth, bool countWork, hipStream_t stream);
+    uint32_t bvhDepth, bool countWork, LaunchTimer *timer, hipStream_t stream);
 void launch_blit_rgba16f(const float4 *in, void *out, uint32_t count, hipStream_t stream);
 void launch_eval_fn(
     uint32_t fn, const float *in, uint32_t inStride, float *out, uint32_t outStride, uint32_t n, hipStream_t stream);

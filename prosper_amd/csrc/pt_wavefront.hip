@@ -493,8 +493,13 @@ __global__ __launch_bounds__(256) void wf_accumulate(
 template <bool COUNT, int STACK>
 static void enqueue_wavefront(
     const DeviceScene &s, const RenderParams &p, float4 *hdr, unsigned long long *counters, const WavefrontBuffers &w,
-    hipStream_t stream)
+    LaunchTimer *timer, hipStream_t stream)
 {
+    unsigned long long *cGen = counters + kStageGenerate * 16u, *cShade = counters + kStageShade * 16u,
+                       *cTrace = counters + kStageTrace * 16u, *cAcc = counters + kStageAccumulate * 16u;
+    auto mark = [&](uint32_t st) {
+        if (timer) timer->mark(st, stream);
+    };
     const uint32_t groups = (w.nSeg + 3u) / 4u;
     const dim3 grid(((groups + 7u) / 8u) * 8u), block(256);
     uint32_t bounces = p.pc.maxBounces < PROSPER_RT_MAX_BOUNCES ? p.pc.maxBounces : PROSPER_RT_MAX_BOUNCES;
@@ -502,37 +507,42 @@ static void enqueue_wavefront(
         p.pc.drawType != PROSPER_DRAW_TYPE_DEFAULT && p.pc.drawType != PROSPER_DRAW_TYPE_MESHLET_ID;
     if (debugDraw && bounces > 1) bounces = 1; // every hit ends its path in the first shade
 
-    hipLaunchKernelGGL((wf_generate_extend<COUNT, STACK>), grid, block, 0, stream, s, p, w, counters);
+    mark(kStageGenerate);
+    hipLaunchKernelGGL((wf_generate_extend<COUNT, STACK>), grid, block, 0, stream, s, p, w, cGen);
     for (uint32_t b = 0; b < bounces; ++b)
     {
         const uint32_t cur = b & 1u;
         const uint32_t last = (b + 1u == bounces) ? 1u : 0u;
-        hipLaunchKernelGGL(wf_shade<COUNT>, grid, block, 0, stream, s, p, w, b, cur, last, counters);
+        mark(kStageShade);
+        hipLaunchKernelGGL(wf_shade<COUNT>, grid, block, 0, stream, s, p, w, b, cur, last, cShade);
         if (!debugDraw)
+        {
+            mark(kStageTrace);
             hipLaunchKernelGGL(
-                (wf_trace<COUNT, STACK>), grid, block, 0, stream, s, p, w, b, cur ^ 1u, last ? 0u : 1u, counters);
+                (wf_trace<COUNT, STACK>), grid, block, 0, stream, s, p, w, b, cur ^ 1u, last ? 0u : 1u, cTrace);
+        }
     }
-    hipLaunchKernelGGL(
-        wf_accumulate<COUNT>, dim3((w.pixelsPadded + 255u) / 256u), block, 0, stream, p, w, hdr, counters);
+    mark(kStageAccumulate);
+    hipLaunchKernelGGL(wf_accumulate<COUNT>, dim3((w.pixelsPadded + 255u) / 256u), block, 0, stream, p, w, hdr, cAcc);
 }
 
 template <bool COUNT>
 static void enqueue_for_depth(
     const DeviceScene &s, const RenderParams &p, float4 *hdr, unsigned long long *counters, const WavefrontBuffers &w,
-    uint32_t bvhDepth, hipStream_t stream)
+    uint32_t bvhDepth, LaunchTimer *timer, hipStream_t stream)
 {
     // smallest LDS stack that holds the deepest root-to-leaf path (the builder caps it at 32)
     if (bvhDepth <= 16)
-        enqueue_wavefront<COUNT, 16>(s, p, hdr, counters, w, stream);
+        enqueue_wavefront<COUNT, 16>(s, p, hdr, counters, w, timer, stream);
     else if (bvhDepth <= 24)
-        enqueue_wavefront<COUNT, 24>(s, p, hdr, counters, w, stream);
+        enqueue_wavefront<COUNT, 24>(s, p, hdr, counters, w, timer, stream);
     else
-        enqueue_wavefront<COUNT, 32>(s, p, hdr, counters, w, stream);
+        enqueue_wavefront<COUNT, 32>(s, p, hdr, counters, w, timer, stream);
 }
 
 void launch_render_wavefront(
     const DeviceScene &s, const RenderParams &p, float4 *hdr, unsigned long long *counters, const WavefrontBuffers &w,
-    uint32_t bvhDepth, bool countWork, hipStream_t stream)
+    uint32_t bvhDepth, bool countWork, LaunchTimer *timer, hipStream_t stream)
 {
     if (w.nSeg == 0) return;
     static_assert(kTraversalStackDepth == 32, "stack variants assume the builder's depth cap");
@@ -543,9 +553,9 @@ void launch_render_wavefront(
         if (v > bvhDepth && v <= kTraversalStackDepth) bvhDepth = v;
     }
     if (countWork)
-        enqueue_for_depth<true>(s, p, hdr, counters, w, bvhDepth, stream);
+        enqueue_for_depth<true>(s, p, hdr, counters, w, bvhDepth, timer, stream);
     else
-        enqueue_for_depth<false>(s, p, hdr, counters, w, bvhDepth, stream);
+        enqueue_for_depth<false>(s, p, hdr, counters, w, bvhDepth, timer, stream);
 }
 
 } // namespace ppt

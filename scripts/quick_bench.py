@@ -46,11 +46,12 @@ def main():
     times = []
     for i in range(args.steps + 2):
         ctx.render(pc, cam, w, h, frames=spp)
-        ms, _ = ctx.last_render_ms()
+        ms, per = ctx.last_render_timing()
         if i >= 2:
             times.append(ms)
     times.sort()
     med = times[len(times) // 2]
+    print("  " + "  ".join("%s %dx%.0fus" % (k.replace("wf_", ""), v[1], v[0] * 1e3 / max(1, v[1])) for k, v in per.items() if v[1]))
     img = ctx.read_hdr()
     print("%s %s: median %.3f ms  min %.3f  => %.1f Mpaths/s  (checksum %.6f)" % (
         args.config, "megakernel" if args.megakernel else ("persistent" if args.persistent else "wavefront"), med, times[0], w * h * spp / med / 1e3,
