@@ -646,7 +646,9 @@ int prosper_pt_render_frames(
             pp.frameCount = frames;
             pp.pc.frameIndex = (p.pc.frameIndex + f0) % PROSPER_RT_FRAME_PERIOD;
             if (f0 > 0) pp.pc.flags &= ~(uint32_t)PROSPER_PC_FLAG_SKIP_HISTORY;
-            launch_render_wavefront(ctx->scene, pp, ctx->hdr, ctx->dCounters, w, ctx->stats.maxDepth, countWork, tp, s);
+            launch_render_wavefront(
+                ctx->scene, pp, ctx->hdr, ctx->dCounters, w, ctx->stats.maxDepth, (uint32_t)ctx->stats.nodeCount,
+                (uint32_t)ctx->stats.triangleCount, countWork, tp, s);
         }
     }
     PPT_HIP(hipGetLastError());

@@ -856,12 +856,60 @@ PPT_D float box_entry(const float lo[3], const float hi[3], f3 o, f3 invd, float
     return hit ? tn : kInf;
 }
 
+// Where the traversal reads BVH nodes and world triangles from.  GlobalGeom: the HBM arrays (through
+// L1/L2).  LdsGeom: a copy a workgroup staged in LDS — for scenes of a few KB (a Cornell box) every
+// node fetch then costs an LDS access (~64 cycles) instead of a vector-memory round trip (~200+),
+// which is what the latency-bound traversal of tiny scenes is made of.  Node stride 80 B and
+// triangle stride 48 B keep 16-byte reads of different records spread over 16 bank groups.
+struct TriangleData
+{
+    float4 a, b, c;
+};
+struct GlobalGeom
+{
+    const BvhNode *nodes;
+    const WorldTriangle *triangles;
+    PPT_D BvhNode node(int32_t i) const { return nodes[i]; }
+    PPT_D TriangleData tri(uint32_t i) const
+    {
+        const float4 *tp = reinterpret_cast<const float4 *>(triangles + i);
+        return TriangleData{tp[0], tp[1], tp[2]};
+    }
+};
+constexpr uint32_t kLdsNodeStride = 5; // float4s per node in LDS (80 B: 64 B payload + 16 B pad)
+struct LdsGeom
+{
+    const float4 *nodes;     // LDS
+    const float4 *triangles; // LDS
+    PPT_D BvhNode node(int32_t i) const
+    {
+        const float4 *np = nodes + (uint32_t)i * kLdsNodeStride;
+        const float4 q0 = np[0], q1 = np[1], q2 = np[2], q3 = np[3];
+        BvhNode n;
+        n.lo0[0] = q0.x; n.lo0[1] = q0.y; n.lo0[2] = q0.z; n.hi0[0] = q0.w;
+        n.hi0[1] = q1.x; n.hi0[2] = q1.y; n.lo1[0] = q1.z; n.lo1[1] = q1.w;
+        n.lo1[2] = q2.x; n.hi1[0] = q2.y; n.hi1[1] = q2.z; n.hi1[2] = q2.w;
+        n.child0 = __builtin_bit_cast(int32_t, q3.x);
+        n.child1 = __builtin_bit_cast(int32_t, q3.y);
+        n.pad[0] = 0;
+        n.pad[1] = 0;
+        return n;
+    }
+    PPT_D TriangleData tri(uint32_t i) const
+    {
+        const float4 *tp = triangles + i * 3u;
+        return TriangleData{tp[0], tp[1], tp[2]};
+    }
+};
+// LDS budget of a staged scene (float4s): nodes * 5 + triangles * 3 must fit
+constexpr uint32_t kLdsSceneFloat4s = 768; // 12 KB
+
 // Shared driver of traceClosest (ANY = false, main.rgen:62-81) and shadow (ANY = true,
 // main.rgen:49-60).  `stack` points at this lane's column of the workgroup's LDS stack
 // (entry e lives at stack[e * 64]).  Returns true on a hit (ANY: occluded).
-template <bool ANY, bool COUNT>
-PPT_D bool trace(
-    const DeviceScene &s, f3 o, f3 d, float tMin, float tMaxIn, uint32_t seed, int32_t *stack, Hit &hit,
+template <bool ANY, bool COUNT, class Geom>
+PPT_D bool trace_in(
+    const Geom &g, const DeviceScene &s, f3 o, f3 d, float tMin, float tMaxIn, uint32_t seed, int32_t *stack, Hit &hit,
     LaneCounters &cnt)
 {
     hit.drawInstance = kMissIndex;
@@ -880,7 +928,7 @@ PPT_D bool trace(
     {
         while (alive && node >= 0)
         {
-            const BvhNode n = s.nodes[node];
+            const BvhNode n = g.node(node);
             if constexpr (COUNT) cnt.nodeVisits++;
             const float e0 = box_entry(n.lo0, n.hi0, o, invd, tMin, hit.t);
             const float e1 = box_entry(n.lo1, n.hi1, o, invd, tMin, hit.t);
@@ -910,8 +958,8 @@ PPT_D bool trace(
             const uint32_t count = (ref & 7u) + 1u;
             for (uint32_t i = 0; i < count; ++i)
             {
-                const float4 *tp = reinterpret_cast<const float4 *>(s.triangles + first + i);
-                const float4 a = tp[0], b = tp[1], c = tp[2];
+                const TriangleData td = g.tri(first + i);
+                const float4 a = td.a, b = td.b, c = td.c;
                 if constexpr (COUNT)
                 {
                     cnt.triangleTests++;
@@ -943,6 +991,14 @@ PPT_D bool trace(
         node = stack[sp * 64];
     }
     return hit.drawInstance != kMissIndex;
+}
+
+template <bool ANY, bool COUNT>
+PPT_D bool trace(
+    const DeviceScene &s, f3 o, f3 d, float tMin, float tMaxIn, uint32_t seed, int32_t *stack, Hit &hit,
+    LaneCounters &cnt)
+{
+    return trace_in<ANY, COUNT>(GlobalGeom{s.nodes, s.triangles}, s, o, d, tMin, tMaxIn, seed, stack, hit, cnt);
 }
 
 // ------------------------------------------------------------------------------------------

@@ -54,7 +54,7 @@ void launch_render_persistent(
     bool countWork, hipStream_t stream);
 void launch_render_wavefront(
     const DeviceScene &s, const RenderParams &p, float4 *hdr, unsigned long long *counters, const WavefrontBuffers &w,
-    uint32_t bvhDepth, bool countWork, LaunchTimer *timer, hipStream_t stream);
+    uint32_t bvhDepth, uint32_t nodeCount, uint32_t triCount, bool countWork, LaunchTimer *timer, hipStream_t stream);
 void launch_blit_rgba16f(const float4 *in, void *out, uint32_t count, hipStream_t stream);
 void launch_eval_fn(
     uint32_t fn, const float *in, uint32_t inStride, float *out, uint32_t outStride, uint32_t n, hipStream_t stream);

@@ -56,9 +56,9 @@ PPT_D float box_entry_fma(const float lo[3], const float hi[3], f3 invd, f3 oid,
 // fetch(i) -> StreamRay for stream position i (called by the lanes that take a new ray);
 // commit(pred, i, found, hit, dir) is called by ALL lanes in converged code; lanes with pred set
 // hand over the result of ray i with direction dir (so commit may compact with ballots).
-template <bool ANY, bool COUNT, class Fetch, class Commit>
+template <bool ANY, bool COUNT, class Geom, class Fetch, class Commit>
 PPT_D void trace_stream(
-    const DeviceScene &s, uint32_t n, int32_t *stack, LaneCounters &cnt, Fetch &&fetch, Commit &&commit)
+    const Geom &g, const DeviceScene &s, uint32_t n, int32_t *stack, LaneCounters &cnt, Fetch &&fetch, Commit &&commit)
 {
     const uint32_t lane = threadIdx.x & 63u;
     const unsigned long long below = (1ull << lane) - 1ull;
@@ -141,7 +141,7 @@ PPT_D void trace_stream(
             {
                 if (state == kLaneNode)
                 {
-                    const BvhNode nd = s.nodes[node];
+                    const BvhNode nd = g.node(node);
                     if constexpr (COUNT) cnt.nodeVisits++;
                     const float e0 = box_entry_fma(nd.lo0, nd.hi0, invd, oid, tMin, hit.t);
                     const float e1 = box_entry_fma(nd.lo1, nd.hi1, invd, oid, tMin, hit.t);
@@ -178,8 +178,8 @@ PPT_D void trace_stream(
             {
                 if (state == kLaneTri)
                 {
-                    const float4 *tp = reinterpret_cast<const float4 *>(s.triangles + triFirst);
-                    const float4 a = tp[0], b = tp[1], c4 = tp[2];
+                    const TriangleData td = g.tri(triFirst);
+                    const float4 a = td.a, b = td.b, c4 = td.c;
                     ++triFirst;
                     --triCount;
                     if constexpr (COUNT)

@@ -110,17 +110,35 @@ __device__ __forceinline__ void add_to_slot(float4 *color, uint32_t slot, uint32
     color[slot] = make_float4(acc.x, acc.y, acc.z, 0.0f);
 }
 
+// Copies the BVH nodes (padded to 80 B) and world triangles into this workgroup's LDS.
+__device__ __forceinline__ LdsGeom stage_scene_in_lds(const DeviceScene &s, float4 *lds, uint32_t nodeCount, uint32_t triCount)
+{
+    const float4 *gn = reinterpret_cast<const float4 *>(s.nodes);
+    for (uint32_t i = threadIdx.x; i < nodeCount * 4u; i += blockDim.x)
+        lds[(i >> 2) * kLdsNodeStride + (i & 3u)] = gn[i];
+    float4 *lt = lds + nodeCount * kLdsNodeStride;
+    const float4 *gt = reinterpret_cast<const float4 *>(s.triangles);
+    for (uint32_t i = threadIdx.x; i < triCount * 3u; i += blockDim.x) lt[i] = gt[i];
+    __syncthreads();
+    return LdsGeom{lds, lt};
+}
+
 } // namespace
 
 // ------------------------------------------------------------------------------------------
 // generate + first extend
 // ------------------------------------------------------------------------------------------
 
-template <bool COUNT, int STACK>
+template <bool COUNT, int STACK, bool LDS_SCENE>
 __global__ __launch_bounds__(256, PPT_GEN_WPE) void wf_generate_extend(
-    DeviceScene s, RenderParams p, WavefrontBuffers w, unsigned long long *__restrict__ counters)
+    DeviceScene s, RenderParams p, WavefrontBuffers w, uint32_t nodeCount, uint32_t triCount,
+    unsigned long long *__restrict__ counters)
 {
     __shared__ int32_t ldsStack[STACK * 256];
+    __shared__ float4 ldsScene[LDS_SCENE ? kLdsSceneFloat4s : 1];
+    LdsGeom lg = {};
+    if constexpr (LDS_SCENE) lg = stage_scene_in_lds(s, ldsScene, nodeCount, triCount);
+    const GlobalGeom gg{s.nodes, s.triangles};
     const SegmentId id = my_segment(w);
     if (!id.valid) return;
     const uint32_t lane = lane_id();
@@ -203,7 +221,11 @@ __global__ __launch_bounds__(256, PPT_GEN_WPE) void wf_generate_extend(
             const uint32_t k = k0 + lane;
             const StreamRay r = fetch(k);
             Hit hit;
-            const bool found = trace<false, COUNT>(s, r.o, r.d, r.tMin, r.tMax, r.seed, stack, hit, cnt);
+            bool found;
+            if constexpr (LDS_SCENE)
+                found = trace_in<false, COUNT>(lg, s, r.o, r.d, r.tMin, r.tMax, r.seed, stack, hit, cnt);
+            else
+                found = trace_in<false, COUNT>(gg, s, r.o, r.d, r.tMin, r.tMax, r.seed, stack, hit, cnt);
             commit(true, k, found, hit, r.d);
         }
     }
@@ -216,9 +238,9 @@ __global__ __launch_bounds__(256, PPT_GEN_WPE) void wf_generate_extend(
 // ------------------------------------------------------------------------------------------
 
 // One wave's extend work: traces the live rays of its segment (buffer set `cur`), compacts the hits.
-template <bool COUNT>
+template <bool COUNT, class Geom>
 __device__ __forceinline__ void extend_segment(
-    const DeviceScene &s, const RenderParams &p, const WavefrontBuffers &w, const SegmentId &id, uint32_t bounce,
+    const Geom &g, const DeviceScene &s, const RenderParams &p, const WavefrontBuffers &w, const SegmentId &id, uint32_t bounce,
     uint32_t cur, int32_t *stack, LaneCounters &cnt)
 {
     const float4 *__restrict__ rayA = w.rayA[cur];
@@ -254,7 +276,7 @@ __device__ __forceinline__ void extend_segment(
         }
         nHit += total;
     };
-    trace_stream<false, COUNT>(s, n, stack, cnt, fetch, commit);
+    trace_stream<false, COUNT>(g, s, n, stack, cnt, fetch, commit);
     if (lane_id() == 0) w.segHits[id.seg] = nHit;
 }
 
@@ -380,9 +402,9 @@ __global__ __launch_bounds__(256, PPT_SHADE_WPE) void wf_shade(
 
 // One wave's shadow work: shadow() for the shadow rays shade queued in its segment; adds the direct
 // term of bounce `bounce` where the light is visible.
-template <bool COUNT>
+template <bool COUNT, class Geom>
 __device__ __forceinline__ void shadow_segment(
-    const DeviceScene &s, const RenderParams &p, const WavefrontBuffers &w, const SegmentId &id, uint32_t bounce,
+    const Geom &g, const DeviceScene &s, const RenderParams &p, const WavefrontBuffers &w, const SegmentId &id, uint32_t bounce,
     int32_t *stack, LaneCounters &cnt)
 {
     const uint32_t n = w.segShadow[id.seg];
@@ -415,7 +437,7 @@ __device__ __forceinline__ void shadow_segment(
             }
         }
     };
-    trace_stream<true, COUNT>(s, n, stack, cnt, fetch, commit);
+    trace_stream<true, COUNT>(g, s, n, stack, cnt, fetch, commit);
 }
 
 // Shadow rays of bounce `bounce` and (unless it was the last bounce) the closest-hit rays of bounce
@@ -423,23 +445,33 @@ __device__ __forceinline__ void shadow_segment(
 // other, and one launch has one tail instead of two.  The reference adds the direct term of bounce b
 // before the sky term of bounce b + 1 (main.rgen:266 then :252); both may touch the same radiance
 // slot from different lanes of this wave, hence shadow first, a fence, then extend.
-template <bool COUNT, int STACK>
+template <bool COUNT, int STACK, bool LDS_SCENE>
 __global__ __launch_bounds__(256, PPT_TRACE_WPE(STACK)) void wf_trace(
     DeviceScene s, RenderParams p, WavefrontBuffers w, uint32_t bounce, uint32_t nextCur, uint32_t doExtend,
-    unsigned long long *__restrict__ counters)
+    uint32_t nodeCount, uint32_t triCount, unsigned long long *__restrict__ counters)
 {
     __shared__ int32_t ldsStack[STACK * 256];
+    __shared__ float4 ldsScene[LDS_SCENE ? kLdsSceneFloat4s : 1];
+    LdsGeom lg = {};
+    if constexpr (LDS_SCENE) lg = stage_scene_in_lds(s, ldsScene, nodeCount, triCount);
+    const GlobalGeom gg{s.nodes, s.triangles};
     const SegmentId id = my_segment(w);
     if (!id.valid) return;
     int32_t *stack = ldsStack + (threadIdx.x >> 6) * (STACK * 64u) + lane_id();
     LaneCounters cnt = {};
-    shadow_segment<COUNT>(s, p, w, id, bounce, stack, cnt);
+    if constexpr (LDS_SCENE)
+        shadow_segment<COUNT>(lg, s, p, w, id, bounce, stack, cnt);
+    else
+        shadow_segment<COUNT>(gg, s, p, w, id, bounce, stack, cnt);
     if (doExtend)
     {
         // same wave, same CU: a workgroup-scope fence (s_waitcnt vmcnt(0)) orders the shadow phase's
         // radiance stores before the extend phase's loads; the vector L1 is write-through
         __threadfence_block();
-        extend_segment<COUNT>(s, p, w, id, bounce + 1u, nextCur, stack, cnt);
+        if constexpr (LDS_SCENE)
+            extend_segment<COUNT>(lg, s, p, w, id, bounce + 1u, nextCur, stack, cnt);
+        else
+            extend_segment<COUNT>(gg, s, p, w, id, bounce + 1u, nextCur, stack, cnt);
     }
     flush_counters<COUNT>(cnt, counters);
 }
@@ -490,10 +522,10 @@ __global__ __launch_bounds__(256) void wf_accumulate(
 // host-side sequencing
 // ------------------------------------------------------------------------------------------
 
-template <bool COUNT, int STACK>
+template <bool COUNT, int STACK, bool LDS_SCENE>
 static void enqueue_wavefront(
     const DeviceScene &s, const RenderParams &p, float4 *hdr, unsigned long long *counters, const WavefrontBuffers &w,
-    LaunchTimer *timer, hipStream_t stream)
+    uint32_t nodeCount, uint32_t triCount, LaunchTimer *timer, hipStream_t stream)
 {
     unsigned long long *cGen = counters + kStageGenerate * 16u, *cShade = counters + kStageShade * 16u,
                        *cTrace = counters + kStageTrace * 16u, *cAcc = counters + kStageAccumulate * 16u;
@@ -508,7 +540,8 @@ static void enqueue_wavefront(
     if (debugDraw && bounces > 1) bounces = 1; // every hit ends its path in the first shade
 
     mark(kStageGenerate);
-    hipLaunchKernelGGL((wf_generate_extend<COUNT, STACK>), grid, block, 0, stream, s, p, w, cGen);
+    hipLaunchKernelGGL(
+        (wf_generate_extend<COUNT, STACK, LDS_SCENE>), grid, block, 0, stream, s, p, w, nodeCount, triCount, cGen);
     for (uint32_t b = 0; b < bounces; ++b)
     {
         const uint32_t cur = b & 1u;
@@ -519,7 +552,8 @@ static void enqueue_wavefront(
         {
             mark(kStageTrace);
             hipLaunchKernelGGL(
-                (wf_trace<COUNT, STACK>), grid, block, 0, stream, s, p, w, b, cur ^ 1u, last ? 0u : 1u, cTrace);
+                (wf_trace<COUNT, STACK, LDS_SCENE>), grid, block, 0, stream, s, p, w, b, cur ^ 1u, last ? 0u : 1u, nodeCount,
+                triCount, cTrace);
         }
     }
     mark(kStageAccumulate);
@@ -529,20 +563,25 @@ static void enqueue_wavefront(
 template <bool COUNT>
 static void enqueue_for_depth(
     const DeviceScene &s, const RenderParams &p, float4 *hdr, unsigned long long *counters, const WavefrontBuffers &w,
-    uint32_t bvhDepth, LaunchTimer *timer, hipStream_t stream)
+    uint32_t bvhDepth, uint32_t nodeCount, uint32_t triCount, LaunchTimer *timer, hipStream_t stream)
 {
+    // a scene of a few KB is traversed out of LDS (its tree is always shallow enough for 16 entries)
+    const bool ldsScene =
+        bvhDepth <= 16 && nodeCount * kLdsNodeStride + triCount * 3u <= kLdsSceneFloat4s && !std::getenv("PROSPER_PT_DEBUG_NO_LDS_SCENE");
     // smallest LDS stack that holds the deepest root-to-leaf path (the builder caps it at 32)
-    if (bvhDepth <= 16)
-        enqueue_wavefront<COUNT, 16>(s, p, hdr, counters, w, timer, stream);
+    if (ldsScene)
+        enqueue_wavefront<COUNT, 16, true>(s, p, hdr, counters, w, nodeCount, triCount, timer, stream);
+    else if (bvhDepth <= 16)
+        enqueue_wavefront<COUNT, 16, false>(s, p, hdr, counters, w, nodeCount, triCount, timer, stream);
     else if (bvhDepth <= 24)
-        enqueue_wavefront<COUNT, 24>(s, p, hdr, counters, w, timer, stream);
+        enqueue_wavefront<COUNT, 24, false>(s, p, hdr, counters, w, nodeCount, triCount, timer, stream);
     else
-        enqueue_wavefront<COUNT, 32>(s, p, hdr, counters, w, timer, stream);
+        enqueue_wavefront<COUNT, 32, false>(s, p, hdr, counters, w, nodeCount, triCount, timer, stream);
 }
 
 void launch_render_wavefront(
     const DeviceScene &s, const RenderParams &p, float4 *hdr, unsigned long long *counters, const WavefrontBuffers &w,
-    uint32_t bvhDepth, bool countWork, LaunchTimer *timer, hipStream_t stream)
+    uint32_t bvhDepth, uint32_t nodeCount, uint32_t triCount, bool countWork, LaunchTimer *timer, hipStream_t stream)
 {
     if (w.nSeg == 0) return;
     static_assert(kTraversalStackDepth == 32, "stack variants assume the builder's depth cap");
@@ -553,9 +592,9 @@ void launch_render_wavefront(
         if (v > bvhDepth && v <= kTraversalStackDepth) bvhDepth = v;
     }
     if (countWork)
-        enqueue_for_depth<true>(s, p, hdr, counters, w, bvhDepth, timer, stream);
+        enqueue_for_depth<true>(s, p, hdr, counters, w, bvhDepth, nodeCount, triCount, timer, stream);
     else
-        enqueue_for_depth<false>(s, p, hdr, counters, w, bvhDepth, timer, stream);
+        enqueue_for_depth<false>(s, p, hdr, counters, w, bvhDepth, nodeCount, triCount, timer, stream);
 }
 
 } // namespace ppt

@@ -462,3 +462,17 @@ def test_lds_stack_variants_agree(gpu_ctx, oracle, sponza_small, monkeypatch):
         gpu_ctx.render(pc, cam, w, h, frames=2)
         assert same_bits(gpu_ctx.read_hdr(), base).all(), forced
     monkeypatch.delenv("PROSPER_PT_DEBUG_STACK")
+
+
+def test_lds_resident_scene_equals_global_memory_traversal(gpu_ctx, oracle, cornell_world, monkeypatch):
+    """Scenes of a few KB are traversed out of LDS (LdsGeom); same pixels as the HBM path."""
+    w, h = 224, 128
+    cam, fl = _camera(oracle, cornell_world, w, h)
+    pc = default_pc(S, fl, max_bounces=4, ibl=True)
+    gpu_ctx.upload_scene(cornell_world)
+    gpu_ctx.render(pc, cam, w, h, frames=2)
+    lds = gpu_ctx.read_hdr()
+    monkeypatch.setenv("PROSPER_PT_DEBUG_NO_LDS_SCENE", "1")
+    gpu_ctx.render(pc, cam, w, h, frames=2)
+    assert same_bits(gpu_ctx.read_hdr(), lds).all()
+    monkeypatch.delenv("PROSPER_PT_DEBUG_NO_LDS_SCENE")
