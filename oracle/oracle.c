@@ -895,11 +895,13 @@ static int intersect_triangle(
     if ((U < 0.0f || V < 0.0f || W < 0.0f) && (U > 0.0f || V > 0.0f || W > 0.0f)) return 0;
     const float det = (U + V) + W;
     if (!(det != 0.0f)) return 0; /* zero or NaN */
-    /* det = U + V + W equals -dot(d, N) in exact arithmetic (N = (v1-v0) x (v2-v0)), so one
-     * reciprocal serves the distance and both barycentrics */
-    const ora_v3 N = ora_cross(ora_sub(v1, v0), ora_sub(v2, v0));
+    /* Distance = the barycentric point's projection on the (unit) ray direction:
+     * t = (U*(A.d) + V*(B.d) + W*(C.d)) / det.  Unlike the plane equation dot(A,N)/dot(d,N) this stays
+     * well conditioned for grazing rays: the point is a convex combination of the vertices, so t always
+     * lies inside the ray's interval through the triangle's bounding box and hit selection cannot depend
+     * on which acceleration structure (or none) enumerated the candidates. */
     const float inv = 1.0f / det;
-    const float tt = -ora_dot(A, N) * inv;
+    const float tt = fmaf(W, ora_dot(C, d), fmaf(V, ora_dot(B, d), U * ora_dot(A, d))) * inv;
     if (!(tt > tMin && tt < tMax)) return 0;
     *t = tt;
     *bu = V * inv;
@@ -1087,7 +1089,10 @@ static void build_node(ora_scene *s, uint32_t nodeIndex, uint32_t first, uint32_
     {
         /* conservative padding so the slab test can never cull a triangle the edge-function
          * test accepts */
-        const float pad = 1e-5f * (hi[k] - lo[k]) + 1e-6f * fmaxf(fabsf(lo[k]), fabsf(hi[k])) + 1e-30f;
+        /* generous padding (2^-9 of the coordinate): a grazing ray that the edge functions accept may pass
+         * the triangle at a distance its rounding error allows, and the oracle should then still find it,
+         * like brute force does */
+        const float pad = 1e-5f * (hi[k] - lo[k]) + 2e-3f * fmaxf(fabsf(lo[k]), fabsf(hi[k])) + 1e-30f;
         n->lo[k] = lo[k] - pad;
         n->hi[k] = hi[k] + pad;
     }

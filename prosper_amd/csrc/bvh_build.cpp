@@ -202,45 +202,151 @@ void padded(const Aabb &b, float lo[3], float hi[3])
     }
 }
 
+// binary32 -> binary16 rounded toward -inf / +inf: child boxes are stored as halfs and must stay
+// conservative (they may only grow).
+uint16_t half_rne(float f)
+{
+    uint32_t x;
+    std::memcpy(&x, &f, 4);
+    const uint32_t sign = (x >> 16) & 0x8000u;
+    const uint32_t ax = x & 0x7FFFFFFFu;
+    if (ax >= 0x7F800000u) return (uint16_t)(sign | 0x7C00u | ((ax > 0x7F800000u) ? 0x200u : 0u));
+    if (ax >= 0x477FF000u) return (uint16_t)(sign | 0x7C00u);
+    if (ax < 0x33000001u) return (uint16_t)sign;
+    const int32_t e = (int32_t)(ax >> 23) - 127;
+    const uint32_t m = (ax & 0x007FFFFFu) | 0x00800000u;
+    const uint32_t shift = e < -14 ? (uint32_t)(13 + (-14 - e)) : 13u;
+    const uint32_t he = e < -14 ? 0u : (uint32_t)(e + 15);
+    uint32_t hm = m >> shift;
+    const uint32_t rem = m & ((1u << shift) - 1u);
+    const uint32_t halfway = 1u << (shift - 1);
+    if (rem > halfway || (rem == halfway && (hm & 1u))) hm += 1;
+    return (uint16_t)(sign | ((he == 0) ? hm : (((he - 1u) << 10) + hm)));
+}
+float half_value(uint16_t h)
+{
+    const uint32_t sign = (uint32_t)(h & 0x8000u) << 16;
+    const uint32_t exp = (h >> 10) & 0x1Fu, man = h & 0x3FFu;
+    uint32_t bits;
+    if (exp == 0)
+    {
+        const float v = (float)man * 5.9604644775390625e-08f;
+        std::memcpy(&bits, &v, 4);
+        bits |= sign;
+    }
+    else if (exp == 31)
+        bits = sign | 0x7F800000u | (man << 13);
+    else
+        bits = sign | ((exp + 112u) << 23) | (man << 13);
+    float f;
+    std::memcpy(&f, &bits, 4);
+    return f;
+}
+// next representable half towards +inf / -inf (as ordered values, handling the sign-magnitude encoding)
+uint16_t half_next_up(uint16_t h)
+{
+    if ((h & 0x7FFFu) == 0) return 0x0001u;          // +-0 -> smallest positive
+    if (h & 0x8000u) return (uint16_t)(h - 1u);       // negative: magnitude shrinks
+    return (h == 0x7C00u) ? h : (uint16_t)(h + 1u);   // positive: magnitude grows (stop at +inf)
+}
+uint16_t half_next_down(uint16_t h)
+{
+    if ((h & 0x7FFFu) == 0) return 0x8001u;
+    if (h & 0x8000u) return (h == 0xFC00u) ? h : (uint16_t)(h + 1u);
+    return (uint16_t)(h - 1u);
+}
+uint16_t half_floor(float f)
+{
+    uint16_t h = half_rne(f);
+    if (half_value(h) > f) h = half_next_down(h);
+    return h;
+}
+uint16_t half_ceil(float f)
+{
+    uint16_t h = half_rne(f);
+    if (half_value(h) < f) h = half_next_up(h);
+    return h;
+}
+
+// Collapses the binary SAH tree into 4-wide nodes (a node adopts its grandchildren, largest box
+// first, until it has four children or only leaves) and emits them depth-first.
 struct Emitter
 {
     const std::vector<TmpNode> &tmp;
     const std::vector<Prim> &prims;
     BvhBuildResult &out;
 
-    // reference to a temporary node as stored in a BvhNode child slot
-    int32_t emit_ref(int32_t t, uint32_t depth)
+    int32_t emit_leaf(int32_t t)
     {
         const TmpNode &n = tmp[t];
-        if (n.left < 0)
-        {
-            // leaves longer than kMaxLeafTriangles cannot occur (builder splits them)
-            const uint32_t first = (uint32_t)out.permutation.size();
-            for (uint32_t i = 0; i < n.count; ++i) out.permutation.push_back(prims[n.first + i].index);
-            return ~(int32_t)((first << 3) | (n.count - 1));
-        }
-        return emit_inner(t, depth);
+        // leaves longer than kMaxLeafTriangles cannot occur (the builder splits them)
+        const uint32_t first = (uint32_t)out.permutation.size();
+        for (uint32_t i = 0; i < n.count; ++i) out.permutation.push_back(prims[n.first + i].index);
+        return ~(int32_t)((first << 3) | (n.count - 1));
     }
 
-    int32_t emit_inner(int32_t t, uint32_t depth)
+    // Emits the 4-wide node rooted at binary node t (an inner node, or a lone leaf wrapped as the
+    // root) and returns its index; `stackNeed` receives the traversal-stack bound of its subtree.
+    int32_t emit_node(int32_t t, uint32_t &stackNeed)
     {
         const int32_t self = (int32_t)out.nodes.size();
         out.nodes.emplace_back();
-        out.maxDepth = std::max(out.maxDepth, depth + 1);
-        const TmpNode &n = tmp[t];
-        float lo0[3], hi0[3], lo1[3], hi1[3];
-        padded(tmp[n.left].box, lo0, hi0);
-        padded(tmp[n.right].box, lo1, hi1);
-        const int32_t c0 = emit_ref(n.left, depth + 1);
-        const int32_t c1 = emit_ref(n.right, depth + 1);
-        BvhNode &o = out.nodes[self];
-        std::memcpy(o.lo0, lo0, 12);
-        std::memcpy(o.hi0, hi0, 12);
-        std::memcpy(o.lo1, lo1, 12);
-        std::memcpy(o.hi1, hi1, 12);
-        o.child0 = c0;
-        o.child1 = c1;
-        o.pad[0] = o.pad[1] = 0;
+        int32_t kids[4];
+        uint32_t k = 0;
+        if (tmp[t].left < 0)
+            kids[k++] = t;
+        else
+        {
+            kids[k++] = tmp[t].left;
+            kids[k++] = tmp[t].right;
+            while (k < 4)
+            {
+                int best = -1;
+                float bestArea = -1.0f;
+                for (uint32_t i = 0; i < k; ++i)
+                    if (tmp[kids[i]].left >= 0 && tmp[kids[i]].box.half_area() > bestArea)
+                    {
+                        bestArea = tmp[kids[i]].box.half_area();
+                        best = (int)i;
+                    }
+                if (best < 0) break;
+                const int32_t open = kids[best];
+                kids[best] = tmp[open].left;
+                kids[k++] = tmp[open].right;
+            }
+        }
+        BvhNode node;
+        // unused slots: lo = hi = +inf (half 0x7C00) can never be entered (see build_bvh)
+        for (int a = 0; a < 3; ++a)
+            for (int c = 0; c < 4; ++c)
+            {
+                node.lo[a][c] = 0x7C00u;
+                node.hi[a][c] = 0x7C00u;
+            }
+        uint32_t deepest = 0;
+        for (uint32_t c = 0; c < 4; ++c)
+        {
+            node.child[c] = ~0;
+            if (c >= k) continue;
+            float lo[3], hi[3];
+            padded(tmp[kids[c]].box, lo, hi);
+            for (int a = 0; a < 3; ++a)
+            {
+                node.lo[a][c] = half_floor(lo[a]);
+                node.hi[a][c] = half_ceil(hi[a]);
+            }
+            if (tmp[kids[c]].left < 0)
+                node.child[c] = emit_leaf(kids[c]);
+            else
+            {
+                uint32_t need = 0;
+                node.child[c] = emit_node(kids[c], need);
+                deepest = std::max(deepest, need);
+            }
+        }
+        // visiting this node leaves at most k-1 siblings on the stack while a child subtree is walked
+        stackNeed = (k > 0 ? k - 1 : 0) + deepest;
+        out.nodes[self] = node;
         return self;
     }
 };
@@ -250,17 +356,9 @@ struct Emitter
 BvhBuildResult build_bvh(const WorldTriangle *triangles, uint64_t count)
 {
     BvhBuildResult out;
-    // An unused child slot gets the box lo = hi = +inf: both slab tests (pt_device.hpp box_entry,
-    // pt_trace_stream.hpp box_entry_fma) then report an entry distance of +inf at best, which the
-    // traversal treats as a miss.  (A NaN box would slip through min/max, an inverted box passes.)
-    const float inf = std::numeric_limits<float>::infinity();
-    auto empty_child = [&](float lo[3], float hi[3]) {
-        for (int k = 0; k < 3; ++k)
-        {
-            lo[k] = inf;
-            hi[k] = inf;
-        }
-    };
+    // An unused child slot gets the box lo = hi = +inf: the slab tests (pt_device.hpp,
+    // pt_trace_stream.hpp) then report an entry distance of +inf at best, which the traversal treats
+    // as a miss.  (A NaN box would slip through min/max, an inverted box passes.)
     if (count >= (1ull << 28)) throw std::runtime_error("too many triangles for the leaf reference encoding");
 
     std::vector<Prim> prims((size_t)count);
@@ -278,11 +376,13 @@ BvhBuildResult build_bvh(const WorldTriangle *triangles, uint64_t count)
     if (count == 0)
     {
         BvhNode root;
-        std::memset(&root, 0, sizeof(root));
-        empty_child(root.lo0, root.hi0);
-        empty_child(root.lo1, root.hi1);
-        root.child0 = ~0; // leaf reference that is never entered
-        root.child1 = ~0;
+        for (int a = 0; a < 3; ++a)
+            for (int c = 0; c < 4; ++c)
+            {
+                root.lo[a][c] = 0x7C00u;
+                root.hi[a][c] = 0x7C00u;
+            }
+        for (int c = 0; c < 4; ++c) root.child[c] = ~0; // leaf references that are never entered
         out.nodes.push_back(root);
         out.maxDepth = 1;
         return out;
@@ -291,30 +391,14 @@ BvhBuildResult build_bvh(const WorldTriangle *triangles, uint64_t count)
     Builder builder(prims);
     builder.nodes.reserve((size_t)count * 2);
     const int32_t rootTmp = builder.build(0, (uint32_t)count, 0);
-    out.nodes.reserve(builder.nodes.size());
+    out.nodes.reserve(builder.nodes.size() / 2 + 1);
     out.permutation.reserve((size_t)count);
     Emitter emitter{builder.nodes, prims, out};
-    if (builder.nodes[rootTmp].left < 0)
-    {
-        // the whole scene is one leaf: wrap it in a root whose second child is empty
-        out.nodes.emplace_back();
-        float lo[3], hi[3];
-        padded(builder.nodes[rootTmp].box, lo, hi);
-        const int32_t ref = emitter.emit_ref(rootTmp, 1);
-        BvhNode &root = out.nodes[0];
-        std::memset(&root, 0, sizeof(root));
-        std::memcpy(root.lo0, lo, 12);
-        std::memcpy(root.hi0, hi, 12);
-        empty_child(root.lo1, root.hi1);
-        root.child0 = ref;
-        root.child1 = ~0;
-        out.maxDepth = 1;
-    }
-    else
-        emitter.emit_inner(rootTmp, 0);
-
-    if (out.maxDepth > kTraversalStackDepth)
-        throw std::runtime_error("BVH depth exceeds the traversal stack bound");
+    uint32_t need = 0;
+    emitter.emit_node(rootTmp, need);
+    out.maxDepth = need + 1; // entries the traversal stack must hold in the worst case
+    if (out.maxDepth > kMaxStackBound)
+        throw std::runtime_error("BVH stack bound exceeds the traversal's overflow capacity");
     return out;
 }
 

@@ -73,6 +73,9 @@ struct prosper_pt_ctx
     unsigned long long *dCounters = nullptr; // kStageCount x 16 u64: one block of work counters per kernel stage
     uint32_t *dWorkCounter = nullptr;        // work-distribution counter of the persistent kernel
     // wavefront workspace (one allocation, carved into the WavefrontBuffers arrays)
+    // global overflow of the traversal stacks (only for trees whose stack bound exceeds the LDS stack)
+    int32_t *stackOverflow = nullptr;
+    size_t stackOverflowBytes = 0;
     void *wfBlock = nullptr;
     size_t wfBytes = 0;
     uint64_t wfSlots = 0;
@@ -429,6 +432,27 @@ int ensure_wavefront_workspace(
     return PROSPER_PT_OK;
 }
 
+// Makes sure the global stack-overflow array covers `gridBlocks` workgroups of 256 lanes for a kernel
+// whose LDS stack holds `ldsEntries` entries; returns nullptr when the tree never needs more.
+int ensure_stack_overflow(prosper_pt_ctx *ctx, uint32_t ldsEntries, uint32_t gridBlocks, hipStream_t stream, int32_t **out)
+{
+    *out = nullptr;
+    const uint32_t bound = ctx->stats.maxDepth;
+    if (bound <= ldsEntries) return PROSPER_PT_OK;
+    const size_t bytes = (size_t)(bound - ldsEntries) * gridBlocks * 256u * sizeof(int32_t);
+    if (bytes > ctx->stackOverflowBytes)
+    {
+        PPT_HIP(hipStreamSynchronize(stream));
+        if (ctx->stackOverflow) PPT_HIP(hipFree(ctx->stackOverflow));
+        ctx->stackOverflow = nullptr;
+        ctx->stackOverflowBytes = 0;
+        PPT_HIP(hipMalloc((void **)&ctx->stackOverflow, bytes));
+        ctx->stackOverflowBytes = bytes;
+    }
+    *out = ctx->stackOverflow;
+    return PROSPER_PT_OK;
+}
+
 uint32_t compute_local_width(uint32_t width, const prosper_pt_tile_desc *tile)
 {
     if (!tile || tile->stripeCount <= 1 || tile->stripeWidth == 0) return width;
@@ -490,6 +514,7 @@ void prosper_pt_destroy(prosper_pt_ctx *ctx)
     if (ctx->dCounters) (void)hipFree(ctx->dCounters);
     if (ctx->dWorkCounter) (void)hipFree(ctx->dWorkCounter);
     if (ctx->wfBlock) (void)hipFree(ctx->wfBlock);
+    if (ctx->stackOverflow) (void)hipFree(ctx->stackOverflow);
     for (auto &e : ctx->events)
         if (e) (void)hipEventDestroy(e);
     delete ctx;
@@ -618,13 +643,19 @@ int prosper_pt_render_frames(
     LaunchTimer *tp = ctx->kernelTiming ? &timer : nullptr;
     if (ctx->flags & PROSPER_PT_CREATE_MEGAKERNEL)
     {
+        int32_t *ovf = nullptr;
+        const int orc = ensure_stack_overflow(ctx, kTraversalStackDepth, megakernel_grid_blocks(p), s, &ovf);
+        if (orc != PROSPER_PT_OK) return orc;
         if (tp) tp->mark(kStageGenerate, s);
-        launch_render_megakernel(ctx->scene, p, ctx->hdr, ctx->dCounters, countWork, s);
+        launch_render_megakernel(ctx->scene, p, ctx->hdr, ctx->dCounters, ovf, countWork, s);
     }
     else if (ctx->flags & PROSPER_PT_CREATE_PERSISTENT)
     {
+        int32_t *ovf = nullptr;
+        const int orc = ensure_stack_overflow(ctx, kTraversalStackDepth, persistent_grid_blocks(), s, &ovf);
+        if (orc != PROSPER_PT_OK) return orc;
         if (tp) tp->mark(kStageGenerate, s);
-        launch_render_persistent(ctx->scene, p, ctx->hdr, ctx->dCounters, ctx->dWorkCounter, countWork, s);
+        launch_render_persistent(ctx->scene, p, ctx->hdr, ctx->dCounters, ctx->dWorkCounter, ovf, countWork, s);
     }
     else
     {
@@ -646,8 +677,12 @@ int prosper_pt_render_frames(
             pp.frameCount = frames;
             pp.pc.frameIndex = (p.pc.frameIndex + f0) % PROSPER_RT_FRAME_PERIOD;
             if (f0 > 0) pp.pc.flags &= ~(uint32_t)PROSPER_PC_FLAG_SKIP_HISTORY;
+            const uint32_t ldsEntries = wavefront_lds_stack_entries(ctx->stats.maxDepth);
+            int32_t *ovf = nullptr;
+            const int orc = ensure_stack_overflow(ctx, ldsEntries, wavefront_grid_blocks(w), s, &ovf);
+            if (orc != PROSPER_PT_OK) return orc;
             launch_render_wavefront(
-                ctx->scene, pp, ctx->hdr, ctx->dCounters, w, ctx->stats.maxDepth, (uint32_t)ctx->stats.nodeCount,
+                ctx->scene, pp, ctx->hdr, ctx->dCounters, w, ldsEntries, ovf, (uint32_t)ctx->stats.nodeCount,
                 (uint32_t)ctx->stats.triangleCount, countWork, tp, s);
         }
     }

@@ -770,11 +770,12 @@ PPT_D bool intersect_triangle(f3 o, f3 d, f3 v0, f3 v1, f3 v2, float tMin, float
     if ((U < 0.0f || V < 0.0f || W < 0.0f) && (U > 0.0f || V > 0.0f || W > 0.0f)) return false;
     const float det = (U + V) + W;
     if (!(det != 0.0f)) return false;
-    // det = U + V + W equals -dot(d, N) in exact arithmetic, so one reciprocal serves t and both
-    // barycentrics (DESIGN.md "hit contract")
-    const f3 N = cross(v1 - v0, v2 - v0);
+    // t = projection of the barycentric point on the (unit) direction: (U*(A.d) + V*(B.d) + W*(C.d)) / det.
+    // Well conditioned for grazing rays (the plane equation is not), so the distance always lies inside
+    // the ray's interval through the triangle's box and hit selection is independent of the BVH
+    // (DESIGN.md "hit contract").
     const float inv = 1.0f / det;
-    const float tt = -dot(A, N) * inv;
+    const float tt = __builtin_fmaf(W, dot(C, d), __builtin_fmaf(V, dot(B, d), U * dot(A, d))) * inv;
     if (!(tt > tMin && tt < tMax)) return false;
     t = tt;
     bu = V * inv;
@@ -838,24 +839,6 @@ PPT_D float safe_rcp_dir(float d)
     return 1.0f / (fabs_(d) < 1e-30f ? (d < 0.0f ? -1e-30f : 1e-30f) : d);
 }
 
-// Conservative slab test of one child box; returns entry distance or +inf on a miss.  The boxes
-// are padded by the builder so a triangle the edge-function test accepts is never culled.
-PPT_D float box_entry(const float lo[3], const float hi[3], f3 o, f3 invd, float tMin, float tMax)
-{
-    float t0 = (lo[0] - o.x) * invd.x, t1 = (hi[0] - o.x) * invd.x;
-    float tn = fminf(t0, t1), tf = fmaxf(t0, t1);
-    t0 = (lo[1] - o.y) * invd.y;
-    t1 = (hi[1] - o.y) * invd.y;
-    tn = fmaxf(tn, fminf(t0, t1));
-    tf = fminf(tf, fmaxf(t0, t1));
-    t0 = (lo[2] - o.z) * invd.z;
-    t1 = (hi[2] - o.z) * invd.z;
-    tn = fmaxf(tn, fminf(t0, t1));
-    tf = fminf(tf, fmaxf(t0, t1));
-    const bool hit = tn <= tf * 1.0000004f && tf >= tMin && tn <= tMax;
-    return hit ? tn : kInf;
-}
-
 // Where the traversal reads BVH nodes and world triangles from.  GlobalGeom: the HBM arrays (through
 // L1/L2).  LdsGeom: a copy a workgroup staged in LDS — for scenes of a few KB (a Cornell box) every
 // node fetch then costs an LDS access (~64 cycles) instead of a vector-memory round trip (~200+),
@@ -865,11 +848,21 @@ struct TriangleData
 {
     float4 a, b, c;
 };
+// one 64-B BvhNode as four 16-B words: q0 = lo.x[4] lo.y[4], q1 = lo.z[4] hi.x[4], q2 = hi.y[4] hi.z[4]
+// (halfs, two per dword), q3 = child[4]
+struct NodeData
+{
+    uint4 q0, q1, q2, q3;
+};
 struct GlobalGeom
 {
     const BvhNode *nodes;
     const WorldTriangle *triangles;
-    PPT_D BvhNode node(int32_t i) const { return nodes[i]; }
+    PPT_D NodeData node(int32_t i) const
+    {
+        const uint4 *np = reinterpret_cast<const uint4 *>(nodes + i);
+        return NodeData{np[0], np[1], np[2], np[3]};
+    }
     PPT_D TriangleData tri(uint32_t i) const
     {
         const float4 *tp = reinterpret_cast<const float4 *>(triangles + i);
@@ -881,19 +874,10 @@ struct LdsGeom
 {
     const float4 *nodes;     // LDS
     const float4 *triangles; // LDS
-    PPT_D BvhNode node(int32_t i) const
+    PPT_D NodeData node(int32_t i) const
     {
-        const float4 *np = nodes + (uint32_t)i * kLdsNodeStride;
-        const float4 q0 = np[0], q1 = np[1], q2 = np[2], q3 = np[3];
-        BvhNode n;
-        n.lo0[0] = q0.x; n.lo0[1] = q0.y; n.lo0[2] = q0.z; n.hi0[0] = q0.w;
-        n.hi0[1] = q1.x; n.hi0[2] = q1.y; n.lo1[0] = q1.z; n.lo1[1] = q1.w;
-        n.lo1[2] = q2.x; n.hi1[0] = q2.y; n.hi1[1] = q2.z; n.hi1[2] = q2.w;
-        n.child0 = __builtin_bit_cast(int32_t, q3.x);
-        n.child1 = __builtin_bit_cast(int32_t, q3.y);
-        n.pad[0] = 0;
-        n.pad[1] = 0;
-        return n;
+        const uint4 *np = reinterpret_cast<const uint4 *>(nodes + (uint32_t)i * kLdsNodeStride);
+        return NodeData{np[0], np[1], np[2], np[3]};
     }
     PPT_D TriangleData tri(uint32_t i) const
     {
@@ -904,13 +888,92 @@ struct LdsGeom
 // LDS budget of a staged scene (float4s): nodes * 5 + triangles * 3 must fit
 constexpr uint32_t kLdsSceneFloat4s = 768; // 12 KB
 
+// The traversal stack of one lane: `cap` entries in LDS (entry e at lds[e * 64], conflict-free for
+// b32 accesses), anything deeper in a global overflow column (entry e at ovf[e * ovfStride]).  The
+// builder bounds the worst case (kMaxStackBound); the LDS part is sized for the common case.
+struct TraversalStack
+{
+    int32_t *lds;
+    int32_t *ovf;
+    uint32_t cap;
+    uint32_t ovfStride;
+    PPT_D void push(int32_t &sp, int32_t v) const
+    {
+        if ((uint32_t)sp < cap)
+            lds[sp * 64] = v;
+        else
+            ovf[(size_t)((uint32_t)sp - cap) * ovfStride] = v;
+        ++sp;
+    }
+    PPT_D int32_t pop(int32_t &sp) const
+    {
+        --sp;
+        return (uint32_t)sp < cap ? lds[sp * 64] : ovf[(size_t)((uint32_t)sp - cap) * ovfStride];
+    }
+};
+
+PPT_D float half_lo(uint32_t d) { return (float)__builtin_bit_cast(_Float16, (uint16_t)(d & 0xFFFFu)); }
+PPT_D float half_hi(uint32_t d) { return (float)__builtin_bit_cast(_Float16, (uint16_t)(d >> 16)); }
+
+// Conservative slab test of one child box given its six planes; entry distance or +inf on a miss.
+// t = (plane - o) * invd keeps the subtraction exact when the origin is near the plane (the fused
+// form plane*invd - o*invd cancels catastrophically there and needs per-axis error terms that cost as
+// much as the subtraction).  With the builder's outward padding, the outward half rounding and the
+// 1 + 4e-7 factor on the exit distance no box that contains a hit is culled.
+PPT_D float slab_entry(float lox, float loy, float loz, float hix, float hiy, float hiz, f3 o, f3 invd, float tMin, float tMax)
+{
+    const float ax = (lox - o.x) * invd.x, bx = (hix - o.x) * invd.x;
+    const float ay = (loy - o.y) * invd.y, by = (hiy - o.y) * invd.y;
+    const float az = (loz - o.z) * invd.z, bz = (hiz - o.z) * invd.z;
+    const float tn = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fminf(az, bz));
+    const float tf = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz));
+    const bool hit = fmaxf(tn, tMin) <= fminf(tf * 1.0000004f, tMax);
+    return hit ? tn : kInf;
+}
+
+// Tests the four children of a node; e[c] = entry distance or +inf, then sorts (e, ref) ascending
+// (5-comparator network) so the nearest child is walked first.  Returns the number of children hit.
+PPT_D uint32_t intersect_node4(const NodeData &n, f3 o, f3 invd, float tMin, float tMax, float e[4], int32_t ref[4])
+{
+    e[0] = slab_entry(half_lo(n.q0.x), half_lo(n.q0.z), half_lo(n.q1.x), half_lo(n.q1.z), half_lo(n.q2.x), half_lo(n.q2.z),
+                      o, invd, tMin, tMax);
+    e[1] = slab_entry(half_hi(n.q0.x), half_hi(n.q0.z), half_hi(n.q1.x), half_hi(n.q1.z), half_hi(n.q2.x), half_hi(n.q2.z),
+                      o, invd, tMin, tMax);
+    e[2] = slab_entry(half_lo(n.q0.y), half_lo(n.q0.w), half_lo(n.q1.y), half_lo(n.q1.w), half_lo(n.q2.y), half_lo(n.q2.w),
+                      o, invd, tMin, tMax);
+    e[3] = slab_entry(half_hi(n.q0.y), half_hi(n.q0.w), half_hi(n.q1.y), half_hi(n.q1.w), half_hi(n.q2.y), half_hi(n.q2.w),
+                      o, invd, tMin, tMax);
+    ref[0] = (int32_t)n.q3.x;
+    ref[1] = (int32_t)n.q3.y;
+    ref[2] = (int32_t)n.q3.z;
+    ref[3] = (int32_t)n.q3.w;
+    const uint32_t hits = (e[0] < kInf ? 1u : 0u) + (e[1] < kInf ? 1u : 0u) + (e[2] < kInf ? 1u : 0u) + (e[3] < kInf ? 1u : 0u);
+#define PPT_CSWAP(i, j)                                                                                                \
+    {                                                                                                                  \
+        const bool sw = e[j] < e[i];                                                                                   \
+        const float te = sw ? e[j] : e[i];                                                                             \
+        e[j] = sw ? e[i] : e[j];                                                                                       \
+        e[i] = te;                                                                                                     \
+        const int32_t tr = sw ? ref[j] : ref[i];                                                                       \
+        ref[j] = sw ? ref[i] : ref[j];                                                                                 \
+        ref[i] = tr;                                                                                                   \
+    }
+    PPT_CSWAP(0, 1)
+    PPT_CSWAP(2, 3)
+    PPT_CSWAP(0, 2)
+    PPT_CSWAP(1, 3)
+    PPT_CSWAP(1, 2)
+#undef PPT_CSWAP
+    return hits;
+}
+
 // Shared driver of traceClosest (ANY = false, main.rgen:62-81) and shadow (ANY = true,
 // main.rgen:49-60).  `stack` points at this lane's column of the workgroup's LDS stack
 // (entry e lives at stack[e * 64]).  Returns true on a hit (ANY: occluded).
 template <bool ANY, bool COUNT, class Geom>
 PPT_D bool trace_in(
-    const Geom &g, const DeviceScene &s, f3 o, f3 d, float tMin, float tMaxIn, uint32_t seed, int32_t *stack, Hit &hit,
-    LaneCounters &cnt)
+    const Geom &g, const DeviceScene &s, f3 o, f3 d, float tMin, float tMaxIn, uint32_t seed, const TraversalStack &stack,
+    Hit &hit, LaneCounters &cnt)
 {
     hit.drawInstance = kMissIndex;
     hit.primitive = kMissIndex;
@@ -922,34 +985,26 @@ PPT_D bool trace_in(
     // (lanes that already do wait), then all lanes intersect their leaf's triangles.  Under
     // divergence this keeps the (long) triangle code out of the node loop and vice versa.
     int32_t sp = 0;
-    int32_t node = 0; // root is always an inner node
+    int32_t node = 0; // the root is always an inner node
     bool alive = true;
     while (alive)
     {
         while (alive && node >= 0)
         {
-            const BvhNode n = g.node(node);
+            const NodeData nd = g.node(node);
             if constexpr (COUNT) cnt.nodeVisits++;
-            const float e0 = box_entry(n.lo0, n.hi0, o, invd, tMin, hit.t);
-            const float e1 = box_entry(n.lo1, n.hi1, o, invd, tMin, hit.t);
-            const bool h0 = e0 < kInf;
-            const bool h1 = e1 < kInf;
-            if (h0 && h1)
-            {
-                const bool firstIs0 = e0 <= e1;
-                stack[sp * 64] = firstIs0 ? n.child1 : n.child0;
-                ++sp;
-                node = firstIs0 ? n.child0 : n.child1;
-            }
-            else if (h0 || h1)
-                node = h0 ? n.child0 : n.child1;
+            float e[4];
+            int32_t ref[4];
+            const uint32_t hits = intersect_node4(nd, o, invd, tMin, hit.t, e, ref);
+            if (hits > 3u) stack.push(sp, ref[3]);
+            if (hits > 2u) stack.push(sp, ref[2]);
+            if (hits > 1u) stack.push(sp, ref[1]);
+            if (hits > 0u)
+                node = ref[0];
             else if (sp == 0)
                 alive = false;
             else
-            {
-                --sp;
-                node = stack[sp * 64];
-            }
+                node = stack.pop(sp);
         }
         if (!alive) break;
         {
@@ -987,15 +1042,14 @@ PPT_D bool trace_in(
             }
         }
         if (sp == 0) break;
-        --sp;
-        node = stack[sp * 64];
+        node = stack.pop(sp);
     }
     return hit.drawInstance != kMissIndex;
 }
 
 template <bool ANY, bool COUNT>
 PPT_D bool trace(
-    const DeviceScene &s, f3 o, f3 d, float tMin, float tMaxIn, uint32_t seed, int32_t *stack, Hit &hit,
+    const DeviceScene &s, f3 o, f3 d, float tMin, float tMaxIn, uint32_t seed, const TraversalStack &stack, Hit &hit,
     LaneCounters &cnt)
 {
     return trace_in<ANY, COUNT>(GlobalGeom{s.nodes, s.triangles}, s, o, d, tMin, tMaxIn, seed, stack, hit, cnt);

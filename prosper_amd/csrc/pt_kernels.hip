@@ -92,7 +92,8 @@ void launch_permute_triangles(
 // One path: rt/reference/main.rgen:225-283.
 template <bool COUNT>
 __device__ f3 trace_path(
-    const DeviceScene &s, const RenderParams &p, uint32_t px, uint32_t py, uint32_t frameIndex, int32_t *stack,
+    const DeviceScene &s, const RenderParams &p, uint32_t px, uint32_t py, uint32_t frameIndex,
+    const TraversalStack &stack,
     LaneCounters &cnt)
 {
     Rng rng{px, py, frameIndex};
@@ -169,7 +170,8 @@ __device__ f3 trace_path(
 // is remapped to give each XCD a contiguous band of tiles (speed only, never correctness).
 template <bool COUNT>
 __global__ __launch_bounds__(256) void render_megakernel(
-    DeviceScene s, RenderParams p, float4 *__restrict__ hdr, unsigned long long *__restrict__ counters)
+    DeviceScene s, RenderParams p, float4 *__restrict__ hdr, unsigned long long *__restrict__ counters,
+    int32_t *__restrict__ stackOverflow)
 {
     __shared__ int32_t ldsStack[kTraversalStackDepth * 256];
 
@@ -184,7 +186,8 @@ __global__ __launch_bounds__(256) void render_megakernel(
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t lx = (tile % tilesX) * 16u + (wave & 1u) * 8u + (lane & 7u);
     const uint32_t py = (tile / tilesX) * 16u + (wave >> 1) * 8u + (lane >> 3);
-    int32_t *stack = ldsStack + wave * (kTraversalStackDepth * 64u) + lane;
+    const TraversalStack stack{ldsStack + wave * (kTraversalStackDepth * 64u) + lane,
+                               stackOverflow + blockIdx.x * 256u + threadIdx.x, kTraversalStackDepth, gridDim.x * 256u};
 
     LaneCounters cnt = {};
     if (lx < p.localWidth && py < p.height)
@@ -219,9 +222,15 @@ __global__ __launch_bounds__(256) void render_megakernel(
     flush_counters<COUNT>(cnt, counters);
 }
 
+uint32_t megakernel_grid_blocks(const RenderParams &p)
+{
+    const uint32_t numTiles = ((p.localWidth + 15u) / 16u) * ((p.height + 15u) / 16u);
+    return ((numTiles + 7u) / 8u) * 8u;
+}
+
 void launch_render_megakernel(
-    const DeviceScene &s, const RenderParams &p, float4 *hdr, unsigned long long *counters, bool countWork,
-    hipStream_t stream)
+    const DeviceScene &s, const RenderParams &p, float4 *hdr, unsigned long long *counters, int32_t *stackOverflow,
+    bool countWork, hipStream_t stream)
 {
     const uint32_t tilesX = (p.localWidth + 15u) / 16u;
     const uint32_t tilesY = (p.height + 15u) / 16u;
@@ -230,9 +239,9 @@ void launch_render_megakernel(
     const uint32_t perXcd = (numTiles + 7u) / 8u;
     const dim3 grid(perXcd * 8u), block(256);
     if (countWork)
-        hipLaunchKernelGGL(render_megakernel<true>, grid, block, 0, stream, s, p, hdr, counters);
+        hipLaunchKernelGGL(render_megakernel<true>, grid, block, 0, stream, s, p, hdr, counters, stackOverflow);
     else
-        hipLaunchKernelGGL(render_megakernel<false>, grid, block, 0, stream, s, p, hdr, counters);
+        hipLaunchKernelGGL(render_megakernel<false>, grid, block, 0, stream, s, p, hdr, counters, stackOverflow);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -253,7 +262,7 @@ void launch_render_megakernel(
 // has ended (its radiance is then in st.color).
 template <bool COUNT>
 __device__ __forceinline__ bool path_bounce(
-    const DeviceScene &s, const RenderParams &p, PathState &st, int32_t *stack, LaneCounters &cnt)
+    const DeviceScene &s, const RenderParams &p, PathState &st, const TraversalStack &stack, LaneCounters &cnt)
 {
     Hit hit;
     if constexpr (COUNT) cnt.closestRays++;
@@ -303,12 +312,13 @@ __device__ __forceinline__ bool path_bounce(
 template <bool COUNT>
 __global__ __launch_bounds__(256) void render_persistent(
     DeviceScene s, RenderParams p, float4 *__restrict__ hdr, unsigned long long *__restrict__ counters,
-    uint32_t *__restrict__ workCounter)
+    uint32_t *__restrict__ workCounter, int32_t *__restrict__ stackOverflow)
 {
     __shared__ int32_t ldsStack[kTraversalStackDepth * 256];
     const uint32_t wave = threadIdx.x >> 6;
     const uint32_t lane = threadIdx.x & 63u;
-    int32_t *stack = ldsStack + wave * (kTraversalStackDepth * 64u) + lane;
+    const TraversalStack stack{ldsStack + wave * (kTraversalStackDepth * 64u) + lane,
+                               stackOverflow + blockIdx.x * 256u + threadIdx.x, kTraversalStackDepth, gridDim.x * 256u};
 
     const uint32_t tilesX = (p.localWidth + 7u) / 8u;
     const uint32_t tilesY = (p.height + 7u) / 8u;
@@ -415,7 +425,7 @@ uint32_t persistent_grid_blocks()
 
 void launch_render_persistent(
     const DeviceScene &s, const RenderParams &p, float4 *hdr, unsigned long long *counters, uint32_t *workCounter,
-    bool countWork, hipStream_t stream)
+    int32_t *stackOverflow, bool countWork, hipStream_t stream)
 {
     const uint32_t tilesX = (p.localWidth + 7u) / 8u;
     const uint32_t tilesY = (p.height + 7u) / 8u;
@@ -427,9 +437,9 @@ void launch_render_persistent(
     if (blocks > needed) blocks = needed;
     const dim3 grid(blocks), block(256);
     if (countWork)
-        hipLaunchKernelGGL(render_persistent<true>, grid, block, 0, stream, s, p, hdr, counters, workCounter);
+        hipLaunchKernelGGL(render_persistent<true>, grid, block, 0, stream, s, p, hdr, counters, workCounter, stackOverflow);
     else
-        hipLaunchKernelGGL(render_persistent<false>, grid, block, 0, stream, s, p, hdr, counters, workCounter);
+        hipLaunchKernelGGL(render_persistent<false>, grid, block, 0, stream, s, p, hdr, counters, workCounter, stackOverflow);
 }
 
 // ------------------------------------------------------------------------------------------

@@ -46,15 +46,23 @@ void launch_flatten_triangles(
     WorldTriangle *out, uint32_t total, hipStream_t stream);
 void launch_permute_triangles(
     const WorldTriangle *in, const uint32_t *permutation, WorldTriangle *out, uint32_t total, hipStream_t stream);
+uint32_t megakernel_grid_blocks(const RenderParams &p);
+uint32_t persistent_grid_blocks();
+uint32_t wavefront_grid_blocks(const WavefrontBuffers &w);
+// `stackOverflow`: global array of (stack bound - LDS entries) x (grid lanes) ints, or nullptr when the
+// BVH's stack bound fits the kernel's LDS stack
 void launch_render_megakernel(
-    const DeviceScene &s, const RenderParams &p, float4 *hdr, unsigned long long *counters, bool countWork,
-    hipStream_t stream);
+    const DeviceScene &s, const RenderParams &p, float4 *hdr, unsigned long long *counters, int32_t *stackOverflow,
+    bool countWork, hipStream_t stream);
 void launch_render_persistent(
     const DeviceScene &s, const RenderParams &p, float4 *hdr, unsigned long long *counters, uint32_t *workCounter,
-    bool countWork, hipStream_t stream);
+    int32_t *stackOverflow, bool countWork, hipStream_t stream);
 void launch_render_wavefront(
     const DeviceScene &s, const RenderParams &p, float4 *hdr, unsigned long long *counters, const WavefrontBuffers &w,
-    uint32_t bvhDepth, uint32_t nodeCount, uint32_t triCount, bool countWork, LaunchTimer *timer, hipStream_t stream);
+    uint32_t ldsStackEntries, int32_t *stackOverflow, uint32_t nodeCount, uint32_t triCount, bool countWork,
+    LaunchTimer *timer, hipStream_t stream);
+// LDS stack entries (16/24/32) the wavefront traversal kernels use for a tree with this stack bound
+uint32_t wavefront_lds_stack_entries(uint32_t stackBound);
 void launch_blit_rgba16f(const float4 *in, void *out, uint32_t count, hipStream_t stream);
 void launch_eval_fn(
     uint32_t fn, const float *in, uint32_t inStride, float *out, uint32_t outStride, uint32_t n, hipStream_t stream);

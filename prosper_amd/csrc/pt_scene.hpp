@@ -13,23 +13,24 @@
 namespace ppt
 {
 
-// BVH2 node, 64 B = one aligned 64-B fetch (4 x dwordx4 per lane).  A child reference >= 0 is
-// an inner node index; < 0 is a leaf: ~ref = (firstTriangle << 3) | (triangleCount - 1).
-// An unused child has the box lo = hi = +inf, which no ray can enter (see bvh_build.cpp).
+// 4-wide BVH node, 64 B = one aligned 64-B fetch.  The four child boxes are stored as halfs,
+// rounded outward (lo down, hi up) so they stay conservative, one 8-byte group per plane:
+// lo[axis][child], hi[axis][child].  A child reference >= 0 is an inner node index; < 0 is a leaf:
+// ~ref = (firstTriangle << 3) | (triangleCount - 1).  An unused child has lo = hi = +inf, which no ray
+// can enter (see bvh_build.cpp).  One node visit tests four boxes: half the dependent fetches per ray of
+// a binary tree at the same bytes per box, which is what a latency-bound traversal needs.
 struct alignas(64) BvhNode
 {
-    float lo0[3];
-    float hi0[3];
-    float lo1[3];
-    float hi1[3];
-    int32_t child0;
-    int32_t child1;
-    uint32_t pad[2];
+    uint16_t lo[3][4];
+    uint16_t hi[3][4];
+    int32_t child[4];
 };
 static_assert(sizeof(BvhNode) == 64, "BVH node is 64 B");
 
 constexpr uint32_t kMaxLeafTriangles = 4;
-constexpr uint32_t kTraversalStackDepth = 32; // LDS entries per lane; the builder caps depth
+constexpr uint32_t kTraversalStackDepth = 32; // most LDS stack entries per lane a kernel variant has
+// worst-case stack entries a tree may need; entries beyond the LDS stack spill to a global array
+constexpr uint32_t kMaxStackBound = 96;
 
 // World-space triangle, 48 B = 3 x dwordx4, stored in BVH leaf order.  Vertices are the fp16
 // positions of the bindless geometry buffers (reference: src/scene/Mesh.hpp:11-12) decoded and

@@ -35,30 +35,13 @@ struct StreamRay
     uint32_t seed;
 };
 
-// Slab test in fma form: t = lo*invd + (-o*invd).  Conservative together with the builder's box
-// padding (rounding of o*invd is ~1 ulp of the coordinate, the padding is >= 8 ulp + 1e-5 extent).
-PPT_D float box_entry_fma(const float lo[3], const float hi[3], f3 invd, f3 oid, float tMin, float tMax)
-{
-    float t0 = __builtin_fmaf(lo[0], invd.x, oid.x), t1 = __builtin_fmaf(hi[0], invd.x, oid.x);
-    float tn = fminf(t0, t1), tf = fmaxf(t0, t1);
-    t0 = __builtin_fmaf(lo[1], invd.y, oid.y);
-    t1 = __builtin_fmaf(hi[1], invd.y, oid.y);
-    tn = fmaxf(tn, fminf(t0, t1));
-    tf = fminf(tf, fmaxf(t0, t1));
-    t0 = __builtin_fmaf(lo[2], invd.z, oid.z);
-    t1 = __builtin_fmaf(hi[2], invd.z, oid.z);
-    tn = fmaxf(tn, fminf(t0, t1));
-    tf = fminf(tf, fmaxf(t0, t1));
-    const bool hit = fmaxf(tn, tMin) <= fminf(tf * 1.0000004f, tMax);
-    return hit ? tn : kInf;
-}
-
 // fetch(i) -> StreamRay for stream position i (called by the lanes that take a new ray);
 // commit(pred, i, found, hit, dir) is called by ALL lanes in converged code; lanes with pred set
 // hand over the result of ray i with direction dir (so commit may compact with ballots).
 template <bool ANY, bool COUNT, class Geom, class Fetch, class Commit>
 PPT_D void trace_stream(
-    const Geom &g, const DeviceScene &s, uint32_t n, int32_t *stack, LaneCounters &cnt, Fetch &&fetch, Commit &&commit)
+    const Geom &g, const DeviceScene &s, uint32_t n, const TraversalStack &stack, LaneCounters &cnt, Fetch &&fetch,
+    Commit &&commit)
 {
     const uint32_t lane = threadIdx.x & 63u;
     const unsigned long long below = (1ull << lane) - 1ull;
@@ -66,7 +49,7 @@ PPT_D void trace_stream(
     uint32_t next = 0; // wave-uniform: next stream position to hand out
     uint32_t state = kLaneIdle;
     uint32_t ray = 0;
-    f3 o = {}, d = {}, invd = {}, oid = {};
+    f3 o = {}, d = {}, invd = {};
     float tMin = 0.0f, tMaxIn = 0.0f;
     uint32_t seed = 0;
     int32_t node = 0, sp = 0;
@@ -82,8 +65,7 @@ PPT_D void trace_stream(
             state = kLaneFinished;
         else
         {
-            --sp;
-            node = stack[sp * 64];
+            node = stack.pop(sp);
             if (node >= 0)
                 state = kLaneNode;
             else
@@ -141,26 +123,22 @@ PPT_D void trace_stream(
             {
                 if (state == kLaneNode)
                 {
-                    const BvhNode nd = g.node(node);
+                    const NodeData nd = g.node(node);
                     if constexpr (COUNT) cnt.nodeVisits++;
-                    const float e0 = box_entry_fma(nd.lo0, nd.hi0, invd, oid, tMin, hit.t);
-                    const float e1 = box_entry_fma(nd.lo1, nd.hi1, invd, oid, tMin, hit.t);
-                    const bool h0 = e0 < kInf;
-                    const bool h1 = e1 < kInf;
-                    if (h0 || h1)
+                    float e[4];
+                    int32_t ref[4];
+                    const uint32_t hits = intersect_node4(nd, o, invd, tMin, hit.t, e, ref);
+                    if (hits > 3u) stack.push(sp, ref[3]);
+                    if (hits > 2u) stack.push(sp, ref[2]);
+                    if (hits > 1u) stack.push(sp, ref[1]);
+                    if (hits > 0u)
                     {
-                        const bool firstIs0 = h0 && (!h1 || e0 <= e1);
-                        if (h0 && h1)
-                        {
-                            stack[sp * 64] = firstIs0 ? nd.child1 : nd.child0;
-                            ++sp;
-                        }
-                        node = firstIs0 ? nd.child0 : nd.child1;
+                        node = ref[0];
                         if (node < 0)
                         {
-                            const uint32_t ref = (uint32_t)~node;
-                            triFirst = ref >> 3;
-                            triCount = (ref & 7u) + 1u;
+                            const uint32_t leaf = (uint32_t)~node;
+                            triFirst = leaf >> 3;
+                            triCount = (leaf & 7u) + 1u;
                             state = kLaneTri;
                         }
                     }
@@ -246,7 +224,6 @@ PPT_D void trace_stream(
                 tMaxIn = r.tMax;
                 seed = r.seed;
                 invd = f3{safe_rcp_dir(d.x), safe_rcp_dir(d.y), safe_rcp_dir(d.z)};
-                oid = f3{-(o.x * invd.x), -(o.y * invd.y), -(o.z * invd.z)};
                 hit.drawInstance = kMissIndex;
                 hit.primitive = kMissIndex;
                 hit.bary = f2{0.0f, 0.0f};

@@ -132,7 +132,7 @@ __device__ __forceinline__ LdsGeom stage_scene_in_lds(const DeviceScene &s, floa
 template <bool COUNT, int STACK, bool LDS_SCENE>
 __global__ __launch_bounds__(256, PPT_GEN_WPE) void wf_generate_extend(
     DeviceScene s, RenderParams p, WavefrontBuffers w, uint32_t nodeCount, uint32_t triCount,
-    unsigned long long *__restrict__ counters)
+    int32_t *__restrict__ stackOverflow, unsigned long long *__restrict__ counters)
 {
     __shared__ int32_t ldsStack[STACK * 256];
     __shared__ float4 ldsScene[LDS_SCENE ? kLdsSceneFloat4s : 1];
@@ -142,7 +142,8 @@ __global__ __launch_bounds__(256, PPT_GEN_WPE) void wf_generate_extend(
     const SegmentId id = my_segment(w);
     if (!id.valid) return;
     const uint32_t lane = lane_id();
-    int32_t *stack = ldsStack + (threadIdx.x >> 6) * (STACK * 64u) + lane;
+    const TraversalStack stack{ldsStack + (threadIdx.x >> 6) * (STACK * 64u) + lane,
+                               stackOverflow + blockIdx.x * 256u + threadIdx.x, (uint32_t)STACK, gridDim.x * 256u};
     const bool traceRays = p.pc.maxBounces > 0;
 
     LaneCounters cnt = {};
@@ -241,7 +242,7 @@ __global__ __launch_bounds__(256, PPT_GEN_WPE) void wf_generate_extend(
 template <bool COUNT, class Geom>
 __device__ __forceinline__ void extend_segment(
     const Geom &g, const DeviceScene &s, const RenderParams &p, const WavefrontBuffers &w, const SegmentId &id, uint32_t bounce,
-    uint32_t cur, int32_t *stack, LaneCounters &cnt)
+    uint32_t cur, const TraversalStack &stack, LaneCounters &cnt)
 {
     const float4 *__restrict__ rayA = w.rayA[cur];
     const float4 *__restrict__ rayB = w.rayB[cur];
@@ -405,7 +406,7 @@ __global__ __launch_bounds__(256, PPT_SHADE_WPE) void wf_shade(
 template <bool COUNT, class Geom>
 __device__ __forceinline__ void shadow_segment(
     const Geom &g, const DeviceScene &s, const RenderParams &p, const WavefrontBuffers &w, const SegmentId &id, uint32_t bounce,
-    int32_t *stack, LaneCounters &cnt)
+    const TraversalStack &stack, LaneCounters &cnt)
 {
     const uint32_t n = w.segShadow[id.seg];
     auto fetch = [&](uint32_t k) {
@@ -448,7 +449,8 @@ __device__ __forceinline__ void shadow_segment(
 template <bool COUNT, int STACK, bool LDS_SCENE>
 __global__ __launch_bounds__(256, PPT_TRACE_WPE(STACK)) void wf_trace(
     DeviceScene s, RenderParams p, WavefrontBuffers w, uint32_t bounce, uint32_t nextCur, uint32_t doExtend,
-    uint32_t nodeCount, uint32_t triCount, unsigned long long *__restrict__ counters)
+    uint32_t nodeCount, uint32_t triCount, int32_t *__restrict__ stackOverflow,
+    unsigned long long *__restrict__ counters)
 {
     __shared__ int32_t ldsStack[STACK * 256];
     __shared__ float4 ldsScene[LDS_SCENE ? kLdsSceneFloat4s : 1];
@@ -457,7 +459,8 @@ __global__ __launch_bounds__(256, PPT_TRACE_WPE(STACK)) void wf_trace(
     const GlobalGeom gg{s.nodes, s.triangles};
     const SegmentId id = my_segment(w);
     if (!id.valid) return;
-    int32_t *stack = ldsStack + (threadIdx.x >> 6) * (STACK * 64u) + lane_id();
+    const TraversalStack stack{ldsStack + (threadIdx.x >> 6) * (STACK * 64u) + lane_id(),
+                               stackOverflow + blockIdx.x * 256u + threadIdx.x, (uint32_t)STACK, gridDim.x * 256u};
     LaneCounters cnt = {};
     if constexpr (LDS_SCENE)
         shadow_segment<COUNT>(lg, s, p, w, id, bounce, stack, cnt);
@@ -525,7 +528,7 @@ __global__ __launch_bounds__(256) void wf_accumulate(
 template <bool COUNT, int STACK, bool LDS_SCENE>
 static void enqueue_wavefront(
     const DeviceScene &s, const RenderParams &p, float4 *hdr, unsigned long long *counters, const WavefrontBuffers &w,
-    uint32_t nodeCount, uint32_t triCount, LaunchTimer *timer, hipStream_t stream)
+    uint32_t nodeCount, uint32_t triCount, int32_t *stackOverflow, LaunchTimer *timer, hipStream_t stream)
 {
     unsigned long long *cGen = counters + kStageGenerate * 16u, *cShade = counters + kStageShade * 16u,
                        *cTrace = counters + kStageTrace * 16u, *cAcc = counters + kStageAccumulate * 16u;
@@ -541,7 +544,8 @@ static void enqueue_wavefront(
 
     mark(kStageGenerate);
     hipLaunchKernelGGL(
-        (wf_generate_extend<COUNT, STACK, LDS_SCENE>), grid, block, 0, stream, s, p, w, nodeCount, triCount, cGen);
+        (wf_generate_extend<COUNT, STACK, LDS_SCENE>), grid, block, 0, stream, s, p, w, nodeCount, triCount,
+        stackOverflow, cGen);
     for (uint32_t b = 0; b < bounces; ++b)
     {
         const uint32_t cur = b & 1u;
@@ -553,48 +557,61 @@ static void enqueue_wavefront(
             mark(kStageTrace);
             hipLaunchKernelGGL(
                 (wf_trace<COUNT, STACK, LDS_SCENE>), grid, block, 0, stream, s, p, w, b, cur ^ 1u, last ? 0u : 1u, nodeCount,
-                triCount, cTrace);
+                triCount, stackOverflow, cTrace);
         }
     }
     mark(kStageAccumulate);
     hipLaunchKernelGGL(wf_accumulate<COUNT>, dim3((w.pixelsPadded + 255u) / 256u), block, 0, stream, p, w, hdr, cAcc);
 }
 
-template <bool COUNT>
-static void enqueue_for_depth(
-    const DeviceScene &s, const RenderParams &p, float4 *hdr, unsigned long long *counters, const WavefrontBuffers &w,
-    uint32_t bvhDepth, uint32_t nodeCount, uint32_t triCount, LaunchTimer *timer, hipStream_t stream)
+uint32_t wavefront_grid_blocks(const WavefrontBuffers &w)
 {
-    // a scene of a few KB is traversed out of LDS (its tree is always shallow enough for 16 entries)
-    const bool ldsScene =
-        bvhDepth <= 16 && nodeCount * kLdsNodeStride + triCount * 3u <= kLdsSceneFloat4s && !std::getenv("PROSPER_PT_DEBUG_NO_LDS_SCENE");
-    // smallest LDS stack that holds the deepest root-to-leaf path (the builder caps it at 32)
+    const uint32_t groups = (w.nSeg + 3u) / 4u;
+    return ((groups + 7u) / 8u) * 8u;
+}
+
+uint32_t wavefront_lds_stack_entries(uint32_t stackBound)
+{
+    // test/tuning hook: PROSPER_PT_DEBUG_STACK=16|24|32 forces a variant (deeper entries then live in
+    // the global overflow array, which is always safe, only slower)
+    if (const char *forced = std::getenv("PROSPER_PT_DEBUG_STACK"))
+    {
+        const uint32_t v = (uint32_t)std::atoi(forced);
+        if (v == 16u || v == 24u || v == 32u) return v;
+    }
+    return stackBound <= 16u ? 16u : (stackBound <= 24u ? 24u : 32u);
+}
+
+template <bool COUNT>
+static void enqueue_for_stack(
+    const DeviceScene &s, const RenderParams &p, float4 *hdr, unsigned long long *counters, const WavefrontBuffers &w,
+    uint32_t ldsStackEntries, int32_t *stackOverflow, uint32_t nodeCount, uint32_t triCount, LaunchTimer *timer,
+    hipStream_t stream)
+{
+    // a scene of a few KB is traversed out of LDS
+    const bool ldsScene = ldsStackEntries == 16u && nodeCount * kLdsNodeStride + triCount * 3u <= kLdsSceneFloat4s &&
+                          !std::getenv("PROSPER_PT_DEBUG_NO_LDS_SCENE");
     if (ldsScene)
-        enqueue_wavefront<COUNT, 16, true>(s, p, hdr, counters, w, nodeCount, triCount, timer, stream);
-    else if (bvhDepth <= 16)
-        enqueue_wavefront<COUNT, 16, false>(s, p, hdr, counters, w, nodeCount, triCount, timer, stream);
-    else if (bvhDepth <= 24)
-        enqueue_wavefront<COUNT, 24, false>(s, p, hdr, counters, w, nodeCount, triCount, timer, stream);
+        enqueue_wavefront<COUNT, 16, true>(s, p, hdr, counters, w, nodeCount, triCount, stackOverflow, timer, stream);
+    else if (ldsStackEntries == 16u)
+        enqueue_wavefront<COUNT, 16, false>(s, p, hdr, counters, w, nodeCount, triCount, stackOverflow, timer, stream);
+    else if (ldsStackEntries == 24u)
+        enqueue_wavefront<COUNT, 24, false>(s, p, hdr, counters, w, nodeCount, triCount, stackOverflow, timer, stream);
     else
-        enqueue_wavefront<COUNT, 32, false>(s, p, hdr, counters, w, nodeCount, triCount, timer, stream);
+        enqueue_wavefront<COUNT, 32, false>(s, p, hdr, counters, w, nodeCount, triCount, stackOverflow, timer, stream);
 }
 
 void launch_render_wavefront(
     const DeviceScene &s, const RenderParams &p, float4 *hdr, unsigned long long *counters, const WavefrontBuffers &w,
-    uint32_t bvhDepth, uint32_t nodeCount, uint32_t triCount, bool countWork, LaunchTimer *timer, hipStream_t stream)
+    uint32_t ldsStackEntries, int32_t *stackOverflow, uint32_t nodeCount, uint32_t triCount, bool countWork,
+    LaunchTimer *timer, hipStream_t stream)
 {
     if (w.nSeg == 0) return;
-    static_assert(kTraversalStackDepth == 32, "stack variants assume the builder's depth cap");
-    // test hook: PROSPER_PT_DEBUG_STACK=24|32 forces a deeper stack variant than the BVH needs
-    if (const char *forced = std::getenv("PROSPER_PT_DEBUG_STACK"))
-    {
-        const uint32_t v = (uint32_t)std::atoi(forced);
-        if (v > bvhDepth && v <= kTraversalStackDepth) bvhDepth = v;
-    }
+    static_assert(kTraversalStackDepth == 32, "largest LDS stack variant");
     if (countWork)
-        enqueue_for_depth<true>(s, p, hdr, counters, w, bvhDepth, nodeCount, triCount, timer, stream);
+        enqueue_for_stack<true>(s, p, hdr, counters, w, ldsStackEntries, stackOverflow, nodeCount, triCount, timer, stream);
     else
-        enqueue_for_depth<false>(s, p, hdr, counters, w, bvhDepth, nodeCount, triCount, timer, stream);
+        enqueue_for_stack<false>(s, p, hdr, counters, w, ldsStackEntries, stackOverflow, nodeCount, triCount, timer, stream);
 }
 
 } // namespace ppt

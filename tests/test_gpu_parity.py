@@ -233,7 +233,7 @@ def test_sponza_class_radiance_bit_exact(gpu_ctx, oracle, sponza_small):
     cam, fl = _camera(oracle, sponza_small, w, h)
     gpu_ctx.upload_scene(sponza_small)
     st = gpu_ctx.scene_stats()
-    assert st.triangleCount == sponza_small.triangle_count() and st.maxDepth <= 32
+    assert st.triangleCount == sponza_small.triangle_count() and st.maxDepth <= 96
     osc = oracle.OracleScene(sponza_small)
     want = None
     for frame in (1, 2, 3):
@@ -454,10 +454,10 @@ def test_lds_stack_variants_agree(gpu_ctx, oracle, sponza_small, monkeypatch):
     cam, fl = _camera(oracle, sponza_small, w, h)
     pc = default_pc(S, fl, max_bounces=3, ibl=True)
     gpu_ctx.upload_scene(sponza_small)
-    assert gpu_ctx.scene_stats().maxDepth <= 32
+    assert gpu_ctx.scene_stats().maxDepth <= 96
     gpu_ctx.render(pc, cam, w, h, frames=2)
     base = gpu_ctx.read_hdr()
-    for forced in ("24", "32"):
+    for forced in ("16", "24", "32"):  # 16 pushes the deeper entries of this tree into the global overflow array
         monkeypatch.setenv("PROSPER_PT_DEBUG_STACK", forced)
         gpu_ctx.render(pc, cam, w, h, frames=2)
         assert same_bits(gpu_ctx.read_hdr(), base).all(), forced
@@ -476,3 +476,23 @@ def test_lds_resident_scene_equals_global_memory_traversal(gpu_ctx, oracle, corn
     gpu_ctx.render(pc, cam, w, h, frames=2)
     assert same_bits(gpu_ctx.read_hdr(), lds).all()
     monkeypatch.delenv("PROSPER_PT_DEBUG_NO_LDS_SCENE")
+
+
+def test_full_sponza_class_scene_parity(gpu_ctx, oracle):
+    """The full 262 k-triangle S-sponza-class scene (64^2 textures) at reduced resolution: grazing rays
+    over tessellated flats are where a traversal could disagree with the oracle about hit selection
+    (DESIGN.md "hit contract"); every pixel must still match bit for bit."""
+    from prosper_amd import scenes
+    world = scenes.sponza_class(texture_size=64, sky_size=64)
+    w, h = 320, 180
+    cam, fl = _camera(oracle, world, w, h)
+    gpu_ctx.upload_scene(world)
+    osc = oracle.OracleScene(world)
+    want = None
+    for frame in (1, 2):
+        pc = default_pc(S, fl, frame_index=frame, max_bounces=4, ibl=True, skip_history=(frame == 1))
+        gpu_ctx.render(pc, cam, w, h)
+        want, _ = osc.render(pc, cam, w, h, history=want)
+    got = gpu_ctx.read_hdr()
+    ok = same_bits(got, want).all(axis=2)
+    assert ok.all(), "%d of %d pixels differ" % ((~ok).sum(), ok.size)
