@@ -368,7 +368,7 @@ int ensure_wavefront_workspace(
     // one segment per wave; ~32k waves give each CU several rounds of segments to balance over
     // (measured sweep, profiles/r01_seglen_sweep.txt: 512 slots is the optimum at 16.6 M slots)
     uint64_t segLen = ((slots / 32768u) + 63u) / 64u * 64u;
-    if (segLen < 256u) segLen = 256u;
+    if (segLen < 128u) segLen = 128u; // single-frame renders: 16 k waves of 128 slots (0.98 vs 1.09 ms at 256)
     if (segLen > 1024u) segLen = 1024u;
     if (const char *forced = std::getenv("PROSPER_PT_DEBUG_SEGLEN")) // tuning/test hook
     {

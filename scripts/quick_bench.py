@@ -18,6 +18,9 @@ def main():
     ap.add_argument("--megakernel", action="store_true")
     ap.add_argument("--persistent", action="store_true")
     ap.add_argument("--stats", action="store_true")
+    ap.add_argument("--spp", type=int, default=0)
+    ap.add_argument("--width", type=int, default=0)
+    ap.add_argument("--height", type=int, default=0)
     ap.add_argument("--lib", default=None)
     ap.add_argument("--small-textures", action="store_true")
     args = ap.parse_args()
@@ -33,6 +36,9 @@ def main():
         "c4": (lambda: scenes.sponza_class(lights=True, foliage=True, texture_size=tex), 1920, 1080, 8, 4, True),
     }[args.config]
     builder, w, h, spp, mb, ibl = cfg
+    spp = args.spp or spp
+    w = args.width or w
+    h = args.height or h
     world = builder()
     cam, focal = Camera.from_world(world, w, h).update_buffer()
     ctx = capi.Context(0, S.CREATE_MEGAKERNEL if args.megakernel else (S.CREATE_PERSISTENT if args.persistent else 0))
