@@ -175,6 +175,11 @@ PPT_HD float pow5(float x)
 // binary16 -> binary32, exact (unpackHalf2x16)
 PPT_HD float half_to_float(uint32_t h)
 {
+#if defined(__HIP_DEVICE_COMPILE__)
+    // v_cvt_f32_f16: binary16 -> binary32 is exact for every input (subnormals included: f16
+    // denormals are enabled in the default float mode), i.e. the same function as the bit recipe below
+    return (float)__builtin_bit_cast(_Float16, (uint16_t)h);
+#endif
     const uint32_t sign = (h & 0x8000u) << 16;
     const uint32_t exp = (h >> 10) & 0x1Fu;
     const uint32_t man = h & 0x3FFu;
