@@ -284,21 +284,23 @@ static ora_vertex transform_vertex(const ora_vertex *v, const prosper_ModelInsta
  * Texture sampling (Vulkan 1.3 §16 texel filtering at LOD 0; see DESIGN.md "texture contract")
  * ---------------------------------------------------------------------------------------- */
 
-static inline int32_t wrap_coord(int32_t i, int32_t size, uint32_t mode)
+/* texel index of integer coordinate i (64-bit so that the +1 neighbour of a saturated coordinate is
+ * still the mathematical successor) */
+static inline int32_t wrap_coord(int64_t i, int32_t size, uint32_t mode)
 {
     if (mode == PROSPER_PT_WRAP_REPEAT)
     {
-        int32_t m = i % size;
-        return m < 0 ? m + size : m;
+        int64_t m = i % size;
+        return (int32_t)(m < 0 ? m + size : m);
     }
     if (mode == PROSPER_PT_WRAP_MIRRORED_REPEAT)
     {
-        const int32_t period = 2 * size;
-        int32_t m = i % period;
+        const int64_t period = 2 * (int64_t)size;
+        int64_t m = i % period;
         if (m < 0) m += period;
-        return m < size ? m : period - 1 - m;
+        return (int32_t)(m < size ? m : period - 1 - m);
     }
-    return i < 0 ? 0 : (i >= size ? size - 1 : i);
+    return (int32_t)(i < 0 ? 0 : (i >= size ? size - 1 : i));
 }
 
 static inline ora_v4 fetch_rgba8(const prosper_pt_texture_desc *t, int32_t i, int32_t j)
@@ -329,9 +331,9 @@ static ora_v4 sample_texture(const ora_scene *s, uint32_t tex, uint32_t smp, ora
     const float a = u - fu;
     const float b = v - fv;
     const int32_t i0 = wrap_coord(ora_f2i(fu), w, sd->wrapS);
-    const int32_t i1 = wrap_coord(ora_f2i(fu) + 1, w, sd->wrapS);
+    const int32_t i1 = wrap_coord((int64_t)ora_f2i(fu) + 1, w, sd->wrapS);
     const int32_t j0 = wrap_coord(ora_f2i(fv), h, sd->wrapT);
-    const int32_t j1 = wrap_coord(ora_f2i(fv) + 1, h, sd->wrapT);
+    const int32_t j1 = wrap_coord((int64_t)ora_f2i(fv) + 1, h, sd->wrapT);
     const ora_v4 t00 = fetch_rgba8(t, i0, j0);
     const ora_v4 t10 = fetch_rgba8(t, i1, j0);
     const ora_v4 t01 = fetch_rgba8(t, i0, j1);

@@ -214,21 +214,41 @@ PPT_D Vertex transform(const Vertex &v, const prosper_ModelInstanceTransforms &t
 // Texture sampling (LOD 0; DESIGN.md "Texture contract")
 // ------------------------------------------------------------------------------------------
 
+// i mod period in [0, period); power-of-two periods (the usual texture sizes) skip the division
+PPT_D int32_t floor_mod(int32_t i, int32_t period)
+{
+    if ((period & (period - 1)) == 0) return i & (period - 1);
+    const int32_t m = i % period;
+    return m < 0 ? m + period : m;
+}
+
 PPT_D int32_t wrap_coord(int32_t i, int32_t size, uint32_t mode)
 {
-    if (mode == PROSPER_PT_WRAP_REPEAT)
-    {
-        const int32_t m = i % size;
-        return m < 0 ? m + size : m;
-    }
+    if (mode == PROSPER_PT_WRAP_REPEAT) return floor_mod(i, size);
     if (mode == PROSPER_PT_WRAP_MIRRORED_REPEAT)
     {
         const int32_t period = 2 * size;
-        int32_t m = i % period;
-        if (m < 0) m += period;
+        const int32_t m = floor_mod(i, period);
         return m < size ? m : period - 1 - m;
     }
     return i < 0 ? 0 : (i >= size ? size - 1 : i);
+}
+
+// texel indices of integer coordinates i and i+1: the second is the successor of the first inside
+// the wrap period, which is (i+1) mod period without a second division (and without overflow)
+PPT_D void wrap_pair(int32_t i, int32_t size, uint32_t mode, int32_t &c0, int32_t &c1)
+{
+    if (mode == PROSPER_PT_WRAP_REPEAT || mode == PROSPER_PT_WRAP_MIRRORED_REPEAT)
+    {
+        const int32_t period = mode == PROSPER_PT_WRAP_REPEAT ? size : 2 * size;
+        const int32_t m = floor_mod(i, period);
+        const int32_t n = m + 1 == period ? 0 : m + 1;
+        c0 = m < size ? m : period - 1 - m;
+        c1 = n < size ? n : period - 1 - n;
+        return;
+    }
+    c0 = i < 0 ? 0 : (i >= size ? size - 1 : i);
+    c1 = i < -1 ? 0 : (i >= size - 1 ? size - 1 : i + 1);
 }
 
 PPT_D f4 fetch_rgba8(const DeviceTexture &t, int32_t i, int32_t j)
@@ -256,10 +276,9 @@ PPT_D f4 sample_texture(const DeviceScene &s, uint32_t tex, uint32_t smp, f2 uv)
     const float fv = __builtin_floorf(v);
     const float a = u - fu;
     const float b = v - fv;
-    const int32_t i0 = wrap_coord(f2i(fu), w, sd.wrapS);
-    const int32_t i1 = wrap_coord(f2i(fu) + 1, w, sd.wrapS);
-    const int32_t j0 = wrap_coord(f2i(fv), h, sd.wrapT);
-    const int32_t j1 = wrap_coord(f2i(fv) + 1, h, sd.wrapT);
+    int32_t i0, i1, j0, j1;
+    wrap_pair(f2i(fu), w, sd.wrapS, i0, i1);
+    wrap_pair(f2i(fv), h, sd.wrapT, j0, j1);
     const f4 t00 = fetch_rgba8(t, i0, j0);
     const f4 t10 = fetch_rgba8(t, i1, j0);
     const f4 t01 = fetch_rgba8(t, i0, j1);

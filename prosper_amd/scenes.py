@@ -542,3 +542,33 @@ def tiny_triangles():
     w.camera = dict(eye=(0.0, 0.0, 5.0), target=(0.0, 0.0, 0.0), up=(0.0, 1.0, 0.0),
                     fov=math.radians(45.0), zN=0.1, zF=100.0)
     return w
+
+
+def texture_wall():
+    """Quads covering every wrap mode x filter with power-of-two and odd texture sizes and UVs far
+    outside [0, 1] (including negative ones): the texel-addressing test scene."""
+    w = World()
+    rng = np.random.default_rng(0x7E47)
+    sizes = [(8, 4), (5, 7), (13, 6), (1, 1), (16, 16), (3, 2)]
+    textures = [w.add_texture(rng.integers(0, 256, size=(h, ww, 4), dtype=np.uint8)) for ww, h in sizes]
+    wraps = [S.WRAP_REPEAT, S.WRAP_MIRRORED_REPEAT, S.WRAP_CLAMP_TO_EDGE]
+    cells = []
+    for flt in (S.FILTER_LINEAR, S.FILTER_NEAREST):
+        for ws in wraps:
+            for wt in wraps:
+                cells.append(w.add_sampler(flt, flt, ws, wt))
+    cols = 6
+    for k, smp in enumerate(cells):
+        tex = textures[k % len(textures)]
+        mat = w.add_material(base_color=(1.0, 1.0, 1.0, 1.0), metallic=0.0, roughness=1.0, base_tex=(tex, smp),
+                             mr_tex=(textures[(k + 1) % len(textures)], smp),
+                             normal_tex=(textures[(k + 2) % len(textures)], smp))
+        cx, cy = (k % cols) - cols / 2.0, (k // cols) - 1.5
+        p, n, t, uv, idx = quad((cx, cy, 0.0), (cx + 0.95, cy, 0.0), (cx + 0.95, cy + 0.95, 0.0), (cx, cy + 0.95, 0.0))
+        uv = uv * (5.3 + 0.37 * k) - (2.6 + 0.21 * k)  # spans several periods on both sides of 0
+        q = _add(w, (p, n, t, uv, idx), mat)
+        w.add_instance(w.add_model([(q, mat)]))
+    w.add_point_light((1.0, 1.0, 1.0), 60.0, (0.0, 0.0, 3.0))
+    w.camera = dict(eye=(0.0, 0.0, 6.5), target=(0.0, 0.0, 0.0), up=(0.0, 1.0, 0.0),
+                    fov=math.radians(50.0), zN=0.1, zF=100.0)
+    return w

@@ -6,7 +6,7 @@ import numpy as np
 import pytest
 
 from conftest import default_pc, same_bits
-from prosper_amd import structs as S
+from prosper_amd import scenes, structs as S
 
 pytestmark = pytest.mark.gpu
 
@@ -117,6 +117,24 @@ def test_cornell_debug_draw_types_bit_exact(gpu_ctx, oracle, cornell_world, draw
     want, _ = osc.render(pc, cam, w, h)
     ok = same_bits(got, want).all(axis=2)
     assert ok.all(), "%s: %d of %d pixels differ" % (draw_type, (~ok).sum(), ok.size)
+
+
+@pytest.mark.parametrize("draw_type", ["Albedo", "Roughness", "ShadingNormal", "Default"])
+def test_texture_addressing_bit_exact(gpu_ctx, oracle, draw_type):
+    """Every wrap mode x filter, power-of-two and odd texture sizes, UVs several periods either side of
+    zero (scenes.texture_wall): texel addressing and bilinear weights, bit for bit."""
+    world = scenes.texture_wall()
+    w, h = 384, 256
+    cam, fl = _camera(oracle, world, w, h)
+    pc = default_pc(S, fl, draw_type=S.DrawType[draw_type], max_bounces=2)
+    gpu_ctx.upload_scene(world)
+    gpu_ctx.render(pc, cam, w, h)
+    got = gpu_ctx.read_hdr()
+    want, _ = oracle.OracleScene(world, brute_force=True).render(pc, cam, w, h)
+    ok = same_bits(got, want).all(axis=2)
+    assert ok.all(), "%s: %d of %d pixels differ" % (draw_type, (~ok).sum(), ok.size)
+    if draw_type == "Albedo":  # the quads really are textured
+        assert len(np.unique(got[..., :3].reshape(-1, 3), axis=0)) > 1000
 
 
 @pytest.mark.parametrize("max_bounces,ibl,dof", [(1, False, False), (4, False, False), (6, True, True)])
