@@ -931,19 +931,28 @@ struct TraversalStack
     }
 };
 
-PPT_D float half_lo(uint32_t d) { return (float)__builtin_bit_cast(_Float16, (uint16_t)(d & 0xFFFFu)); }
-PPT_D float half_hi(uint32_t d) { return (float)__builtin_bit_cast(_Float16, (uint16_t)(d >> 16)); }
+typedef float v2f __attribute__((ext_vector_type(2)));
 
-// Conservative slab test of one child box given its six planes; entry distance or +inf on a miss.
-// t = (plane - o) * invd keeps the subtraction exact when the origin is near the plane (the fused
-// form plane*invd - o*invd cancels catastrophically there and needs per-axis error terms that cost as
-// much as the subtraction).  With the builder's outward padding, the outward half rounding and the
-// 1 + 4e-7 factor on the exit distance no box that contains a hit is culled.
-PPT_D float slab_entry(float lox, float loy, float loz, float hix, float hiy, float hiz, f3 o, f3 invd, float tMin, float tMax)
+// (plane - o) for the two binary16 planes packed in one dword, each as ONE v_fma_mix_f32
+// (fma(float(half), 1.0, -o): the half -> float conversion rides on the instruction and the
+// difference is rounded once, i.e. the value v_cvt_f32_f16 + v_sub_f32 gives).  Written as asm
+// because the optimiser folds fma(x, 1, y) back into convert + add.
+PPT_D v2f plane_offsets(uint32_t packed, float o)
 {
-    const float ax = (lox - o.x) * invd.x, bx = (hix - o.x) * invd.x;
-    const float ay = (loy - o.y) * invd.y, by = (hiy - o.y) * invd.y;
-    const float az = (loz - o.z) * invd.z, bz = (hiz - o.z) * invd.z;
+    v2f r;
+    asm("v_fma_mix_f32 %0, %1, 1.0, -%2 op_sel_hi:[1,0,0]" : "=v"(r.x) : "v"(packed), "v"(o));
+    asm("v_fma_mix_f32 %0, %1, 1.0, -%2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r.y) : "v"(packed), "v"(o));
+    return r;
+}
+
+// Conservative slab test of one child box from the distances to its six planes; entry distance or
+// +inf on a miss.  The distances are t = (plane - o) * invd: the subtraction stays exact when the
+// origin is near the plane (the fused form plane*invd - o*invd cancels catastrophically there and
+// needs per-axis error terms that cost as much as the subtraction).  With the builder's outward
+// padding, the outward half rounding and the 1 + 4e-7 factor on the exit distance no box that
+// contains a hit is culled.
+PPT_D float slab_entry(float ax, float ay, float az, float bx, float by, float bz, float tMin, float tMax)
+{
     const float tn = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fminf(az, bz));
     const float tf = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz));
     const bool hit = fmaxf(tn, tMin) <= fminf(tf * 1.0000004f, tMax);
@@ -952,16 +961,20 @@ PPT_D float slab_entry(float lox, float loy, float loz, float hix, float hiy, fl
 
 // Tests the four children of a node; e[c] = entry distance or +inf, then sorts (e, ref) ascending
 // (5-comparator network) so the nearest child is walked first.  Returns the number of children hit.
+// 24 v_fma_mix_f32 + 12 v_pk_mul_f32 produce the 24 plane distances (children c, c+1 share a dword).
 PPT_D uint32_t intersect_node4(const NodeData &n, f3 o, f3 invd, float tMin, float tMax, float e[4], int32_t ref[4])
 {
-    e[0] = slab_entry(half_lo(n.q0.x), half_lo(n.q0.z), half_lo(n.q1.x), half_lo(n.q1.z), half_lo(n.q2.x), half_lo(n.q2.z),
-                      o, invd, tMin, tMax);
-    e[1] = slab_entry(half_hi(n.q0.x), half_hi(n.q0.z), half_hi(n.q1.x), half_hi(n.q1.z), half_hi(n.q2.x), half_hi(n.q2.z),
-                      o, invd, tMin, tMax);
-    e[2] = slab_entry(half_lo(n.q0.y), half_lo(n.q0.w), half_lo(n.q1.y), half_lo(n.q1.w), half_lo(n.q2.y), half_lo(n.q2.w),
-                      o, invd, tMin, tMax);
-    e[3] = slab_entry(half_hi(n.q0.y), half_hi(n.q0.w), half_hi(n.q1.y), half_hi(n.q1.w), half_hi(n.q2.y), half_hi(n.q2.w),
-                      o, invd, tMin, tMax);
+    // q0 = lo.x[0..3] lo.y[0..3], q1 = lo.z[0..3] hi.x[0..3], q2 = hi.y[0..3] hi.z[0..3]
+    const v2f lox01 = plane_offsets(n.q0.x, o.x) * invd.x, lox23 = plane_offsets(n.q0.y, o.x) * invd.x;
+    const v2f loy01 = plane_offsets(n.q0.z, o.y) * invd.y, loy23 = plane_offsets(n.q0.w, o.y) * invd.y;
+    const v2f loz01 = plane_offsets(n.q1.x, o.z) * invd.z, loz23 = plane_offsets(n.q1.y, o.z) * invd.z;
+    const v2f hix01 = plane_offsets(n.q1.z, o.x) * invd.x, hix23 = plane_offsets(n.q1.w, o.x) * invd.x;
+    const v2f hiy01 = plane_offsets(n.q2.x, o.y) * invd.y, hiy23 = plane_offsets(n.q2.y, o.y) * invd.y;
+    const v2f hiz01 = plane_offsets(n.q2.z, o.z) * invd.z, hiz23 = plane_offsets(n.q2.w, o.z) * invd.z;
+    e[0] = slab_entry(lox01.x, loy01.x, loz01.x, hix01.x, hiy01.x, hiz01.x, tMin, tMax);
+    e[1] = slab_entry(lox01.y, loy01.y, loz01.y, hix01.y, hiy01.y, hiz01.y, tMin, tMax);
+    e[2] = slab_entry(lox23.x, loy23.x, loz23.x, hix23.x, hiy23.x, hiz23.x, tMin, tMax);
+    e[3] = slab_entry(lox23.y, loy23.y, loz23.y, hix23.y, hiy23.y, hiz23.y, tMin, tMax);
     ref[0] = (int32_t)n.q3.x;
     ref[1] = (int32_t)n.q3.y;
     ref[2] = (int32_t)n.q3.z;
@@ -1211,6 +1224,18 @@ PPT_D f3 direct_lighting_value(const DeviceScene &s, f3 throughput, f3 irradianc
     irradiance = irradiance * visibility;
     irradiance = irradiance * (float)lightCount;
     return (throughput * irradiance) * brdfTimesNoL;
+}
+// A shadow ray only has to be traced when it can change the radiance bits.  `lit` / `blocked` are the
+// direct term with visibility 1 / 0 (main.rgen:216-222 multiplies the irradiance by the visibility, so
+// `blocked` is +-0 per channel unless a factor is non-finite).  When both are +-0 in every channel,
+// `color += direct` leaves the accumulator unchanged whatever the traversal finds (it starts at +0
+// and x + (+-0) == x for every x that is not -0, which a sum that started at +0 never is): lights
+// with zero radiance, samples outside a spot cone or beyond a light's range cost no traversal.
+PPT_D bool shadow_ray_matters(f3 lit, f3 blocked)
+{
+    const bool litZero = lit.x == 0.0f && lit.y == 0.0f && lit.z == 0.0f;
+    const bool blockedZero = blocked.x == 0.0f && blocked.y == 0.0f && blocked.z == 0.0f;
+    return !(litZero && blockedZero);
 }
 PPT_D f3 finish_direct_lighting(const DeviceScene &s, const Surface &sf, f3 throughput, f3 l, f3 irradiance, float visibility)
 {

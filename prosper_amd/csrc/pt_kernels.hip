@@ -142,11 +142,16 @@ __device__ f3 trace_path(
             f3 direct = f3{0.0f, 0.0f, 0.0f};
             if (prepare_direct_lighting<COUNT>(s, sf, throughput, rng, l, d, irradiance, cnt))
             {
-                // shadow(): main.rgen:49-60
+                // shadow(): main.rgen:49-60, traced only when it can change the result
                 Hit sh;
                 if constexpr (COUNT) cnt.shadowRays++;
-                const bool occluded = trace<true, COUNT>(s, sf.positionWS, l, 0.1f, d, pcg(rng.x ^ rng.y), stack, sh, cnt);
-                direct = finish_direct_lighting(s, sf, throughput, l, irradiance, occluded ? 0.0f : 1.0f);
+                const f3 brdf = eval_brdf_times_nol(l, sf);
+                const f3 lit = direct_lighting_value(s, throughput, irradiance, brdf, 1.0f);
+                const f3 blocked = direct_lighting_value(s, throughput, irradiance, brdf, 0.0f);
+                bool occluded = false;
+                if (shadow_ray_matters(lit, blocked))
+                    occluded = trace<true, COUNT>(s, sf.positionWS, l, 0.1f, d, pcg(rng.x ^ rng.y), stack, sh, cnt);
+                direct = occluded ? blocked : lit;
             }
             add_bounce(p.pc.flags, color, direct, bounce);
         }
@@ -290,9 +295,13 @@ __device__ __forceinline__ bool path_bounce(
         {
             Hit sh;
             if constexpr (COUNT) cnt.shadowRays++;
-            const bool occluded =
-                trace<true, COUNT>(s, sf.positionWS, l, 0.1f, d, pcg(st.rng.x ^ st.rng.y), stack, sh, cnt);
-            direct = finish_direct_lighting(s, sf, st.throughput, l, irradiance, occluded ? 0.0f : 1.0f);
+            const f3 brdf = eval_brdf_times_nol(l, sf);
+            const f3 lit = direct_lighting_value(s, st.throughput, irradiance, brdf, 1.0f);
+            const f3 blocked = direct_lighting_value(s, st.throughput, irradiance, brdf, 0.0f);
+            bool occluded = false;
+            if (shadow_ray_matters(lit, blocked))
+                occluded = trace<true, COUNT>(s, sf.positionWS, l, 0.1f, d, pcg(st.rng.x ^ st.rng.y), stack, sh, cnt);
+            direct = occluded ? blocked : lit;
         }
         add_bounce(p.pc.flags, st.color, direct, st.bounce);
     }

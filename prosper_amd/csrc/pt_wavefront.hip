@@ -339,7 +339,6 @@ __global__ __launch_bounds__(256, PPT_SHADE_WPE) void wf_shade(
                 float d;
                 if (prepare_direct_lighting<COUNT>(s, sf, throughput, rng, l, d, irradiance, cnt))
                 {
-                    wantShadow = true;
                     if constexpr (COUNT) cnt.shadowRays++;
                     shSeed = pcg(rng.x ^ rng.y);
                     shP = sf.positionWS;
@@ -351,6 +350,9 @@ __global__ __launch_bounds__(256, PPT_SHADE_WPE) void wf_shade(
                     // +-0 unless a factor is non-finite; remember which channels come out NaN
                     const f3 c0 = direct_lighting_value(s, throughput, irradiance, brdf, 0.0f);
                     nanMask = (c0.x != c0.x ? 1u : 0u) | (c0.y != c0.y ? 2u : 0u) | (c0.z != c0.z ? 4u : 0u);
+                    // a ray that cannot change the radiance bits is not queued (zero-radiance light,
+                    // outside the spot cone, beyond the light's range)
+                    wantShadow = shadow_ray_matters(shC1, c0);
                 }
                 if (!lastBounce)
                 {
