@@ -885,6 +885,37 @@ static ora_v3 offset_ray(ora_v3 p, ora_v3 n)
  *   - non-opaque geometry runs the any-hit of rt/scene.rahit:18-39 on every candidate.
  * ---------------------------------------------------------------------------------------- */
 
+/* 1 / d with |d| clamped to 1e-30: the per-axis reciprocal of a ray direction (box guard and slab tests) */
+static inline float safe_rcp_dir(float d) { return 1.0f / (ora_abs(d) < 1e-30f ? (d < 0.0f ? -1e-30f : 1e-30f) : d); }
+
+/* Hit contract (iii), the box guard.  The edge functions are sums of products of size |v - o|^2, so for a
+ * small triangle far from the ray origin rounding lets them accept a ray that passes a little OUTSIDE the
+ * triangle - possibly outside any bounding box an acceleration structure keeps for it, which would make
+ * the set of hits depend on that structure.  The contract therefore bounds the acceptance zone by
+ * construction: t must lie in the ray's parametric interval through the triangle's bounding box grown by
+ * 2^-16 of its largest |coordinate|, within a factor 1 + 2^-18.  Any hierarchy whose boxes contain these
+ * guard boxes and whose slab test is the same monotone arithmetic with a tolerance >= 1 + 2^-18 can then
+ * never cull a valid candidate, so the hits are the same with a BVH, another BVH, or none. */
+#define ORA_GUARD_PAD 1.52587890625e-05f  /* 2^-16 */
+#define ORA_GUARD_TOL 1.000003814697265625f /* 1 + 2^-18 */
+static int box_guard(ora_v3 o, ora_v3 d, ora_v3 v0, ora_v3 v1, ora_v3 v2, float tt)
+{
+    const float lox = fminf(fminf(v0.x, v1.x), v2.x), hix = fmaxf(fmaxf(v0.x, v1.x), v2.x);
+    const float loy = fminf(fminf(v0.y, v1.y), v2.y), hiy = fmaxf(fmaxf(v0.y, v1.y), v2.y);
+    const float loz = fminf(fminf(v0.z, v1.z), v2.z), hiz = fmaxf(fmaxf(v0.z, v1.z), v2.z);
+    const float mx = fmaxf(ora_abs(lox), ora_abs(hix));
+    const float my = fmaxf(ora_abs(loy), ora_abs(hiy));
+    const float mz = fmaxf(ora_abs(loz), ora_abs(hiz));
+    const float pad = fmaxf(fmaxf(mx, my), mz) * ORA_GUARD_PAD;
+    const float ix = safe_rcp_dir(d.x), iy = safe_rcp_dir(d.y), iz = safe_rcp_dir(d.z);
+    const float ax = ((lox - pad) - o.x) * ix, bx = ((hix + pad) - o.x) * ix;
+    const float ay = ((loy - pad) - o.y) * iy, by = ((hiy + pad) - o.y) * iy;
+    const float az = ((loz - pad) - o.z) * iz, bz = ((hiz + pad) - o.z) * iz;
+    const float tn = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fminf(az, bz));
+    const float tf = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz));
+    return tn <= tt * ORA_GUARD_TOL && tt <= tf * ORA_GUARD_TOL;
+}
+
 static int intersect_triangle(
     ora_v3 o, ora_v3 d, ora_v3 v0, ora_v3 v1, ora_v3 v2, float tMin, float tMax, float *t, float *bu, float *bv)
 {
@@ -905,6 +936,7 @@ static int intersect_triangle(
     const float inv = 1.0f / det;
     const float tt = fmaf(W, ora_dot(C, d), fmaf(V, ora_dot(B, d), U * ora_dot(A, d))) * inv;
     if (!(tt > tMin && tt < tMax)) return 0;
+    if (!box_guard(o, d, v0, v1, v2, tt)) return 0;
     *t = tt;
     *bu = V * inv;
     *bv = W * inv;
@@ -968,19 +1000,17 @@ static inline void consider_triangle(
     best->t = t;
 }
 
+/* Slab test of the oracle's BVH: the same (plane - o) * invd arithmetic as the box guard (monotone in the
+ * plane, so a box that contains a guard box yields an interval that contains the guard's), tolerance
+ * 1 + 2^-16 > (1 + 2^-18)^2 on the far side. */
 static inline int ray_box(const float lo[3], const float hi[3], ora_v3 o, ora_v3 invd, float tMin, float tMax)
 {
-    float t0 = (lo[0] - o.x) * invd.x, t1 = (hi[0] - o.x) * invd.x;
-    float tn = ora_min(t0, t1), tf = ora_max(t0, t1);
-    t0 = (lo[1] - o.y) * invd.y;
-    t1 = (hi[1] - o.y) * invd.y;
-    tn = ora_max(tn, ora_min(t0, t1));
-    tf = ora_min(tf, ora_max(t0, t1));
-    t0 = (lo[2] - o.z) * invd.z;
-    t1 = (hi[2] - o.z) * invd.z;
-    tn = ora_max(tn, ora_min(t0, t1));
-    tf = ora_min(tf, ora_max(t0, t1));
-    return tn <= tf * 1.0000004f && tf >= tMin && tn <= tMax;
+    const float ax = (lo[0] - o.x) * invd.x, bx = (hi[0] - o.x) * invd.x;
+    const float ay = (lo[1] - o.y) * invd.y, by = (hi[1] - o.y) * invd.y;
+    const float az = (lo[2] - o.z) * invd.z, bz = (hi[2] - o.z) * invd.z;
+    const float tn = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fminf(az, bz));
+    const float tf = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz));
+    return fmaxf(tn, tMin) <= fminf(tf, tMax) * 1.0000152587890625f;
 }
 
 /* Shared driver of traceClosest (anyTerminate = 0) and shadow (anyTerminate = 1). */
@@ -1002,9 +1032,9 @@ static int trace(
     else
     {
         ora_v3 invd;
-        invd.x = 1.0f / (ora_abs(d.x) < 1e-30f ? (d.x < 0.0f ? -1e-30f : 1e-30f) : d.x);
-        invd.y = 1.0f / (ora_abs(d.y) < 1e-30f ? (d.y < 0.0f ? -1e-30f : 1e-30f) : d.y);
-        invd.z = 1.0f / (ora_abs(d.z) < 1e-30f ? (d.z < 0.0f ? -1e-30f : 1e-30f) : d.z);
+        invd.x = safe_rcp_dir(d.x);
+        invd.y = safe_rcp_dir(d.y);
+        invd.z = safe_rcp_dir(d.z);
         uint32_t stack[128];
         int sp = 0;
         stack[sp++] = 0;
@@ -1087,14 +1117,14 @@ static void build_node(ora_scene *s, uint32_t nodeIndex, uint32_t first, uint32_
             chi[k] = fmaxf(chi[k], c);
         }
     }
+    /* the node box must contain the guard box of every triangle below it (box_guard: the triangle's
+     * bounds grown by 2^-16 of its largest |coordinate|); 1.6e-5 > 2^-16 of the node's largest
+     * |coordinate| does, and the slab arithmetic is monotone in the planes, so nothing else is needed */
+    float mall = 0.0f;
+    for (int k = 0; k < 3; ++k) mall = fmaxf(mall, fmaxf(fabsf(lo[k]), fabsf(hi[k])));
     for (int k = 0; k < 3; ++k)
     {
-        /* conservative padding so the slab test can never cull a triangle the edge-function
-         * test accepts */
-        /* generous padding (2^-9 of the coordinate): a grazing ray that the edge functions accept may pass
-         * the triangle at a distance its rounding error allows, and the oracle should then still find it,
-         * like brute force does */
-        const float pad = 1e-5f * (hi[k] - lo[k]) + 2e-3f * fmaxf(fabsf(lo[k]), fabsf(hi[k])) + 1e-30f;
+        const float pad = 1.6e-5f * mall + 1e-30f;
         n->lo[k] = lo[k] - pad;
         n->hi[k] = hi[k] + pad;
     }

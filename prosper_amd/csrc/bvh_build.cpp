@@ -3,6 +3,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <future>
 #include <limits>
@@ -190,13 +191,20 @@ struct Builder
     }
 };
 
-void padded(const Aabb &b, float lo[3], float hi[3])
+// Conservative padding.  A valid hit (pt_device.hpp box_guard) lies in the ray's interval through the
+// triangle's bounds grown by 2^-16 of its largest |coordinate|; a node box must contain those guard
+// boxes (1.6e-5 > 2^-16 of the box's own largest |coordinate| does, and the term is monotone up the
+// tree).  On top of that the node test works on fl(o - nodeOrigin), off by up to 2^-24 of the distance
+// between the ray origin and the node: `slack` = 2e-6 * scene diagonal (32 * 2^-24) covers ray origins
+// up to ~16 scene diagonals away; the relative term covers the fp32 subtractions that form the offsets.
+void padded(const Aabb &b, float slack, float lo[3], float hi[3])
 {
+    float mall = 0.0f;
+    for (int k = 0; k < 3; ++k) mall = std::max(mall, std::max(std::fabs(b.lo[k]), std::fabs(b.hi[k])));
     for (int k = 0; k < 3; ++k)
     {
-        // conservative padding: the slab test must never cull a triangle the edge-function test
-        // accepts (rounding in (lo - o) * invd and in the triple products)
-        const float pad = 1e-5f * (b.hi[k] - b.lo[k]) + 1e-6f * std::max(std::fabs(b.lo[k]), std::fabs(b.hi[k])) + 1e-30f;
+        static const float coeff = std::getenv("PROSPER_PT_DEBUG_PAD") ? (float)std::atof(std::getenv("PROSPER_PT_DEBUG_PAD")) : 1.6e-5f;
+        const float pad = coeff * mall + 1e-6f * (b.hi[k] - b.lo[k]) + slack;
         lo[k] = b.lo[k] - pad;
         hi[k] = b.hi[k] + pad;
     }
@@ -275,6 +283,7 @@ struct Emitter
     const std::vector<TmpNode> &tmp;
     const std::vector<Prim> &prims;
     BvhBuildResult &out;
+    float slack;
 
     int32_t emit_leaf(int32_t t)
     {
@@ -316,6 +325,7 @@ struct Emitter
             }
         }
         BvhNode node;
+        node.reserved = 0;
         // unused slots: lo = hi = +inf (half 0x7C00) can never be entered (see build_bvh)
         for (int a = 0; a < 3; ++a)
             for (int c = 0; c < 4; ++c)
@@ -323,17 +333,26 @@ struct Emitter
                 node.lo[a][c] = 0x7C00u;
                 node.hi[a][c] = 0x7C00u;
             }
+        float lo[4][3], hi[4][3];
+        for (int a = 0; a < 3; ++a) node.origin[a] = std::numeric_limits<float>::infinity();
+        for (uint32_t c = 0; c < k; ++c)
+        {
+            padded(tmp[kids[c]].box, slack, lo[c], hi[c]);
+            for (int a = 0; a < 3; ++a) node.origin[a] = std::min(node.origin[a], lo[c][a]);
+        }
         uint32_t deepest = 0;
         for (uint32_t c = 0; c < 4; ++c)
         {
             node.child[c] = ~0;
             if (c >= k) continue;
-            float lo[3], hi[3];
-            padded(tmp[kids[c]].box, lo, hi);
             for (int a = 0; a < 3; ++a)
             {
-                node.lo[a][c] = half_floor(lo[a]);
-                node.hi[a][c] = half_ceil(hi[a]);
+                // offsets from the node origin; the fp32 subtraction is pushed one ulp outward before
+                // the outward half rounding, so origin + offset never lies inside the padded box
+                const float offLo = std::nextafter(lo[c][a] - node.origin[a], -std::numeric_limits<float>::infinity());
+                const float offHi = std::nextafter(hi[c][a] - node.origin[a], std::numeric_limits<float>::infinity());
+                node.lo[a][c] = half_floor(std::max(offLo, 0.0f));
+                node.hi[a][c] = half_ceil(offHi);
             }
             if (tmp[kids[c]].left < 0)
                 node.child[c] = emit_leaf(kids[c]);
@@ -376,6 +395,8 @@ BvhBuildResult build_bvh(const WorldTriangle *triangles, uint64_t count)
     if (count == 0)
     {
         BvhNode root;
+        root.reserved = 0;
+        for (int a = 0; a < 3; ++a) root.origin[a] = 0.0f;
         for (int a = 0; a < 3; ++a)
             for (int c = 0; c < 4; ++c)
             {
@@ -393,7 +414,10 @@ BvhBuildResult build_bvh(const WorldTriangle *triangles, uint64_t count)
     const int32_t rootTmp = builder.build(0, (uint32_t)count, 0);
     out.nodes.reserve(builder.nodes.size() / 2 + 1);
     out.permutation.reserve((size_t)count);
-    Emitter emitter{builder.nodes, prims, out};
+    const Aabb &scene = builder.nodes[(size_t)rootTmp].box;
+    const float dx = scene.hi[0] - scene.lo[0], dy = scene.hi[1] - scene.lo[1], dz = scene.hi[2] - scene.lo[2];
+    const float slack = 2e-6f * std::sqrt(dx * dx + dy * dy + dz * dz) + 1e-30f;
+    Emitter emitter{builder.nodes, prims, out, slack};
     uint32_t need = 0;
     emitter.emit_node(rootTmp, need);
     out.maxDepth = need + 1; // entries the traversal stack must hold in the worst case

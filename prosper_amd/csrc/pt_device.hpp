@@ -778,7 +778,40 @@ PPT_D f3 offset_ray(f3 p, f3 n)
 // primitive), any-hit (rt/scene.rahit:18-39) on non-opaque geometry.
 // ------------------------------------------------------------------------------------------
 
-PPT_D bool intersect_triangle(f3 o, f3 d, f3 v0, f3 v1, f3 v2, float tMin, float tMax, float &t, float &bu, float &bv)
+PPT_D float safe_rcp_dir(float d)
+{
+    return 1.0f / (fabs_(d) < 1e-30f ? (d < 0.0f ? -1e-30f : 1e-30f) : d);
+}
+
+// Hit contract (iii), the box guard: t must lie in the ray's parametric interval through the triangle's
+// bounding box grown by 2^-16 of its largest |coordinate|, within a factor 1 + 2^-18.  The edge
+// functions are sums of products of size |v - o|^2; for a small triangle far from the ray origin
+// rounding lets them accept a ray that passes slightly outside the triangle, possibly outside every box
+// a hierarchy keeps for it.  The guard bounds the acceptance zone by construction, so a hierarchy whose
+// boxes contain the guard boxes (bvh_build.cpp) and whose slab test is the same monotone arithmetic
+// with a larger tolerance (slab_entry) can never cull a valid candidate.
+constexpr float kGuardPad = 1.52587890625e-05f;    // 2^-16
+constexpr float kGuardTol = 1.000003814697265625f; // 1 + 2^-18
+PPT_D bool box_guard(f3 o, f3 invd, f3 v0, f3 v1, f3 v2, float tt)
+{
+    const float lox = fminf(fminf(v0.x, v1.x), v2.x), hix = fmaxf(fmaxf(v0.x, v1.x), v2.x);
+    const float loy = fminf(fminf(v0.y, v1.y), v2.y), hiy = fmaxf(fmaxf(v0.y, v1.y), v2.y);
+    const float loz = fminf(fminf(v0.z, v1.z), v2.z), hiz = fmaxf(fmaxf(v0.z, v1.z), v2.z);
+    const float mx = fmaxf(fabs_(lox), fabs_(hix));
+    const float my = fmaxf(fabs_(loy), fabs_(hiy));
+    const float mz = fmaxf(fabs_(loz), fabs_(hiz));
+    const float pad = fmaxf(fmaxf(mx, my), mz) * kGuardPad;
+    const float ax = ((lox - pad) - o.x) * invd.x, bx = ((hix + pad) - o.x) * invd.x;
+    const float ay = ((loy - pad) - o.y) * invd.y, by = ((hiy + pad) - o.y) * invd.y;
+    const float az = ((loz - pad) - o.z) * invd.z, bz = ((hiz + pad) - o.z) * invd.z;
+    const float tn = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fminf(az, bz));
+    const float tf = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz));
+    return tn <= tt * kGuardTol && tt <= tf * kGuardTol;
+}
+
+// `invd` = safe_rcp_dir of each component of d (the traversal keeps it per ray)
+PPT_D bool intersect_triangle(
+    f3 o, f3 d, f3 invd, f3 v0, f3 v1, f3 v2, float tMin, float tMax, float &t, float &bu, float &bv)
 {
     const f3 A = v0 - o;
     const f3 B = v1 - o;
@@ -790,12 +823,11 @@ PPT_D bool intersect_triangle(f3 o, f3 d, f3 v0, f3 v1, f3 v2, float tMin, float
     const float det = (U + V) + W;
     if (!(det != 0.0f)) return false;
     // t = projection of the barycentric point on the (unit) direction: (U*(A.d) + V*(B.d) + W*(C.d)) / det.
-    // Well conditioned for grazing rays (the plane equation is not), so the distance always lies inside
-    // the ray's interval through the triangle's box and hit selection is independent of the BVH
-    // (DESIGN.md "hit contract").
+    // Well conditioned for grazing rays (the plane equation is not).
     const float inv = 1.0f / det;
     const float tt = __builtin_fmaf(W, dot(C, d), __builtin_fmaf(V, dot(B, d), U * dot(A, d))) * inv;
     if (!(tt > tMin && tt < tMax)) return false;
+    if (!box_guard(o, invd, v0, v1, v2, tt)) return false;
     t = tt;
     bu = V * inv;
     bv = W * inv;
@@ -853,11 +885,6 @@ PPT_D bool any_hit(
     return true;
 }
 
-PPT_D float safe_rcp_dir(float d)
-{
-    return 1.0f / (fabs_(d) < 1e-30f ? (d < 0.0f ? -1e-30f : 1e-30f) : d);
-}
-
 // Where the traversal reads BVH nodes and world triangles from.  GlobalGeom: the HBM arrays (through
 // L1/L2).  LdsGeom: a copy a workgroup staged in LDS — for scenes of a few KB (a Cornell box) every
 // node fetch then costs an LDS access (~64 cycles) instead of a vector-memory round trip (~200+),
@@ -867,11 +894,11 @@ struct TriangleData
 {
     float4 a, b, c;
 };
-// one 64-B BvhNode as four 16-B words: q0 = lo.x[4] lo.y[4], q1 = lo.z[4] hi.x[4], q2 = hi.y[4] hi.z[4]
-// (halfs, two per dword), q3 = child[4]
+// one 80-B BvhNode as five 16-B words: q0 = origin.xyz, q1 = lo.x[4] lo.y[4], q2 = lo.z[4] hi.x[4],
+// q3 = hi.y[4] hi.z[4] (halfs, two per dword), q4 = child[4]
 struct NodeData
 {
-    uint4 q0, q1, q2, q3;
+    uint4 q0, q1, q2, q3, q4;
 };
 struct GlobalGeom
 {
@@ -880,7 +907,7 @@ struct GlobalGeom
     PPT_D NodeData node(int32_t i) const
     {
         const uint4 *np = reinterpret_cast<const uint4 *>(nodes + i);
-        return NodeData{np[0], np[1], np[2], np[3]};
+        return NodeData{np[0], np[1], np[2], np[3], np[4]};
     }
     PPT_D TriangleData tri(uint32_t i) const
     {
@@ -888,7 +915,7 @@ struct GlobalGeom
         return TriangleData{tp[0], tp[1], tp[2]};
     }
 };
-constexpr uint32_t kLdsNodeStride = 5; // float4s per node in LDS (80 B: 64 B payload + 16 B pad)
+constexpr uint32_t kLdsNodeStride = 5; // float4s per node in LDS (80 B)
 struct LdsGeom
 {
     const float4 *nodes;     // LDS
@@ -896,7 +923,7 @@ struct LdsGeom
     PPT_D NodeData node(int32_t i) const
     {
         const uint4 *np = reinterpret_cast<const uint4 *>(nodes + (uint32_t)i * kLdsNodeStride);
-        return NodeData{np[0], np[1], np[2], np[3]};
+        return NodeData{np[0], np[1], np[2], np[3], np[4]};
     }
     PPT_D TriangleData tri(uint32_t i) const
     {
@@ -955,7 +982,7 @@ PPT_D float slab_entry(float ax, float ay, float az, float bx, float by, float b
 {
     const float tn = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fminf(az, bz));
     const float tf = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz));
-    const bool hit = fmaxf(tn, tMin) <= fminf(tf * 1.0000004f, tMax);
+    const bool hit = fmaxf(tn, tMin) <= fminf(tf, tMax) * 1.0000152587890625f; // 1 + 2^-16 > (1 + 2^-18)^2
     return hit ? tn : kInf;
 }
 
@@ -964,21 +991,24 @@ PPT_D float slab_entry(float ax, float ay, float az, float bx, float by, float b
 // 24 v_fma_mix_f32 + 12 v_pk_mul_f32 produce the 24 plane distances (children c, c+1 share a dword).
 PPT_D uint32_t intersect_node4(const NodeData &n, f3 o, f3 invd, float tMin, float tMax, float e[4], int32_t ref[4])
 {
-    // q0 = lo.x[0..3] lo.y[0..3], q1 = lo.z[0..3] hi.x[0..3], q2 = hi.y[0..3] hi.z[0..3]
-    const v2f lox01 = plane_offsets(n.q0.x, o.x) * invd.x, lox23 = plane_offsets(n.q0.y, o.x) * invd.x;
-    const v2f loy01 = plane_offsets(n.q0.z, o.y) * invd.y, loy23 = plane_offsets(n.q0.w, o.y) * invd.y;
-    const v2f loz01 = plane_offsets(n.q1.x, o.z) * invd.z, loz23 = plane_offsets(n.q1.y, o.z) * invd.z;
-    const v2f hix01 = plane_offsets(n.q1.z, o.x) * invd.x, hix23 = plane_offsets(n.q1.w, o.x) * invd.x;
-    const v2f hiy01 = plane_offsets(n.q2.x, o.y) * invd.y, hiy23 = plane_offsets(n.q2.y, o.y) * invd.y;
-    const v2f hiz01 = plane_offsets(n.q2.z, o.z) * invd.z, hiz23 = plane_offsets(n.q2.w, o.z) * invd.z;
+    // the ray origin relative to the node (one rounding of 2^-24 |o - origin|, inside the builder's slack)
+    const float ox = o.x - __builtin_bit_cast(float, n.q0.x);
+    const float oy = o.y - __builtin_bit_cast(float, n.q0.y);
+    const float oz = o.z - __builtin_bit_cast(float, n.q0.z);
+    const v2f lox01 = plane_offsets(n.q1.x, ox) * invd.x, lox23 = plane_offsets(n.q1.y, ox) * invd.x;
+    const v2f loy01 = plane_offsets(n.q1.z, oy) * invd.y, loy23 = plane_offsets(n.q1.w, oy) * invd.y;
+    const v2f loz01 = plane_offsets(n.q2.x, oz) * invd.z, loz23 = plane_offsets(n.q2.y, oz) * invd.z;
+    const v2f hix01 = plane_offsets(n.q2.z, ox) * invd.x, hix23 = plane_offsets(n.q2.w, ox) * invd.x;
+    const v2f hiy01 = plane_offsets(n.q3.x, oy) * invd.y, hiy23 = plane_offsets(n.q3.y, oy) * invd.y;
+    const v2f hiz01 = plane_offsets(n.q3.z, oz) * invd.z, hiz23 = plane_offsets(n.q3.w, oz) * invd.z;
     e[0] = slab_entry(lox01.x, loy01.x, loz01.x, hix01.x, hiy01.x, hiz01.x, tMin, tMax);
     e[1] = slab_entry(lox01.y, loy01.y, loz01.y, hix01.y, hiy01.y, hiz01.y, tMin, tMax);
     e[2] = slab_entry(lox23.x, loy23.x, loz23.x, hix23.x, hiy23.x, hiz23.x, tMin, tMax);
     e[3] = slab_entry(lox23.y, loy23.y, loz23.y, hix23.y, hiy23.y, hiz23.y, tMin, tMax);
-    ref[0] = (int32_t)n.q3.x;
-    ref[1] = (int32_t)n.q3.y;
-    ref[2] = (int32_t)n.q3.z;
-    ref[3] = (int32_t)n.q3.w;
+    ref[0] = (int32_t)n.q4.x;
+    ref[1] = (int32_t)n.q4.y;
+    ref[2] = (int32_t)n.q4.z;
+    ref[3] = (int32_t)n.q4.w;
     const uint32_t hits = (e[0] < kInf ? 1u : 0u) + (e[1] < kInf ? 1u : 0u) + (e[2] < kInf ? 1u : 0u) + (e[3] < kInf ? 1u : 0u);
 #define PPT_CSWAP(i, j)                                                                                                \
     {                                                                                                                  \
@@ -1054,7 +1084,7 @@ PPT_D bool trace_in(
                 }
                 float t, bu, bv;
                 if (!intersect_triangle(
-                        o, d, f3{a.x, a.y, a.z}, f3{b.x, b.y, b.z}, f3{c.x, c.y, c.z}, tMin, tMaxIn, t, bu, bv))
+                        o, d, invd, f3{a.x, a.y, a.z}, f3{b.x, b.y, b.z}, f3{c.x, c.y, c.z}, tMin, tMaxIn, t, bu, bv))
                     continue;
                 const uint32_t di = __builtin_bit_cast(uint32_t, a.w);
                 const uint32_t prim = __builtin_bit_cast(uint32_t, b.w);

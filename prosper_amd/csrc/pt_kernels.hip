@@ -568,9 +568,10 @@ __global__ void eval_fn_kernel(
     case PROSPER_PT_FN_TRIANGLE:
     {
         float t = 0.0f, bu = 0.0f, bv = 0.0f;
+        const f3 dir = f3{a[3], a[4], a[5]};
         const bool hit = intersect_triangle(
-            f3{a[0], a[1], a[2]}, f3{a[3], a[4], a[5]}, f3{a[6], a[7], a[8]}, f3{a[9], a[10], a[11]},
-            f3{a[12], a[13], a[14]}, a[15], a[16], t, bu, bv);
+            f3{a[0], a[1], a[2]}, dir, f3{safe_rcp_dir(dir.x), safe_rcp_dir(dir.y), safe_rcp_dir(dir.z)},
+            f3{a[6], a[7], a[8]}, f3{a[9], a[10], a[11]}, f3{a[12], a[13], a[14]}, a[15], a[16], t, bu, bv);
         o[0] = hit ? 1.0f : 0.0f; o[1] = hit ? t : 0.0f; o[2] = hit ? bu : 0.0f; o[3] = hit ? bv : 0.0f;
         break;
     }

@@ -13,19 +13,24 @@
 namespace ppt
 {
 
-// 4-wide BVH node, 64 B = one aligned 64-B fetch.  The four child boxes are stored as halfs,
-// rounded outward (lo down, hi up) so they stay conservative, one 8-byte group per plane:
-// lo[axis][child], hi[axis][child].  A child reference >= 0 is an inner node index; < 0 is a leaf:
-// ~ref = (firstTriangle << 3) | (triangleCount - 1).  An unused child has lo = hi = +inf, which no ray
-// can enter (see bvh_build.cpp).  One node visit tests four boxes: half the dependent fetches per ray of
-// a binary tree at the same bytes per box, which is what a latency-bound traversal needs.
-struct alignas(64) BvhNode
+// 4-wide BVH node, 80 B = five 16-byte words.  The four child boxes are stored as binary16 OFFSETS
+// from the node's own origin (the minimum corner of the union of its children, an fp32 point),
+// rounded outward (lo down, hi up), one 8-byte group per plane: lo[axis][child], hi[axis][child].
+// A half has 11 significant bits: stored as absolute coordinates a 5 cm box 10 m from the world
+// origin would grow by ~8 mm per side (+60 % surface area, i.e. +60 % false-positive visits at the
+// leaf level, where most visits happen); relative to the node the rounding is <= extent / 2048.
+// A child reference >= 0 is an inner node index; < 0 is a leaf: ~ref = (firstTriangle << 3) |
+// (triangleCount - 1).  An unused child has lo = hi = +inf, which no ray can enter (bvh_build.cpp).
+// One node visit tests four boxes: half the dependent fetches per ray of a binary tree.
+struct alignas(16) BvhNode
 {
+    float origin[3];
+    uint32_t reserved;
     uint16_t lo[3][4];
     uint16_t hi[3][4];
     int32_t child[4];
 };
-static_assert(sizeof(BvhNode) == 64, "BVH node is 64 B");
+static_assert(sizeof(BvhNode) == 80, "BVH node is 80 B");
 
 constexpr uint32_t kMaxLeafTriangles = 4;
 constexpr uint32_t kTraversalStackDepth = 32; // most LDS stack entries per lane a kernel variant has

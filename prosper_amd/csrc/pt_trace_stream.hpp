@@ -168,7 +168,7 @@ PPT_D void trace_stream(
                     }
                     float t, bu, bv;
                     bool candidate = intersect_triangle(
-                        o, d, f3{a.x, a.y, a.z}, f3{b.x, b.y, b.z}, f3{c4.x, c4.y, c4.z}, tMin, tMaxIn, t, bu, bv);
+                        o, d, invd, f3{a.x, a.y, a.z}, f3{b.x, b.y, b.z}, f3{c4.x, c4.y, c4.z}, tMin, tMaxIn, t, bu, bv);
                     const uint32_t di = __builtin_bit_cast(uint32_t, a.w);
                     const uint32_t prim = __builtin_bit_cast(uint32_t, b.w);
                     const uint32_t flags = __builtin_bit_cast(uint32_t, c4.w);

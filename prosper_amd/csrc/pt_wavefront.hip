@@ -110,12 +110,11 @@ __device__ __forceinline__ void add_to_slot(float4 *color, uint32_t slot, uint32
     color[slot] = make_float4(acc.x, acc.y, acc.z, 0.0f);
 }
 
-// Copies the BVH nodes (padded to 80 B) and world triangles into this workgroup's LDS.
+// Copies the BVH nodes and world triangles into this workgroup's LDS.
 __device__ __forceinline__ LdsGeom stage_scene_in_lds(const DeviceScene &s, float4 *lds, uint32_t nodeCount, uint32_t triCount)
 {
     const float4 *gn = reinterpret_cast<const float4 *>(s.nodes);
-    for (uint32_t i = threadIdx.x; i < nodeCount * 4u; i += blockDim.x)
-        lds[(i >> 2) * kLdsNodeStride + (i & 3u)] = gn[i];
+    for (uint32_t i = threadIdx.x; i < nodeCount * kLdsNodeStride; i += blockDim.x) lds[i] = gn[i];
     float4 *lt = lds + nodeCount * kLdsNodeStride;
     const float4 *gt = reinterpret_cast<const float4 *>(s.triangles);
     for (uint32_t i = threadIdx.x; i < triCount * 3u; i += blockDim.x) lt[i] = gt[i];

@@ -73,8 +73,21 @@ def _fn_inputs(fn, n, rng):
                               axis=1).astype(np.float32)
     if fn == 13:
         o, tgt = g(n, 3) * 3, g(n, 3)
-        d = _unit(tgt - o)
         v0, v1, v2 = tgt + g(n, 3), tgt + g(n, 3), tgt + g(n, 3)
+        # second half: 2-5 cm triangles 10-40 units away, aimed at their interior, an edge or just past a
+        # vertex (where the rounding of the edge functions decides), some axis-aligned and flat: the
+        # population the box guard of the hit contract exists for
+        h, m = n // 2, n - n // 2
+        far = _unit(g(m, 3)) * (u(m, 1) * 30 + 10)
+        e1, e2 = g(m, 3) * np.float32(0.03), g(m, 3) * np.float32(0.03)
+        flat = np.arange(m) % 4 == 0
+        e1[flat, 1] = 0.0
+        e2[flat, 1] = 0.0
+        a, b = u(m, 1) * 1.2 - 0.1, u(m, 1) * 1.2 - 0.1   # barycentrics slightly outside [0, 1] too
+        b[np.arange(m) % 3 == 0] = 0.0                     # exactly on the v0-v1 edge (before rounding)
+        tgt[h:] = far + a * e1 + b * e2
+        v0[h:], v1[h:], v2[h:] = far, far + e1, far + e2
+        d = _unit(tgt - o)
         return np.concatenate([o, d, v0, v1, v2, np.zeros((n, 1)), np.full((n, 1), np.inf)], axis=1).astype(np.float32)
     if fn == 14:
         x = g(n, 1) * np.float32(100.0)
