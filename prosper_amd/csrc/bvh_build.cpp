@@ -61,8 +61,20 @@ struct TmpNode
 };
 
 constexpr int kBins = 16;
-constexpr float kTraversalCost = 1.0f;
 constexpr float kIntersectCost = 1.0f;
+
+// tuning knobs (PROSPER_PT_DEBUG_SAH_TC, PROSPER_PT_DEBUG_LEAF): experiments only
+float traversal_cost()
+{
+    const char *v = std::getenv("PROSPER_PT_DEBUG_SAH_TC");
+    return v ? (float)std::atof(v) : 1.0f;
+}
+uint32_t max_leaf()
+{
+    const char *v = std::getenv("PROSPER_PT_DEBUG_LEAF");
+    const uint32_t n = v ? (uint32_t)std::atoi(v) : kMaxLeafTriangles;
+    return std::min(std::max(n, 1u), 8u);
+}
 
 uint32_t ceil_log2(uint64_t n)
 {
@@ -75,6 +87,8 @@ struct Builder
 {
     std::vector<Prim> &prims;
     std::vector<TmpNode> nodes;
+    const float kTraversalCost = traversal_cost();
+    const uint32_t kMaxLeaf = max_leaf();
 
     explicit Builder(std::vector<Prim> &p) : prims(p) {}
 
@@ -155,7 +169,7 @@ struct Builder
                 const float parentArea = std::max(box.half_area(), 1e-30f);
                 const float splitCost = kTraversalCost + kIntersectCost * bestCost / parentArea;
                 const float leafCost = kIntersectCost * (float)count;
-                if (count <= kMaxLeafTriangles && leafCost <= splitCost) return make_leaf();
+                if (count <= kMaxLeaf && leafCost <= splitCost) return make_leaf();
                 const float extent = cbox.hi[bestAxis] - cbox.lo[bestAxis];
                 const float scale = (float)kBins / extent;
                 const float lo = cbox.lo[bestAxis];
@@ -168,7 +182,7 @@ struct Builder
                 split = mid > first && mid < first + count;
                 axis = bestAxis;
             }
-            else if (count <= kMaxLeafTriangles)
+            else if (count <= kMaxLeaf)
                 return make_leaf(); // all centroids coincide
         }
         if (!split)
@@ -177,7 +191,7 @@ struct Builder
             axis = 0;
             if (cbox.hi[1] - cbox.lo[1] > cbox.hi[axis] - cbox.lo[axis]) axis = 1;
             if (cbox.hi[2] - cbox.lo[2] > cbox.hi[axis] - cbox.lo[axis]) axis = 2;
-            if (forceMedian && count <= kMaxLeafTriangles) return make_leaf();
+            if (forceMedian && count <= kMaxLeaf) return make_leaf();
             mid = first + count / 2;
             std::nth_element(
                 prims.begin() + first, prims.begin() + mid, prims.begin() + first + count,
@@ -199,11 +213,14 @@ struct Builder
 // up to ~16 scene diagonals away; the relative term covers the fp32 subtractions that form the offsets.
 void padded(const Aabb &b, float slack, float lo[3], float hi[3])
 {
+    // PROSPER_PT_DEBUG_PAD (>= 1.6e-5) fattens the boxes: a different hierarchy for the tests that
+    // check that hits do not depend on it
+    const char *forced = std::getenv("PROSPER_PT_DEBUG_PAD");
+    const float coeff = forced ? std::max(1.6e-5f, (float)std::atof(forced)) : 1.6e-5f;
     float mall = 0.0f;
     for (int k = 0; k < 3; ++k) mall = std::max(mall, std::max(std::fabs(b.lo[k]), std::fabs(b.hi[k])));
     for (int k = 0; k < 3; ++k)
     {
-        static const float coeff = std::getenv("PROSPER_PT_DEBUG_PAD") ? (float)std::atof(std::getenv("PROSPER_PT_DEBUG_PAD")) : 1.6e-5f;
         const float pad = coeff * mall + 1e-6f * (b.hi[k] - b.lo[k]) + slack;
         lo[k] = b.lo[k] - pad;
         hi[k] = b.hi[k] + pad;

@@ -972,44 +972,67 @@ PPT_D v2f plane_offsets(uint32_t packed, float o)
     return r;
 }
 
-// Conservative slab test of one child box from the distances to its six planes; entry distance or
-// +inf on a miss.  The distances are t = (plane - o) * invd: the subtraction stays exact when the
-// origin is near the plane (the fused form plane*invd - o*invd cancels catastrophically there and
-// needs per-axis error terms that cost as much as the subtraction).  With the builder's outward
-// padding, the outward half rounding and the 1 + 4e-7 factor on the exit distance no box that
-// contains a hit is culled.
-PPT_D float slab_entry(float ax, float ay, float az, float bx, float by, float bz, float tMin, float tMax)
+// Conservative slab test of one child box from the distances to its three near and three far planes;
+// entry distance or +inf on a miss.  The distances are t = (plane - o) * invd: the subtraction stays
+// exact when the origin is near the plane (the fused form plane*invd - o*invd cancels catastrophically
+// there and needs per-axis error terms that cost as much as the subtraction).  The far distances
+// arrive scaled by 1 + 2^-16 (> (1 + 2^-18)^2, the box guard's tolerance on both sides), as does tMaxK.
+PPT_D float slab_entry(float nx, float ny, float nz, float fx, float fy, float fz, float tMin, float tMaxK)
 {
-    const float tn = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fminf(az, bz));
-    const float tf = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz));
-    const bool hit = fmaxf(tn, tMin) <= fminf(tf, tMax) * 1.0000152587890625f; // 1 + 2^-16 > (1 + 2^-18)^2
+    const float tn = fmaxf(fmaxf(nx, ny), nz);
+    const float tf = fminf(fminf(fx, fy), fz);
+    const bool hit = fmaxf(tn, tMin) <= fminf(tf, tMaxK);
     return hit ? tn : kInf;
 }
 
+// What the node test needs per ray besides the origin: 1/d per axis, the same scaled by the slab
+// tolerance (for the far planes) and which planes are the near ones.
+struct RaySlabs
+{
+    f3 invd;  // safe_rcp_dir(d)
+    f3 invdK; // invd * (1 + 2^-16)
+};
+constexpr float kSlabTol = 1.0000152587890625f; // 1 + 2^-16
+PPT_D RaySlabs make_ray_slabs(f3 invd)
+{
+    return RaySlabs{invd, f3{invd.x * kSlabTol, invd.y * kSlabTol, invd.z * kSlabTol}};
+}
+
 // Tests the four children of a node; e[c] = entry distance or +inf, then sorts (e, ref) ascending
-// (5-comparator network) so the nearest child is walked first.  Returns the number of children hit.
-// 24 v_fma_mix_f32 + 12 v_pk_mul_f32 produce the 24 plane distances (children c, c+1 share a dword).
-PPT_D uint32_t intersect_node4(const NodeData &n, f3 o, f3 invd, float tMin, float tMax, float e[4], int32_t ref[4])
+// (5-comparator network) so the nearest child is walked first: children that were hit come first,
+// e[k] < inf says whether the k-th nearest exists.
+// Per axis the near planes are the lo planes when the ray travels in + and the hi planes otherwise, so
+// the dwords (two children each) are swapped up front (12 v_cndmask) instead of taking min/max of the
+// 24 products; 24 v_fma_mix_f32 + 12 v_pk_mul_f32 then produce the distances.
+PPT_D void intersect_node4(const NodeData &n, f3 o, const RaySlabs &rs, float tMin, float tMax, float e[4], int32_t ref[4])
 {
     // the ray origin relative to the node (one rounding of 2^-24 |o - origin|, inside the builder's slack)
     const float ox = o.x - __builtin_bit_cast(float, n.q0.x);
     const float oy = o.y - __builtin_bit_cast(float, n.q0.y);
     const float oz = o.z - __builtin_bit_cast(float, n.q0.z);
-    const v2f lox01 = plane_offsets(n.q1.x, ox) * invd.x, lox23 = plane_offsets(n.q1.y, ox) * invd.x;
-    const v2f loy01 = plane_offsets(n.q1.z, oy) * invd.y, loy23 = plane_offsets(n.q1.w, oy) * invd.y;
-    const v2f loz01 = plane_offsets(n.q2.x, oz) * invd.z, loz23 = plane_offsets(n.q2.y, oz) * invd.z;
-    const v2f hix01 = plane_offsets(n.q2.z, ox) * invd.x, hix23 = plane_offsets(n.q2.w, ox) * invd.x;
-    const v2f hiy01 = plane_offsets(n.q3.x, oy) * invd.y, hiy23 = plane_offsets(n.q3.y, oy) * invd.y;
-    const v2f hiz01 = plane_offsets(n.q3.z, oz) * invd.z, hiz23 = plane_offsets(n.q3.w, oz) * invd.z;
-    e[0] = slab_entry(lox01.x, loy01.x, loz01.x, hix01.x, hiy01.x, hiz01.x, tMin, tMax);
-    e[1] = slab_entry(lox01.y, loy01.y, loz01.y, hix01.y, hiy01.y, hiz01.y, tMin, tMax);
-    e[2] = slab_entry(lox23.x, loy23.x, loz23.x, hix23.x, hiy23.x, hiz23.x, tMin, tMax);
-    e[3] = slab_entry(lox23.y, loy23.y, loz23.y, hix23.y, hiy23.y, hiz23.y, tMin, tMax);
+    const bool sx = rs.invd.x < 0.0f, sy = rs.invd.y < 0.0f, sz = rs.invd.z < 0.0f;
+    // q1 = lo.x[0..3] lo.y[0..3], q2 = lo.z[0..3] hi.x[0..3], q3 = hi.y[0..3] hi.z[0..3]
+    const uint32_t nx01 = sx ? n.q2.z : n.q1.x, nx23 = sx ? n.q2.w : n.q1.y;
+    const uint32_t fx01 = sx ? n.q1.x : n.q2.z, fx23 = sx ? n.q1.y : n.q2.w;
+    const uint32_t ny01 = sy ? n.q3.x : n.q1.z, ny23 = sy ? n.q3.y : n.q1.w;
+    const uint32_t fy01 = sy ? n.q1.z : n.q3.x, fy23 = sy ? n.q1.w : n.q3.y;
+    const uint32_t nz01 = sz ? n.q3.z : n.q2.x, nz23 = sz ? n.q3.w : n.q2.y;
+    const uint32_t fz01 = sz ? n.q2.x : n.q3.z, fz23 = sz ? n.q2.y : n.q3.w;
+    const v2f tnx01 = plane_offsets(nx01, ox) * rs.invd.x, tnx23 = plane_offsets(nx23, ox) * rs.invd.x;
+    const v2f tny01 = plane_offsets(ny01, oy) * rs.invd.y, tny23 = plane_offsets(ny23, oy) * rs.invd.y;
+    const v2f tnz01 = plane_offsets(nz01, oz) * rs.invd.z, tnz23 = plane_offsets(nz23, oz) * rs.invd.z;
+    const v2f tfx01 = plane_offsets(fx01, ox) * rs.invdK.x, tfx23 = plane_offsets(fx23, ox) * rs.invdK.x;
+    const v2f tfy01 = plane_offsets(fy01, oy) * rs.invdK.y, tfy23 = plane_offsets(fy23, oy) * rs.invdK.y;
+    const v2f tfz01 = plane_offsets(fz01, oz) * rs.invdK.z, tfz23 = plane_offsets(fz23, oz) * rs.invdK.z;
+    const float tMaxK = tMax * kSlabTol;
+    e[0] = slab_entry(tnx01.x, tny01.x, tnz01.x, tfx01.x, tfy01.x, tfz01.x, tMin, tMaxK);
+    e[1] = slab_entry(tnx01.y, tny01.y, tnz01.y, tfx01.y, tfy01.y, tfz01.y, tMin, tMaxK);
+    e[2] = slab_entry(tnx23.x, tny23.x, tnz23.x, tfx23.x, tfy23.x, tfz23.x, tMin, tMaxK);
+    e[3] = slab_entry(tnx23.y, tny23.y, tnz23.y, tfx23.y, tfy23.y, tfz23.y, tMin, tMaxK);
     ref[0] = (int32_t)n.q4.x;
     ref[1] = (int32_t)n.q4.y;
     ref[2] = (int32_t)n.q4.z;
     ref[3] = (int32_t)n.q4.w;
-    const uint32_t hits = (e[0] < kInf ? 1u : 0u) + (e[1] < kInf ? 1u : 0u) + (e[2] < kInf ? 1u : 0u) + (e[3] < kInf ? 1u : 0u);
 #define PPT_CSWAP(i, j)                                                                                                \
     {                                                                                                                  \
         const bool sw = e[j] < e[i];                                                                                   \
@@ -1026,7 +1049,6 @@ PPT_D uint32_t intersect_node4(const NodeData &n, f3 o, f3 invd, float tMin, flo
     PPT_CSWAP(1, 3)
     PPT_CSWAP(1, 2)
 #undef PPT_CSWAP
-    return hits;
 }
 
 // Shared driver of traceClosest (ANY = false, main.rgen:62-81) and shadow (ANY = true,
@@ -1042,6 +1064,7 @@ PPT_D bool trace_in(
     hit.bary = f2{0.0f, 0.0f};
     hit.t = tMaxIn;
     const f3 invd = f3{safe_rcp_dir(d.x), safe_rcp_dir(d.y), safe_rcp_dir(d.z)};
+    const RaySlabs rs = make_ray_slabs(invd);
 
     // while-while traversal: all lanes first descend inner nodes until every live lane holds a leaf
     // (lanes that already do wait), then all lanes intersect their leaf's triangles.  Under
@@ -1057,11 +1080,11 @@ PPT_D bool trace_in(
             if constexpr (COUNT) cnt.nodeVisits++;
             float e[4];
             int32_t ref[4];
-            const uint32_t hits = intersect_node4(nd, o, invd, tMin, hit.t, e, ref);
-            if (hits > 3u) stack.push(sp, ref[3]);
-            if (hits > 2u) stack.push(sp, ref[2]);
-            if (hits > 1u) stack.push(sp, ref[1]);
-            if (hits > 0u)
+            intersect_node4(nd, o, rs, tMin, hit.t, e, ref);
+            if (e[3] < kInf) stack.push(sp, ref[3]);
+            if (e[2] < kInf) stack.push(sp, ref[2]);
+            if (e[1] < kInf) stack.push(sp, ref[1]);
+            if (e[0] < kInf)
                 node = ref[0];
             else if (sp == 0)
                 alive = false;

@@ -127,11 +127,11 @@ PPT_D void trace_stream(
                     if constexpr (COUNT) cnt.nodeVisits++;
                     float e[4];
                     int32_t ref[4];
-                    const uint32_t hits = intersect_node4(nd, o, invd, tMin, hit.t, e, ref);
-                    if (hits > 3u) stack.push(sp, ref[3]);
-                    if (hits > 2u) stack.push(sp, ref[2]);
-                    if (hits > 1u) stack.push(sp, ref[1]);
-                    if (hits > 0u)
+                    intersect_node4(nd, o, make_ray_slabs(invd), tMin, hit.t, e, ref);
+                    if (e[3] < kInf) stack.push(sp, ref[3]);
+                    if (e[2] < kInf) stack.push(sp, ref[2]);
+                    if (e[1] < kInf) stack.push(sp, ref[1]);
+                    if (e[0] < kInf)
                     {
                         node = ref[0];
                         if (node < 0)

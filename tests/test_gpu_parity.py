@@ -495,6 +495,28 @@ def test_lds_stack_variants_agree(gpu_ctx, oracle, sponza_small, monkeypatch):
     monkeypatch.delenv("PROSPER_PT_DEBUG_STACK")
 
 
+def test_hits_do_not_depend_on_the_hierarchy(gpu_ctx, oracle, sponza_small, monkeypatch):
+    """Hit contract: the box guard bounds where a triangle can be hit, so fatter BVH boxes (a different
+    tree: other culling, other traversal order) must give the same bits."""
+    w, h = 160, 96
+    cam, fl = _camera(oracle, sponza_small, w, h)
+    pc = default_pc(S, fl, max_bounces=4, ibl=True)
+    images, nodes = [], []
+    for pad in (None, "1e-4", "3e-3"):
+        if pad is None:
+            monkeypatch.delenv("PROSPER_PT_DEBUG_PAD", raising=False)
+        else:
+            monkeypatch.setenv("PROSPER_PT_DEBUG_PAD", pad)
+        gpu_ctx.upload_scene(sponza_small)
+        gpu_ctx.reset_counters()
+        gpu_ctx.render(pc, cam, w, h, frames=2, flags=S.RENDER_COUNT_WORK)
+        images.append(gpu_ctx.read_hdr())
+        nodes.append(gpu_ctx.counters().nodeVisits)
+    monkeypatch.delenv("PROSPER_PT_DEBUG_PAD", raising=False)
+    assert nodes[0] < nodes[1] < nodes[2]  # the hierarchies really differ
+    assert same_bits(images[0], images[1]).all() and same_bits(images[0], images[2]).all()
+
+
 def test_lds_resident_scene_equals_global_memory_traversal(gpu_ctx, oracle, cornell_world, monkeypatch):
     """Scenes of a few KB are traversed out of LDS (LdsGeom); same pixels as the HBM path."""
     w, h = 224, 128
