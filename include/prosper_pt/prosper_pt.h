@@ -198,7 +198,8 @@ typedef struct prosper_pt_counters
     uint64_t historyReads;     /* output texels whose history was read */
     uint64_t shortIndexHits;   /* of closestHits + anyHitCalls: those on u16-indexed meshes */
     uint64_t shortIndexTriangleTests; /* of triangleTests: those on u16-indexed meshes */
-    uint64_t reserved[2];
+    uint64_t nodePhaseSteps;     /* wavefront pipeline: wave-level steps of the node phase (x64 lanes = issue slots) */
+    uint64_t trianglePhaseSteps; /* same for the triangle phase; lane utilisation = visits / (64 * steps) */
 } prosper_pt_counters;
 
 /* Sizes the roofline model needs about the acceleration structure the library built. */

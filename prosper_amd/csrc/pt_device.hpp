@@ -17,7 +17,8 @@ constexpr uint32_t kMissIndex = 0xFFFFFFFFu; // rt/reference/main.rgen:47
 struct LaneCounters
 {
     uint32_t closestRays, shadowRays, nodeVisits, triangleTests, closestHits, anyHitCalls, lightSamples,
-        spotLightSamples, skyLookups, shortIndexHits, paths, pixelsWritten, historyReads, shortIndexTriangleTests;
+        spotLightSamples, skyLookups, shortIndexHits, paths, pixelsWritten, historyReads, shortIndexTriangleTests,
+        nodePhaseSteps, trianglePhaseSteps;
 };
 
 // ------------------------------------------------------------------------------------------
@@ -937,9 +938,10 @@ constexpr uint32_t kLdsSceneFloat4s = 768; // 12 KB
 // The traversal stack of one lane: `cap` entries in LDS (entry e at lds[e * 64], conflict-free for
 // b32 accesses), anything deeper in a global overflow column (entry e at ovf[e * ovfStride]).  The
 // builder bounds the worst case (kMaxStackBound); the LDS part is sized for the common case.
+typedef __attribute__((address_space(3))) int32_t lds_int32; // ds_read/ds_write, never a flat access
 struct TraversalStack
 {
-    int32_t *lds;
+    lds_int32 *lds;
     int32_t *ovf;
     uint32_t cap;
     uint32_t ovfStride;
@@ -954,7 +956,8 @@ struct TraversalStack
     PPT_D int32_t pop(int32_t &sp) const
     {
         --sp;
-        return (uint32_t)sp < cap ? lds[sp * 64] : ovf[(size_t)((uint32_t)sp - cap) * ovfStride];
+        if ((uint32_t)sp < cap) return lds[sp * 64];
+        return ovf[(size_t)((uint32_t)sp - cap) * ovfStride];
     }
 };
 

@@ -191,7 +191,7 @@ __global__ __launch_bounds__(256) void render_megakernel(
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t lx = (tile % tilesX) * 16u + (wave & 1u) * 8u + (lane & 7u);
     const uint32_t py = (tile / tilesX) * 16u + (wave >> 1) * 8u + (lane >> 3);
-    const TraversalStack stack{ldsStack + wave * (kTraversalStackDepth * 64u) + lane,
+    const TraversalStack stack{(lds_int32 *)ldsStack + wave * (kTraversalStackDepth * 64u) + lane,
                                stackOverflow + blockIdx.x * 256u + threadIdx.x, kTraversalStackDepth, gridDim.x * 256u};
 
     LaneCounters cnt = {};
@@ -326,7 +326,7 @@ __global__ __launch_bounds__(256) void render_persistent(
     __shared__ int32_t ldsStack[kTraversalStackDepth * 256];
     const uint32_t wave = threadIdx.x >> 6;
     const uint32_t lane = threadIdx.x & 63u;
-    const TraversalStack stack{ldsStack + wave * (kTraversalStackDepth * 64u) + lane,
+    const TraversalStack stack{(lds_int32 *)ldsStack + wave * (kTraversalStackDepth * 64u) + lane,
                                stackOverflow + blockIdx.x * 256u + threadIdx.x, kTraversalStackDepth, gridDim.x * 256u};
 
     const uint32_t tilesX = (p.localWidth + 7u) / 8u;

@@ -18,10 +18,11 @@ __device__ void flush_counters(const LaneCounters &c, unsigned long long *counte
     if constexpr (COUNT)
     {
         // order = prosper_pt_counters fields
-        const uint32_t vals[14] = {c.paths, c.closestRays, c.shadowRays, c.nodeVisits, c.triangleTests, c.closestHits,
+        const uint32_t vals[16] = {c.paths, c.closestRays, c.shadowRays, c.nodeVisits, c.triangleTests, c.closestHits,
                                    c.anyHitCalls, c.lightSamples, c.spotLightSamples, c.skyLookups, c.pixelsWritten,
-                                   c.historyReads, c.shortIndexHits, c.shortIndexTriangleTests};
-        for (int i = 0; i < 14; ++i)
+                                   c.historyReads, c.shortIndexHits, c.shortIndexTriangleTests, c.nodePhaseSteps,
+                                   c.trianglePhaseSteps};
+        for (int i = 0; i < 16; ++i)
         {
             const uint32_t sum = wave_sum(vals[i]);
             if ((threadIdx.x & 63) == 0 && sum) atomicAdd(&counters[i], (unsigned long long)sum);

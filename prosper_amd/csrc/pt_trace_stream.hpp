@@ -121,6 +121,7 @@ PPT_D void trace_stream(
             uint32_t c = nNode;
             do
             {
+                if constexpr (COUNT) cnt.nodePhaseSteps += lane == 0 ? 1u : 0u;
                 if (state == kLaneNode)
                 {
                     const NodeData nd = g.node(node);
@@ -154,6 +155,7 @@ PPT_D void trace_stream(
             uint32_t c = nTri;
             do
             {
+                if constexpr (COUNT) cnt.trianglePhaseSteps += lane == 0 ? 1u : 0u;
                 if (state == kLaneTri)
                 {
                     const TriangleData td = g.tri(triFirst);

@@ -141,7 +141,7 @@ __global__ __launch_bounds__(256, PPT_GEN_WPE) void wf_generate_extend(
     const SegmentId id = my_segment(w);
     if (!id.valid) return;
     const uint32_t lane = lane_id();
-    const TraversalStack stack{ldsStack + (threadIdx.x >> 6) * (STACK * 64u) + lane,
+    const TraversalStack stack{(lds_int32 *)ldsStack + (threadIdx.x >> 6) * (STACK * 64u) + lane,
                                stackOverflow + blockIdx.x * 256u + threadIdx.x, (uint32_t)STACK, gridDim.x * 256u};
     const bool traceRays = p.pc.maxBounces > 0;
 
@@ -460,7 +460,7 @@ __global__ __launch_bounds__(256, PPT_TRACE_WPE(STACK)) void wf_trace(
     const GlobalGeom gg{s.nodes, s.triangles};
     const SegmentId id = my_segment(w);
     if (!id.valid) return;
-    const TraversalStack stack{ldsStack + (threadIdx.x >> 6) * (STACK * 64u) + lane_id(),
+    const TraversalStack stack{(lds_int32 *)ldsStack + (threadIdx.x >> 6) * (STACK * 64u) + lane_id(),
                                stackOverflow + blockIdx.x * 256u + threadIdx.x, (uint32_t)STACK, gridDim.x * 256u};
     LaneCounters cnt = {};
     if constexpr (LDS_SCENE)

@@ -241,7 +241,8 @@ class Counters(C.Structure):
         ("historyReads", C.c_uint64),
         ("shortIndexHits", C.c_uint64),
         ("shortIndexTriangleTests", C.c_uint64),
-        ("reserved", C.c_uint64 * 2),
+        ("nodePhaseSteps", C.c_uint64),
+        ("trianglePhaseSteps", C.c_uint64),
     ]
 
     def as_dict(self):
