@@ -87,16 +87,24 @@ struct Vertex
     f2 uv;
 };
 
-PPT_D const uint32_t *geo_u32(const DeviceScene &s, uint32_t buffer)
+// Pointers that are themselves loaded from memory (geometry buffers, texel arrays) are typed as
+// global-address-space pointers: the compiler cannot prove it and would emit flat_load for them, which
+// occupies the LDS path too and waits on both counters.
+typedef const __attribute__((address_space(1))) uint32_t *global_u32_ptr;
+typedef const __attribute__((address_space(1))) uint16_t *global_u16_ptr;
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+typedef const __attribute__((address_space(1))) u32x2 *global_u32x2_ptr;
+
+PPT_D global_u32_ptr geo_u32(const DeviceScene &s, uint32_t buffer)
 {
-    return static_cast<const uint32_t *>(s.geometryBuffers[buffer]);
+    return (global_u32_ptr)s.geometryBuffers[buffer];
 }
 
 // geometry.glsl:51-59
 PPT_D uint32_t load_index(const DeviceScene &s, const prosper_GeometryMetadata &m, uint32_t index)
 {
     if (m.usesShortIndices == 1)
-        return (uint32_t) static_cast<const uint16_t *>(s.geometryBuffers[m.bufferIndex])[m.indicesOffset + index];
+        return (uint32_t)((global_u16_ptr)s.geometryBuffers[m.bufferIndex])[m.indicesOffset + index];
     return geo_u32(s, m.bufferIndex)[m.indicesOffset + index];
 }
 
@@ -112,7 +120,7 @@ PPT_D f2 load_r16g16(const DeviceScene &s, uint32_t buffer, uint32_t offset, uin
 PPT_D f3 load_r16g16b16a16(const DeviceScene &s, uint32_t buffer, uint32_t offset, uint32_t index)
 {
     if (offset == PROSPER_PT_ABSENT) return f3{0.0f, 0.0f, 0.0f};
-    const uint2 p = *reinterpret_cast<const uint2 *>(geo_u32(s, buffer) + offset + index * 2);
+    const u32x2 p = *(global_u32x2_ptr)(geo_u32(s, buffer) + offset + index * 2);
     return f3{half_to_float(p.x & 0xFFFFu), half_to_float(p.x >> 16), half_to_float(p.y & 0xFFFFu)};
 }
 
@@ -254,7 +262,7 @@ PPT_D void wrap_pair(int32_t i, int32_t size, uint32_t mode, int32_t &c0, int32_
 
 PPT_D f4 fetch_rgba8(const DeviceTexture &t, int32_t i, int32_t j)
 {
-    const uint32_t p = reinterpret_cast<const uint32_t *>(t.texels)[(size_t)j * t.width + (size_t)i];
+    const uint32_t p = ((global_u32_ptr)t.texels)[(size_t)j * t.width + (size_t)i];
     const float k = 1.0f / 255.0f;
     return f4{(float)(p & 0xFFu) * k, (float)((p >> 8) & 0xFFu) * k, (float)((p >> 16) & 0xFFu) * k, (float)(p >> 24) * k};
 }
