@@ -299,7 +299,18 @@ int upload_scene_impl(prosper_pt_ctx *ctx, const prosper_pt_scene_view *v)
         cleanupTemp();
         return fail(PROSPER_PT_ERR_HIP, std::string("scene upload: ") + hipGetErrorString(e));
     }
-    launch_flatten_triangles(s, dOffsets, v->drawInstanceCount, dFlags, dFlat, (uint32_t)total, nullptr);
+    // persistent (scene-lifetime) arrays the flatten kernel fills: shading records + their per-instance bases
+    void *dShade = nullptr, *dTriOffsets = nullptr;
+    if ((rc = device_alloc(ctx, sizeof(ShadeTriangle) * (size_t)(total ? total : 1), &dShade)) ||
+        (rc = upload(ctx, triOffsets.data(), triOffsets.size() * 4, &dTriOffsets)))
+    {
+        cleanupTemp();
+        return rc;
+    }
+    s.shadeTriangles = static_cast<const ShadeTriangle *>(dShade);
+    s.triangleOffsets = static_cast<const uint32_t *>(dTriOffsets);
+    launch_flatten_triangles(
+        s, dOffsets, v->drawInstanceCount, dFlags, dFlat, static_cast<ShadeTriangle *>(dShade), (uint32_t)total, nullptr);
     std::vector<WorldTriangle> flat((size_t)total);
     if ((e = hipGetLastError()) != hipSuccess ||
         (total && (e = hipMemcpy(flat.data(), dFlat, sizeof(WorldTriangle) * (size_t)total, hipMemcpyDeviceToHost)) != hipSuccess) ||

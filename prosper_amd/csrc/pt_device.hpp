@@ -108,6 +108,12 @@ PPT_D uint32_t load_index(const DeviceScene &s, const prosper_GeometryMetadata &
     return geo_u32(s, m.bufferIndex)[m.indicesOffset + index];
 }
 
+PPT_D f2 unpack_half2(uint32_t packed) { return f2{half_to_float(packed & 0xFFFFu), half_to_float(packed >> 16)}; }
+PPT_D f3 unpack_half3(uint32_t xy, uint32_t z_)
+{
+    return f3{half_to_float(xy & 0xFFFFu), half_to_float(xy >> 16), half_to_float(z_ & 0xFFFFu)};
+}
+
 // geometry.glsl:71-80
 PPT_D f2 load_r16g16(const DeviceScene &s, uint32_t buffer, uint32_t offset, uint32_t index)
 {
@@ -865,14 +871,14 @@ PPT_D bool any_hit(
     if constexpr (COUNT) cnt.anyHitCalls++;
     if (baseTex > 0 || COUNT)
     {
-        const prosper_GeometryMetadata m = s.geometryMetadatas[inst.meshIndex];
-        if constexpr (COUNT) cnt.shortIndexHits += m.usesShortIndices == 1 ? 1u : 0u;
+        const ShadeTriangle *rec = s.shadeTriangles + (s.triangleOffsets[drawInstance] + primitive);
+        if constexpr (COUNT) cnt.shortIndexHits += (rec->flags & kTriFlagShortIndices) ? 1u : 0u;
         if (baseTex > 0)
         {
-            // geometry.glsl:246-256
-            const f2 uv0 = load_r16g16(s, m.bufferIndex, m.texCoord0sOffset, load_index(s, m, primitive * 3 + 0));
-            const f2 uv1 = load_r16g16(s, m.bufferIndex, m.texCoord0sOffset, load_index(s, m, primitive * 3 + 1));
-            const f2 uv2 = load_r16g16(s, m.bufferIndex, m.texCoord0sOffset, load_index(s, m, primitive * 3 + 2));
+            // geometry.glsl:246-256, from the triangle's precomputed record
+            const f2 uv0 = unpack_half2(__builtin_bit_cast(uint32_t, rec->normalUv[0][3]));
+            const f2 uv1 = unpack_half2(__builtin_bit_cast(uint32_t, rec->normalUv[1][3]));
+            const f2 uv2 = unpack_half2(__builtin_bit_cast(uint32_t, rec->normalUv[2][3]));
             const float a = (1.0f - bary.x) - bary.y;
             const f2 uv =
                 f2{bary1(uv0.x, uv1.x, uv2.x, a, bary.x, bary.y), bary1(uv0.y, uv1.y, uv2.y, a, bary.x, bary.y)};
@@ -1164,17 +1170,30 @@ PPT_D f3 mapped_normal(f3 tsn, f3 normal, f3 tangent, float sgn)
 template <bool COUNT>
 PPT_D Surface evaluate_surface(const DeviceScene &s, f3 rayDir, const Hit &hit, LaneCounters &cnt)
 {
+    // loadVertexThroughIndexBuffer x 3 (geometry.glsl:220-244) from the triangle's precomputed record
     const prosper_DrawInstance inst = s.drawInstances[hit.drawInstance];
-    const prosper_GeometryMetadata m = s.geometryMetadatas[inst.meshIndex];
-    const Vertex v0 = load_vertex_through_index_buffer(s, m, hit.primitive * 3 + 0);
-    const Vertex v1 = load_vertex_through_index_buffer(s, m, hit.primitive * 3 + 1);
-    const Vertex v2 = load_vertex_through_index_buffer(s, m, hit.primitive * 3 + 2);
+    const float4 *rec =
+        reinterpret_cast<const float4 *>(s.shadeTriangles + (s.triangleOffsets[hit.drawInstance] + hit.primitive));
+    const float4 q0 = rec[0], q1 = rec[1], q2 = rec[2], q3 = rec[3], q4 = rec[4], q5 = rec[5], q6 = rec[6], q7 = rec[7];
+    Vertex v0, v1, v2;
+    v0.normal = f3{q0.x, q0.y, q0.z};
+    v1.normal = f3{q1.x, q1.y, q1.z};
+    v2.normal = f3{q2.x, q2.y, q2.z};
+    v0.uv = unpack_half2(__builtin_bit_cast(uint32_t, q0.w));
+    v1.uv = unpack_half2(__builtin_bit_cast(uint32_t, q1.w));
+    v2.uv = unpack_half2(__builtin_bit_cast(uint32_t, q2.w));
+    v0.tangent = f4{q3.x, q3.y, q3.z, q3.w};
+    v1.tangent = f4{q4.x, q4.y, q4.z, q4.w};
+    v2.tangent = f4{q5.x, q5.y, q5.z, q5.w};
+    v0.position = unpack_half3(__builtin_bit_cast(uint32_t, q6.x), __builtin_bit_cast(uint32_t, q6.y));
+    v1.position = unpack_half3(__builtin_bit_cast(uint32_t, q6.z), __builtin_bit_cast(uint32_t, q6.w));
+    v2.position = unpack_half3(__builtin_bit_cast(uint32_t, q7.x), __builtin_bit_cast(uint32_t, q7.y));
     const Vertex vi = interpolate(v0, v1, v2, hit.bary);
     const Vertex v = transform(vi, s.modelInstanceTransforms[inst.modelInstanceIndex]);
     if constexpr (COUNT)
     {
         cnt.closestHits++;
-        cnt.shortIndexHits += m.usesShortIndices == 1 ? 1u : 0u;
+        cnt.shortIndexHits += (__builtin_bit_cast(uint32_t, q7.z) & kTriFlagShortIndices) ? 1u : 0u;
     }
     Surface sf;
     sf.positionWS = v.position;

@@ -19,7 +19,8 @@ namespace ppt
 
 __global__ void flatten_triangles_kernel(
     DeviceScene s, const uint32_t *__restrict__ triOffsets, uint32_t drawInstanceCount,
-    const uint32_t *__restrict__ drawInstanceFlags, WorldTriangle *__restrict__ out, uint32_t total)
+    const uint32_t *__restrict__ drawInstanceFlags, WorldTriangle *__restrict__ out,
+    ShadeTriangle *__restrict__ shadeOut, uint32_t total)
 {
     const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= total) return;
@@ -52,6 +53,35 @@ __global__ void flatten_triangles_kernel(
     t.primitive = prim;
     t.flags = drawInstanceFlags[di];
     out[g] = t;
+
+    // the shading record of this triangle (pt_scene.hpp ShadeTriangle): geometry.glsl:220-244 per corner
+    ShadeTriangle sh;
+    const uint32_t vi[3] = {i0, i1, i2};
+    for (int c = 0; c < 3; ++c)
+    {
+        const Vertex vtx = load_vertex_through_index_buffer(s, m, prim * 3 + c);
+        sh.normalUv[c][0] = vtx.normal.x;
+        sh.normalUv[c][1] = vtx.normal.y;
+        sh.normalUv[c][2] = vtx.normal.z;
+        const uint32_t uvBits =
+            m.texCoord0sOffset == PROSPER_PT_ABSENT ? 0u : geo_u32(s, m.bufferIndex)[m.texCoord0sOffset + vi[c]];
+        sh.normalUv[c][3] = __builtin_bit_cast(float, uvBits);
+        sh.tangent[c][0] = vtx.tangent.x;
+        sh.tangent[c][1] = vtx.tangent.y;
+        sh.tangent[c][2] = vtx.tangent.z;
+        sh.tangent[c][3] = vtx.tangent.w;
+        if (m.positionsOffset == PROSPER_PT_ABSENT)
+            sh.position[c][0] = sh.position[c][1] = 0u;
+        else
+        {
+            const u32x2 pp = *(global_u32x2_ptr)(geo_u32(s, m.bufferIndex) + m.positionsOffset + vi[c] * 2);
+            sh.position[c][0] = pp.x;
+            sh.position[c][1] = pp.y;
+        }
+    }
+    sh.flags = drawInstanceFlags[di];
+    sh.reserved = 0;
+    shadeOut[g] = sh;
 }
 
 __global__ void permute_triangles_kernel(
@@ -69,12 +99,12 @@ __global__ void permute_triangles_kernel(
 
 void launch_flatten_triangles(
     const DeviceScene &s, const uint32_t *triOffsets, uint32_t drawInstanceCount, const uint32_t *drawInstanceFlags,
-    WorldTriangle *out, uint32_t total, hipStream_t stream)
+    WorldTriangle *out, ShadeTriangle *shadeOut, uint32_t total, hipStream_t stream)
 {
     if (total == 0) return;
     hipLaunchKernelGGL(
         flatten_triangles_kernel, dim3((total + 255) / 256), dim3(256), 0, stream, s, triOffsets, drawInstanceCount,
-        drawInstanceFlags, out, total);
+        drawInstanceFlags, out, shadeOut, total);
 }
 
 void launch_permute_triangles(

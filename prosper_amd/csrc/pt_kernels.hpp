@@ -43,7 +43,7 @@ struct LaunchTimer
 
 void launch_flatten_triangles(
     const DeviceScene &s, const uint32_t *triOffsets, uint32_t drawInstanceCount, const uint32_t *drawInstanceFlags,
-    WorldTriangle *out, uint32_t total, hipStream_t stream);
+    WorldTriangle *out, ShadeTriangle *shadeOut, uint32_t total, hipStream_t stream);
 void launch_permute_triangles(
     const WorldTriangle *in, const uint32_t *permutation, WorldTriangle *out, uint32_t total, hipStream_t stream);
 uint32_t megakernel_grid_blocks(const RenderParams &p);

@@ -53,6 +53,24 @@ static_assert(sizeof(WorldTriangle) == 48, "world triangle is 48 B");
 constexpr uint32_t kTriFlagOpaque = 1u;
 constexpr uint32_t kTriFlagShortIndices = 2u; // the mesh is u16-indexed (only the byte model cares)
 
+// Decoded object-space corner attributes of one triangle, 128 B = eight 16-byte words, stored in
+// (drawInstance, primitive) order (record = triangleOffsets[drawInstance] + primitive).  What
+// geometry.glsl:220-256 fetches per hit through drawInstance -> mesh metadata -> index buffer -> four
+// vertex streams (three dependent round trips, 3 x (unpack + normalize) x 2) is precomputed ONCE at
+// upload by the same device functions, so a hit reads one record: same bits, five hops fewer.
+//   q0..q2: normal of corner i (xyz, unpackSnorm + normalize), w = texCoord0 of corner i (two halfs)
+//   q3..q5: tangent of corner i (xyz, w = sign)
+//   q6: position halfs of corner 0 (x: xy, y: z_) and corner 1 (z, w);  q7: corner 2 (x, y), z = flags
+struct alignas(16) ShadeTriangle
+{
+    float normalUv[3][4];
+    float tangent[3][4];
+    uint32_t position[3][2];
+    uint32_t flags; // bit 1: u16-indexed mesh (kTriFlagShortIndices)
+    uint32_t reserved;
+};
+static_assert(sizeof(ShadeTriangle) == 128, "shade triangle is 128 B");
+
 struct DeviceTexture
 {
     const uint8_t *texels;
@@ -66,7 +84,9 @@ struct DeviceScene
 {
     const BvhNode *nodes;
     const WorldTriangle *triangles;
-    const void *const *geometryBuffers; // device array of device pointers
+    const ShadeTriangle *shadeTriangles; // (drawInstance, primitive) order
+    const uint32_t *triangleOffsets;     // first record of each draw instance
+    const void *const *geometryBuffers;  // device array of device pointers
     const prosper_GeometryMetadata *geometryMetadatas;
     const prosper_DrawInstance *drawInstances;
     const prosper_ModelInstanceTransforms *modelInstanceTransforms;
