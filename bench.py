@@ -62,6 +62,17 @@ def measured_traffic(config, kernel):
         return None
 
 
+def measured_issue(config, kernel):
+    """Vector-ALU issue-slot occupancy and lane utilisation of `kernel` from the committed PMC pass
+    (profiles/r01_valu_issue.json): what actually bounds the traversal kernels."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_valu_issue.json")) as f:
+            k = json.load(f)["configs"][config][kernel]
+        return {"valu_busy": k["valu_busy"], "lane_util": k["lane_util"], "source": "profiles/r01_valu_issue.json"}
+    except (OSError, KeyError, ValueError):
+        return None
+
+
 def make_pc(focal, frame_index, max_bounces, ibl, skip_history):
     flags = S.PC_FLAG_ACCUMULATE | S.PC_FLAG_CLAMP_INDIRECT
     if ibl:
@@ -262,6 +273,7 @@ def main():
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
                 "traffic": measured_traffic(args.config, dominant),
+                "issue": measured_issue(args.config, dominant),
                 "algorithmic_bytes_per_launch": kernels[dominant]["algorithmic_bytes_per_launch"],
                 "kernel_ms": kernels[dominant]["ms_per_launch"],
                 "launches_per_step": kernels[dominant]["launches_per_step"],
