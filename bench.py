@@ -145,10 +145,18 @@ def main():
         if world_size == 1 and args.gpus > 1:
             raise SystemExit("--gpus %d needs torch.distributed.run with --nproc-per-node %d" % (args.gpus, args.gpus))
         raise SystemExit("WORLD_SIZE %d != --gpus %d" % (world_size, args.gpus))
+    # PROSPER_BENCH_REHEARSE=1: every rank on GPU 0 with the gloo backend, to rehearse the N > 1 flow
+    # (stripes, gather, de-interleave, max-over-ranks timing) on a one-GPU box; never a measurement.
+    rehearse = os.environ.get("PROSPER_BENCH_REHEARSE") == "1"
+    if rehearse:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world_size > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world_size, device_id=torch.device("cuda", local_rank))
+        if rehearse:
+            dist.init_process_group("gloo", rank=rank, world_size=world_size)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world_size, device_id=torch.device("cuda", local_rank))
 
     workload, builder, width, height, spp, max_bounces, ibl = CONFIGS[args.config]
     if not tiling.check_divisible(width, world_size):
@@ -169,16 +177,22 @@ def main():
     gathered = [torch.empty_like(hdr) for _ in range(world_size)] if (world_size > 1 and rank == 0) else None
     full = None
 
+    def gather_tiles():
+        """The one data-path collective: per-rank RGBA32F stripes to rank 0 (RCCL gather over xGMI)."""
+        if rehearse:  # gloo: through host memory
+            torch.cuda.synchronize()
+            host = hdr.cpu()
+            parts = [torch.empty_like(host) for _ in range(world_size)] if rank == 0 else None
+            dist.gather(host, parts, dst=0)
+            return tiling.deinterleave([p.cuda() for p in parts], width) if rank == 0 else None
+        dist.gather(hdr, gathered, dst=0)
+        return tiling.deinterleave(gathered, width) if rank == 0 else None
+
     def step():
         nonlocal full
         pc = make_pc(focal, 1, max_bounces, ibl, True)
         ctx.render(pc, cam, width, height, tile=tile, frames=spp, stream=stream)
-        if world_size > 1:
-            dist.gather(hdr, gathered, dst=0)
-            if rank == 0:
-                full = tiling.deinterleave(gathered, width)
-        else:
-            full = hdr
+        full = gather_tiles() if world_size > 1 else hdr
 
     # deterministic work counters of one launch (outside the timed region)
     ctx.reset_counters(stream)
@@ -207,19 +221,14 @@ def main():
         starts[i].record()
         ctx.render(pc, cam, width, height, tile=tile, frames=spp, stream=stream)
         stops[i].record()
-        if world_size > 1:
-            dist.gather(hdr, gathered, dst=0)
-            if rank == 0:
-                full = tiling.deinterleave(gathered, width)
-        else:
-            full = hdr
+        full = gather_tiles() if world_size > 1 else hdr
     barrier()
     elapsed = time.perf_counter() - t0
     kernel_ms = sum(s.elapsed_time(e) for s, e in zip(starts, stops)) / max(1, args.steps)
     # per-kernel split of the LAST timed step, from the hipEvents recorded around every launch
     _, per_kernel = ctx.last_render_timing()
 
-    t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+    t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if rehearse else "cuda")
     if world_size > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
