@@ -289,6 +289,20 @@ def test_traversal_semantics_on_gpu(gpu_ctx, oracle):
         gpu_ctx.render(pc, cam, w, h)
         want, _ = osc.render(pc, cam, w, h)
         assert same_bits(gpu_ctx.read_hdr(), want).all()
+    # an instance whose mesh has no indices yet (inactive TLAS instance, World.cpp:878-928) is invisible;
+    # seen from behind (no face culling) the scene still renders
+    from test_oracle_traversal import _with_inactive_instance
+    world2 = _with_inactive_instance()
+    gpu_ctx.upload_scene(world2)
+    gpu_ctx.render(pc, cam, w, h)
+    assert same_bits(gpu_ctx.read_hdr(), want).all()
+    world.camera = dict(world.camera, eye=(0.0, 0.0, -5.0))
+    cam2, fl2 = _camera(oracle, world, w, h)
+    pc2 = default_pc(S, fl2, draw_type=S.DrawType["PrimitiveID"], max_bounces=1)
+    gpu_ctx.upload_scene(world)
+    gpu_ctx.render(pc2, cam2, w, h)
+    back, _ = osc.render(pc2, cam2, w, h)
+    assert same_bits(gpu_ctx.read_hdr(), back).all() and (back[..., :3].sum(axis=2) > 0).any()
 
 
 def test_stripe_tiles_equal_whole_image(gpu_ctx, oracle, cornell_world):

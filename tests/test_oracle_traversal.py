@@ -79,6 +79,34 @@ def test_miss_and_barycentrics(oracle, tiny):
         np.testing.assert_allclose(bary, (0.5, 0.25), atol=1e-6)  # weights of v1, v2
 
 
+def test_no_back_face_culling(oracle, tiny):
+    """main.rgen:57,73 trace with no cull flags: the quads face +z and are hit from -z as well."""
+    for sc in tiny:
+        hit, di, prim, _ = sc.trace_closest((0.2, 0.1, -5.0), (0, 0, 1))
+        assert hit and di == 3  # the first of the two coincident quads at z = -1, seen from behind
+        assert sc.trace_shadow((0.2, 0.1, -5.0), (0, 0, 1), 0.1, 100.0)
+
+
+def _with_inactive_instance():
+    """tiny_triangles plus a draw instance whose mesh has no indices yet (World.cpp:878-928: a TLAS
+    instance stays inactive, reference 0, until its BLAS exists), placed in front of everything."""
+    w = scenes.tiny_triangles()
+    p, n, t, uv, _ = scenes.quad((-1, -1, 3), (1, -1, 3), (1, 1, 3), (-1, 1, 3))
+    m = w.add_mesh(p, np.zeros(0, np.uint32), 0, normals=n, tangents=t, uvs=uv)
+    w.add_instance(w.add_model([(m, 0)]))
+    return w
+
+
+def test_inactive_instance_is_never_hit(oracle):
+    w = _with_inactive_instance()
+    ref = oracle.OracleScene(scenes.tiny_triangles(), brute_force=True)
+    for brute in (True, False):
+        sc = oracle.OracleScene(w, brute_force=brute)
+        for seed in range(8):
+            assert sc.trace_closest((0.2, 0.1, 5.0), (0, 0, -1), seed=seed) == \
+                ref.trace_closest((0.2, 0.1, 5.0), (0, 0, -1), seed=seed)
+
+
 def test_bvh_equals_brute_force_on_random_rays(oracle):
     w = scenes.sponza_class(texture_size=16, sky_size=8, detail=0.02)
     brute = oracle.OracleScene(w, brute_force=True)
