@@ -457,6 +457,36 @@ def test_full_size_c2_properties(gpu_ctx, oracle, cornell_world):
     assert same_bits(got2, want).all()
 
 
+def test_c5_rank_tile_chunked_batch_properties(gpu_ctx, oracle, cornell_world):
+    """BASELINE C5 as one of its 8 ranks sees it: 3840x2160, 64 spp, stripe 3 of 8.  66 M path slots exceed
+    the 64 M-slot workspace cap, so the batch runs as two chunks: it must equal the same 64 frames
+    accumulated 16 at a time, bit for bit, and the first stripe columns must equal a whole-width render."""
+    from prosper_amd import tiling
+    w, h, spp = 3840, 2160, 64
+    cam, fl = _camera(oracle, cornell_world, w, h)
+    gpu_ctx.upload_scene(cornell_world)
+    tile = tiling.tile_for_rank(3, 8)
+    pc = default_pc(S, fl, max_bounces=4)
+    gpu_ctx.reset_counters()
+    gpu_ctx.render(pc, cam, w, h, tile=tile, frames=spp, flags=S.RENDER_COUNT_WORK)
+    a = gpu_ctx.read_hdr()
+    lw = tiling.local_width(w, 3, 8)
+    assert a.shape == (h, lw, 4) and np.isfinite(a).all() and (a[..., 3] == spp).all()
+    c = gpu_ctx.counters().as_dict()
+    assert c["paths"] == lw * h * spp and c["historyReads"] == lw * h * (spp - 1)
+    for k in range(4):
+        p = default_pc(S, fl, frame_index=1 + 16 * k, max_bounces=4, skip_history=(k == 0))
+        gpu_ctx.render(p, cam, w, h, tile=tile, frames=16)
+    assert same_bits(gpu_ctx.read_hdr(), a).all()
+    # 2 spp of the same rank tile against the untiled image (absolute pixel seeds): stripe 3 = columns 48..63, ...
+    gpu_ctx.render(pc, cam, w, h, tile=tile, frames=2)
+    t2 = gpu_ctx.read_hdr()
+    gpu_ctx.render(pc, cam, w, h, frames=2)
+    full = gpu_ctx.read_hdr()
+    cols = np.concatenate([np.arange(16) + 16 * (3 + 8 * j) for j in range(lw // 16)])
+    assert same_bits(t2, full[:, cols]).all()
+
+
 def test_all_pipelines_produce_identical_pixels(gpu_ctx, oracle, cornell_world):
     """Default wavefront pipeline, PROSPER_PT_CREATE_PERSISTENT and PROSPER_PT_CREATE_MEGAKERNEL are
     the same function of (pixel, frame): identical images, identical counters, all equal to the oracle."""
