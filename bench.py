@@ -133,6 +133,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--megakernel", action="store_true", help="use the one-lane-per-pixel kernel (A/B)")
     ap.add_argument("--persistent", action="store_true", help="use the persistent path-regeneration kernel (A/B)")
+    ap.add_argument("--single-chain", action="store_true",
+                    help="one chain of launches on one stream instead of two overlapping half-batches (A/B)")
     args = ap.parse_args()
 
     import torch
@@ -166,7 +168,8 @@ def main():
     camera = Camera.from_world(world, width, height)
     cam, focal = camera.update_buffer()
 
-    ctx = capi.Context(device=local_rank, flags=S.CREATE_MEGAKERNEL if args.megakernel else (S.CREATE_PERSISTENT if args.persistent else 0))
+    ctx = capi.Context(device=local_rank, flags=S.CREATE_MEGAKERNEL if args.megakernel else (
+        S.CREATE_PERSISTENT if args.persistent else (S.CREATE_SINGLE_CHAIN if args.single_chain else 0)))
     ctx.upload_scene(world)
     stats = ctx.scene_stats()
     tile = tiling.tile_for_rank(rank, world_size)
@@ -272,7 +275,8 @@ def main():
                 "triangles": int(stats.triangleCount),
                 "bvh_nodes": int(stats.nodeCount),
                 "parallelism": "image stripes x%d%s" % (world_size, " + RCCL gather" if world_size > 1 else ""),
-                "pipeline": "megakernel" if args.megakernel else ("persistent" if args.persistent else "wavefront"),
+                "pipeline": "megakernel" if args.megakernel else ("persistent" if args.persistent else (
+                    "wavefront, 1 launch chain" if args.single_chain else "wavefront, 2 concurrent launch chains")),
             },
             "roofline": {
                 "bound": "hbm",
@@ -286,6 +290,10 @@ def main():
                 "algorithmic_bytes_per_launch": kernels[dominant]["algorithmic_bytes_per_launch"],
                 "kernel_ms": kernels[dominant]["ms_per_launch"],
                 "launches_per_step": kernels[dominant]["launches_per_step"],
+                # the default pipeline runs two half-batches as two chains of launches on two streams: a launch's
+                # duration (hipEvents, = rocprofv3's) includes the time it shares the GPU with the other chain's
+                # launch, so sum(kernel time) > wall time and `frac` is a per-launch, not a whole-GPU, figure
+                "concurrent_chains": 1 if (args.single_chain or args.megakernel or args.persistent) else 2,
             },
             "kernels": kernels,
             "whole_pass": {

@@ -68,6 +68,9 @@ enum
      * PERSISTENT = resident waves that regenerate finished paths from a global counter. */
     PROSPER_PT_CREATE_MEGAKERNEL = 1u << 0,
     PROSPER_PT_CREATE_PERSISTENT = 1u << 1,
+    /* run the wavefront pipeline as ONE chain of launches on the caller's stream instead of two
+     * half-batches on two internal streams (A/B switch; the two-chain default hides launch tails) */
+    PROSPER_PT_CREATE_SINGLE_CHAIN = 1u << 2,
 };
 
 /* Texel formats of material textures (reference: src/scene/Texture.cpp:217-296 stores UNORM,

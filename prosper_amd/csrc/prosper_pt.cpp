@@ -86,7 +86,16 @@ struct prosper_pt_ctx
     uint32_t eventStage[kMaxTimedLaunches] = {};
     uint32_t timedLaunches = 0;
     bool timingValid = false;
+
+    // the two launch chains of the wavefront pipeline (pt_kernels.hpp WavefrontChains)
+    hipStream_t chainStreams[2] = {};
+    hipEvent_t chainFork = nullptr;
+    hipEvent_t chainJoin[2] = {};
+    hipEvent_t chainEvents[2][kMaxTimedLaunches + 1] = {};
+    uint32_t chainStage[2][kMaxTimedLaunches] = {};
+    uint32_t chainLaunches[2] = {};
 };
+constexpr uint32_t kStageChains = 4; // unnamed interval of the caller's stream: fork .. join of the chains
 
 namespace
 {
@@ -504,6 +513,13 @@ int prosper_pt_create(const prosper_pt_device_desc *desc, prosper_pt_ctx **out_c
     ctx->flags = desc->flags;
     bool eventsOk = true;
     for (auto &e : ctx->events) eventsOk = eventsOk && hipEventCreate(&e) == hipSuccess;
+    for (int i = 0; i < 2; ++i)
+    {
+        eventsOk = eventsOk && hipStreamCreateWithFlags(&ctx->chainStreams[i], hipStreamNonBlocking) == hipSuccess;
+        eventsOk = eventsOk && hipEventCreateWithFlags(&ctx->chainJoin[i], hipEventDisableTiming) == hipSuccess;
+        for (auto &e : ctx->chainEvents[i]) eventsOk = eventsOk && hipEventCreate(&e) == hipSuccess;
+    }
+    eventsOk = eventsOk && hipEventCreateWithFlags(&ctx->chainFork, hipEventDisableTiming) == hipSuccess;
     if (!eventsOk || hipMalloc((void **)&ctx->dCounters, kStageCount * 16 * sizeof(unsigned long long)) != hipSuccess ||
         hipMemset(ctx->dCounters, 0, kStageCount * 16 * sizeof(unsigned long long)) != hipSuccess ||
         hipMalloc((void **)&ctx->dWorkCounter, 64) != hipSuccess)
@@ -528,6 +544,14 @@ void prosper_pt_destroy(prosper_pt_ctx *ctx)
     if (ctx->stackOverflow) (void)hipFree(ctx->stackOverflow);
     for (auto &e : ctx->events)
         if (e) (void)hipEventDestroy(e);
+    for (int i = 0; i < 2; ++i)
+    {
+        for (auto &e : ctx->chainEvents[i])
+            if (e) (void)hipEventDestroy(e);
+        if (ctx->chainJoin[i]) (void)hipEventDestroy(ctx->chainJoin[i]);
+        if (ctx->chainStreams[i]) (void)hipStreamDestroy(ctx->chainStreams[i]);
+    }
+    if (ctx->chainFork) (void)hipEventDestroy(ctx->chainFork);
     delete ctx;
 }
 
@@ -678,6 +702,20 @@ int prosper_pt_render_frames(
         if (pixelsPadded > kMaxWavefrontSlots) return fail(PROSPER_PT_ERR_UNSUPPORTED, "image too large for the wavefront workspace");
         uint32_t framesPerChunk = (uint32_t)(kMaxWavefrontSlots / pixelsPadded);
         if (framesPerChunk > frame_count) framesPerChunk = frame_count;
+        WavefrontChains chains;
+        LaunchTimer chainTimers[2];
+        chains.count = (ctx->flags & PROSPER_PT_CREATE_SINGLE_CHAIN) ? 1u : 2u;
+        chains.fork = ctx->chainFork;
+        for (int i = 0; i < 2; ++i)
+        {
+            chains.streams[i] = ctx->chainStreams[i];
+            chains.join[i] = ctx->chainJoin[i];
+            chainTimers[i].events = ctx->chainEvents[i];
+            chainTimers[i].stage = ctx->chainStage[i];
+            chainTimers[i].capacity = prosper_pt_ctx::kMaxTimedLaunches;
+            chains.timers[i] = tp ? &chainTimers[i] : nullptr;
+            ctx->chainLaunches[i] = 0;
+        }
         for (uint32_t f0 = 0; f0 < frame_count; f0 += framesPerChunk)
         {
             const uint32_t frames = (frame_count - f0 < framesPerChunk) ? frame_count - f0 : framesPerChunk;
@@ -692,10 +730,13 @@ int prosper_pt_render_frames(
             int32_t *ovf = nullptr;
             const int orc = ensure_stack_overflow(ctx, ldsEntries, wavefront_grid_blocks(w), s, &ovf);
             if (orc != PROSPER_PT_OK) return orc;
+            const uint32_t overflowEntries = ctx->stats.maxDepth > ldsEntries ? ctx->stats.maxDepth - ldsEntries : 0u;
+            if (tp) tp->mark(kStageChains, s);
             launch_render_wavefront(
-                ctx->scene, pp, ctx->hdr, ctx->dCounters, w, ldsEntries, ovf, (uint32_t)ctx->stats.nodeCount,
-                (uint32_t)ctx->stats.triangleCount, countWork, tp, s);
+                ctx->scene, pp, ctx->hdr, ctx->dCounters, w, ldsEntries, ovf, overflowEntries, (uint32_t)ctx->stats.nodeCount,
+                (uint32_t)ctx->stats.triangleCount, countWork, tp, chains, s);
         }
+        for (int i = 0; i < 2; ++i) ctx->chainLaunches[i] = chainTimers[i].count;
     }
     PPT_HIP(hipGetLastError());
     if (tp)
@@ -845,6 +886,28 @@ int prosper_pt_get_last_render_timing(
         perStage[ctx->eventStage[i]] += ms;
         launches[ctx->eventStage[i]] += 1;
         total += ms;
+    }
+    // The wavefront chains: their launches ran on the internal streams, between the caller's-stream
+    // events counted above as the (unnamed) chains interval.  Their durations are as the device saw
+    // them, i.e. a launch that shared the GPU with the other chain's is counted in full: per-stage sums
+    // can exceed the wall time in `total_ms`, which stays the caller's-stream time.
+    if (perStage[kStageChains] > 0.0f || launches[kStageChains] > 0)
+    {
+        bool any = false;
+        for (int c = 0; c < 2; ++c)
+            for (uint32_t i = 0; i < ctx->chainLaunches[c]; ++i)
+            {
+                float ms = 0.0f;
+                PPT_HIP(hipEventElapsedTime(&ms, ctx->chainEvents[c][i], ctx->chainEvents[c][i + 1]));
+                perStage[ctx->chainStage[c][i]] += ms;
+                launches[ctx->chainStage[c][i]] += 1;
+                any = true;
+            }
+        if (any)
+        {
+            perStage[kStageChains] = 0.0f;
+            launches[kStageChains] = 0;
+        }
     }
     *total_ms = total;
     for (int i = 0; i < PROSPER_PT_MAX_KERNELS; ++i)

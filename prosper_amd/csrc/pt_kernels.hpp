@@ -57,10 +57,23 @@ void launch_render_megakernel(
 void launch_render_persistent(
     const DeviceScene &s, const RenderParams &p, float4 *hdr, unsigned long long *counters, uint32_t *workCounter,
     int32_t *stackOverflow, bool countWork, hipStream_t stream);
+// The wavefront pipeline runs its segment groups as `count` independent chains of launches (generate,
+// shade/trace per bounce), chain i on streams[i] with its own launch timer, forked from and joined back
+// into the caller's stream around them; the accumulate kernel follows on the caller's stream.  With
+// count == 1 (or a batch too small to split) everything runs on the caller's stream.
+struct WavefrontChains
+{
+    uint32_t count = 1;
+    hipStream_t streams[2] = {};
+    hipEvent_t fork = nullptr;
+    hipEvent_t join[2] = {};
+    LaunchTimer *timers[2] = {};
+};
+// `overflowEntries`: ints per lane in `stackOverflow` (stack bound - LDS entries), 0 when unused
 void launch_render_wavefront(
     const DeviceScene &s, const RenderParams &p, float4 *hdr, unsigned long long *counters, const WavefrontBuffers &w,
-    uint32_t ldsStackEntries, int32_t *stackOverflow, uint32_t nodeCount, uint32_t triCount, bool countWork,
-    LaunchTimer *timer, hipStream_t stream);
+    uint32_t ldsStackEntries, int32_t *stackOverflow, uint32_t overflowEntries, uint32_t nodeCount, uint32_t triCount,
+    bool countWork, LaunchTimer *timer, const WavefrontChains &chains, hipStream_t stream);
 // LDS stack entries (16/24/32) the wavefront traversal kernels use for a tree with this stack bound
 uint32_t wavefront_lds_stack_entries(uint32_t stackBound);
 void launch_blit_rgba16f(const float4 *in, void *out, uint32_t count, hipStream_t stream);

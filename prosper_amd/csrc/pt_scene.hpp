@@ -149,7 +149,8 @@ struct WavefrontBuffers
     uint32_t pixelsPadded; // tilesX * tilesY * 64
     uint32_t tilesX;
     uint32_t tilesY;
-    uint32_t pad;
+    uint32_t groupBase;  // this launch covers segment groups [groupBase, groupBase + groupCount)
+    uint32_t groupCount; // (a group = the 4 segments of one workgroup)
 };
 
 } // namespace ppt

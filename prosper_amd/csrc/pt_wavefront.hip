@@ -54,18 +54,19 @@ struct SegmentId
     bool valid;
 };
 
-// Workgroup -> 4 consecutive segments; block ids are remapped so that each XCD (blocks b, b+8, ...)
-// works on one contiguous range of segments, i.e. one band of the image (speed only).
+// Workgroup -> 4 consecutive segments of this launch's group range; block ids are remapped so that each
+// XCD (blocks b, b+8, ...) works on one contiguous range of segments, i.e. one band of the image
+// (speed only).
 __device__ __forceinline__ SegmentId my_segment(const WavefrontBuffers &w)
 {
-    const uint32_t groups = (w.nSeg + 3u) / 4u;
+    const uint32_t groups = w.groupCount;
     const uint32_t perXcd = (groups + 7u) / 8u;
-    const uint32_t group = (blockIdx.x % 8u) * perXcd + (blockIdx.x / 8u);
-    const uint32_t seg = group * 4u + (threadIdx.x >> 6);
+    const uint32_t local = (blockIdx.x % 8u) * perXcd + (blockIdx.x / 8u);
+    const uint32_t seg = (w.groupBase + local) * 4u + (threadIdx.x >> 6);
     SegmentId id;
     id.seg = seg;
     id.base = seg * w.segLen;
-    id.valid = group < groups && seg < w.nSeg;
+    id.valid = local < groups && seg < w.nSeg;
     return id;
 }
 
@@ -528,16 +529,15 @@ __global__ __launch_bounds__(256) void wf_accumulate(
 
 template <bool COUNT, int STACK, bool LDS_SCENE>
 static void enqueue_wavefront(
-    const DeviceScene &s, const RenderParams &p, float4 *hdr, unsigned long long *counters, const WavefrontBuffers &w,
+    const DeviceScene &s, const RenderParams &p, unsigned long long *counters, const WavefrontBuffers &w,
     uint32_t nodeCount, uint32_t triCount, int32_t *stackOverflow, LaunchTimer *timer, hipStream_t stream)
 {
     unsigned long long *cGen = counters + kStageGenerate * 16u, *cShade = counters + kStageShade * 16u,
-                       *cTrace = counters + kStageTrace * 16u, *cAcc = counters + kStageAccumulate * 16u;
+                       *cTrace = counters + kStageTrace * 16u;
     auto mark = [&](uint32_t st) {
         if (timer) timer->mark(st, stream);
     };
-    const uint32_t groups = (w.nSeg + 3u) / 4u;
-    const dim3 grid(((groups + 7u) / 8u) * 8u), block(256);
+    const dim3 grid(((w.groupCount + 7u) / 8u) * 8u), block(256);
     uint32_t bounces = p.pc.maxBounces < PROSPER_RT_MAX_BOUNCES ? p.pc.maxBounces : PROSPER_RT_MAX_BOUNCES;
     const bool debugDraw =
         p.pc.drawType != PROSPER_DRAW_TYPE_DEFAULT && p.pc.drawType != PROSPER_DRAW_TYPE_MESHLET_ID;
@@ -561,14 +561,12 @@ static void enqueue_wavefront(
                 triCount, stackOverflow, cTrace);
         }
     }
-    mark(kStageAccumulate);
-    hipLaunchKernelGGL(wf_accumulate<COUNT>, dim3((w.pixelsPadded + 255u) / 256u), block, 0, stream, p, w, hdr, cAcc);
 }
 
 uint32_t wavefront_grid_blocks(const WavefrontBuffers &w)
 {
     const uint32_t groups = (w.nSeg + 3u) / 4u;
-    return ((groups + 7u) / 8u) * 8u;
+    return ((groups + 7u) / 8u) * 8u + 16u; // + the per-chain rounding of a split launch
 }
 
 uint32_t wavefront_lds_stack_entries(uint32_t stackBound)
@@ -588,7 +586,7 @@ uint32_t wavefront_lds_stack_entries(uint32_t stackBound)
 
 template <bool COUNT>
 static void enqueue_for_stack(
-    const DeviceScene &s, const RenderParams &p, float4 *hdr, unsigned long long *counters, const WavefrontBuffers &w,
+    const DeviceScene &s, const RenderParams &p, unsigned long long *counters, const WavefrontBuffers &w,
     uint32_t ldsStackEntries, int32_t *stackOverflow, uint32_t nodeCount, uint32_t triCount, LaunchTimer *timer,
     hipStream_t stream)
 {
@@ -596,26 +594,58 @@ static void enqueue_for_stack(
     const bool ldsScene = ldsStackEntries == 16u && nodeCount * kLdsNodeStride + triCount * 3u <= kLdsSceneFloat4s &&
                           !std::getenv("PROSPER_PT_DEBUG_NO_LDS_SCENE");
     if (ldsScene)
-        enqueue_wavefront<COUNT, 16, true>(s, p, hdr, counters, w, nodeCount, triCount, stackOverflow, timer, stream);
+        enqueue_wavefront<COUNT, 16, true>(s, p, counters, w, nodeCount, triCount, stackOverflow, timer, stream);
     else if (ldsStackEntries == 16u)
-        enqueue_wavefront<COUNT, 16, false>(s, p, hdr, counters, w, nodeCount, triCount, stackOverflow, timer, stream);
+        enqueue_wavefront<COUNT, 16, false>(s, p, counters, w, nodeCount, triCount, stackOverflow, timer, stream);
     else if (ldsStackEntries == 24u)
-        enqueue_wavefront<COUNT, 24, false>(s, p, hdr, counters, w, nodeCount, triCount, stackOverflow, timer, stream);
+        enqueue_wavefront<COUNT, 24, false>(s, p, counters, w, nodeCount, triCount, stackOverflow, timer, stream);
     else
-        enqueue_wavefront<COUNT, 32, false>(s, p, hdr, counters, w, nodeCount, triCount, stackOverflow, timer, stream);
+        enqueue_wavefront<COUNT, 32, false>(s, p, counters, w, nodeCount, triCount, stackOverflow, timer, stream);
 }
 
 void launch_render_wavefront(
     const DeviceScene &s, const RenderParams &p, float4 *hdr, unsigned long long *counters, const WavefrontBuffers &w,
-    uint32_t ldsStackEntries, int32_t *stackOverflow, uint32_t nodeCount, uint32_t triCount, bool countWork,
-    LaunchTimer *timer, hipStream_t stream)
+    uint32_t ldsStackEntries, int32_t *stackOverflow, uint32_t overflowEntries, uint32_t nodeCount, uint32_t triCount,
+    bool countWork, LaunchTimer *timer, const WavefrontChains &chains, hipStream_t stream)
 {
     if (w.nSeg == 0) return;
     static_assert(kTraversalStackDepth == 32, "largest LDS stack variant");
+    const uint32_t groups = (w.nSeg + 3u) / 4u;
+    // Two chains only pay when each still fills the machine a few times over (>= 1024 workgroups each).
+    const uint32_t parts = (chains.count >= 2u && groups >= 2048u) ? 2u : 1u;
+    const uint32_t per = (groups + parts - 1u) / parts;
+    if (parts > 1u) (void)hipEventRecord(chains.fork, stream);
+    uint32_t blocksBefore = 0;
+    for (uint32_t i = 0; i < parts; ++i)
+    {
+        WavefrontBuffers part = w;
+        part.groupBase = i * per;
+        part.groupCount = (part.groupBase + per <= groups) ? per : groups - part.groupBase;
+        hipStream_t cs = parts > 1u ? chains.streams[i] : stream;
+        LaunchTimer *ct = parts > 1u ? chains.timers[i] : timer;
+        if (parts > 1u) (void)hipStreamWaitEvent(cs, chains.fork, 0);
+        // every chain gets its own region of the stack-overflow array: its kernels index it by their own
+        // blockIdx / gridDim (TraversalStack), and the chains run concurrently
+        int32_t *ovf = stackOverflow ? stackOverflow + (size_t)blocksBefore * 256u * overflowEntries : nullptr;
+        if (countWork)
+            enqueue_for_stack<true>(s, p, counters, part, ldsStackEntries, ovf, nodeCount, triCount, ct, cs);
+        else
+            enqueue_for_stack<false>(s, p, counters, part, ldsStackEntries, ovf, nodeCount, triCount, ct, cs);
+        blocksBefore += ((part.groupCount + 7u) / 8u) * 8u;
+        if (parts > 1u)
+        {
+            if (ct) ct->close(cs);
+            (void)hipEventRecord(chains.join[i], cs);
+            (void)hipStreamWaitEvent(stream, chains.join[i], 0);
+        }
+    }
+    if (timer) timer->mark(kStageAccumulate, stream);
+    unsigned long long *cAcc = counters + kStageAccumulate * 16u;
+    const dim3 grid((w.pixelsPadded + 255u) / 256u), block(256);
     if (countWork)
-        enqueue_for_stack<true>(s, p, hdr, counters, w, ldsStackEntries, stackOverflow, nodeCount, triCount, timer, stream);
+        hipLaunchKernelGGL(wf_accumulate<true>, grid, block, 0, stream, p, w, hdr, cAcc);
     else
-        enqueue_for_stack<false>(s, p, hdr, counters, w, ldsStackEntries, stackOverflow, nodeCount, triCount, timer, stream);
+        hipLaunchKernelGGL(wf_accumulate<false>, grid, block, 0, stream, p, w, hdr, cAcc);
 }
 
 } // namespace ppt

@@ -153,6 +153,7 @@ WRAP_REPEAT, WRAP_MIRRORED_REPEAT, WRAP_CLAMP_TO_EDGE = 0, 1, 2
 
 CREATE_MEGAKERNEL = 1 << 0
 CREATE_PERSISTENT = 1 << 1
+CREATE_SINGLE_CHAIN = 1 << 2
 RENDER_COUNT_WORK = 1 << 0
 MAX_KERNELS = 8
 

@@ -17,6 +17,7 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--megakernel", action="store_true")
     ap.add_argument("--persistent", action="store_true")
+    ap.add_argument("--single-chain", action="store_true", help="PROSPER_PT_CREATE_SINGLE_CHAIN (A/B)")
     ap.add_argument("--stats", action="store_true")
     ap.add_argument("--counters", action="store_true", help="one counted render: per-stage work counters")
     ap.add_argument("--spp", type=int, default=0)
@@ -42,7 +43,8 @@ def main():
     h = args.height or h
     world = builder()
     cam, focal = Camera.from_world(world, w, h).update_buffer()
-    ctx = capi.Context(0, S.CREATE_MEGAKERNEL if args.megakernel else (S.CREATE_PERSISTENT if args.persistent else 0))
+    ctx = capi.Context(0, S.CREATE_MEGAKERNEL if args.megakernel else (
+        S.CREATE_PERSISTENT if args.persistent else (S.CREATE_SINGLE_CHAIN if args.single_chain else 0)))
     ctx.upload_scene(world)
     if args.stats:
         st = ctx.scene_stats()

@@ -487,6 +487,38 @@ def test_c5_rank_tile_chunked_batch_properties(gpu_ctx, oracle, cornell_world):
     assert same_bits(t2, full[:, cols]).all()
 
 
+def test_two_launch_chains_equal_one_chain(gpu_ctx, oracle, sponza_small, monkeypatch):
+    """The default pipeline runs the segment groups as two chains of launches on two internal streams
+    (tails of one overlap the other); PROSPER_PT_CREATE_SINGLE_CHAIN runs one chain on the caller's stream.
+    Same pixels, same counters - also when the traversal stacks spill to the (per-chain) global overflow
+    region, which a 16-entry LDS stack forces on this tree."""
+    from prosper_amd import capi
+    w, h = 1920, 1080  # 16 k segments: large enough for the split to happen
+    cam, fl = _camera(oracle, sponza_small, w, h)
+    pc = default_pc(S, fl, max_bounces=3, ibl=True)
+    single = capi.Context(device=0, flags=S.CREATE_SINGLE_CHAIN)
+    try:
+        for forced in (None, "16"):
+            if forced:
+                monkeypatch.setenv("PROSPER_PT_DEBUG_STACK", forced)
+            out = []
+            for ctx in (gpu_ctx, single):
+                ctx.upload_scene(sponza_small)
+                ctx.reset_counters()
+                ctx.set_kernel_timing(True)
+                ctx.render(pc, cam, w, h, frames=2, flags=S.RENDER_COUNT_WORK)
+                total, per = ctx.last_render_timing()
+                ctx.set_kernel_timing(False)
+                out.append((ctx.read_hdr(), ctx.counters().as_dict(), per))
+            assert same_bits(out[0][0], out[1][0]).all(), forced
+            for k in ("paths", "closestRays", "shadowRays", "closestHits", "nodeVisits", "triangleTests", "skyLookups"):
+                assert out[0][1][k] == out[1][1][k], (forced, k)
+            assert out[0][2]["wf_trace"][1] == 2 * out[1][2]["wf_trace"][1]  # twice the launches, half the size
+    finally:
+        monkeypatch.delenv("PROSPER_PT_DEBUG_STACK", raising=False)
+        single.close()
+
+
 def test_all_pipelines_produce_identical_pixels(gpu_ctx, oracle, cornell_world):
     """Default wavefront pipeline, PROSPER_PT_CREATE_PERSISTENT and PROSPER_PT_CREATE_MEGAKERNEL are
     the same function of (pixel, frame): identical images, identical counters, all equal to the oracle."""
