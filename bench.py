@@ -252,6 +252,10 @@ def main():
                 }
         dominant = max(kernels, key=lambda k: kernels[k]["ms_per_launch"] * kernels[k]["launches_per_step"])
         achieved = kernels[dominant]["achieved_GBps"]
+        # with two concurrent launch chains the per-launch durations overlap in time: the share of the step's
+        # device time a launch accounts for is its duration scaled by (device time per step) / (sum of durations)
+        summed_ms = sum(k["ms_per_launch"] * k["launches_per_step"] for k in kernels.values())
+        exclusive_scale = min(1.0, kernel_ms / summed_ms) if summed_ms > 0 else 1.0
         result = {
             "metric": "Mpaths/s",
             "value": paths_per_step * args.steps / elapsed / 1e6,
@@ -294,6 +298,8 @@ def main():
                 # duration (hipEvents, = rocprofv3's) includes the time it shares the GPU with the other chain's
                 # launch, so sum(kernel time) > wall time and `frac` is a per-launch, not a whole-GPU, figure
                 "concurrent_chains": 1 if (args.single_chain or args.megakernel or args.persistent) else 2,
+                "kernel_ms_exclusive": kernels[dominant]["ms_per_launch"] * exclusive_scale,
+                "frac_exclusive": achieved / exclusive_scale / HBM_PEAK_GBS,
             },
             "kernels": kernels,
             "whole_pass": {
