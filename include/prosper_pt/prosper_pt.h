@@ -245,7 +245,10 @@ int prosper_pt_get_scene_stats(prosper_pt_ctx *ctx, prosper_pt_scene_stats *out)
 int prosper_pt_set_output_buffer(prosper_pt_ctx *ctx, void *device_rgba32f, size_t byte_size);
 
 /* One accumulated frame = one path per pixel (the reference's traceRaysKHR(W,H,1)).
- * `stream` is a hipStream_t (NULL = the null stream); the call only enqueues work. */
+ * `stream` is a hipStream_t (NULL = the null stream); the call only enqueues work.  Stream semantics are
+ * those of a kernel launch on `stream`: the render starts after the work already queued there and work
+ * queued afterwards sees its result.  (Internally large batches run as two chains of launches on two
+ * streams the context owns, forked from and joined back into `stream` with events.) */
 int prosper_pt_render(
     prosper_pt_ctx *ctx, const prosper_ReferencePC *pc, const prosper_CameraUniforms *camera,
     uint32_t width, uint32_t height, const prosper_pt_tile_desc *tile, uint32_t render_flags,
@@ -277,8 +280,11 @@ int prosper_pt_get_stage_counters(prosper_pt_ctx *ctx, uint32_t stage, prosper_p
 int prosper_pt_reset_counters(prosper_pt_ctx *ctx, void *stream);
 
 /* Device time (ms) of the kernels launched by the last `prosper_pt_render(_frames)`, measured with
- * hipEvents on the launch stream; blocks until they finish.  kernel_ms[i] is the SUM over the
- * kernel_launches[i] launches of stage i, named by prosper_pt_kernel_name(i). */
+ * hipEvents around every launch on the stream it was launched on; blocks until they finish.
+ * total_ms is the time on the caller's stream (wall time of the render on the device).  kernel_ms[i] is
+ * the SUM over the kernel_launches[i] launches of stage i, named by prosper_pt_kernel_name(i); with the
+ * two-chain default a launch that shared the GPU with the other chain's launch counts in full, so the
+ * kernel_ms can add up to more than total_ms. */
 #define PROSPER_PT_MAX_KERNELS 8
 int prosper_pt_get_last_render_ms(prosper_pt_ctx *ctx, float *total_ms, float kernel_ms[PROSPER_PT_MAX_KERNELS]);
 int prosper_pt_get_last_render_timing(
