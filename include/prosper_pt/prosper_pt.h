@@ -273,6 +273,18 @@ int prosper_pt_read_hdr(prosper_pt_ctx *ctx, float *rgba32f, size_t byte_size, v
 /* RGBA32F -> RGBA16F (round-to-nearest-even), the image later passes consume. */
 int prosper_pt_blit_rgba16f(prosper_pt_ctx *ctx, uint16_t *host_rgba16f, size_t byte_size, void *stream);
 
+/* The step after the path: prosper tone-maps the RGBA16F illumination into an RGBA8 UNORM
+ * image with res/shader/tone_map.comp (src/render/ToneMap.cpp:62-128): exposure, HSV contrast, the
+ * Tony McMapface 3-D LUT (res/texture/tony_mc_mapface.dds, 48^3 R9G9B9E5, linear / clamp sampler), 1/2.2
+ * gamma.  prosper_pt_set_tone_map_lut copies dim^3 R9G9B9E5 texels (x fastest) to the device;
+ * prosper_pt_tone_map runs blit + tone map in one kernel over the current HDR tile and writes
+ * localWidth*height RGBA8 texels to `device_rgba8` (device memory, may be NULL) and/or `host_rgba8`
+ * (host memory, may be NULL; synchronises `stream`). */
+int prosper_pt_set_tone_map_lut(prosper_pt_ctx *ctx, const uint32_t *lut_r9g9b9e5, uint32_t dim);
+int prosper_pt_tone_map(
+    prosper_pt_ctx *ctx, float exposure, float contrast, void *device_rgba8, uint8_t *host_rgba8, size_t byte_size,
+    void *stream);
+
 int prosper_pt_get_counters(prosper_pt_ctx *ctx, prosper_pt_counters *out, void *stream);
 /* The same counters for one kernel stage (index as in prosper_pt_kernel_name): lets the roofline
  * of a single kernel be priced from the work that kernel did. */

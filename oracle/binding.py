@@ -70,6 +70,8 @@ def lib():
         L.ora_unpack_half.argtypes = [C.c_uint16]
         L.ora_pack_snorm3x10_1x2.restype = C.c_uint32
         L.ora_pack_snorm3x10_1x2.argtypes = [C.POINTER(C.c_float)]
+        L.ora_tone_map.restype = None
+        L.ora_tone_map.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_float, C.c_float, C.c_void_p, C.c_uint64]
         L.ora_eval_fn.restype = C.c_int
         L.ora_eval_fn.argtypes = [C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_uint32]
         L.ora_camera_uniforms.argtypes = [
@@ -147,6 +149,16 @@ def eval_fn(fn, inputs):
     rc = lib().ora_eval_fn(fid, a.ctypes.data, in_stride, out.ctypes.data, out_stride, a.shape[0])
     if rc != 0:
         raise ValueError("unknown oracle fn %r" % (fn,))
+    return out
+
+
+def tone_map(hdr, lut_r9g9b9e5, exposure=1.0, contrast=1.0):
+    """oracle.c ora_tone_map: RGBA32F [h, w, 4] + uint32 [dim, dim, dim] R9G9B9E5 LUT -> uint8 [h, w, 4]."""
+    hdr = np.ascontiguousarray(hdr, dtype=np.float32)
+    lut = np.ascontiguousarray(lut_r9g9b9e5, dtype=np.uint32)
+    assert hdr.shape[-1] == 4 and lut.ndim == 3 and lut.shape[0] == lut.shape[1] == lut.shape[2]
+    out = np.empty(hdr.shape, np.uint8)
+    lib().ora_tone_map(hdr.ctypes.data, lut.ctypes.data, lut.shape[0], exposure, contrast, out.ctypes.data, hdr.size // 4)
     return out
 
 

@@ -1666,6 +1666,124 @@ void ora_camera_uniforms(
  * Known-answer test dispatcher
  * ---------------------------------------------------------------------------------------- */
 
+/* ------------------------------------------------------------------------------------------
+ * Tone map (res/shader/tone_map.comp, common/math.glsl:17-85).  Arithmetic contract additions:
+ * mod(x, y) = x - y * floor(x / y) (GLSL), pow through ora_pow, constants as the GLSL front end folds
+ * them (47/48, 0.5/48, 1/2.2), R9G9B9E5 decode mantissa * 2^(e - 24) (exact), trilinear weights in fp32
+ * summed as an fma chain in the order (x0y0z0, x1y0z0, x0y1z0, x1y1z0, x0y0z1, ...), UNORM8 store =
+ * round-half-even(saturate(x) * 255) with NaN -> 0.
+ * ---------------------------------------------------------------------------------------- */
+static inline float ora_mod(float x, float y) { return x - y * floorf(x / y); }
+
+static ora_v3 rgb_to_hsv(ora_v3 rgb) /* math.glsl:17-44 */
+{
+    const float value = ora_max(ora_max(rgb.x, rgb.y), rgb.z);
+    const float valueMinusChroma = ora_min(ora_min(rgb.x, rgb.y), rgb.z);
+    const float chroma = value - valueMinusChroma;
+    float hue;
+    if (chroma == 0.0f)
+        hue = 0.0f;
+    else if (value == rgb.x)
+        hue = ora_mod((rgb.y - rgb.z) / chroma, 6.0f);
+    else if (value == rgb.y)
+        hue = (rgb.z - rgb.x) / chroma + 2.0f;
+    else
+        hue = (rgb.x - rgb.y) / chroma + 4.0f;
+    const float saturation = value == 0.0f ? 0.0f : chroma / value;
+    return ora_v3_make(hue, saturation, value);
+}
+
+static ora_v3 hsv_to_rgb(ora_v3 hsv) /* math.glsl:47-83 */
+{
+    const float hue = hsv.x, saturation = hsv.y, value = hsv.z;
+    const float chroma = value * saturation;
+    const float x = chroma * (1.0f - ora_abs(ora_mod(hue, 2.0f) - 1.0f));
+    ora_v3 rgb;
+    if (hue < 1.0f)
+        rgb = ora_v3_make(chroma, x, 0.0f);
+    else if (hue < 2.0f)
+        rgb = ora_v3_make(x, chroma, 0.0f);
+    else if (hue < 3.0f)
+        rgb = ora_v3_make(0.0f, chroma, x);
+    else if (hue < 4.0f)
+        rgb = ora_v3_make(0.0f, x, chroma);
+    else if (hue < 5.0f)
+        rgb = ora_v3_make(x, 0.0f, chroma);
+    else
+        rgb = ora_v3_make(chroma, 0.0f, x);
+    const float m = value - chroma;
+    return ora_v3_make(rgb.x + m, rgb.y + m, rgb.z + m);
+}
+
+static inline ora_v3 decode_r9g9b9e5(uint32_t p)
+{
+    const float scale = ora_u2f(((p >> 27) + 103u) << 23); /* 2^(e - 15 - 9) */
+    return ora_v3_make((float)(p & 0x1FFu) * scale, (float)((p >> 9) & 0x1FFu) * scale, (float)((p >> 18) & 0x1FFu) * scale);
+}
+
+static inline int32_t clamp_texel(int32_t i, int32_t n) { return i < 0 ? 0 : (i >= n ? n - 1 : i); }
+
+/* textureLod(sampler3D(lut, linear/clamp), uv, 0).xyz */
+static ora_v3 sample_lut(const uint32_t *lut, int32_t n, ora_v3 uv)
+{
+    const float u = fmaf(uv.x, (float)n, -0.5f), v = fmaf(uv.y, (float)n, -0.5f), w = fmaf(uv.z, (float)n, -0.5f);
+    const float fu = floorf(u), fv = floorf(v), fw = floorf(w);
+    const float a = u - fu, b = v - fv, c = w - fw;
+    const int32_t i0 = clamp_texel(ora_f2i(fu), n), i1 = clamp_texel(ora_f2i(fu) + 1, n);
+    const int32_t j0 = clamp_texel(ora_f2i(fv), n), j1 = clamp_texel(ora_f2i(fv) + 1, n);
+    const int32_t k0 = clamp_texel(ora_f2i(fw), n), k1 = clamp_texel(ora_f2i(fw) + 1, n);
+    const int32_t is[2] = {i0, i1}, js[2] = {j0, j1}, ks[2] = {k0, k1};
+    const float wx[2] = {1.0f - a, a}, wy[2] = {1.0f - b, b}, wz[2] = {1.0f - c, c};
+    ora_v3 acc = ora_v3_make(0.0f, 0.0f, 0.0f);
+    for (int z = 0; z < 2; ++z)
+        for (int y = 0; y < 2; ++y)
+            for (int x = 0; x < 2; ++x)
+            {
+                const ora_v3 t = decode_r9g9b9e5(lut[((size_t)ks[z] * n + (size_t)js[y]) * n + (size_t)is[x]]);
+                const float wgt = (wx[x] * wy[y]) * wz[z];
+                if (x == 0 && y == 0 && z == 0)
+                    acc = ora_v3_make(wgt * t.x, wgt * t.y, wgt * t.z);
+                else
+                    acc = ora_v3_make(fmaf(wgt, t.x, acc.x), fmaf(wgt, t.y, acc.y), fmaf(wgt, t.z, acc.z));
+            }
+    return acc;
+}
+
+static inline uint8_t to_unorm8(float x)
+{
+    if (x != x) return 0;
+    return (uint8_t)rintf(ora_clamp(x, 0.0f, 1.0f) * 255.0f);
+}
+
+void ora_tone_map(
+    const float *hdr, const uint32_t *lut, uint32_t dim, float exposure, float contrast, uint8_t *out, uint64_t count)
+{
+#pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < (int64_t)count; ++i)
+    {
+        /* the RGBA16F image the tone map reads (blit of the RGBA32F accumulation, round-to-nearest-even) */
+        ora_v3 color = ora_v3_make(
+            ora_half_to_float(ora_float_to_half(hdr[4 * i + 0])), ora_half_to_float(ora_float_to_half(hdr[4 * i + 1])),
+            ora_half_to_float(ora_float_to_half(hdr[4 * i + 2])));
+        color = ora_v3_make(color.x * exposure, color.y * exposure, color.z * exposure);
+        ora_v3 hsv = rgb_to_hsv(color);
+        hsv.z = ora_pow(hsv.z, contrast);
+        color = hsv_to_rgb(hsv);
+        /* tonyMcMapface, tone_map.comp:17-29 */
+        const ora_v3 enc = ora_v3_make(color.x / (color.x + 1.0f), color.y / (color.y + 1.0f), color.z / (color.z + 1.0f));
+        const float k1 = 47.0f / 48.0f, k0 = 0.5f / 48.0f;
+        const float kd1 = ((float)dim - 1.0f) / (float)dim, kd0 = 0.5f / (float)dim;
+        const float s1 = dim == 48u ? k1 : kd1, s0 = dim == 48u ? k0 : kd0;
+        const ora_v3 uv = ora_v3_make(enc.x * s1 + s0, enc.y * s1 + s0, enc.z * s1 + s0);
+        color = sample_lut(lut, (int32_t)dim, uv);
+        const float invGamma = 1.0f / 2.2f;
+        out[4 * i + 0] = to_unorm8(ora_pow(color.x, invGamma));
+        out[4 * i + 1] = to_unorm8(ora_pow(color.y, invGamma));
+        out[4 * i + 2] = to_unorm8(ora_pow(color.z, invGamma));
+        out[4 * i + 3] = 255;
+    }
+}
+
 int ora_eval_fn(uint32_t fn, const float *in, uint32_t in_stride, float *out, uint32_t out_stride, uint32_t n)
 {
     for (uint32_t i = 0; i < n; ++i)

@@ -79,6 +79,14 @@ uint32_t ora_pack_snorm3x10_1x2(const float v[4]);
 /* Evaluates function `fn` over n records; see oracle.c:ora_eval_fn for the record layouts. */
 int ora_eval_fn(uint32_t fn, const float *in, uint32_t in_stride, float *out, uint32_t out_stride, uint32_t n);
 
+/* The step after the path: RGBA32F -> RGBA16F blit (RtReference.cpp:339-377) followed by
+ * res/shader/tone_map.comp:17-60 (exposure, HSV contrast, Tony McMapface 3-D LUT lookup, 1/2.2 gamma) into
+ * RGBA8 UNORM (ToneMap.cpp:62-128).  `lut` = dim^3 R9G9B9E5 texels (x fastest), sampled like
+ * textureLod(sampler3D, uv, 0) with a linear / clamp-to-edge sampler. */
+void ora_tone_map(
+    const float *hdr_rgba32f, const uint32_t *lut_r9g9b9e5, uint32_t dim, float exposure, float contrast,
+    uint8_t *out_rgba8, uint64_t pixel_count);
+
 /* ---- host-side mirrors ---- */
 /* Camera::updateWorldToCamera + Camera::perspective + updateBuffer (src/scene/Camera.cpp:105-204,
  * 366-395) for a non-jittered camera; also returns CameraParameters::focalLength. */

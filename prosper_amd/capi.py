@@ -60,6 +60,8 @@ def lib():
     L.prosper_pt_get_hdr_device_ptr.argtypes = [vp, C.POINTER(vp), C.POINTER(C.c_size_t)]
     L.prosper_pt_read_hdr.argtypes = [vp, vp, C.c_size_t, vp]
     L.prosper_pt_blit_rgba16f.argtypes = [vp, vp, C.c_size_t, vp]
+    L.prosper_pt_set_tone_map_lut.argtypes = [vp, vp, u32]
+    L.prosper_pt_tone_map.argtypes = [vp, C.c_float, C.c_float, vp, vp, C.c_size_t, vp]
     L.prosper_pt_get_counters.argtypes = [vp, C.POINTER(S.Counters), vp]
     L.prosper_pt_reset_counters.argtypes = [vp, vp]
     L.prosper_pt_get_stage_counters.argtypes = [vp, u32, C.POINTER(S.Counters), vp]
@@ -186,6 +188,20 @@ class Context:
         lw, h = self.local_extent()
         out = np.empty((h, lw, 4), np.float16)
         _check(lib().prosper_pt_blit_rgba16f(self._h, out.ctypes.data, out.nbytes, C.c_void_p(stream)))
+        return out
+
+    def set_tone_map_lut(self, lut_r9g9b9e5):
+        """lut: uint32 [dim, dim, dim] (z, y, x) R9G9B9E5 texels, e.g. from prosper_amd.dds.read_lut."""
+        lut = np.ascontiguousarray(lut_r9g9b9e5, dtype=np.uint32)
+        assert lut.ndim == 3 and lut.shape[0] == lut.shape[1] == lut.shape[2]
+        _check(lib().prosper_pt_set_tone_map_lut(self._h, lut.ctypes.data, lut.shape[0]))
+
+    def tone_map(self, exposure=1.0, contrast=1.0, device_ptr=None, to_host=True, stream=None):
+        """tone_map.comp over the current HDR tile -> uint8 [h, localWidth, 4] (or None with to_host=False)."""
+        lw, h = self.local_extent()
+        out = np.empty((h, lw, 4), np.uint8) if to_host else None
+        _check(lib().prosper_pt_tone_map(self._h, exposure, contrast, C.c_void_p(device_ptr),
+                                         out.ctypes.data if to_host else None, lw * h * 4, C.c_void_p(stream)))
         return out
 
     def counters(self, stream=None):

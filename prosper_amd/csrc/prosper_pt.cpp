@@ -87,6 +87,11 @@ struct prosper_pt_ctx
     uint32_t timedLaunches = 0;
     bool timingValid = false;
 
+    uint32_t *toneLut = nullptr; // dim^3 R9G9B9E5 texels
+    uint32_t toneLutDim = 0;
+    void *toneScratch = nullptr; // RGBA8 output when the caller only wants a host copy
+    size_t toneScratchBytes = 0;
+
     // the two launch chains of the wavefront pipeline (pt_kernels.hpp WavefrontChains)
     hipStream_t chainStreams[2] = {};
     hipEvent_t chainFork = nullptr;
@@ -542,6 +547,8 @@ void prosper_pt_destroy(prosper_pt_ctx *ctx)
     if (ctx->dWorkCounter) (void)hipFree(ctx->dWorkCounter);
     if (ctx->wfBlock) (void)hipFree(ctx->wfBlock);
     if (ctx->stackOverflow) (void)hipFree(ctx->stackOverflow);
+    if (ctx->toneLut) (void)hipFree(ctx->toneLut);
+    if (ctx->toneScratch) (void)hipFree(ctx->toneScratch);
     for (auto &e : ctx->events)
         if (e) (void)hipEventDestroy(e);
     for (int i = 0; i < 2; ++i)
@@ -801,6 +808,57 @@ int prosper_pt_blit_rgba16f(prosper_pt_ctx *ctx, uint16_t *host_rgba16f, size_t 
     if (e == hipSuccess) e = hipStreamSynchronize(s);
     (void)hipFree(tmp);
     if (e != hipSuccess) return fail(PROSPER_PT_ERR_HIP, std::string("blit: ") + hipGetErrorString(e));
+    return PROSPER_PT_OK;
+}
+
+int prosper_pt_set_tone_map_lut(prosper_pt_ctx *ctx, const uint32_t *lut, uint32_t dim)
+{
+    if (!ctx || !lut || dim < 2 || dim > 256) return fail(PROSPER_PT_ERR_INVALID_ARGUMENT, "prosper_pt_set_tone_map_lut: bad argument");
+    PPT_HIP(hipSetDevice(ctx->device));
+    PPT_HIP(hipDeviceSynchronize());
+    if (ctx->toneLut) PPT_HIP(hipFree(ctx->toneLut));
+    ctx->toneLut = nullptr;
+    ctx->toneLutDim = 0;
+    const size_t bytes = (size_t)dim * dim * dim * sizeof(uint32_t);
+    PPT_HIP(hipMalloc((void **)&ctx->toneLut, bytes));
+    PPT_HIP(hipMemcpy(ctx->toneLut, lut, bytes, hipMemcpyHostToDevice));
+    ctx->toneLutDim = dim;
+    return PROSPER_PT_OK;
+}
+
+int prosper_pt_tone_map(
+    prosper_pt_ctx *ctx, float exposure, float contrast, void *device_rgba8, uint8_t *host_rgba8, size_t byte_size,
+    void *stream)
+{
+    if (!ctx || (!device_rgba8 && !host_rgba8)) return fail(PROSPER_PT_ERR_INVALID_ARGUMENT, "prosper_pt_tone_map: null argument");
+    if (!ctx->hdr) return fail(PROSPER_PT_ERR_NO_SCENE, "nothing has been rendered yet");
+    if (!ctx->toneLut) return fail(PROSPER_PT_ERR_INVALID_ARGUMENT, "prosper_pt_tone_map: no LUT (prosper_pt_set_tone_map_lut)");
+    const uint32_t count = ctx->localWidth * ctx->height;
+    const size_t bytes = (size_t)count * 4u;
+    if (byte_size < bytes) return fail(PROSPER_PT_ERR_INVALID_ARGUMENT, "prosper_pt_tone_map: destination too small");
+    PPT_HIP(hipSetDevice(ctx->device));
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    void *out = device_rgba8;
+    if (!out)
+    {
+        if (ctx->toneScratchBytes < bytes)
+        {
+            PPT_HIP(hipStreamSynchronize(s));
+            if (ctx->toneScratch) PPT_HIP(hipFree(ctx->toneScratch));
+            ctx->toneScratch = nullptr;
+            ctx->toneScratchBytes = 0;
+            PPT_HIP(hipMalloc(&ctx->toneScratch, bytes + 16));
+            ctx->toneScratchBytes = bytes;
+        }
+        out = ctx->toneScratch;
+    }
+    launch_tone_map(ctx->hdr, ctx->toneLut, ctx->toneLutDim, exposure, contrast, out, count, s);
+    PPT_HIP(hipGetLastError());
+    if (host_rgba8)
+    {
+        PPT_HIP(hipMemcpyAsync(host_rgba8, out, bytes, hipMemcpyDeviceToHost, s));
+        PPT_HIP(hipStreamSynchronize(s));
+    }
     return PROSPER_PT_OK;
 }
 

@@ -501,6 +501,136 @@ void launch_blit_rgba16f(const float4 *in, void *out, uint32_t count, hipStream_
 }
 
 // ------------------------------------------------------------------------------------------
+// tone map: the step after the path (res/shader/tone_map.comp:17-60, src/render/ToneMap.cpp:62-128),
+// fused with the RGBA32F -> RGBA16F blit it reads through (RtReference.cpp:339-377).  One thread per
+// pixel: 16 B in, 4 B out, eight taps of the 442 KB LUT (L2-resident).  Arithmetic: DESIGN.md
+// "tone map" (GLSL mod, pow through pow_, folded constants, exact R9G9B9E5 decode, fma-chain trilinear).
+// ------------------------------------------------------------------------------------------
+
+PPT_D float mod_(float x, float y) { return x - y * __builtin_floorf(x / y); }
+
+// common/math.glsl:17-44
+PPT_D f3 rgb_to_hsv(f3 rgb)
+{
+    const float value = fmax_(fmax_(rgb.x, rgb.y), rgb.z);
+    const float valueMinusChroma = fmin_(fmin_(rgb.x, rgb.y), rgb.z);
+    const float chroma = value - valueMinusChroma;
+    float hue;
+    if (chroma == 0.0f)
+        hue = 0.0f;
+    else if (value == rgb.x)
+        hue = mod_((rgb.y - rgb.z) / chroma, 6.0f);
+    else if (value == rgb.y)
+        hue = (rgb.z - rgb.x) / chroma + 2.0f;
+    else
+        hue = (rgb.x - rgb.y) / chroma + 4.0f;
+    const float saturation = value == 0.0f ? 0.0f : chroma / value;
+    return f3{hue, saturation, value};
+}
+
+// common/math.glsl:47-83
+PPT_D f3 hsv_to_rgb(f3 hsv)
+{
+    const float hue = hsv.x, saturation = hsv.y, value = hsv.z;
+    const float chroma = value * saturation;
+    const float x = chroma * (1.0f - fabs_(mod_(hue, 2.0f) - 1.0f));
+    f3 rgb;
+    if (hue < 1.0f)
+        rgb = f3{chroma, x, 0.0f};
+    else if (hue < 2.0f)
+        rgb = f3{x, chroma, 0.0f};
+    else if (hue < 3.0f)
+        rgb = f3{0.0f, chroma, x};
+    else if (hue < 4.0f)
+        rgb = f3{0.0f, x, chroma};
+    else if (hue < 5.0f)
+        rgb = f3{x, 0.0f, chroma};
+    else
+        rgb = f3{chroma, 0.0f, x};
+    const float m = value - chroma;
+    return f3{rgb.x + m, rgb.y + m, rgb.z + m};
+}
+
+PPT_D f3 decode_r9g9b9e5(uint32_t p)
+{
+    const float scale = u2f(((p >> 27) + 103u) << 23); // 2^(e - 15 - 9)
+    return f3{(float)(p & 0x1FFu) * scale, (float)((p >> 9) & 0x1FFu) * scale, (float)((p >> 18) & 0x1FFu) * scale};
+}
+
+PPT_D int32_t clamp_texel(int32_t i, int32_t n) { return i < 0 ? 0 : (i >= n ? n - 1 : i); }
+
+// textureLod(sampler3D(lut, linear / clamp-to-edge), uv, 0).xyz
+PPT_D f3 sample_lut(const uint32_t *__restrict__ lut, int32_t n, f3 uv)
+{
+    const float u = __builtin_fmaf(uv.x, (float)n, -0.5f), v = __builtin_fmaf(uv.y, (float)n, -0.5f),
+                w = __builtin_fmaf(uv.z, (float)n, -0.5f);
+    const float fu = __builtin_floorf(u), fv = __builtin_floorf(v), fw = __builtin_floorf(w);
+    const float a = u - fu, b = v - fv, c = w - fw;
+    const int32_t is[2] = {clamp_texel(f2i(fu), n), clamp_texel(f2i(fu) + 1, n)};
+    const int32_t js[2] = {clamp_texel(f2i(fv), n), clamp_texel(f2i(fv) + 1, n)};
+    const int32_t ks[2] = {clamp_texel(f2i(fw), n), clamp_texel(f2i(fw) + 1, n)};
+    const float wx[2] = {1.0f - a, a}, wy[2] = {1.0f - b, b}, wz[2] = {1.0f - c, c};
+    f3 acc = {0.0f, 0.0f, 0.0f};
+#pragma unroll
+    for (int z = 0; z < 2; ++z)
+#pragma unroll
+        for (int y = 0; y < 2; ++y)
+#pragma unroll
+            for (int x = 0; x < 2; ++x)
+            {
+                const f3 t = decode_r9g9b9e5(lut[((size_t)ks[z] * n + (size_t)js[y]) * n + (size_t)is[x]]);
+                const float wgt = (wx[x] * wy[y]) * wz[z];
+                if (x == 0 && y == 0 && z == 0)
+                    acc = f3{wgt * t.x, wgt * t.y, wgt * t.z};
+                else
+                    acc = f3{__builtin_fmaf(wgt, t.x, acc.x), __builtin_fmaf(wgt, t.y, acc.y), __builtin_fmaf(wgt, t.z, acc.z)};
+            }
+    return acc;
+}
+
+PPT_D uint32_t to_unorm8(float x)
+{
+    if (x != x) return 0u;
+    return (uint32_t)__builtin_rintf(clamp_(x, 0.0f, 1.0f) * 255.0f);
+}
+
+__global__ __launch_bounds__(256) void tone_map_kernel(
+    const float4 *__restrict__ hdr, const uint32_t *__restrict__ lut, uint32_t dim, float exposure, float contrast,
+    uint32_t *__restrict__ out, uint32_t count)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    const float4 h = hdr[i];
+    // the RGBA16F image the tone map reads: the blit rounds to nearest even
+    // (v_cvt_f16_f32 / v_cvt_f32_f16: the same values as float_to_half / half_to_float; a NaN's payload may
+    // differ but cannot reach the UNORM8 output)
+    f3 color = f3{(float)(_Float16)h.x, (float)(_Float16)h.y, (float)(_Float16)h.z};
+    color = color * exposure;
+    f3 hsv = rgb_to_hsv(color);
+    hsv.z = pow_(hsv.z, contrast);
+    color = hsv_to_rgb(hsv);
+    // tonyMcMapface, tone_map.comp:17-29
+    const f3 enc = f3{color.x / (color.x + 1.0f), color.y / (color.y + 1.0f), color.z / (color.z + 1.0f)};
+    const float s1 = dim == 48u ? 47.0f / 48.0f : ((float)dim - 1.0f) / (float)dim;
+    const float s0 = dim == 48u ? 0.5f / 48.0f : 0.5f / (float)dim;
+    const f3 uv = f3{enc.x * s1 + s0, enc.y * s1 + s0, enc.z * s1 + s0};
+    color = sample_lut(lut, (int32_t)dim, uv);
+    const float invGamma = 1.0f / 2.2f;
+    out[i] = to_unorm8(pow_(color.x, invGamma)) | (to_unorm8(pow_(color.y, invGamma)) << 8) |
+             (to_unorm8(pow_(color.z, invGamma)) << 16) | 0xFF000000u;
+}
+
+void launch_tone_map(
+    const float4 *hdr, const uint32_t *lut, uint32_t dim, float exposure, float contrast, void *outRgba8, uint32_t count,
+    hipStream_t stream)
+{
+    if (count == 0) return;
+    hipLaunchKernelGGL(
+        tone_map_kernel, dim3((count + 255) / 256), dim3(256), 0, stream, hdr, lut, dim, exposure, contrast,
+        static_cast<uint32_t *>(outRgba8), count);
+}
+
+// ------------------------------------------------------------------------------------------
 // device self-test
 // ------------------------------------------------------------------------------------------
 

@@ -46,6 +46,9 @@ void launch_flatten_triangles(
     WorldTriangle *out, ShadeTriangle *shadeOut, uint32_t total, hipStream_t stream);
 void launch_permute_triangles(
     const WorldTriangle *in, const uint32_t *permutation, WorldTriangle *out, uint32_t total, hipStream_t stream);
+void launch_tone_map(
+    const float4 *hdr, const uint32_t *lut, uint32_t dim, float exposure, float contrast, void *outRgba8, uint32_t count,
+    hipStream_t stream);
 uint32_t megakernel_grid_blocks(const RenderParams &p);
 uint32_t persistent_grid_blocks();
 uint32_t wavefront_grid_blocks(const WavefrontBuffers &w);
