@@ -62,8 +62,10 @@ def test_half_conversion_exhaustive(oracle, kat):
         assert L.ora_pack_half(float(x)) == int(bits)
     rng = np.random.default_rng(5)
     xs = np.concatenate([rng.standard_normal(4000) * 1000, rng.standard_normal(4000) * 1e-5, [65519.9, 65520.0, 5.96e-8, 2.98e-8, 2.99e-8]]).astype(np.float32)
-    for x in xs:
-        assert L.ora_pack_half(float(x)) == int(np.float32(x).astype(np.float16).view(np.uint16)), float(x)
+    with np.errstate(over="ignore"):  # 65520.0 -> inf is the point of that sample
+        want16 = xs.astype(np.float16).view(np.uint16)
+    for x, w16 in zip(xs, want16):
+        assert L.ora_pack_half(float(x)) == int(w16), float(x)
 
 
 def test_snorm_unpack(oracle, kat):
