@@ -197,28 +197,79 @@ def main():
     stats = ctx.scene_stats()
     tile = tiling.tile_for_rank(rank, world_size)
     local_w = tiling.local_width(width, rank, world_size)
-    hdr = torch.zeros((height, local_w, 4), dtype=torch.float32, device="cuda")
+    # Two HDR tiles, used alternately: while the tile of step i is gathered (RCCL's own stream), step i + 1
+    # already renders into the other one.  N = 1 only ever uses the first.
+    tiles = [torch.zeros((height, local_w, 4), dtype=torch.float32, device="cuda") for _ in range(2 if world_size > 1 else 1)]
+    hdr = tiles[0]
     ctx.set_output_buffer(hdr.data_ptr(), hdr.numel() * 4)
     stream = torch.cuda.current_stream().cuda_stream
-    gathered = [torch.empty_like(hdr) for _ in range(world_size)] if (world_size > 1 and rank == 0) else None
+    recv = [[torch.empty_like(hdr) for _ in range(world_size)] if (world_size > 1 and rank == 0) else None for _ in tiles]
+    pending = [None for _ in tiles]  # in-flight gather of each tile
+    overlap = [True]
     full = None
 
-    def gather_tiles():
-        """The one data-path collective: per-rank RGBA32F stripes to rank 0 (RCCL gather over xGMI)."""
-        if rehearse:  # gloo: through host memory
-            torch.cuda.synchronize()
-            host = hdr.cpu()
-            parts = [torch.empty_like(host) for _ in range(world_size)] if rank == 0 else None
-            dist.gather(host, parts, dst=0)
-            return tiling.deinterleave([p.cuda() for p in parts], width) if rank == 0 else None
-        dist.gather(hdr, gathered, dst=0)
-        return tiling.deinterleave(gathered, width) if rank == 0 else None
+    def gather_sync(t):
+        """Rehearsal path (gloo, through host memory)."""
+        torch.cuda.synchronize()
+        host = t.cpu()
+        parts = [torch.empty_like(host) for _ in range(world_size)] if rank == 0 else None
+        dist.gather(host, parts, dst=0)
+        return tiling.deinterleave([p.cuda() for p in parts], width) if rank == 0 else None
 
-    def step():
+    def finish_gather(b):
+        """Waits (stream-side) for tile b's gather and de-interleaves it on rank 0."""
         nonlocal full
+        if pending[b] is not None:
+            pending[b].wait()
+            pending[b] = None
+            if rank == 0:
+                full = tiling.deinterleave(recv[b], width)
+
+    def render_and_gather(i, record=None):
+        """Step i: render the rank's stripes into tile i % 2, start its gather (the one data-path collective:
+        per-rank RGBA32F stripes to rank 0, RCCL over xGMI), then complete the previous step's."""
+        nonlocal full
+        b = i % len(tiles)
+        finish_gather(b)  # the gather that last read this tile (two steps ago)
+        ctx.set_output_buffer(tiles[b].data_ptr(), tiles[b].numel() * 4)
         pc = make_pc(focal, 1, max_bounces, ibl, True)
+        if record:
+            record[0].record()
         ctx.render(pc, cam, width, height, tile=tile, frames=spp, stream=stream)
-        full = gather_tiles() if world_size > 1 else hdr
+        if record:
+            record[1].record()
+        if world_size == 1:
+            full = tiles[b]
+        elif rehearse:
+            full = gather_sync(tiles[b])
+        elif overlap[0]:
+            try:
+                pending[b] = dist.gather(tiles[b], recv[b], dst=0, async_op=True)
+            except (RuntimeError, TypeError, ValueError) as e:  # a backend without async gather: plain gather
+                if step_index > 0:
+                    raise
+                print("bench: async gather unavailable (%s); gathering synchronously" % e, file=sys.stderr)
+                overlap[0] = False
+                dist.gather(tiles[b], recv[b], dst=0)
+                if rank == 0:
+                    full = tiling.deinterleave(recv[b], width)
+            else:
+                finish_gather(1 - b)
+        else:
+            dist.gather(tiles[b], recv[b], dst=0)
+            if rank == 0:
+                full = tiling.deinterleave(recv[b], width)
+
+    def drain():
+        for b in range(len(tiles)):
+            finish_gather((b + 1) % len(tiles))
+
+    step_index = 0
+
+    def step(record=None):
+        nonlocal step_index
+        render_and_gather(step_index, record)
+        step_index += 1
 
     # deterministic work counters of one launch (outside the timed region)
     ctx.reset_counters(stream)
@@ -231,6 +282,7 @@ def main():
 
     for _ in range(args.warmup):
         step()
+    drain()
 
     def barrier():
         if world_size > 1:
@@ -243,11 +295,8 @@ def main():
     t0 = time.perf_counter()
     for i in range(args.steps):
         # kernel-only time: events on the stream the render kernels are launched on
-        pc = make_pc(focal, 1, max_bounces, ibl, True)
-        starts[i].record()
-        ctx.render(pc, cam, width, height, tile=tile, frames=spp, stream=stream)
-        stops[i].record()
-        full = gather_tiles() if world_size > 1 else hdr
+        step((starts[i], stops[i]))
+    drain()
     barrier()
     elapsed = time.perf_counter() - t0
     kernel_ms = sum(s.elapsed_time(e) for s, e in zip(starts, stops)) / max(1, args.steps)
