@@ -24,6 +24,8 @@ def oracle():
 def gpu_ctx():
     """One prosper_pt context on cuda:0 for the whole session (loads libprosper_pt.so; no fallback)."""
     from prosper_amd import capi
+    if not os.path.exists(capi.LIB_PATH):
+        capi.build()  # the test harness may build the product; the product itself never falls back
     ctx = capi.Context(device=0)
     yield ctx
     ctx.close()
