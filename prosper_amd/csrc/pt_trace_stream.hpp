@@ -16,6 +16,20 @@
 
 #include "pt_device.hpp"
 
+// A phase keeps stepping while more than a third of the lanes that entered it are still in it.  Swept on
+// C2/C3/C4 (profiles/r01_occupancy_ab.txt): leaving earlier to follow the majority costs more in censuses
+// and half-empty first steps than the emptier late steps do (wf_trace -10 % on C2, -5 % on C3/C4 against the
+// previous "2c > runner-up + c0").
+// Finished rays are committed and lanes refilled once half of the wave waits for it (or nothing else can
+// run): a refill step runs the commit and fetch code for the waiting lanes only, so it should be a full one.
+// wf_trace C2 481 -> 457 us, C3 2901 -> 2871 us against "more lanes than any other phase" (C4 +3 %).
+#ifndef PPT_REFILL
+#define PPT_REFILL(r, best) ((r) >= 32u)
+#endif
+#ifndef PPT_CONTINUE
+#define PPT_CONTINUE(c, c0, other) (3u * (c) > (c0))
+#endif
+
 namespace ppt
 {
 
@@ -110,14 +124,14 @@ PPT_D void trace_stream(
             best = nAny;
             pick = kLaneAny;
         }
-        if (nRefill > best || nWork == 0) pick = kLaneFinished;
+        if (PPT_REFILL(nRefill, best) || nWork == 0) pick = kLaneFinished;
 
-        // A phase keeps stepping while it stays (by estimate) the phase most lanes wait for:
-        // lanes that leave it are assumed to join the runner-up, so continue while
-        // 2 * stillInPhase > runnerUp + startedInPhase.  Saves the full five-ballot census per step.
+        // the picked phase then steps several times in a row (PPT_CONTINUE above): saves the five-ballot census
+        // per step
         if (pick == kLaneNode)
         {
             const uint32_t other = nTri > nAny ? (nTri > nRefill ? nTri : nRefill) : (nAny > nRefill ? nAny : nRefill);
+            (void)other;
             uint32_t c = nNode;
             do
             {
@@ -147,11 +161,12 @@ PPT_D void trace_stream(
                         pop();
                 }
                 c = (uint32_t)__builtin_popcountll(__ballot(state == kLaneNode));
-            } while (2u * c > other + nNode);
+            } while (PPT_CONTINUE(c, nNode, other));
         }
         else if (pick == kLaneTri)
         {
             const uint32_t other = nNode > nAny ? (nNode > nRefill ? nNode : nRefill) : (nAny > nRefill ? nAny : nRefill);
+            (void)other;
             uint32_t c = nTri;
             do
             {
@@ -197,7 +212,7 @@ PPT_D void trace_stream(
                     if (state == kLaneTri && triCount == 0) pop();
                 }
                 c = (uint32_t)__builtin_popcountll(__ballot(state == kLaneTri));
-            } while (2u * c > other + nTri);
+            } while (PPT_CONTINUE(c, nTri, other));
         }
         else if (pick == kLaneAny)
         {
