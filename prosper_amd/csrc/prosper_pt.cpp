@@ -390,10 +390,11 @@ int ensure_wavefront_workspace(
 {
     const uint64_t pixelsPadded = (uint64_t)tilesX * tilesY * 64u;
     const uint64_t slots = pixelsPadded * frames;
-    // one segment per wave; ~32k waves give each CU several rounds of segments to balance over
-    // (measured sweep, profiles/r01_seglen_sweep.txt: 512 slots is the optimum at 16.6 M slots)
-    uint64_t segLen = ((slots / 32768u) + 63u) / 64u * 64u;
-    if (segLen < 128u) segLen = 128u; // single-frame renders: 16 k waves of 128 slots (0.98 vs 1.09 ms at 256)
+    // one segment per wave, several rounds of segments per CU to balance over
+    // segment length: about 25 600 segments per batch (five times the 5120 waves the GPU holds), rounded to
+    // whole 64-lane batches - 640 slots at 1920x1080 x 8 spp (swept: profiles/r01_seglen_sweep.txt)
+    uint64_t segLen = ((slots / 25600u) + 32u) / 64u * 64u;
+    if (segLen < 128u) segLen = 128u; // single-frame renders: 16 k waves of 128 slots
     if (segLen > 1024u) segLen = 1024u;
     if (const char *forced = std::getenv("PROSPER_PT_DEBUG_SEGLEN")) // tuning/test hook
     {
