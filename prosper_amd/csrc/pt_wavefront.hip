@@ -33,7 +33,7 @@
 // caps a CU at 20 waves, so that variant is allocated for 5 waves/SIMD.
 #define PPT_SHADE_WPE 4
 #ifndef PPT_GEN_WPE
-#define PPT_GEN_WPE 4
+#define PPT_GEN_WPE 5
 #endif
 #ifndef PPT_TRACE_WPE
 #define PPT_TRACE_WPE(stack) 5
