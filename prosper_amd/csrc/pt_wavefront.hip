@@ -27,10 +27,9 @@
 #include "pt_render_common.hpp"
 #include "pt_trace_stream.hpp"
 
-// Register budgets (measured on C2/C3, profiles/r01_occupancy_ab.txt): the traversal kernels run
-// best at 6 waves/SIMD (<= 80 VGPRs, a few spilled dwords), the shade kernel at 4.  The LDS stack
-// is sized to the BVH depth (16/24/32 entries x 64 lanes x 4 B per wave); at 32 entries the LDS
-// caps a CU at 20 waves, so that variant is allocated for 5 waves/SIMD.
+// Register budgets (measured on C2/C3, profiles/r01_occupancy_ab.txt): the traversal kernels (generate,
+// trace) run at 5 waves/SIMD (<= 96 VGPRs, no spill), the shade kernel at 4 (120 VGPRs; 5 would spill).
+// The LDS stack is 16 or 24 entries x 64 lanes x 4 B per wave, deeper entries go to global memory.
 #define PPT_SHADE_WPE 4
 #ifndef PPT_GEN_WPE
 #define PPT_GEN_WPE 5
