@@ -162,9 +162,11 @@ __global__ __launch_bounds__(256, PPT_GEN_WPE) void wf_generate_extend(
     }
     else
     {
+        bool slotValid = false; // of the slot the last fetch() decoded: commit() follows it in lockstep
         auto fetch = [&](uint32_t k) {
             const uint32_t slot = id.base + k;
             const SlotPixel sp = decode_slot(w, p, slot);
+            slotValid = sp.valid;
             StreamRay r;
             if (!sp.valid)
             {
@@ -192,7 +194,7 @@ __global__ __launch_bounds__(256, PPT_GEN_WPE) void wf_generate_extend(
         };
         auto commit = [&](bool pred, uint32_t k, bool found, const Hit &hit, const f3 &dir) {
             const uint32_t slot = id.base + k;
-            const bool valid = pred && decode_slot(w, p, slot).valid;
+            const bool valid = pred && slotValid;
             if (valid)
             {
                 f3 color = f3{0.0f, 0.0f, 0.0f};
