@@ -162,10 +162,19 @@ __global__ __launch_bounds__(256, PPT_GEN_WPE) void wf_generate_extend(
     }
     else
     {
+        // A batch of 64 consecutive slots is one 8x8 tile of one frame (segment bases and the frame stride are
+        // multiples of 64), so frame / tile row / tile column are wave-uniform: decoded once per segment with
+        // the two integer divisions, then stepped tile by tile.
+        const SlotPixel first = decode_slot(w, p, id.base);
+        uint32_t tileFrame = first.frame, tileX = first.lx >> 3, tileY = first.py >> 3;
         bool slotValid = false; // of the slot the last fetch() decoded: commit() follows it in lockstep
         auto fetch = [&](uint32_t k) {
             const uint32_t slot = id.base + k;
-            const SlotPixel sp = decode_slot(w, p, slot);
+            SlotPixel sp;
+            sp.frame = tileFrame;
+            sp.lx = tileX * 8u + (lane & 7u);
+            sp.py = tileY * 8u + (lane >> 3);
+            sp.valid = sp.frame < p.frameCount && sp.lx < p.localWidth && sp.py < p.height;
             slotValid = sp.valid;
             StreamRay r;
             if (!sp.valid)
@@ -229,6 +238,16 @@ __global__ __launch_bounds__(256, PPT_GEN_WPE) void wf_generate_extend(
             else
                 found = trace_in<false, COUNT>(gg, s, r.o, r.d, r.tMin, r.tMax, r.seed, stack, hit, cnt);
             commit(true, k, found, hit, r.d);
+            // next tile of the frame, next frame after the last tile
+            if (++tileX == w.tilesX)
+            {
+                tileX = 0;
+                if (++tileY == w.tilesY)
+                {
+                    tileY = 0;
+                    ++tileFrame;
+                }
+            }
         }
     }
     if (lane == 0) w.segHits[id.seg] = nHit;
