@@ -211,12 +211,16 @@ struct Builder
 // tree).  On top of that the node test works on fl(o - nodeOrigin), off by up to 2^-24 of the distance
 // between the ray origin and the node: `slack` = 2e-6 * scene diagonal (32 * 2^-24) covers ray origins
 // up to ~16 scene diagonals away; the relative term covers the fp32 subtractions that form the offsets.
-void padded(const Aabb &b, float slack, float lo[3], float hi[3])
+// PROSPER_PT_DEBUG_PAD (>= 1.6e-5) fattens the boxes: a different hierarchy for the tests that check
+// that hits do not depend on it
+float pad_coefficient()
 {
-    // PROSPER_PT_DEBUG_PAD (>= 1.6e-5) fattens the boxes: a different hierarchy for the tests that
-    // check that hits do not depend on it
     const char *forced = std::getenv("PROSPER_PT_DEBUG_PAD");
-    const float coeff = forced ? std::max(1.6e-5f, (float)std::atof(forced)) : 1.6e-5f;
+    return forced ? std::max(1.6e-5f, (float)std::atof(forced)) : 1.6e-5f;
+}
+
+void padded(const Aabb &b, float coeff, float slack, float lo[3], float hi[3])
+{
     float mall = 0.0f;
     for (int k = 0; k < 3; ++k) mall = std::max(mall, std::max(std::fabs(b.lo[k]), std::fabs(b.hi[k])));
     for (int k = 0; k < 3; ++k)
@@ -301,6 +305,7 @@ struct Emitter
     const std::vector<Prim> &prims;
     BvhBuildResult &out;
     float slack;
+    float padCoeff;
 
     int32_t emit_leaf(int32_t t)
     {
@@ -354,7 +359,7 @@ struct Emitter
         for (int a = 0; a < 3; ++a) node.origin[a] = std::numeric_limits<float>::infinity();
         for (uint32_t c = 0; c < k; ++c)
         {
-            padded(tmp[kids[c]].box, slack, lo[c], hi[c]);
+            padded(tmp[kids[c]].box, padCoeff, slack, lo[c], hi[c]);
             for (int a = 0; a < 3; ++a) node.origin[a] = std::min(node.origin[a], lo[c][a]);
         }
         uint32_t deepest = 0;
@@ -434,7 +439,7 @@ BvhBuildResult build_bvh(const WorldTriangle *triangles, uint64_t count)
     const Aabb &scene = builder.nodes[(size_t)rootTmp].box;
     const float dx = scene.hi[0] - scene.lo[0], dy = scene.hi[1] - scene.lo[1], dz = scene.hi[2] - scene.lo[2];
     const float slack = 2e-6f * std::sqrt(dx * dx + dy * dy + dz * dz) + 1e-30f;
-    Emitter emitter{builder.nodes, prims, out, slack};
+    Emitter emitter{builder.nodes, prims, out, slack, pad_coefficient()};
     uint32_t need = 0;
     emitter.emit_node(rootTmp, need);
     out.maxDepth = need + 1; // entries the traversal stack must hold in the worst case
