@@ -824,29 +824,50 @@ PPT_D bool box_guard(f3 o, f3 invd, f3 v0, f3 v1, f3 v2, float tt)
     return tn <= tt * kGuardTol && tt <= tf * kGuardTol;
 }
 
-// `invd` = safe_rcp_dir of each component of d (the traversal keeps it per ray)
-PPT_D bool intersect_triangle(
-    f3 o, f3 d, f3 invd, f3 v0, f3 v1, f3 v2, float tMin, float tMax, float &t, float &bu, float &bv)
+// The triangle test in two halves, so that a leaf of two triangles can share the second one between
+// them (pt_trace_stream.hpp): first the edge functions of hit contract (1), then distance, range and
+// box guard, (2) and (3).  intersect_triangle is the two in a row: same operations, same bits.
+struct EdgeFunctions
+{
+    float U, V, W, det;
+    bool pass;
+};
+PPT_D EdgeFunctions edge_functions(f3 o, f3 d, f3 v0, f3 v1, f3 v2)
 {
     const f3 A = v0 - o;
     const f3 B = v1 - o;
     const f3 C = v2 - o;
-    const float U = dot(d, cross(C, B));
-    const float V = dot(d, cross(A, C));
-    const float W = dot(d, cross(B, A));
-    if ((U < 0.0f || V < 0.0f || W < 0.0f) && (U > 0.0f || V > 0.0f || W > 0.0f)) return false;
-    const float det = (U + V) + W;
-    if (!(det != 0.0f)) return false;
+    EdgeFunctions e;
+    e.U = dot(d, cross(C, B));
+    e.V = dot(d, cross(A, C));
+    e.W = dot(d, cross(B, A));
+    e.det = (e.U + e.V) + e.W;
+    const bool mixed = (e.U < 0.0f || e.V < 0.0f || e.W < 0.0f) && (e.U > 0.0f || e.V > 0.0f || e.W > 0.0f);
+    e.pass = !mixed && e.det != 0.0f;
+    return e;
+}
+// `invd` = safe_rcp_dir of each component of d (the traversal keeps it per ray)
+PPT_D bool finish_triangle(
+    const EdgeFunctions &e, f3 o, f3 d, f3 invd, f3 v0, f3 v1, f3 v2, float tMin, float tMax, float &t, float &bu, float &bv)
+{
     // t = projection of the barycentric point on the (unit) direction: (U*(A.d) + V*(B.d) + W*(C.d)) / det.
     // Well conditioned for grazing rays (the plane equation is not).
-    const float inv = 1.0f / det;
-    const float tt = __builtin_fmaf(W, dot(C, d), __builtin_fmaf(V, dot(B, d), U * dot(A, d))) * inv;
+    const float inv = 1.0f / e.det;
+    const float tt =
+        __builtin_fmaf(e.W, dot(v2 - o, d), __builtin_fmaf(e.V, dot(v1 - o, d), e.U * dot(v0 - o, d))) * inv;
     if (!(tt > tMin && tt < tMax)) return false;
     if (!box_guard(o, invd, v0, v1, v2, tt)) return false;
     t = tt;
-    bu = V * inv;
-    bv = W * inv;
+    bu = e.V * inv;
+    bv = e.W * inv;
     return true;
+}
+PPT_D bool intersect_triangle(
+    f3 o, f3 d, f3 invd, f3 v0, f3 v1, f3 v2, float tMin, float tMax, float &t, float &bu, float &bv)
+{
+    const EdgeFunctions e = edge_functions(o, d, v0, v1, v2);
+    if (!e.pass) return false;
+    return finish_triangle(e, o, d, invd, v0, v1, v2, tMin, tMax, t, bu, bv);
 }
 
 struct Hit

@@ -38,6 +38,8 @@
 namespace ppt
 {
 
+PPT_D f3 xyz3(float4 v) { return f3{v.x, v.y, v.z}; }
+
 enum : uint32_t
 {
     kLaneIdle = 0,
@@ -176,21 +178,42 @@ PPT_D void trace_stream(
             do
             {
                 if constexpr (COUNT) cnt.trianglePhaseSteps += lane == 0 ? 1u : 0u;
-                if (state == kLaneTri)
+                // One step tests the next TWO triangles of the leaf when some lane has two left (SAH leaves are
+                // mostly pairs: a quad, a box face): both edge-function sets (the cheap rejection), then ONE pass
+                // through distance / guard / acceptance for whichever of them the ray goes through.  A ray through
+                // both (the shared diagonal) takes the first now and meets the second again next step.
+                const bool inTri = state == kLaneTri;
+                const bool two = inTri && triCount >= 2u;
+                const bool anyTwo = __any(two);
+                if (inTri)
                 {
-                    const TriangleData td = g.tri(triFirst);
+                    TriangleData td = g.tri(triFirst);
+                    EdgeFunctions e = edge_functions(o, d, xyz3(td.a), xyz3(td.b), xyz3(td.c));
+                    uint32_t consumed = 1u;
+                    if (anyTwo)
+                    {
+                        const TriangleData td2 = g.tri(two ? triFirst + 1u : triFirst);
+                        EdgeFunctions e2 = edge_functions(o, d, xyz3(td2.a), xyz3(td2.b), xyz3(td2.c));
+                        e2.pass = e2.pass && two;
+                        if (two && !(e.pass && e2.pass)) consumed = 2u;
+                        if (!e.pass && e2.pass)
+                        {
+                            td = td2;
+                            e = e2;
+                        }
+                    }
                     const float4 a = td.a, b = td.b, c4 = td.c;
-                    ++triFirst;
-                    --triCount;
+                    triFirst += consumed;
+                    triCount -= consumed;
                     if constexpr (COUNT)
                     {
-                        cnt.triangleTests++;
+                        cnt.triangleTests += consumed;
                         cnt.shortIndexTriangleTests +=
-                            (__builtin_bit_cast(uint32_t, c4.w) & kTriFlagShortIndices) ? 1u : 0u;
+                            (__builtin_bit_cast(uint32_t, c4.w) & kTriFlagShortIndices) ? consumed : 0u;
                     }
                     float t, bu, bv;
-                    bool candidate = intersect_triangle(
-                        o, d, invd, f3{a.x, a.y, a.z}, f3{b.x, b.y, b.z}, f3{c4.x, c4.y, c4.z}, tMin, tMaxIn, t, bu, bv);
+                    bool candidate =
+                        e.pass && finish_triangle(e, o, d, invd, xyz3(a), xyz3(b), xyz3(c4), tMin, tMaxIn, t, bu, bv);
                     const uint32_t di = __builtin_bit_cast(uint32_t, a.w);
                     const uint32_t prim = __builtin_bit_cast(uint32_t, b.w);
                     const uint32_t flags = __builtin_bit_cast(uint32_t, c4.w);
