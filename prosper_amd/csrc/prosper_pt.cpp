@@ -265,6 +265,9 @@ int upload_scene_impl(prosper_pt_ctx *ctx, const prosper_pt_scene_view *v)
     s.spotLights = ctx->dSpotLights;
     s.pointLightCount = v->pointLights->count;
     s.spotLightCount = v->spotLights->count;
+    s.materialCount = v->materialCount;
+    s.drawInstanceCount = v->drawInstanceCount;
+    s.modelInstanceCount = v->modelInstanceCount;
 
     // skybox
     s.skybox = nullptr;

@@ -100,7 +100,9 @@ struct DeviceScene
     uint32_t skyboxFaceSize;
     uint32_t pointLightCount; // snapshot of pointLights->count at upload (kept in SGPRs)
     uint32_t spotLightCount;
-    uint32_t pad;
+    uint32_t materialCount; // table sizes, for staging the tables in LDS (wf_shade)
+    uint32_t drawInstanceCount;
+    uint32_t modelInstanceCount;
 };
 
 // Per-launch constants: push constants, the camera terms the path reads, extent and tile.

@@ -305,11 +305,54 @@ __device__ __forceinline__ void extend_segment(
 // shade
 // ------------------------------------------------------------------------------------------
 
-template <bool COUNT>
+// The small scene tables every hit walks through - draw instances, instance transforms, materials and the
+// light lists - staged into LDS per workgroup when they fit: the shade kernel streams ~200 B of path state
+// per hit through the 16 KB vector L1, which keeps evicting them otherwise (an L2 round trip per table on the
+// dependent chain hit -> instance -> material / transform -> light).
+constexpr uint32_t kLdsTableBytes = 16u * 1024u;
+__host__ __device__ inline uint32_t shade_table_bytes(const DeviceScene &s)
+{
+    return s.drawInstanceCount * (uint32_t)sizeof(prosper_DrawInstance) +
+           s.modelInstanceCount * (uint32_t)sizeof(prosper_ModelInstanceTransforms) +
+           s.materialCount * (uint32_t)sizeof(prosper_MaterialData) + s.pointLightCount * (uint32_t)sizeof(prosper_PointLight) +
+           s.spotLightCount * (uint32_t)sizeof(prosper_SpotLight) + (uint32_t)sizeof(prosper_DirectionalLightParameters) + 64u;
+}
+// copies `bytes` (a multiple of 4) from global memory to the next 16-byte aligned LDS offset
+__device__ __forceinline__ const void *stage_table(uint32_t *lds, uint32_t &offsetWords, const void *src, uint32_t bytes)
+{
+    offsetWords = (offsetWords + 3u) & ~3u;
+    uint32_t *dst = lds + offsetWords;
+    const uint32_t words = bytes / 4u;
+    const uint32_t *from = static_cast<const uint32_t *>(src);
+    for (uint32_t i = threadIdx.x; i < words; i += blockDim.x) dst[i] = from[i];
+    offsetWords += words;
+    return dst;
+}
+
+template <bool COUNT, bool LDS_TABLES>
 __global__ __launch_bounds__(256, PPT_SHADE_WPE) void wf_shade(
     DeviceScene s, RenderParams p, WavefrontBuffers w, uint32_t bounce, uint32_t cur, uint32_t lastBounce,
     unsigned long long *__restrict__ counters)
 {
+    __shared__ uint32_t ldsTables[LDS_TABLES ? kLdsTableBytes / 4u : 4u];
+    if constexpr (LDS_TABLES)
+    {
+        uint32_t off = 0;
+        s.drawInstances = static_cast<const prosper_DrawInstance *>(
+            stage_table(ldsTables, off, s.drawInstances, s.drawInstanceCount * (uint32_t)sizeof(prosper_DrawInstance)));
+        s.modelInstanceTransforms = static_cast<const prosper_ModelInstanceTransforms *>(stage_table(
+            ldsTables, off, s.modelInstanceTransforms, s.modelInstanceCount * (uint32_t)sizeof(prosper_ModelInstanceTransforms)));
+        s.materials = static_cast<const prosper_MaterialData *>(
+            stage_table(ldsTables, off, s.materials, s.materialCount * (uint32_t)sizeof(prosper_MaterialData)));
+        s.directionalLight = static_cast<const prosper_DirectionalLightParameters *>(
+            stage_table(ldsTables, off, s.directionalLight, (uint32_t)sizeof(prosper_DirectionalLightParameters)));
+        // only the first `count` lights of each list are ever indexed (sample_light)
+        s.pointLights = static_cast<const prosper_PointLightsBuffer *>(
+            stage_table(ldsTables, off, s.pointLights, s.pointLightCount * (uint32_t)sizeof(prosper_PointLight)));
+        s.spotLights = static_cast<const prosper_SpotLightsBuffer *>(
+            stage_table(ldsTables, off, s.spotLights, s.spotLightCount * (uint32_t)sizeof(prosper_SpotLight)));
+        __syncthreads();
+    }
     const SegmentId id = my_segment(w);
     if (!id.valid) return;
     const uint32_t lane = lane_id();
@@ -572,7 +615,10 @@ static void enqueue_wavefront(
         const uint32_t cur = b & 1u;
         const uint32_t last = (b + 1u == bounces) ? 1u : 0u;
         mark(kStageShade);
-        hipLaunchKernelGGL(wf_shade<COUNT>, grid, block, 0, stream, s, p, w, b, cur, last, cShade);
+        if (shade_table_bytes(s) <= kLdsTableBytes && !std::getenv("PROSPER_PT_DEBUG_NO_LDS_TABLES"))
+            hipLaunchKernelGGL((wf_shade<COUNT, true>), grid, block, 0, stream, s, p, w, b, cur, last, cShade);
+        else
+            hipLaunchKernelGGL((wf_shade<COUNT, false>), grid, block, 0, stream, s, p, w, b, cur, last, cShade);
         if (!debugDraw)
         {
             mark(kStageTrace);

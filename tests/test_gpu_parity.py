@@ -594,6 +594,21 @@ def test_lds_stack_variants_agree(gpu_ctx, oracle, sponza_small, monkeypatch):
     monkeypatch.delenv("PROSPER_PT_DEBUG_STACK")
 
 
+def test_lds_staged_tables_equal_global_memory_tables(gpu_ctx, oracle, sponza_small, monkeypatch):
+    """wf_shade stages draw instances, transforms, materials and lights in LDS when they fit in 16 KB
+    (sponza_small: 64 lights, 40 instances); PROSPER_PT_DEBUG_NO_LDS_TABLES reads them from global memory."""
+    w, h = 200, 120
+    cam, fl = _camera(oracle, sponza_small, w, h)
+    pc = default_pc(S, fl, max_bounces=4, ibl=True)
+    gpu_ctx.upload_scene(sponza_small)
+    gpu_ctx.render(pc, cam, w, h, frames=2)
+    base = gpu_ctx.read_hdr()
+    monkeypatch.setenv("PROSPER_PT_DEBUG_NO_LDS_TABLES", "1")
+    gpu_ctx.render(pc, cam, w, h, frames=2)
+    monkeypatch.delenv("PROSPER_PT_DEBUG_NO_LDS_TABLES")
+    assert same_bits(gpu_ctx.read_hdr(), base).all()
+
+
 def test_hits_do_not_depend_on_the_hierarchy(gpu_ctx, oracle, sponza_small, monkeypatch):
     """Hit contract: the box guard bounds where a triangle can be hit, so fatter BVH boxes (a different
     tree: other culling, other traversal order) must give the same bits."""
