@@ -242,13 +242,24 @@ int upload_scene_impl(prosper_pt_ctx *ctx, const prosper_pt_scene_view *v)
     if ((rc = upload(ctx, v->samplers, sizeof(prosper_pt_sampler_desc) * v->samplerCount, &d))) return rc;
     s.samplers = static_cast<const prosper_pt_sampler_desc *>(d);
 
-    // textures: one allocation each (256-B aligned by hipMalloc) + descriptor table
+    // textures: one allocation each (256-B aligned by hipMalloc), re-laid out in 8x4-texel tiles of one
+    // cache line each (pt_scene.hpp DeviceTexture), + descriptor table
     std::vector<DeviceTexture> textures(v->textureCount ? v->textureCount : 1);
+    std::vector<uint32_t> tiled;
     for (uint32_t i = 0; i < v->textureCount; ++i)
     {
         const prosper_pt_texture_desc &t = v->textures[i];
-        if ((rc = upload(ctx, t.texels, (size_t)t.width * t.height * 4u, &d))) return rc;
-        textures[i] = DeviceTexture{static_cast<const uint8_t *>(d), t.width, t.height};
+        const uint32_t tilesX = (t.width + kTexTileW - 1u) / kTexTileW, tilesY = (t.height + kTexTileH - 1u) / kTexTileH;
+        tiled.assign((size_t)tilesX * tilesY * (kTexTileW * kTexTileH), 0u);
+        const uint32_t *src = static_cast<const uint32_t *>(t.texels);
+        for (uint32_t y = 0; y < t.height; ++y)
+        {
+            const uint32_t *row = src + (size_t)y * t.width;
+            uint32_t *dstRow = tiled.data() + (size_t)(y >> 2) * tilesX * 32u + ((y & 3u) << 3);
+            for (uint32_t x = 0; x < t.width; ++x) dstRow[(size_t)(x >> 3) * 32u + (x & 7u)] = row[x];
+        }
+        if ((rc = upload(ctx, tiled.data(), tiled.size() * 4u, &d))) return rc;
+        textures[i] = DeviceTexture{static_cast<const uint8_t *>(d), t.width, t.height, tilesX, 0u};
     }
     if ((rc = upload(ctx, textures.data(), textures.size() * sizeof(DeviceTexture), &d))) return rc;
     s.textures = static_cast<const DeviceTexture *>(d);

@@ -268,7 +268,8 @@ PPT_D void wrap_pair(int32_t i, int32_t size, uint32_t mode, int32_t &c0, int32_
 
 PPT_D f4 fetch_rgba8(const DeviceTexture &t, int32_t i, int32_t j)
 {
-    const uint32_t p = ((global_u32_ptr)t.texels)[(size_t)j * t.width + (size_t)i];
+    const uint32_t tile = ((uint32_t)j >> 2) * t.tilesPerRow + ((uint32_t)i >> 3);
+    const uint32_t p = ((global_u32_ptr)t.texels)[(size_t)tile * 32u + ((((uint32_t)j & 3u) << 3) | ((uint32_t)i & 7u))];
     const float k = 1.0f / 255.0f;
     return f4{(float)(p & 0xFFu) * k, (float)((p >> 8) & 0xFFu) * k, (float)((p >> 16) & 0xFFu) * k, (float)(p >> 24) * k};
 }

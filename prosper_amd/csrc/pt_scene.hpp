@@ -71,12 +71,20 @@ struct alignas(16) ShadeTriangle
 };
 static_assert(sizeof(ShadeTriangle) == 128, "shade triangle is 128 B");
 
+// RGBA8 texels in 8 x 4 tiles of one 128-byte cache line each (texel (i, j) at tile (i >> 3, j >> 2),
+// row-major inside the tile; the allocation is padded to whole tiles).  The 2 x 2 footprint of a bilinear
+// fetch then falls into one line two times out of three instead of always two (rows are `width * 4` bytes
+// apart in a linear image): 1.4 instead of 2.1 lines per sample at LOD 0, where neighbouring pixels already
+// land on unrelated texels.
 struct DeviceTexture
 {
     const uint8_t *texels;
     uint32_t width;
     uint32_t height;
+    uint32_t tilesPerRow; // (width + 7) / 8
+    uint32_t pad;
 };
+constexpr uint32_t kTexTileW = 8, kTexTileH = 4;
 
 // Everything a kernel needs about the scene; passed by value as a kernel argument so every
 // pointer arrives in SGPRs.
