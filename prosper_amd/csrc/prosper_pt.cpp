@@ -680,8 +680,12 @@ int prosper_pt_render_frames(
     p.right[0] = w2c.col[0].x; p.right[1] = w2c.col[1].x; p.right[2] = w2c.col[2].x;
     p.up[0] = w2c.col[0].y; p.up[1] = w2c.col[1].y; p.up[2] = w2c.col[2].y;
     p.fwd[0] = -w2c.col[0].z; p.fwd[1] = -w2c.col[1].z; p.fwd[2] = -w2c.col[2].z;
-    p.c2c00 = camera->cameraToClip.col[0].x;
-    p.c2c11 = camera->cameraToClip.col[1].y;
+    {
+        // volatile: keep the compiler from folding the two divisions into anything but IEEE fp32 divides
+        volatile float c00 = camera->cameraToClip.col[0].x, c11 = camera->cameraToClip.col[1].y;
+        p.aspect = c11 / c00;
+        p.tanHalfFovY = 1.0f / c11;
+    }
     std::memcpy(p.cameraToWorld, &camera->cameraToWorld, 64);
     p.width = width;
     p.height = height;

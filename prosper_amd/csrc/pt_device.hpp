@@ -736,8 +736,8 @@ PPT_D Ray pinhole_camera_ray(const RenderParams &p, f2 uv)
     ray.o = f3{p.eye[0], p.eye[1], p.eye[2]};
     ray.tMin = 0.0f;
     ray.tMax = kInf;
-    const float aspect = p.c2c11 / p.c2c00;
-    const float tanHalfFovY = 1.0f / p.c2c11;
+    const float aspect = p.aspect;
+    const float tanHalfFovY = p.tanHalfFovY;
     const f3 right = f3{p.right[0], p.right[1], p.right[2]};
     const f3 up = f3{p.up[0], p.up[1], p.up[2]};
     const f3 fwd = f3{p.fwd[0], p.fwd[1], p.fwd[2]};

@@ -122,8 +122,8 @@ struct RenderParams
     float right[3];
     float up[3];
     float fwd[3];
-    float c2c00;
-    float c2c11;
+    float aspect;      // cameraToClip[1][1] / cameraToClip[0][0] (ray.glsl:21-24): per-frame constants, divided once
+    float tanHalfFovY; // 1 / cameraToClip[1][1]                        on the host (IEEE fp32 division, same bits)
     float cameraToWorld[16];
     uint32_t width;
     uint32_t height;
