@@ -147,6 +147,48 @@ def bench_tone_map(ctx, torch, width, height, stream, repeats=50):
             "achieved_GBps": nbytes / (ms * 1e-3) / 1e9, "frac_of_hbm_peak": nbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
 
 
+def bench_restir_di(ctx, torch, cam, focal, width, height, stream, repeats=30):
+    """A second client of the traversal (not part of `value`): the ReSTIR-DI trace pass over a
+    G-buffer made from the product's own debug views of the primary hits, one random light per pixel."""
+    import numpy as np
+
+    def view(name):
+        pc = S.ReferencePC(S.DrawType[name], S.PC_FLAG_SKIP_HISTORY, 1, 1e-5, 1.0, focal, 3, 1)
+        ctx.render(pc, cam, width, height, stream=stream)
+        return ctx.read_hdr(stream)[..., :3].astype(np.float64)
+    pos, raw_n, alb = view("Position"), view("ShadingNormal"), view("Albedo")
+    rough, metal = view("Roughness")[..., 0], view("Metallic")[..., 0]
+    hit = raw_n.sum(axis=-1) > 0.0
+    n = np.where(hit[..., None], raw_n * 2.0 - 1.0, np.array([0.0, 0.0, 1.0]))
+    n = n / np.abs(n).sum(axis=-1, keepdims=True)           # gbuffer.frag signedOctEncode
+    ey = n[..., 1] * 0.5 + 0.5
+    enc = np.stack([n[..., 0] * 0.5 + ey, n[..., 0] * -0.5 + ey, np.clip(n[..., 2] * 1e30, 0.0, 1.0)], axis=-1)
+    c2c = np.frombuffer(bytes(cam.cameraToClip), np.float32).reshape(4, 4).T.astype(np.float64)
+    w2c = np.frombuffer(bytes(cam.worldToCamera), np.float32).reshape(4, 4).T.astype(np.float64)
+    clip = np.concatenate([pos, np.ones(pos.shape[:2] + (1,))], axis=-1) @ (c2c @ w2c).T
+    depth = np.where(hit, clip[..., 2] / np.where(clip[..., 3] == 0, 1.0, clip[..., 3]), 0.0).astype(np.float32)
+    ar = np.concatenate([alb, np.maximum(rough, 0.05)[..., None]], axis=-1).astype(np.float32)
+    nm = np.stack([enc[..., 0], enc[..., 1], metal, enc[..., 2]], axis=-1).astype(np.float32)
+    rng = np.random.default_rng(1)
+    world = ctx._world
+    lights = 1 + world.point_lights.count + world.spot_lights.count
+    idx = rng.integers(0, lights, size=(height, width)).astype(np.int32)
+    res = np.stack([idx.view(np.float32), np.ones((height, width), np.float32)], axis=-1)
+    t = [torch.from_numpy(np.ascontiguousarray(a)).cuda() for a in (ar, nm, depth, res)]
+    pc = S.RestirTracePC(0, 1, 3)
+    for _ in range(3):
+        ctx.restir_di_trace_device(pc, cam, width, height, *[x.data_ptr() for x in t], stream=stream)
+    start, stop = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    start.record()
+    for _ in range(repeats):
+        ctx.restir_di_trace_device(pc, cam, width, height, *[x.data_ptr() for x in t], stream=stream)
+    stop.record()
+    torch.cuda.synchronize()
+    ms = start.elapsed_time(stop) / repeats
+    return {"kernel": "restir_di_trace_kernel", "ms_per_frame": ms, "Mpixels_per_s": width * height / ms / 1e3,
+            "gbuffer_bytes_per_pixel": 60, "lights": int(lights)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -386,6 +428,7 @@ def main():
         }
         if world_size == 1:
             result["tone_map"] = bench_tone_map(ctx, torch, width, height, stream)
+            result["restir_di_trace"] = bench_restir_di(ctx, torch, cam, focal, width, height, stream)
         if world_size == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(world, cam, focal, width, height, spp, max_bounces, ibl)
             result["gpu_over_cpu"] = result["value"] / result["cpu_baseline"]["value"]

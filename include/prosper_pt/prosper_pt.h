@@ -285,6 +285,31 @@ int prosper_pt_tone_map(
     prosper_pt_ctx *ctx, float exposure, float contrast, void *device_rgba8, uint8_t *host_rgba8, size_t byte_size,
     void *stream);
 
+/* A second client of the traversal: prosper's ReSTIR-DI trace pass,
+ * res/shader/rt/direct_illumination/main.rgen:44-165 dispatched by src/render/rtdi/Trace.cpp:297.  Per pixel:
+ * the surface from the G-buffer (world position from the non-linear depth through camera->clipToWorld,
+ * signed-octahedral normal), the light its reservoir holds, one shadow ray with the scene's any-hit rules, the
+ * BRDF, and the running mean into the context's HDR image (whole image, no stripes).
+ * TracePC = res/shader/shared/shader_structs/push_constants/restir_di/trace.h. */
+typedef struct prosper_pt_restir_trace_pc
+{
+    uint32_t drawType;   /* PROSPER_DRAW_TYPE_*: Default traces; Position shows positions, others the albedo */
+    uint32_t frameIndex;
+    uint32_t flags;      /* bit 0 skipHistory, bit 1 accumulate */
+} prosper_pt_restir_trace_pc;
+typedef struct prosper_pt_restir_inputs
+{
+    const void *albedoRoughness;  /* width*height float4: albedo.rgb, roughness        (gbuffer.frag) */
+    const void *normalMetallic;   /* width*height float4: octNormal.xy, metallic, octNormal.z */
+    const float *nonLinearDepth;  /* width*height */
+    const void *reservoirs;       /* width*height float2: bits of the int light index (< 0 = none), weight */
+    uint32_t onDevice;            /* 1: the pointers are device memory; 0: host memory, copied by the call */
+    uint32_t reserved;
+} prosper_pt_restir_inputs;
+int prosper_pt_restir_di_trace(
+    prosper_pt_ctx *ctx, const prosper_pt_restir_trace_pc *pc, const prosper_CameraUniforms *camera, uint32_t width,
+    uint32_t height, const prosper_pt_restir_inputs *inputs, void *stream);
+
 int prosper_pt_get_counters(prosper_pt_ctx *ctx, prosper_pt_counters *out, void *stream);
 /* The same counters for one kernel stage (index as in prosper_pt_kernel_name): lets the roofline
  * of a single kernel be priced from the work that kernel did. */

@@ -70,6 +70,9 @@ def lib():
         L.ora_unpack_half.argtypes = [C.c_uint16]
         L.ora_pack_snorm3x10_1x2.restype = C.c_uint32
         L.ora_pack_snorm3x10_1x2.argtypes = [C.POINTER(C.c_float)]
+        L.ora_restir_di_trace.restype = None
+        L.ora_restir_di_trace.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(S.CameraUniforms), C.c_uint32, C.c_uint32,
+                                          C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
         L.ora_tone_map.restype = None
         L.ora_tone_map.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_float, C.c_float, C.c_void_p, C.c_uint64]
         L.ora_eval_fn.restype = C.c_int
@@ -115,6 +118,19 @@ class OracleScene:
         lib().ora_render(self._h, C.byref(pc), C.byref(camera), width, height,
                          C.byref(tile) if tile is not None else None, img.ctypes.data, threads, C.byref(counters))
         return img, counters
+
+    def restir_di_trace(self, pc, camera, albedo_roughness, normal_metallic, depth, reservoirs, history=None, threads=0):
+        """oracle.c ora_restir_di_trace; pc = (drawType, frameIndex, flags); returns rgba float32 [h, w, 4]."""
+        ar = np.ascontiguousarray(albedo_roughness, np.float32)
+        nm = np.ascontiguousarray(normal_metallic, np.float32)
+        dp = np.ascontiguousarray(depth, np.float32)
+        rs = np.ascontiguousarray(reservoirs, np.float32)
+        h, w = dp.shape
+        img = np.zeros((h, w, 4), np.float32) if history is None else np.ascontiguousarray(history, np.float32).copy()
+        cpc = (C.c_uint32 * 3)(*pc)
+        lib().ora_restir_di_trace(self._h, cpc, C.byref(camera), w, h, ar.ctypes.data, nm.ctypes.data, dp.ctypes.data,
+                                  rs.ctypes.data, img.ctypes.data, threads)
+        return img
 
     def trace_closest(self, origin, direction, t_min=0.0, t_max=float("inf"), seed=0):
         o = (C.c_float * 3)(*origin)

@@ -1667,6 +1667,115 @@ void ora_camera_uniforms(
  * ---------------------------------------------------------------------------------------- */
 
 /* ------------------------------------------------------------------------------------------
+ * ReSTIR-DI trace (res/shader/rt/direct_illumination/main.rgen:44-165): reuses sample_light, the shadow
+ * ray with its any-hit, and evalBRDFTimesNoL.
+ * ---------------------------------------------------------------------------------------- */
+
+/* scene/material.glsl:20-32 */
+static ora_v3 signed_oct_decode(ora_v3 n)
+{
+    ora_v3 o;
+    o.x = n.x - n.y;
+    o.y = (n.x + n.y) - 1.0f;
+    o.z = n.z * 2.0f - 1.0f;
+    o.z = o.z * ((1.0f - ora_abs(o.x)) - ora_abs(o.y));
+    return ora_normalize(o);
+}
+
+/* scene/camera.glsl:27-33: clipToWorld * vec4(uv * 2 - 1, depth, 1), then xyz / w */
+static ora_v3 world_pos(const prosper_CameraUniforms *c, ora_v2 uv, float depth)
+{
+    const prosper_mat4 *m = &c->clipToWorld;
+    const float x = uv.x * 2.0f - 1.0f, y = uv.y * 2.0f - 1.0f;
+    const float vx = fmaf(m->col[2].x, depth, fmaf(m->col[1].x, y, fmaf(m->col[0].x, x, m->col[3].x)));
+    const float vy = fmaf(m->col[2].y, depth, fmaf(m->col[1].y, y, fmaf(m->col[0].y, x, m->col[3].y)));
+    const float vz = fmaf(m->col[2].z, depth, fmaf(m->col[1].z, y, fmaf(m->col[0].z, x, m->col[3].z)));
+    const float vw = fmaf(m->col[2].w, depth, fmaf(m->col[1].w, y, fmaf(m->col[0].w, x, m->col[3].w)));
+    return ora_scale(ora_v3_make(vx, vy, vz), 1.0f / vw);
+}
+
+void ora_restir_di_trace(
+    const ora_scene *s, const ora_restir_pc *pc, const prosper_CameraUniforms *camera, uint32_t width, uint32_t height,
+    const float *albedoRoughness, const float *normalMetallic, const float *nonLinearDepth, const float *reservoirs,
+    float *hdr, int threads)
+{
+    const int skipHistory = (pc->flags & 1u) != 0, accumulate = (pc->flags & 2u) != 0;
+    if (threads > 0) omp_set_num_threads(threads);
+#pragma omp parallel for schedule(dynamic, 8)
+    for (int64_t py = 0; py < (int64_t)height; ++py)
+        for (uint32_t px = 0; px < width; ++px)
+        {
+            const size_t i = (size_t)py * width + px;
+            /* main.rgen:113-129 */
+            ora_v2 uv;
+            uv.x = (float)px / (float)width;
+            uv.y = (float)py / (float)height;
+            const float depth = nonLinearDepth[i];
+            ora_surface sf;
+            sf.positionWS = world_pos(camera, uv, depth);
+            sf.invViewRayWS =
+                ora_normalize(ora_sub(ora_v3_make(camera->eye.x, camera->eye.y, camera->eye.z), sf.positionWS));
+            /* loadFromGbuffer, scene/material.glsl:34-49 */
+            sf.material.albedo = ora_v3_make(albedoRoughness[4 * i], albedoRoughness[4 * i + 1], albedoRoughness[4 * i + 2]);
+            sf.material.roughness = albedoRoughness[4 * i + 3];
+            sf.material.normal =
+                signed_oct_decode(ora_v3_make(normalMetallic[4 * i], normalMetallic[4 * i + 1], normalMetallic[4 * i + 3]));
+            sf.material.metallic = normalMetallic[4 * i + 2];
+            sf.material.alpha = -1.0f;
+            sf.normalWS = sf.material.normal;
+            sf.uv.x = 0.0f;
+            sf.uv.y = 0.0f;
+            sf.NoV = ora_saturate(ora_dot(sf.normalWS, sf.invViewRayWS));
+            ora_v3 color;
+            if (pc->drawType != PROSPER_DRAW_TYPE_DEFAULT)
+            {
+                /* main.rgen:131-146: Position through commonDebugDraw, everything else shows the albedo channel */
+                color = pc->drawType == PROSPER_DRAW_TYPE_POSITION ? sf.positionWS : sf.material.albedo;
+                hdr[4 * i] = color.x;
+                hdr[4 * i + 1] = color.y;
+                hdr[4 * i + 2] = color.z;
+                hdr[4 * i + 3] = 1.0f;
+                continue;
+            }
+            /* evaluateDirectLightingReSTIR, main.rgen:88-109 */
+            const int32_t lightIndex = (int32_t)ora_f2u(reservoirs[2 * i]);
+            const float weight = reservoirs[2 * i + 1];
+            color = ora_v3_make(0.0f, 0.0f, 0.0f);
+            if (!(sf.material.alpha == 0.0f || lightIndex < 0))
+            {
+                ora_v3 l, irradiance;
+                float d;
+                sample_light(s, sf.positionWS, (uint32_t)lightIndex, &l, &d, &irradiance);
+                if (ora_dot(l, sf.normalWS) > 0.0f)
+                {
+                    /* shadow(): seed pcg(px ^ py) - the state (px, py, frameIndex) is never advanced here */
+                    ora_hit h;
+                    const float visible = trace(s, sf.positionWS, l, 0.1f, d, ora_pcg(px ^ (uint32_t)py), 1, &h) ? 0.0f : 1.0f;
+                    irradiance = ora_scale(irradiance, visible);
+                    color = ora_scale(ora_mul(irradiance, eval_brdf_times_nol(l, &sf)), weight);
+                }
+            }
+            if (skipHistory || !accumulate)
+            {
+                hdr[4 * i] = color.x;
+                hdr[4 * i + 1] = color.y;
+                hdr[4 * i + 2] = color.z;
+                hdr[4 * i + 3] = 1.0f;
+            }
+            else
+            {
+                /* the same running mean as the reference pass (ora_render): hist + (c - hist) * (1 / count), fused */
+                const float count = hdr[4 * i + 3] + 1.0f;
+                const float inv = 1.0f / count;
+                hdr[4 * i] = fmaf(color.x - hdr[4 * i], inv, hdr[4 * i]);
+                hdr[4 * i + 1] = fmaf(color.y - hdr[4 * i + 1], inv, hdr[4 * i + 1]);
+                hdr[4 * i + 2] = fmaf(color.z - hdr[4 * i + 2], inv, hdr[4 * i + 2]);
+                hdr[4 * i + 3] = count;
+            }
+        }
+}
+
+/* ------------------------------------------------------------------------------------------
  * Tone map (res/shader/tone_map.comp, common/math.glsl:17-85).  Arithmetic contract additions:
  * mod(x, y) = x - y * floor(x / y) (GLSL), pow through ora_pow, constants as the GLSL front end folds
  * them (47/48, 0.5/48, 1/2.2), R9G9B9E5 decode mantissa * 2^(e - 24) (exact), trilinear weights in fp32

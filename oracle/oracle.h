@@ -79,6 +79,21 @@ uint32_t ora_pack_snorm3x10_1x2(const float v[4]);
 /* Evaluates function `fn` over n records; see oracle.c:ora_eval_fn for the record layouts. */
 int ora_eval_fn(uint32_t fn, const float *in, uint32_t in_stride, float *out, uint32_t out_stride, uint32_t n);
 
+/* A second client of the traversal: the ReSTIR-DI trace pass, res/shader/rt/direct_illumination/
+ * main.rgen:44-165 (src/render/rtdi/Trace.cpp:297).  Per pixel: surface from the G-buffer (albedoRoughness,
+ * normalMetallic as float4 texels, non-linear depth), the pixel's light reservoir (lightIndex bits, weight),
+ * one shadow ray towards that light, BRDF, running-mean accumulation into `hdr` (rgba32f, in/out). */
+typedef struct ora_restir_pc
+{
+    uint32_t drawType;
+    uint32_t frameIndex;
+    uint32_t flags; /* bit 0 skipHistory, bit 1 accumulate */
+} ora_restir_pc;
+void ora_restir_di_trace(
+    const ora_scene *scene, const ora_restir_pc *pc, const prosper_CameraUniforms *camera, uint32_t width, uint32_t height,
+    const float *albedoRoughness, const float *normalMetallic, const float *nonLinearDepth, const float *reservoirs,
+    float *hdr, int threads);
+
 /* The step after the path: RGBA32F -> RGBA16F blit (RtReference.cpp:339-377) followed by
  * res/shader/tone_map.comp:17-60 (exposure, HSV contrast, Tony McMapface 3-D LUT lookup, 1/2.2 gamma) into
  * RGBA8 UNORM (ToneMap.cpp:62-128).  `lut` = dim^3 R9G9B9E5 texels (x fastest), sampled like

@@ -60,6 +60,8 @@ def lib():
     L.prosper_pt_get_hdr_device_ptr.argtypes = [vp, C.POINTER(vp), C.POINTER(C.c_size_t)]
     L.prosper_pt_read_hdr.argtypes = [vp, vp, C.c_size_t, vp]
     L.prosper_pt_blit_rgba16f.argtypes = [vp, vp, C.c_size_t, vp]
+    L.prosper_pt_restir_di_trace.argtypes = [
+        vp, C.POINTER(S.RestirTracePC), C.POINTER(S.CameraUniforms), u32, u32, C.POINTER(S.RestirInputs), vp]
     L.prosper_pt_set_tone_map_lut.argtypes = [vp, vp, u32]
     L.prosper_pt_tone_map.argtypes = [vp, C.c_float, C.c_float, vp, vp, C.c_size_t, vp]
     L.prosper_pt_get_counters.argtypes = [vp, C.POINTER(S.Counters), vp]
@@ -189,6 +191,23 @@ class Context:
         out = np.empty((h, lw, 4), np.float16)
         _check(lib().prosper_pt_blit_rgba16f(self._h, out.ctypes.data, out.nbytes, C.c_void_p(stream)))
         return out
+
+    def restir_di_trace(self, pc, camera, albedo_roughness, normal_metallic, depth, reservoirs, stream=None):
+        """ReSTIR-DI trace over host G-buffer arrays ([h, w, 4], [h, w, 4], [h, w], [h, w, 2] float32)."""
+        ar = np.ascontiguousarray(albedo_roughness, np.float32)
+        nm = np.ascontiguousarray(normal_metallic, np.float32)
+        dp = np.ascontiguousarray(depth, np.float32)
+        rs = np.ascontiguousarray(reservoirs, np.float32)
+        h, w = dp.shape
+        assert ar.shape == (h, w, 4) and nm.shape == (h, w, 4) and rs.shape == (h, w, 2)
+        inp = S.RestirInputs(ar.ctypes.data, nm.ctypes.data, dp.ctypes.data, rs.ctypes.data, 0, 0)
+        _check(lib().prosper_pt_restir_di_trace(self._h, C.byref(pc), C.byref(camera), w, h, C.byref(inp), C.c_void_p(stream)))
+
+    def restir_di_trace_device(self, pc, camera, width, height, ar_ptr, nm_ptr, depth_ptr, res_ptr, stream=None):
+        """Same with device-resident inputs (raw device pointers, e.g. torch tensors' data_ptr())."""
+        inp = S.RestirInputs(ar_ptr, nm_ptr, depth_ptr, res_ptr, 1, 0)
+        _check(lib().prosper_pt_restir_di_trace(self._h, C.byref(pc), C.byref(camera), width, height, C.byref(inp),
+                                                C.c_void_p(stream)))
 
     def set_tone_map_lut(self, lut_r9g9b9e5):
         """lut: uint32 [dim, dim, dim] (z, y, x) R9G9B9E5 texels, e.g. from prosper_amd.dds.read_lut."""

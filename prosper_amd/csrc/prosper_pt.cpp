@@ -87,6 +87,8 @@ struct prosper_pt_ctx
     uint32_t timedLaunches = 0;
     bool timingValid = false;
 
+    void *restirScratch = nullptr; // device copies of host G-buffer inputs (prosper_pt_restir_di_trace)
+    size_t restirScratchBytes = 0;
     uint32_t *toneLut = nullptr; // dim^3 R9G9B9E5 texels
     uint32_t toneLutDim = 0;
     void *toneScratch = nullptr; // RGBA8 output when the caller only wants a host copy
@@ -562,6 +564,7 @@ void prosper_pt_destroy(prosper_pt_ctx *ctx)
     if (ctx->dWorkCounter) (void)hipFree(ctx->dWorkCounter);
     if (ctx->wfBlock) (void)hipFree(ctx->wfBlock);
     if (ctx->stackOverflow) (void)hipFree(ctx->stackOverflow);
+    if (ctx->restirScratch) (void)hipFree(ctx->restirScratch);
     if (ctx->toneLut) (void)hipFree(ctx->toneLut);
     if (ctx->toneScratch) (void)hipFree(ctx->toneScratch);
     for (auto &e : ctx->events)
@@ -827,6 +830,77 @@ int prosper_pt_blit_rgba16f(prosper_pt_ctx *ctx, uint16_t *host_rgba16f, size_t 
     if (e == hipSuccess) e = hipStreamSynchronize(s);
     (void)hipFree(tmp);
     if (e != hipSuccess) return fail(PROSPER_PT_ERR_HIP, std::string("blit: ") + hipGetErrorString(e));
+    return PROSPER_PT_OK;
+}
+
+int prosper_pt_restir_di_trace(
+    prosper_pt_ctx *ctx, const prosper_pt_restir_trace_pc *pc, const prosper_CameraUniforms *camera, uint32_t width,
+    uint32_t height, const prosper_pt_restir_inputs *in, void *stream)
+{
+    if (!ctx || !pc || !camera || !in || !in->albedoRoughness || !in->normalMetallic || !in->nonLinearDepth || !in->reservoirs)
+        return fail(PROSPER_PT_ERR_INVALID_ARGUMENT, "prosper_pt_restir_di_trace: null argument");
+    if (!ctx->haveScene) return fail(PROSPER_PT_ERR_NO_SCENE, "prosper_pt_restir_di_trace called before prosper_pt_upload_scene");
+    if (width == 0 || height == 0) return fail(PROSPER_PT_ERR_INVALID_ARGUMENT, "prosper_pt_restir_di_trace: empty extent");
+    if (pc->drawType >= PROSPER_DRAW_TYPE_COUNT) return fail(PROSPER_PT_ERR_INVALID_ARGUMENT, "drawType out of range");
+    PPT_HIP(hipSetDevice(ctx->device));
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const size_t pixels = (size_t)width * height;
+    const size_t bytes = pixels * sizeof(float4);
+    if (ctx->externalHdr)
+    {
+        if (ctx->externalHdrBytes < bytes) return fail(PROSPER_PT_ERR_INVALID_ARGUMENT, "caller-owned output buffer is too small");
+        ctx->hdr = static_cast<float4 *>(ctx->externalHdr);
+    }
+    else
+    {
+        if (ctx->ownedHdrBytes < bytes || !ctx->ownedHdr)
+        {
+            PPT_HIP(hipStreamSynchronize(s));
+            if (ctx->ownedHdr) PPT_HIP(hipFree(ctx->ownedHdr));
+            ctx->ownedHdr = nullptr;
+            PPT_HIP(hipMalloc((void **)&ctx->ownedHdr, bytes));
+            PPT_HIP(hipMemset(ctx->ownedHdr, 0, bytes));
+            ctx->ownedHdrBytes = bytes;
+        }
+        ctx->hdr = ctx->ownedHdr;
+    }
+    ctx->localWidth = width;
+    ctx->height = height;
+
+    const void *ar = in->albedoRoughness, *nm = in->normalMetallic, *res = in->reservoirs;
+    const float *depth = in->nonLinearDepth;
+    if (!in->onDevice)
+    {
+        // host inputs: one scratch allocation, 16 + 16 + 4 + 8 bytes per pixel
+        const size_t need = pixels * 44u + 64u;
+        if (ctx->restirScratchBytes < need)
+        {
+            PPT_HIP(hipStreamSynchronize(s));
+            if (ctx->restirScratch) PPT_HIP(hipFree(ctx->restirScratch));
+            ctx->restirScratch = nullptr;
+            ctx->restirScratchBytes = 0;
+            PPT_HIP(hipMalloc(&ctx->restirScratch, need));
+            ctx->restirScratchBytes = need;
+        }
+        uint8_t *base = static_cast<uint8_t *>(ctx->restirScratch);
+        PPT_HIP(hipMemcpyAsync(base, in->albedoRoughness, pixels * 16u, hipMemcpyHostToDevice, s));
+        PPT_HIP(hipMemcpyAsync(base + pixels * 16u, in->normalMetallic, pixels * 16u, hipMemcpyHostToDevice, s));
+        PPT_HIP(hipMemcpyAsync(base + pixels * 32u, in->reservoirs, pixels * 8u, hipMemcpyHostToDevice, s));
+        PPT_HIP(hipMemcpyAsync(base + pixels * 40u, in->nonLinearDepth, pixels * 4u, hipMemcpyHostToDevice, s));
+        ar = base;
+        nm = base + pixels * 16u;
+        res = base + pixels * 32u;
+        depth = reinterpret_cast<const float *>(base + pixels * 40u);
+    }
+    int32_t *ovf = nullptr;
+    const int orc = ensure_stack_overflow(ctx, kTraversalStackDepth, restir_grid_blocks(width, height), s, &ovf);
+    if (orc != PROSPER_PT_OK) return orc;
+    const float eye[3] = {camera->eye.x, camera->eye.y, camera->eye.z};
+    float c2w[16];
+    std::memcpy(c2w, &camera->clipToWorld, 64);
+    launch_restir_di_trace(
+        ctx->scene, pc->drawType, pc->frameIndex, pc->flags, width, height, eye, c2w, ar, nm, depth, res, ctx->hdr, ovf, s);
+    PPT_HIP(hipGetLastError());
     return PROSPER_PT_OK;
 }
 

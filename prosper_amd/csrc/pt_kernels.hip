@@ -501,6 +501,137 @@ void launch_blit_rgba16f(const float4 *in, void *out, uint32_t count, hipStream_
 }
 
 // ------------------------------------------------------------------------------------------
+// ReSTIR-DI trace (res/shader/rt/direct_illumination/main.rgen:44-165, src/render/rtdi/Trace.cpp:297): a second
+// client of the traversal.  One lane per pixel, a wave per 8x8 tile: surface from the G-buffer, the pixel's
+// reservoir light, one shadow ray (any-hit included), BRDF, running mean into the HDR image.
+// ------------------------------------------------------------------------------------------
+
+// scene/material.glsl:20-32
+PPT_D f3 signed_oct_decode(f3 n)
+{
+    f3 o;
+    o.x = n.x - n.y;
+    o.y = (n.x + n.y) - 1.0f;
+    o.z = n.z * 2.0f - 1.0f;
+    o.z = o.z * ((1.0f - fabs_(o.x)) - fabs_(o.y));
+    return normalize(o);
+}
+
+struct RestirParams
+{
+    uint32_t drawType, frameIndex, flags, width, height;
+    float eye[3];
+    float clipToWorld[16]; // column-major
+};
+
+__global__ __launch_bounds__(256) void restir_di_trace_kernel(
+    DeviceScene s, RestirParams p, const float4 *__restrict__ albedoRoughness, const float4 *__restrict__ normalMetallic,
+    const float *__restrict__ nonLinearDepth, const float2 *__restrict__ reservoirs, float4 *__restrict__ hdr,
+    int32_t *__restrict__ stackOverflow)
+{
+    __shared__ int32_t ldsStack[kTraversalStackDepth * 256];
+    const uint32_t tilesX = (p.width + 15u) / 16u, tilesY = (p.height + 15u) / 16u;
+    const uint32_t numTiles = tilesX * tilesY;
+    const uint32_t perXcd = (numTiles + 7u) / 8u;
+    const uint32_t tile = (blockIdx.x % 8u) * perXcd + (blockIdx.x / 8u);
+    if (tile >= numTiles) return;
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    const uint32_t px = (tile % tilesX) * 16u + (wave & 1u) * 8u + (lane & 7u);
+    const uint32_t py = (tile / tilesX) * 16u + (wave >> 1) * 8u + (lane >> 3);
+    const TraversalStack stack{(lds_int32 *)ldsStack + wave * (kTraversalStackDepth * 64u) + lane,
+                               stackOverflow + blockIdx.x * 256u + threadIdx.x, kTraversalStackDepth, gridDim.x * 256u};
+    if (px >= p.width || py >= p.height) return;
+    const size_t i = (size_t)py * p.width + px;
+
+    // main.rgen:113-129
+    const f2 uv = f2{(float)px / (float)p.width, (float)py / (float)p.height};
+    const float depth = nonLinearDepth[i];
+    Surface sf;
+    {
+        // worldPos, scene/camera.glsl:27-33
+        const float *m = p.clipToWorld;
+        const float x = uv.x * 2.0f - 1.0f, y = uv.y * 2.0f - 1.0f;
+        const float vx = __builtin_fmaf(m[8], depth, __builtin_fmaf(m[4], y, __builtin_fmaf(m[0], x, m[12])));
+        const float vy = __builtin_fmaf(m[9], depth, __builtin_fmaf(m[5], y, __builtin_fmaf(m[1], x, m[13])));
+        const float vz = __builtin_fmaf(m[10], depth, __builtin_fmaf(m[6], y, __builtin_fmaf(m[2], x, m[14])));
+        const float vw = __builtin_fmaf(m[11], depth, __builtin_fmaf(m[7], y, __builtin_fmaf(m[3], x, m[15])));
+        sf.positionWS = f3{vx, vy, vz} * (1.0f / vw);
+    }
+    sf.invViewRayWS = normalize(f3{p.eye[0], p.eye[1], p.eye[2]} - sf.positionWS);
+    const float4 ar = albedoRoughness[i], nm = normalMetallic[i];
+    sf.material.albedo = f3{ar.x, ar.y, ar.z};
+    sf.material.roughness = ar.w;
+    sf.material.normal = signed_oct_decode(f3{nm.x, nm.y, nm.w});
+    sf.material.metallic = nm.z;
+    sf.material.alpha = -1.0f;
+    sf.normalWS = sf.material.normal;
+    sf.uv = f2{0.0f, 0.0f};
+    sf.NoV = saturate(dot(sf.normalWS, sf.invViewRayWS));
+
+    if (p.drawType != PROSPER_DRAW_TYPE_DEFAULT)
+    {
+        const f3 c = p.drawType == PROSPER_DRAW_TYPE_POSITION ? sf.positionWS : sf.material.albedo;
+        hdr[i] = make_float4(c.x, c.y, c.z, 1.0f);
+        return;
+    }
+    // evaluateDirectLightingReSTIR, main.rgen:88-109
+    const float2 packed = reservoirs[i];
+    const int32_t lightIndex = (int32_t)f2u(packed.x);
+    f3 color = f3{0.0f, 0.0f, 0.0f};
+    if (!(sf.material.alpha == 0.0f || lightIndex < 0))
+    {
+        f3 l, irradiance;
+        float d;
+        sample_light(s, sf.positionWS, (uint32_t)lightIndex, l, d, irradiance);
+        if (dot(l, sf.normalWS) > 0.0f)
+        {
+            LaneCounters cnt = {};
+            Hit sh;
+            const bool occluded = trace<true, false>(s, sf.positionWS, l, 0.1f, d, pcg(px ^ py), stack, sh, cnt);
+            irradiance = irradiance * (occluded ? 0.0f : 1.0f);
+            color = (irradiance * eval_brdf_times_nol(l, sf)) * packed.y;
+        }
+    }
+    if ((p.flags & 1u) || !(p.flags & 2u))
+        hdr[i] = make_float4(color.x, color.y, color.z, 1.0f);
+    else
+    {
+        const float4 h = hdr[i];
+        const float count = h.w + 1.0f;
+        const float inv = 1.0f / count;
+        hdr[i] = make_float4(
+            __builtin_fmaf(color.x - h.x, inv, h.x), __builtin_fmaf(color.y - h.y, inv, h.y),
+            __builtin_fmaf(color.z - h.z, inv, h.z), count);
+    }
+}
+
+uint32_t restir_grid_blocks(uint32_t width, uint32_t height)
+{
+    const uint32_t numTiles = ((width + 15u) / 16u) * ((height + 15u) / 16u);
+    return ((numTiles + 7u) / 8u) * 8u;
+}
+
+void launch_restir_di_trace(
+    const DeviceScene &s, uint32_t drawType, uint32_t frameIndex, uint32_t flags, uint32_t width, uint32_t height,
+    const float eye[3], const float clipToWorld[16], const void *albedoRoughness, const void *normalMetallic,
+    const float *nonLinearDepth, const void *reservoirs, float4 *hdr, int32_t *stackOverflow, hipStream_t stream)
+{
+    if (width == 0 || height == 0) return;
+    RestirParams p;
+    p.drawType = drawType;
+    p.frameIndex = frameIndex;
+    p.flags = flags;
+    p.width = width;
+    p.height = height;
+    for (int k = 0; k < 3; ++k) p.eye[k] = eye[k];
+    for (int k = 0; k < 16; ++k) p.clipToWorld[k] = clipToWorld[k];
+    hipLaunchKernelGGL(
+        restir_di_trace_kernel, dim3(restir_grid_blocks(width, height)), dim3(256), 0, stream, s, p,
+        static_cast<const float4 *>(albedoRoughness), static_cast<const float4 *>(normalMetallic), nonLinearDepth,
+        static_cast<const float2 *>(reservoirs), hdr, stackOverflow);
+}
+
+// ------------------------------------------------------------------------------------------
 // tone map: the step after the path (res/shader/tone_map.comp:17-60, src/render/ToneMap.cpp:62-128),
 // fused with the RGBA32F -> RGBA16F blit it reads through (RtReference.cpp:339-377).  One thread per
 // pixel: 16 B in, 4 B out, eight taps of the 442 KB LUT (L2-resident).  Arithmetic: DESIGN.md

@@ -46,6 +46,11 @@ void launch_flatten_triangles(
     WorldTriangle *out, ShadeTriangle *shadeOut, uint32_t total, hipStream_t stream);
 void launch_permute_triangles(
     const WorldTriangle *in, const uint32_t *permutation, WorldTriangle *out, uint32_t total, hipStream_t stream);
+uint32_t restir_grid_blocks(uint32_t width, uint32_t height);
+void launch_restir_di_trace(
+    const DeviceScene &s, uint32_t drawType, uint32_t frameIndex, uint32_t flags, uint32_t width, uint32_t height,
+    const float eye[3], const float clipToWorld[16], const void *albedoRoughness, const void *normalMetallic,
+    const float *nonLinearDepth, const void *reservoirs, float4 *hdr, int32_t *stackOverflow, hipStream_t stream);
 void launch_tone_map(
     const float4 *hdr, const uint32_t *lut, uint32_t dim, float exposure, float contrast, void *outRgba8, uint32_t count,
     hipStream_t stream);

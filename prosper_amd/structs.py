@@ -266,3 +266,13 @@ class SceneStats(C.Structure):
 def as_numpy(struct_array, dtype=np.uint8):
     """View a ctypes structure/array as a numpy byte array (no copy)."""
     return np.frombuffer(struct_array, dtype=dtype)
+
+
+class RestirTracePC(C.Structure):
+    """TracePC, res/shader/shared/shader_structs/push_constants/restir_di/trace.h"""
+    _fields_ = [("drawType", C.c_uint32), ("frameIndex", C.c_uint32), ("flags", C.c_uint32)]
+
+
+class RestirInputs(C.Structure):
+    _fields_ = [("albedoRoughness", C.c_void_p), ("normalMetallic", C.c_void_p), ("nonLinearDepth", C.c_void_p),
+                ("reservoirs", C.c_void_p), ("onDevice", C.c_uint32), ("reserved", C.c_uint32)]
