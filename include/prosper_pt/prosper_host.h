@@ -58,6 +58,16 @@ int prosper_host_rt_reference_record(
     const prosper_host_record_options *options, uint32_t frameCount, const prosper_pt_tile_desc *tile,
     uint32_t renderFlags, void *stream, prosper_ReferencePC *outPushConstants);
 
+/* render::ToneMap (host/tone_map.hpp; reference src/render/ToneMap.hpp:16-52): init with the LUT file
+ * (res/texture/tony_mc_mapface.dds) or its texels, drawUi's two sliders, record into caller-owned device memory. */
+typedef struct prosper_host_tone_map prosper_host_tone_map;
+int prosper_host_tone_map_create(prosper_pt_ctx *ctx, const char *lutDdsPath, prosper_host_tone_map **out);
+int prosper_host_tone_map_create_from_texels(
+    prosper_pt_ctx *ctx, const uint32_t *lutR9G9B9E5, uint32_t dim, prosper_host_tone_map **out);
+void prosper_host_tone_map_destroy(prosper_host_tone_map *pass);
+void prosper_host_tone_map_draw_ui(prosper_host_tone_map *pass, float exposure, float contrast);
+int prosper_host_tone_map_record(prosper_host_tone_map *pass, void *stream, void *deviceRgba8, size_t byteSize);
+
 #ifdef __cplusplus
 }
 #endif

@@ -104,6 +104,13 @@ def lib():
     L.prosper_host_rt_reference_release_preserved.restype = None
     L.prosper_host_rt_reference_record.argtypes = [
         vp, vp, u32, u32, C.POINTER(RecordOptions), u32, C.POINTER(S.TileDesc), u32, vp, C.POINTER(S.ReferencePC)]
+    L.prosper_host_tone_map_create.argtypes = [vp, C.c_char_p, C.POINTER(vp)]
+    L.prosper_host_tone_map_create_from_texels.argtypes = [vp, vp, u32, C.POINTER(vp)]
+    L.prosper_host_tone_map_destroy.argtypes = [vp]
+    L.prosper_host_tone_map_destroy.restype = None
+    L.prosper_host_tone_map_draw_ui.argtypes = [vp, C.c_float, C.c_float]
+    L.prosper_host_tone_map_draw_ui.restype = None
+    L.prosper_host_tone_map_record.argtypes = [vp, vp, vp, C.c_size_t]
     _lib = L
     return L
 

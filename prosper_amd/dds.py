@@ -53,3 +53,16 @@ def encode_r9g9b9e5(rgb):
     e = np.where(over, e + 1, e)
     m = np.clip(np.rint(rgb * np.ldexp(1.0, 24 - e)[..., None]).astype(np.int64), 0, 511)
     return (m[..., 0] | (m[..., 1] << 9) | (m[..., 2] << 18) | (e << 27)).astype(np.uint32)
+
+
+def write_lut(path, texels):
+    """uint32 [d, h, w] R9G9B9E5 texels -> a DX10-header DDS like tony_mc_mapface.dds (fixture writer)."""
+    t = np.ascontiguousarray(texels, dtype="<u4")
+    d, h, w = t.shape
+    header = [0] * 31
+    header[0], header[1], header[2], header[3], header[4], header[5], header[6] = 124, 0x80100F, h, w, w * 4, d, 1
+    header[18], header[19], header[20] = 32, 0x4, 0x30315844  # pixel format: size, DDPF_FOURCC, 'DX10'
+    header[26], header[27] = 0x1008, 0x200000                # caps: texture | complex, caps2: volume
+    with open(path, "wb") as f:
+        f.write(b"DDS " + struct.pack("<31I", *header) +
+                struct.pack("<5I", DXGI_FORMAT_R9G9B9E5_SHAREDEXP, _DIMENSION_TEXTURE3D, 0, 1, 0) + t.tobytes())

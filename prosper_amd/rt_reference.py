@@ -5,6 +5,9 @@ Same names, argument meaning and error behaviour as prosper's `scene::Camera`
 goes through libprosper_pt.so (no Python re-implementation of the pass).
 """
 import ctypes as C
+import os
+
+import numpy as np
 
 from . import structs as S
 from .capi import Context, ProsperPtError, RecordOptions, lib
@@ -131,3 +134,31 @@ class RtReference:
 
     def release_preserved(self):
         lib().prosper_host_rt_reference_release_preserved(self._h)
+
+
+class ToneMap:
+    """Handle on the C++ render::ToneMap (csrc/host/tone_map.hpp; reference src/render/ToneMap.hpp)."""
+
+    def __init__(self, ctx, lut_path=None, lut_texels=None):
+        h = C.c_void_p()
+        if lut_path is not None:
+            rc = lib().prosper_host_tone_map_create(ctx._h, os.fsencode(lut_path), C.byref(h))
+        else:
+            lut = np.ascontiguousarray(lut_texels, dtype=np.uint32)
+            rc = lib().prosper_host_tone_map_create_from_texels(ctx._h, lut.ctypes.data, lut.shape[0], C.byref(h))
+        if rc != 0:
+            raise ProsperPtError(rc, lib().prosper_host_last_error().decode())
+        self._h = h
+
+    def draw_ui(self, exposure, contrast):
+        lib().prosper_host_tone_map_draw_ui(self._h, exposure, contrast)
+
+    def record(self, device_ptr, byte_size, stream=None):
+        rc = lib().prosper_host_tone_map_record(self._h, C.c_void_p(stream), C.c_void_p(device_ptr), byte_size)
+        if rc != 0:
+            raise ProsperPtError(rc, lib().prosper_host_last_error().decode())
+
+    def close(self):
+        if self._h:
+            lib().prosper_host_tone_map_destroy(self._h)
+            self._h = None

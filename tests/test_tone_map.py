@@ -157,3 +157,49 @@ def test_gpu_tone_map_edge_values_and_errors(gpu_ctx, oracle, cornell_world):
             assert np.array_equal(got, oracle.tone_map(hdr, lut, 1.7, 1.1)), dim
     finally:
         ctx.close()
+
+
+def test_dds_lut_write_read_round_trip(tmp_path):
+    lut = synthetic_lut(12)
+    p = tmp_path / "lut.dds"
+    dds.write_lut(str(p), lut)
+    assert np.array_equal(dds.read_lut(str(p)), lut)
+    if os.path.exists(LUT_PATH):  # same header fields as the reference's file
+        assert open(LUT_PATH, "rb").read(148)[76:92] == p.read_bytes()[76:92]
+
+
+@pytest.mark.gpu
+def test_host_tone_map_class(gpu_ctx, oracle, cornell_world, tmp_path):
+    """render::ToneMap (C++ host layer): init from a DDS file == init from texels == the C-ABI call; drawUi clamps."""
+    import torch
+    from conftest import default_pc
+    from prosper_amd import capi
+    from prosper_amd.rt_reference import ToneMap
+    w, h = 128, 96
+    c = cornell_world.camera
+    cam, fl = oracle.camera_uniforms(c["eye"], c["target"], c["up"], c["fov"], c["zN"], c["zF"], w, h)
+    gpu_ctx.upload_scene(cornell_world)
+    gpu_ctx.render(default_pc(S, fl, max_bounces=3), cam, w, h, frames=2)
+    hdr = gpu_ctx.read_hdr()
+    lut = synthetic_lut(16)
+    path = tmp_path / "lut.dds"
+    dds.write_lut(str(path), lut)
+    out = torch.zeros((h, w), dtype=torch.int32, device="cuda")
+    for tm in (ToneMap(gpu_ctx, lut_path=str(path)), ToneMap(gpu_ctx, lut_texels=lut)):
+        tm.draw_ui(2.0, 1.2)
+        out.zero_()
+        tm.record(out.data_ptr(), out.numel() * 4)
+        torch.cuda.synchronize()
+        got = out.cpu().numpy().view(np.uint8).reshape(h, w, 4)
+        assert np.array_equal(got, oracle.tone_map(hdr, lut, 2.0, 1.2))
+        tm.draw_ui(1e9, 0.0)  # sliders clamp to [0.001, 10000] (ToneMap.cpp:58-59)
+        tm.record(out.data_ptr(), out.numel() * 4)
+        torch.cuda.synchronize()
+        got = out.cpu().numpy().view(np.uint8).reshape(h, w, 4)
+        assert np.array_equal(got, oracle.tone_map(hdr, lut, 10000.0, 0.001))
+        tm.close()
+    with pytest.raises(capi.ProsperPtError):
+        ToneMap(gpu_ctx, lut_path=str(tmp_path / "missing.dds"))
+    (tmp_path / "bad.dds").write_bytes(b"DDS " + bytes(200))
+    with pytest.raises(capi.ProsperPtError):
+        ToneMap(gpu_ctx, lut_path=str(tmp_path / "bad.dds"))
