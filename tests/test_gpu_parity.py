@@ -173,6 +173,32 @@ def test_cornell_radiance_bit_exact_over_accumulated_frames(gpu_ctx, oracle, cor
     assert (got[..., 3] == 4.0).all()
 
 
+@pytest.mark.parametrize("kw", [
+    dict(accumulate=False, skip_history=False),           # no running mean: (colour, 1) every frame
+    dict(clamp=False, max_bounces=6, roulette=0),          # unclamped indirect, roulette from the second bounce
+    dict(max_bounces=9, roulette=6),                       # PC above the shader's MAX_BOUNCES cap: 6 bounces, no roulette
+    dict(max_bounces=2, ibl=True, dof=True, roulette=0),
+    dict(max_bounces=1, ibl=True, clamp=False),
+])
+def test_push_constant_flag_matrix_bit_exact(gpu_ctx, oracle, cornell_world, kw):
+    """ReferencePC flag / bound combinations (RtReference.cpp:77-88, main.rgen:26-30,241-244,269-276): three frames each."""
+    w, h = 128, 96
+    cam, fl = _camera(oracle, cornell_world, w, h)
+    gpu_ctx.upload_scene(cornell_world)
+    osc = oracle.OracleScene(cornell_world, brute_force=True)
+    want = None
+    for frame in (1, 2, 3):
+        args = dict(kw)
+        args.setdefault("skip_history", frame == 1)
+        pc = default_pc(S, fl, frame_index=frame, **args)
+        pc.apertureDiameter = 0.08 if kw.get("dof") else 1e-5
+        pc.focusDistance = 2.5
+        gpu_ctx.render(pc, cam, w, h)
+        want, _ = osc.render(pc, cam, w, h, history=want)
+    ok = same_bits(gpu_ctx.read_hdr(), want).all(axis=2)
+    assert ok.all(), "%r: %d of %d pixels differ" % (kw, (~ok).sum(), ok.size)
+
+
 def test_render_frames_equals_repeated_render(gpu_ctx, oracle, cornell_world):
     """prosper_pt_render_frames(n) == n x prosper_pt_render (history kept in registers vs HBM)."""
     w, h = 320, 200
