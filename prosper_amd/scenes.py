@@ -572,3 +572,34 @@ def texture_wall():
     w.camera = dict(eye=(0.0, 0.0, 6.5), target=(0.0, 0.0, 0.0), up=(0.0, 1.0, 0.0),
                     fov=math.radians(50.0), zN=0.1, zF=100.0)
     return w
+
+
+def transform_zoo():
+    """One normal-mapped, textured box instanced under rotations, non-uniform scales, a shear and mirrors
+    (negative determinant): the inverse-transpose normal path, tangent signs and instance transforms
+    (scene/instances.glsl:36-53, World.cpp:405-414)."""
+    w = World()
+    base = w.add_texture(noise_texture(32, 11, base=(0.6, 0.5, 0.4), amplitude=0.3, cells=6))
+    nrm = w.add_texture(normal_texture(32, 12, strength=0.6, cells=5))
+    mat = w.add_material(base_color=(1.0, 1.0, 1.0, 1.0), metallic=0.3, roughness=0.45, base_tex=(base, 0),
+                         normal_tex=(nrm, 0))
+    cube = _add(w, box(uv_scale=2.0), mat)
+    model = w.add_model([(cube, mat)])
+    shear = np.eye(4)
+    shear[0, 1] = 0.6
+    xs = [
+        np.eye(4),
+        rotate_y(0.7) @ rotate_x(0.4),
+        scale((1.8, 0.4, 0.7)),
+        rotate_z(0.5) @ scale((0.3, 1.6, 1.1)) @ rotate_y(1.1),
+        scale((-1.0, 1.0, 1.0)),
+        rotate_y(-0.6) @ scale((0.8, -1.3, 0.9)),
+        shear,
+        scale((-0.7, -0.9, -1.2)) @ rotate_x(0.9),
+    ]
+    for k, m in enumerate(xs):
+        w.add_instance(model, translate(((k % 4) * 2.2 - 3.3, (k // 4) * 2.4 - 1.6, 0.0)) @ m)
+    w.add_point_light((1.0, 0.95, 0.9), 400.0, (0.0, 0.5, 6.0))
+    w.add_spot_light((0.8, 0.9, 1.0), 600.0, (-4.0, 3.0, 5.0), (0.6, -0.4, -0.7), math.radians(25.0), math.radians(45.0))
+    w.camera = dict(eye=(0.0, 0.3, 9.0), target=(0.0, 0.2, 0.0), up=(0.0, 1.0, 0.0), fov=math.radians(50.0), zN=0.1, zF=100.0)
+    return w

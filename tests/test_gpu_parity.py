@@ -173,6 +173,24 @@ def test_cornell_radiance_bit_exact_over_accumulated_frames(gpu_ctx, oracle, cor
     assert (got[..., 3] == 4.0).all()
 
 
+@pytest.mark.parametrize("draw_type", ["ShadingNormal", "Position", "TexCoord0", "Default"])
+def test_instance_transform_zoo_bit_exact(gpu_ctx, oracle, draw_type):
+    """Rotations, non-uniform scales, a shear and mirrored instances of a normal-mapped box (scenes.transform_zoo)."""
+    world = scenes.transform_zoo()
+    w, h = 320, 200
+    cam, fl = _camera(oracle, world, w, h)
+    gpu_ctx.upload_scene(world)
+    osc = oracle.OracleScene(world, brute_force=True)
+    want = None
+    for frame in (1, 2):
+        pc = default_pc(S, fl, frame_index=frame, draw_type=S.DrawType[draw_type], max_bounces=3, skip_history=(frame == 1))
+        gpu_ctx.render(pc, cam, w, h)
+        want, _ = osc.render(pc, cam, w, h, history=want)
+    ok = same_bits(gpu_ctx.read_hdr(), want).all(axis=2)
+    assert ok.all(), "%s: %d of %d pixels differ" % (draw_type, (~ok).sum(), ok.size)
+    assert (want[..., :3].sum(axis=2) != 0).mean() > 0.05
+
+
 @pytest.mark.parametrize("kw", [
     dict(accumulate=False, skip_history=False),           # no running mean: (colour, 1) every frame
     dict(clamp=False, max_bounces=6, roulette=0),          # unclamped indirect, roulette from the second bounce
