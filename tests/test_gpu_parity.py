@@ -173,6 +173,44 @@ def test_cornell_radiance_bit_exact_over_accumulated_frames(gpu_ctx, oracle, cor
     assert (got[..., 3] == 4.0).all()
 
 
+@pytest.mark.parametrize("factor", [0.01, 100.0, 3000.0])
+def test_scene_scale_sweep_bit_exact(gpu_ctx, oracle, factor):
+    """S-cornell scaled through its instance transforms (lights and camera with it): the BVH padding, the node-local
+    fp16 boxes and the box guard are all relative to coordinate magnitude, so parity must hold at 2 cm, 200 m
+    and 6 km scene size alike (positions stay fp16 in object space)."""
+    from prosper_amd.world import scale as scale_matrix
+    world = scenes.cornell(with_skybox=True)
+    sm = scale_matrix((factor, factor, factor))
+    world.model_instances = [(mi, sm @ m) for mi, m in world.model_instances]
+    for i in range(world.point_lights.count):
+        p = world.point_lights.lights[i].position
+        p.x, p.y, p.z = p.x * factor, p.y * factor, p.z * factor
+        r = world.point_lights.lights[i].radianceAndRadius
+        r.x, r.y, r.z, r.w = r.x * factor * factor, r.y * factor * factor, r.z * factor * factor, r.w * factor
+    for i in range(world.spot_lights.count):
+        p = world.spot_lights.lights[i].positionAndAngleOffset
+        p.x, p.y, p.z = p.x * factor, p.y * factor, p.z * factor
+        r = world.spot_lights.lights[i].radianceAndAngleScale
+        r.x, r.y, r.z = r.x * factor * factor, r.y * factor * factor, r.z * factor * factor
+    c = world.camera
+    world.camera = dict(c, eye=tuple(v * factor for v in c["eye"]), target=tuple(v * factor for v in c["target"]))
+    w, h = 192, 128
+    cam, fl = _camera(oracle, world, w, h)
+    gpu_ctx.upload_scene(world)
+    osc = oracle.OracleScene(world, brute_force=True)
+    want = None
+    for frame in (1, 2):
+        pc = default_pc(S, fl, frame_index=frame, max_bounces=4, ibl=True, skip_history=(frame == 1))
+        gpu_ctx.render(pc, cam, w, h)
+        want, _ = osc.render(pc, cam, w, h, history=want)
+    ok = same_bits(gpu_ctx.read_hdr(), want).all(axis=2)
+    assert ok.all(), "scale %g: %d of %d pixels differ" % (factor, (~ok).sum(), ok.size)
+    pos_pc = default_pc(S, fl, draw_type=S.DrawType["PrimitiveID"], max_bounces=1)
+    gpu_ctx.render(pos_pc, cam, w, h)
+    want_id, _ = osc.render(pos_pc, cam, w, h)
+    assert same_bits(gpu_ctx.read_hdr(), want_id).all() and (want_id[..., :3].sum(axis=2) > 0).mean() > 0.5
+
+
 @pytest.mark.parametrize("draw_type", ["ShadingNormal", "Position", "TexCoord0", "Default"])
 def test_instance_transform_zoo_bit_exact(gpu_ctx, oracle, draw_type):
     """Rotations, non-uniform scales, a shear and mirrored instances of a normal-mapped box (scenes.transform_zoo)."""
