@@ -406,18 +406,38 @@ int ensure_wavefront_workspace(
 {
     const uint64_t pixelsPadded = (uint64_t)tilesX * tilesY * 64u;
     const uint64_t slots = pixelsPadded * frames;
-    // one segment per wave, several rounds of segments per CU to balance over
-    // segment length: about 25 600 segments per batch (five times the 5120 waves the GPU holds), rounded to
-    // whole 64-lane batches - 640 slots at 1920x1080 x 8 spp (swept: profiles/r01_seglen_sweep.txt)
-    uint64_t segLen = ((slots / 25600u) + 32u) / 64u * 64u;
-    if (segLen < 128u) segLen = 128u; // single-frame renders: 16 k waves of 128 slots
-    if (segLen > 1024u) segLen = 1024u;
+    // One segment per wave.  Segments take their 8x8 tiles strided over the whole batch (wf_generate_extend), so
+    // all waves carry statistically equal work and there is nothing to balance dynamically: the best segment
+    // count is about one round of resident waves for each of the two launch chains plus a little, ~11 500 segments (swept:
+    // profiles/r01_seglen_sweep.txt).  The length is an ODD multiple of 64 slots: at even multiples the waves'
+    // concurrent accesses to their segments' records, `segLen * 16` bytes apart, pile onto a few HBM channels.
+    uint64_t target = 11500u;
+    if (const char *forced = std::getenv("PROSPER_PT_DEBUG_SEGMENTS")) // tuning hook
+    {
+        const uint64_t v = (uint64_t)std::atoll(forced);
+        if (v >= 64u && v <= (1u << 20)) target = v;
+    }
+    uint64_t batches = (slots / target + 32u) / 64u;
+    if (batches < 2u) batches = 2u; // small renders: 128-slot segments
+    if (batches > 2u && batches % 2u == 0u) batches += 1u;
+    if (batches > 33u) batches = 33u;
+    uint64_t segLen = batches * 64u;
     if (const char *forced = std::getenv("PROSPER_PT_DEBUG_SEGLEN")) // tuning/test hook
     {
         const uint64_t v = (uint64_t)std::atoll(forced);
         if (v >= 64u && v <= 8192u && v % 64u == 0u) segLen = v;
     }
-    const uint64_t nSeg = (slots + segLen - 1u) / segLen;
+    uint64_t nSeg = (slots + segLen - 1u) / segLen;
+    // The stride between a segment's tiles is nSeg tiles.  A stride that is nearly a whole number of tile rows
+    // would keep a segment in the same few tile columns (correlated work, the balance is gone): add segments
+    // until the column step is at least an eighth of a row away from 0.
+    if (tilesX >= 16u)
+        for (uint32_t tries = 0; tries < tilesX; ++tries)
+        {
+            const uint64_t cols = (nSeg % ((uint64_t)tilesX * tilesY)) % tilesX;
+            if (cols >= tilesX / 8u && tilesX - cols >= tilesX / 8u) break;
+            ++nSeg;
+        }
     const uint64_t padded = nSeg * segLen;
     // per slot: 8 x 16 B ping-pong state, hit 16 + idx 4, shadow 48, colour 16; + 3 counters per segment
     const size_t bytes = (size_t)padded * (8u * 16u + 16u + 4u + 48u + 16u) + (size_t)nSeg * 12u + 4096u;

@@ -165,11 +165,21 @@ __global__ __launch_bounds__(256, PPT_GEN_WPE) void wf_generate_extend(
         // A batch of 64 consecutive slots is one 8x8 tile of one frame (segment bases and the frame stride are
         // multiples of 64), so frame / tile row / tile column are wave-uniform: decoded once per segment with
         // the two integer divisions, then stepped tile by tile.
-        const SlotPixel first = decode_slot(w, p, id.base);
+        // Batch b of segment s is tile number b * nSeg + s of the (frame, tile) sequence: every segment gets
+        // tiles from all over the image (and all frames), so the waves of a launch carry statistically equal
+        // work and finish together; consecutive segments still start on neighbouring tiles.
+        const SlotPixel first = decode_slot(w, p, id.seg * 64u);
         uint32_t tileFrame = first.frame, tileX = first.lx >> 3, tileY = first.py >> 3;
+        // one step of nSeg tiles, split into whole frames, tile rows and tile columns
+        const uint32_t tilesPerFrame = w.pixelsPadded >> 6;
+        const uint32_t stepFrames = w.nSeg / tilesPerFrame;
+        const uint32_t stepRem = w.nSeg - stepFrames * tilesPerFrame;
+        const uint32_t stepRows = stepRem / w.tilesX, stepCols = stepRem - stepRows * w.tilesX;
+        uint32_t batchSlot = id.seg * 64u; // image slot of lane 0 of the current batch
         bool slotValid = false; // of the slot the last fetch() decoded: commit() follows it in lockstep
         auto fetch = [&](uint32_t k) {
-            const uint32_t slot = id.base + k;
+            const uint32_t at = id.base + k; // where the path's records live in this segment
+            const uint32_t slot = batchSlot + lane;
             SlotPixel sp;
             sp.frame = tileFrame;
             sp.lx = tileX * 8u + (lane & 7u);
@@ -191,9 +201,9 @@ __global__ __launch_bounds__(256, PPT_GEN_WPE) void wf_generate_extend(
             start_path<COUNT>(p, local_to_global_x(p, sp.lx), sp.py, (p.pc.frameIndex + sp.frame) % PROSPER_RT_FRAME_PERIOD,
                               st, cnt);
             if constexpr (COUNT) cnt.closestRays++;
-            w.rayB[0][slot] = make_float4(st.d.x, st.d.y, st.d.z, 0.0f);
-            w.pathT[0][slot] = make_float4(1.0f, 1.0f, 1.0f, asf(slot));
-            w.pathR[0][slot] = make_uint4(st.rng.x, st.rng.y, st.rng.z, 0u);
+            w.rayB[0][at] = make_float4(st.d.x, st.d.y, st.d.z, 0.0f);
+            w.pathT[0][at] = make_float4(1.0f, 1.0f, 1.0f, asf(slot));
+            w.pathR[0][at] = make_uint4(st.rng.x, st.rng.y, st.rng.z, 0u);
             r.o = st.o;
             r.d = st.d;
             r.tMin = 0.0f;
@@ -202,7 +212,7 @@ __global__ __launch_bounds__(256, PPT_GEN_WPE) void wf_generate_extend(
             return r;
         };
         auto commit = [&](bool pred, uint32_t k, bool found, const Hit &hit, const f3 &dir) {
-            const uint32_t slot = id.base + k;
+            const uint32_t slot = batchSlot + lane;
             const bool valid = pred && slotValid;
             if (valid)
             {
@@ -238,16 +248,21 @@ __global__ __launch_bounds__(256, PPT_GEN_WPE) void wf_generate_extend(
             else
                 found = trace_in<false, COUNT>(gg, s, r.o, r.d, r.tMin, r.tMax, r.seed, stack, hit, cnt);
             commit(true, k, found, hit, r.d);
-            // next tile of the frame, next frame after the last tile
-            if (++tileX == w.tilesX)
+            // nSeg tiles on: columns, rows, frames, with carries
+            batchSlot += w.nSeg * 64u;
+            tileX += stepCols;
+            if (tileX >= w.tilesX)
             {
-                tileX = 0;
-                if (++tileY == w.tilesY)
-                {
-                    tileY = 0;
-                    ++tileFrame;
-                }
+                tileX -= w.tilesX;
+                ++tileY;
             }
+            tileY += stepRows;
+            if (tileY >= w.tilesY)
+            {
+                tileY -= w.tilesY;
+                ++tileFrame;
+            }
+            tileFrame += stepFrames;
         }
     }
     if (lane == 0) w.segHits[id.seg] = nHit;
@@ -678,7 +693,7 @@ void launch_render_wavefront(
     static_assert(kTraversalStackDepth == 32, "largest LDS stack variant");
     const uint32_t groups = (w.nSeg + 3u) / 4u;
     // Two chains only pay when each still fills the machine a few times over (>= 1024 workgroups each).
-    const uint32_t parts = (chains.count >= 2u && groups >= 2048u) ? 2u : 1u;
+    const uint32_t parts = (chains.count >= 2u && groups >= 512u) ? 2u : 1u;
     const uint32_t per = (groups + parts - 1u) / parts;
     if (parts > 1u) (void)hipEventRecord(chains.fork, stream);
     uint32_t blocksBefore = 0;

@@ -25,6 +25,7 @@ def main():
     ap.add_argument("--height", type=int, default=0)
     ap.add_argument("--lib", default=None)
     ap.add_argument("--small-textures", action="store_true")
+    ap.add_argument("--ranks", type=int, default=1, help="render only rank 0's stripes of an N-rank job (strong-scaling share)")
     args = ap.parse_args()
     from prosper_amd import capi
     if args.lib:
@@ -58,10 +59,14 @@ def main():
             c = ctx.stage_counters(stage)
             d = {n: int(getattr(c, n)) for n, _ in c._fields_ if n != "reserved"}
             print("  %-16s %s" % (name, " ".join("%s=%d" % kv for kv in d.items() if kv[1])))
+    tile = None
+    if args.ranks > 1:
+        from prosper_amd import tiling
+        tile = tiling.tile_for_rank(0, args.ranks)
     ctx.set_kernel_timing(True)
     times = []
     for i in range(args.steps + 2):
-        ctx.render(pc, cam, w, h, frames=spp)
+        ctx.render(pc, cam, w, h, frames=spp, tile=tile)
         ms, per = ctx.last_render_timing()
         if i >= 2:
             times.append(ms)
@@ -70,7 +75,7 @@ def main():
     print("  " + "  ".join("%s %dx%.0fus" % (k.replace("wf_", ""), v[1], v[0] * 1e3 / max(1, v[1])) for k, v in per.items() if v[1]))
     img = ctx.read_hdr()
     print("%s %s: median %.3f ms  min %.3f  => %.1f Mpaths/s  (checksum %.6f)" % (
-        args.config, "megakernel" if args.megakernel else ("persistent" if args.persistent else "wavefront"), med, times[0], w * h * spp / med / 1e3,
+        args.config, "megakernel" if args.megakernel else ("persistent" if args.persistent else "wavefront"), med, times[0], w * h * spp / args.ranks / med / 1e3,
         float(img[..., :3].astype("float64").mean())))
 
 
