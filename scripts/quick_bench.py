@@ -52,17 +52,17 @@ def main():
         print('triangles %d nodes %d maxDepth %d build %.3fs deviceMB %.1f' % (st.triangleCount, st.nodeCount, st.maxDepth, st.buildSeconds, st.deviceBytes / 1e6))
     flags = S.PC_FLAG_ACCUMULATE | S.PC_FLAG_CLAMP_INDIRECT | S.PC_FLAG_SKIP_HISTORY | (S.PC_FLAG_IBL if ibl else 0)
     pc = S.ReferencePC(0, flags, 1, 1e-5, 1.0, focal, 3, mb)
-    if args.counters:
-        ctx.reset_counters()
-        ctx.render(pc, cam, w, h, frames=spp, flags=S.RENDER_COUNT_WORK)
-        for stage, name in enumerate(("generate_extend", "shade", "trace", "accumulate")):
-            c = ctx.stage_counters(stage)
-            d = {n: int(getattr(c, n)) for n, _ in c._fields_ if n != "reserved"}
-            print("  %-16s %s" % (name, " ".join("%s=%d" % kv for kv in d.items() if kv[1])))
     tile = None
     if args.ranks > 1:
         from prosper_amd import tiling
         tile = tiling.tile_for_rank(0, args.ranks)
+    if args.counters:
+        ctx.reset_counters()
+        ctx.render(pc, cam, w, h, frames=spp, flags=S.RENDER_COUNT_WORK, tile=tile)
+        for stage, name in enumerate(("generate_extend", "shade", "trace", "accumulate")):
+            c = ctx.stage_counters(stage)
+            d = {n: int(getattr(c, n)) for n, _ in c._fields_ if n != "reserved"}
+            print("  %-16s %s" % (name, " ".join("%s=%d" % kv for kv in d.items() if kv[1])))
     ctx.set_kernel_timing(True)
     times = []
     for i in range(args.steps + 2):
