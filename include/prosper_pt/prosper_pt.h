@@ -78,6 +78,11 @@ enum
 enum
 {
     PROSPER_PT_FORMAT_RGBA8_UNORM = 0,
+    /* level 0 of prosper's texture cache as it is (src/scene/Texture.cpp:255-287 compresses every texture whose
+     * mip chain divides by 4; src/utils/Dds.cpp:118-131 layout): (width/4)*(height/4) 16-byte blocks, row-major;
+     * width and height are multiples of 4.  Decoded once at upload by a HIP kernel to the texels the GPU's
+     * BC7 sampler returns in prosper. */
+    PROSPER_PT_FORMAT_BC7_UNORM = 1,
 };
 enum
 {
@@ -95,7 +100,7 @@ enum
  * RT stages have no derivatives and sample LOD 0. Index 0 is the "no texture" slot. */
 typedef struct prosper_pt_texture_desc
 {
-    const void *texels; /* width*height texels, row-major, tightly packed */
+    const void *texels; /* RGBA8: width*height texels, row-major, tightly packed; BC7: the level's blocks */
     uint32_t width;
     uint32_t height;
     uint32_t format; /* PROSPER_PT_FORMAT_* */
@@ -349,7 +354,8 @@ enum
     PROSPER_PT_FN_TRIANGLE = 13,      /* in: o3, d3, v0, v1, v2, tmin, tmax   out: hit, t, bu, bv */
     PROSPER_PT_FN_HALF = 14,          /* in: f                                out: unpack(pack(f)), bits */
     PROSPER_PT_FN_RNG = 15,           /* in: px, py, frame (u32 bits)         out: rnd01, rnd2d01, seed */
-    PROSPER_PT_FN_COUNT = 16,
+    PROSPER_PT_FN_BC7_BLOCK = 16,     /* in: 4 words of a block (u32 bits)    out: 16 RGBA8 texels (u32 bits) */
+    PROSPER_PT_FN_COUNT = 17,
 };
 
 /* Device self-test: evaluates device function `fn` (PROSPER_PT_FN_*) element-wise over `n`

@@ -157,8 +157,10 @@ int validate_scene(const prosper_pt_scene_view *v)
     for (uint32_t i = 0; i < v->textureCount; ++i)
     {
         const prosper_pt_texture_desc &t = v->textures[i];
-        if (!t.texels || t.width == 0 || t.height == 0 || t.format != PROSPER_PT_FORMAT_RGBA8_UNORM)
+        if (!t.texels || t.width == 0 || t.height == 0 || t.format > PROSPER_PT_FORMAT_BC7_UNORM)
             return fail(PROSPER_PT_ERR_SCENE, "texture " + std::to_string(i) + " is invalid");
+        if (t.format == PROSPER_PT_FORMAT_BC7_UNORM && (t.width % 4u != 0u || t.height % 4u != 0u))
+            return fail(PROSPER_PT_ERR_SCENE, "BC7 texture " + std::to_string(i) + " is not a whole number of 4x4 blocks");
     }
     for (uint32_t i = 0; i < v->samplerCount; ++i)
     {
@@ -252,6 +254,28 @@ int upload_scene_impl(prosper_pt_ctx *ctx, const prosper_pt_scene_view *v)
     {
         const prosper_pt_texture_desc &t = v->textures[i];
         const uint32_t tilesX = (t.width + kTexTileW - 1u) / kTexTileW, tilesY = (t.height + kTexTileH - 1u) / kTexTileH;
+        if (t.format == PROSPER_PT_FORMAT_BC7_UNORM)
+        {
+            // the blocks go up as they are and a kernel decodes them into the tiles (pt_bc7.hpp)
+            const size_t blockBytes = (size_t)(t.width / 4u) * (t.height / 4u) * 16u;
+            void *dBlocks = nullptr;
+            PPT_HIP(hipMalloc(&dBlocks, blockBytes));
+            hipError_t e = hipMemcpy(dBlocks, t.texels, blockBytes, hipMemcpyHostToDevice);
+            if (e == hipSuccess && (rc = device_alloc(ctx, (size_t)tilesX * tilesY * (kTexTileW * kTexTileH) * 4u, &d)) == PROSPER_PT_OK)
+            {
+                e = hipMemset(d, 0, (size_t)tilesX * tilesY * (kTexTileW * kTexTileH) * 4u);
+                if (e == hipSuccess)
+                {
+                    launch_decode_bc7(dBlocks, t.width, t.height, tilesX, d, nullptr);
+                    e = hipDeviceSynchronize();
+                }
+            }
+            (void)hipFree(dBlocks);
+            if (rc != PROSPER_PT_OK) return rc;
+            PPT_HIP(e);
+            textures[i] = DeviceTexture{static_cast<const uint8_t *>(d), t.width, t.height, tilesX, 0u};
+            continue;
+        }
         tiled.assign((size_t)tilesX * tilesY * (kTexTileW * kTexTileH), 0u);
         const uint32_t *src = static_cast<const uint32_t *>(t.texels);
         for (uint32_t y = 0; y < t.height; ++y)
@@ -1092,7 +1116,8 @@ int prosper_pt_get_last_render_timing(
 int prosper_pt_eval_device_fn(
     prosper_pt_ctx *ctx, uint32_t fn, const float *in, uint32_t in_stride, float *out, uint32_t out_stride, uint32_t n)
 {
-    if (!ctx || !in || !out || fn >= PROSPER_PT_FN_COUNT || in_stride == 0 || out_stride == 0)
+    if (!ctx || !in || !out || fn >= PROSPER_PT_FN_COUNT || in_stride == 0 || out_stride == 0 ||
+        (fn == PROSPER_PT_FN_BC7_BLOCK && (in_stride < 4 || out_stride < 16)))
         return fail(PROSPER_PT_ERR_INVALID_ARGUMENT, "prosper_pt_eval_device_fn: bad argument");
     PPT_HIP(hipSetDevice(ctx->device));
     float *dIn = nullptr, *dOut = nullptr;

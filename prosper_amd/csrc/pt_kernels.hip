@@ -7,6 +7,7 @@
 //   eval_fn             device self-test entry (prosper_pt_eval_device_fn)
 #include "pt_kernels.hpp"
 
+#include "pt_bc7.hpp"
 #include "pt_device.hpp"
 #include "pt_render_common.hpp"
 
@@ -882,8 +883,45 @@ __global__ void eval_fn_kernel(
         o[3] = u2f(pcg(r.x ^ r.z));
         break;
     }
+    case PROSPER_PT_FN_BC7_BLOCK:
+    {
+        const uint32_t block[4] = {f2u(a[0]), f2u(a[1]), f2u(a[2]), f2u(a[3])};
+        uint32_t texel[16];
+        bc7_decode_block(block, texel);
+        for (int k = 0; k < 16; ++k) o[k] = u2f(texel[k]);
+        break;
+    }
     default: break;
     }
+}
+
+// One thread per 4x4 block: decode, then store the four rows into the 8x4-texel tiles of DeviceTexture
+// (a block is the left or right half of one tile: four 16-byte stores).
+__global__ __launch_bounds__(256) void decode_bc7_kernel(
+    const uint4 *__restrict__ blocks, uint32_t blocksX, uint32_t blocksY, uint32_t tilesPerRow, uint32_t *__restrict__ tiled)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= blocksX * blocksY) return;
+    const uint4 raw = blocks[i];
+    const uint32_t block[4] = {raw.x, raw.y, raw.z, raw.w};
+    uint32_t texel[16];
+    bc7_decode_block(block, texel);
+    const uint32_t bx = i % blocksX, by = i / blocksX;
+    uint32_t *tile = tiled + ((size_t)by * tilesPerRow + (bx >> 1)) * (kTexTileW * kTexTileH) + (bx & 1u) * 4u;
+    for (uint32_t row = 0; row < 4u; ++row)
+        *reinterpret_cast<uint4 *>(tile + row * kTexTileW) =
+            make_uint4(texel[row * 4u], texel[row * 4u + 1u], texel[row * 4u + 2u], texel[row * 4u + 3u]);
+}
+
+void launch_decode_bc7(
+    const void *blocks, uint32_t width, uint32_t height, uint32_t tilesPerRow, void *tiled, hipStream_t stream)
+{
+    const uint32_t blocksX = width / 4u, blocksY = height / 4u;
+    const uint32_t n = blocksX * blocksY;
+    if (n == 0) return;
+    hipLaunchKernelGGL(
+        decode_bc7_kernel, dim3((n + 255u) / 256u), dim3(256), 0, stream, static_cast<const uint4 *>(blocks), blocksX, blocksY,
+        tilesPerRow, static_cast<uint32_t *>(tiled));
 }
 
 void launch_eval_fn(

@@ -85,6 +85,10 @@ void launch_render_wavefront(
 // LDS stack entries (16/24/32) the wavefront traversal kernels use for a tree with this stack bound
 uint32_t wavefront_lds_stack_entries(uint32_t stackBound);
 void launch_blit_rgba16f(const float4 *in, void *out, uint32_t count, hipStream_t stream);
+// BC7 blocks of one level (row-major, 16 B each; width and height multiples of 4) -> RGBA8 texels in the tiled
+// layout of DeviceTexture
+void launch_decode_bc7(
+    const void *blocks, uint32_t width, uint32_t height, uint32_t tilesPerRow, void *tiled, hipStream_t stream);
 void launch_eval_fn(
     uint32_t fn, const float *in, uint32_t inStride, float *out, uint32_t outStride, uint32_t n, hipStream_t stream);
 

@@ -1,12 +1,15 @@
-"""DDS reader for the one asset the tone-map step needs: a DX10-header DDS holding a 3-D
-R9G9B9E5_SHAREDEXP texture, i.e. prosper's `res/texture/tony_mc_mapface.dds` (48^3), as the reference's own
-reader accepts it (src/utils/Dds.cpp: magic, 124-byte header, 'DX10' four-cc, DXGI format, TEXTURE3D)."""
+"""DDS reader for the assets on either side of the path, DX10-header files only, like the
+reference's own reader (src/utils/Dds.cpp: magic, 124-byte header, 'DX10' four-cc, DXGI format):
+  * the tone-map LUT, a 3-D R9G9B9E5_SHAREDEXP texture (`res/texture/tony_mc_mapface.dds`, 48^3);
+  * prosper's texture cache, 2-D R8G8B8A8_UNORM / BC7_UNORM with mips (`prosper_cache/<name>.dds`)."""
 import struct
 
 import numpy as np
 
 DXGI_FORMAT_R8G8B8A8_UNORM = 28
 DXGI_FORMAT_R9G9B9E5_SHAREDEXP = 67
+DXGI_FORMAT_BC7_UNORM = 98
+_DIMENSION_TEXTURE2D = 3
 _DIMENSION_TEXTURE3D = 4
 
 
@@ -66,3 +69,101 @@ def write_lut(path, texels):
     with open(path, "wb") as f:
         f.write(b"DDS " + struct.pack("<31I", *header) +
                 struct.pack("<5I", DXGI_FORMAT_R9G9B9E5_SHAREDEXP, _DIMENSION_TEXTURE3D, 0, 1, 0) + t.tobytes())
+
+
+def _level_sizes(width, height, fmt, mips):
+    """(width, height, byte size) of every mip level, as the reference lays them out (src/utils/Dds.cpp:100-135:
+    levels back to back, `max(extent >> i, 1)`, BC7 levels in whole 16-byte 4x4 blocks)."""
+    out = []
+    for i in range(mips):
+        w, h = max(width >> i, 1), max(height >> i, 1)
+        if fmt == DXGI_FORMAT_R8G8B8A8_UNORM:
+            size = w * h * 4
+        elif fmt == DXGI_FORMAT_BC7_UNORM:
+            if w % 4 or h % 4:
+                raise DdsError("BC7 mip %d is %dx%d: levels must divide evenly by 4x4" % (i, w, h))
+            size = (w // 4) * (h // 4) * 16
+        else:
+            raise DdsError("unsupported DXGI format %d" % fmt)
+        out.append((w, h, size))
+    return out
+
+
+def _texture_header(blob):
+    if len(blob) < 148 or blob[:4] != b"DDS ":
+        raise DdsError("not a DDS file")
+    header = struct.unpack_from("<31I", blob, 4)
+    size, _, height, width, _, depth, mips = header[:7]
+    if size != 124 or header[20] != 0x30315844:
+        raise DdsError("only DX10-header DDS files are supported (as in the reference)")
+    fmt, dimension, _, array_size, _ = struct.unpack_from("<5I", blob, 128)
+    if dimension != _DIMENSION_TEXTURE2D or array_size != 1 or depth > 1:
+        raise DdsError("expected a single 2-D texture")
+    if fmt not in (DXGI_FORMAT_R8G8B8A8_UNORM, DXGI_FORMAT_BC7_UNORM):
+        raise DdsError("only R8G8B8A8_UNORM and BC7_UNORM 2-D textures are supported (src/utils/Dds.cpp:299-302)")
+    return fmt, width, height, _level_sizes(width, height, fmt, max(mips, 1))
+
+
+def read_texture_raw(path):
+    """-> (DXGI format, width, height, level-0 payload bytes) of a texture-cache DDS, undecoded: BC7 blocks can go
+    to the library as they are (PROSPER_PT_FORMAT_BC7_UNORM, decoded on the GPU at upload)."""
+    with open(path, "rb") as f:
+        blob = f.read()
+    fmt, width, height, sizes = _texture_header(blob)
+    if len(blob) < 148 + sizes[0][2]:
+        raise DdsError("truncated DDS payload")
+    return fmt, width, height, blob[148: 148 + sizes[0][2]]
+
+
+def read_texture(path, levels=1):
+    """A 2-D texture of prosper's texture cache (`prosper_cache/<name>.dds`, src/scene/Texture.cpp:38-47, 213-296):
+    DX10-header DDS, R8G8B8A8_UNORM or BC7_UNORM, mip chain down to 4x4.  -> list of uint8 [h, w, 4] RGBA levels
+    (the first `levels` of them; None = all).  BC7 levels are decoded by prosper_amd.bc7 - the texels the GPU's
+    sampler sees in prosper.  The path tracer samples LOD 0 only (no derivatives in ray-tracing stages)."""
+    from . import bc7
+    with open(path, "rb") as f:
+        blob = f.read()
+    fmt, width, height, sizes = _texture_header(blob)
+    out, offset = [], 148
+    for i, (w, h, nbytes) in enumerate(sizes):
+        if levels is not None and i >= levels:
+            break
+        if len(blob) < offset + nbytes:
+            raise DdsError("truncated DDS payload")
+        data = blob[offset: offset + nbytes]
+        if fmt == DXGI_FORMAT_BC7_UNORM:
+            out.append(bc7.decode_image(data, w, h))
+        else:
+            out.append(np.frombuffer(data, np.uint8).reshape(h, w, 4).copy())
+        offset += nbytes
+    return out
+
+
+def write_texture(path, fmt, width, height, level_payloads):
+    """Fixture writer: a DX10-header 2-D DDS from ready-made level payloads (bytes: RGBA8 texels or BC7 blocks),
+    with the header fields the reference writes (src/utils/Dds.cpp:160-230)."""
+    sizes = _level_sizes(width, height, fmt, len(level_payloads))
+    for (w, h, nbytes), payload in zip(sizes, level_payloads):
+        if len(payload) != nbytes:
+            raise DdsError("level payload of %d bytes, expected %d" % (len(payload), nbytes))
+    compressed = fmt == DXGI_FORMAT_BC7_UNORM
+    mips = len(level_payloads)
+    header = [0] * 31
+    # caps | height | width | pixelformat (+ linearsize / pitch) (+ mipmapcount)
+    header[0], header[1] = 124, 0x1007 | (0x80000 if compressed else 0x8) | (0x20000 if mips > 1 else 0)
+    header[2], header[3] = height, width
+    header[4] = sizes[0][2] if compressed else width * 4
+    header[5], header[6] = 1, mips
+    header[18], header[19], header[20] = 32, 0x4, 0x30315844
+    header[26] = 0x1000 | (0x400008 if mips > 1 else 0)
+    with open(path, "wb") as f:
+        f.write(b"DDS " + struct.pack("<31I", *header) + struct.pack("<5I", fmt, _DIMENSION_TEXTURE2D, 0, 1, 0))
+        for payload in level_payloads:
+            f.write(payload)
+
+
+def cache_path(source):
+    """Where prosper caches the compressed copy of texture file `source` (src/scene/Texture.cpp:38-47)."""
+    import os
+    folder = os.path.join(os.path.dirname(source), "prosper_cache")
+    return os.path.join(folder, os.path.splitext(os.path.basename(source))[0] + ".dds")

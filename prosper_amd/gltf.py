@@ -36,7 +36,7 @@ import zlib
 
 import numpy as np
 
-from . import structs as S
+from . import dds, structs as S
 from .world import World
 
 _COMPONENT = {5120: np.int8, 5121: np.uint8, 5122: np.int16, 5123: np.uint16, 5125: np.uint32, 5126: np.float32}
@@ -314,8 +314,14 @@ _FILTERS = {9728: S.FILTER_NEAREST, 9984: S.FILTER_NEAREST, 9986: S.FILTER_NEARE
 _WRAPS = {33071: S.WRAP_CLAMP_TO_EDGE, 33648: S.WRAP_MIRRORED_REPEAT, 10497: S.WRAP_REPEAT}
 
 
-def load_gltf(path, load_images=True, scene=None):
+def load_gltf(path, load_images=True, scene=None, use_texture_cache=True, bc7_on_gpu=False):
     """Reads `path` (.gltf or .glb) into a World laid out the way prosper lays the same file out.
+
+    With `use_texture_cache`, an image file whose `prosper_cache/<name>.dds` exists (prosper's BC7 / RGBA8 cache,
+    src/scene/Texture.cpp:377-415) is read from there: level 0 of that file is what prosper's sampler returns, the
+    PNG next to it is only the encoder's input.  (No staleness check: prosper's cache tag holds a file time.)
+    With `bc7_on_gpu` a BC7 cache file is handed to the library undecoded (`World.add_texture_bc7`: decoded by the
+    HIP kernel at upload); otherwise `prosper_amd.bc7` decodes it here - same texels either way (tested).
 
     `world.missing_images` lists the image URIs that could not be read; they become 1x1 white textures
     (what prosper's texture slot 0, `empty.png`, is)."""
@@ -323,6 +329,7 @@ def load_gltf(path, load_images=True, scene=None):
     doc = d.doc
     w = World()
     w.missing_images = []
+    w.cached_images = []
 
     # samplers: index + 1 (WorldData.cpp:699-719)
     for smp in doc.get("samplers", []):
@@ -334,13 +341,23 @@ def load_gltf(path, load_images=True, scene=None):
         rgba = None
         if load_images:
             try:
-                if "uri" in img:
+                cached = None
+                if use_texture_cache and "uri" in img and not img["uri"].startswith("data:"):
+                    cached = dds.cache_path(os.path.join(d.base, img["uri"].replace("%20", " ")))
+                if cached is not None and os.path.exists(cached):
+                    w.cached_images.append(cached)
+                    fmt, tw, th, payload = dds.read_texture_raw(cached)
+                    if bc7_on_gpu and fmt == dds.DXGI_FORMAT_BC7_UNORM:
+                        w.add_texture_bc7(payload, tw, th)
+                        continue
+                    rgba = dds.read_texture(cached, levels=1)[0]
+                elif "uri" in img:
                     rgba = decode_image(_load_uri(img["uri"], d.base))
                 elif "bufferView" in img:
                     view = doc["bufferViews"][img["bufferView"]]
                     start = view.get("byteOffset", 0)
                     rgba = decode_image(d.buffers[view["buffer"]][start: start + view["byteLength"]])
-            except (OSError, GltfError):
+            except (OSError, GltfError, dds.DdsError):
                 rgba = None
         if rgba is None:
             w.missing_images.append(img.get("uri", "<bufferView>"))

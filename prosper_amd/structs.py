@@ -148,6 +148,7 @@ class SpotLightsBuffer(C.Structure):
 # ---- prosper_pt.h ----
 
 FORMAT_RGBA8_UNORM = 0
+FORMAT_BC7_UNORM = 1
 FILTER_NEAREST, FILTER_LINEAR = 0, 1
 WRAP_REPEAT, WRAP_MIRRORED_REPEAT, WRAP_CLAMP_TO_EDGE = 0, 1, 2
 

@@ -76,6 +76,13 @@ def rotate_z(angle):
     return np.array([[c, -s, 0, 0], [s, c, 0, 0], [0, 0, 1, 0], [0, 0, 0, 1]], dtype=np.float64)
 
 
+class Bc7Texture:
+    """BC7 blocks of one texture level, [N, 16] uint8, row-major."""
+
+    def __init__(self, blocks, width, height):
+        self.blocks, self.width, self.height = blocks, width, height
+
+
 class World:
     """Builder + container for everything `prosper_pt_scene_view` points at."""
 
@@ -108,6 +115,15 @@ class World:
         rgba8 = np.ascontiguousarray(rgba8, dtype=np.uint8)
         assert rgba8.ndim == 3 and rgba8.shape[2] == 4
         self.textures.append(rgba8)
+        return len(self.textures) - 1
+
+    def add_texture_bc7(self, blocks, width, height):
+        """Level 0 of a BC7 texture as prosper's cache stores it (`dds.read_texture_level0_raw`): the library
+        decodes it on the GPU at upload (PROSPER_PT_FORMAT_BC7_UNORM)."""
+        blocks = np.ascontiguousarray(np.frombuffer(bytes(blocks), np.uint8) if not isinstance(blocks, np.ndarray) else blocks,
+                                      dtype=np.uint8).reshape(-1, 16)
+        assert width % 4 == 0 and height % 4 == 0 and blocks.shape[0] == (width // 4) * (height // 4)
+        self.textures.append(Bc7Texture(blocks, width, height))
         return len(self.textures) - 1
 
     def add_sampler(self, mag=S.FILTER_LINEAR, min_=S.FILTER_LINEAR, wrap_s=S.WRAP_REPEAT, wrap_t=S.WRAP_REPEAT):
@@ -257,6 +273,11 @@ class World:
         f["materials"] = (S.MaterialData * len(self.materials))(*self.materials)
         tex = (S.TextureDesc * len(self.textures))()
         for i, t in enumerate(self.textures):
+            if isinstance(t, Bc7Texture):
+                tex[i].texels = t.blocks.ctypes.data
+                tex[i].height, tex[i].width = t.height, t.width
+                tex[i].format = S.FORMAT_BC7_UNORM
+                continue
             tex[i].texels = t.ctypes.data
             tex[i].height, tex[i].width = t.shape[0], t.shape[1]
             tex[i].format = S.FORMAT_RGBA8_UNORM
