@@ -47,7 +47,7 @@ def main():
     from prosper_amd import capi, dds, gltf, ktx, structs as S
     from prosper_amd.rt_reference import Camera
     w, h = (int(v) for v in args.size.lower().split("x"))
-    world = gltf.load_gltf(args.gltf)
+    world = gltf.load_gltf(args.gltf, bc7_on_gpu=True)  # prosper_cache BC7 files are decoded by the library at upload
     if world.missing_images:
         print("missing images replaced by white: %s" % ", ".join(world.missing_images), file=sys.stderr)
     if args.env:
