@@ -572,16 +572,21 @@ PPT_D f3 eval_brdf_times_nol(f3 l, const Surface &sf)
 // ------------------------------------------------------------------------------------------
 
 // sampling.glsl:18-33
-PPT_D f3 cosine_sample_hemisphere(f3 n, f2 u)
+// (sn, cs) = sincos(2 pi u.y): both lobes of importanceSampleBounce turn the same random number into the same
+// angle, so the caller evaluates it once, outside the divergent branch
+PPT_D f3 cosine_sample_hemisphere(f3 n, float ux, float sn, float cs)
 {
-    float a = __builtin_fmaf(-2.0f, u.x, 1.0f);
+    float a = __builtin_fmaf(-2.0f, ux, 1.0f);
     a *= 0.99999f;
     float b = sqrt_(__builtin_fmaf(-a, a, 1.0f));
     b *= 0.99999f;
-    const float phi = kTwoPi * u.y;
-    float sn, cs;
-    sincos_(phi, sn, cs);
     return normalize(f3{__builtin_fmaf(b, cs, n.x), __builtin_fmaf(b, sn, n.y), n.z + a});
+}
+PPT_D f3 cosine_sample_hemisphere(f3 n, f2 u)
+{
+    float sn, cs;
+    sincos_(kTwoPi * u.y, sn, cs);
+    return cosine_sample_hemisphere(n, u.x, sn, cs);
 }
 
 // sampling.glsl:37-47 (rows b1, b2, n)
@@ -609,7 +614,7 @@ PPT_D Onb orthonormal_basis(f3 n)
 }
 
 // sampling.glsl:53-79
-PPT_D f3 sample_visible_trowbridge_reitz(f3 Ve, float alpha, f2 Us)
+PPT_D f3 sample_visible_trowbridge_reitz(f3 Ve, float alpha, float ux, float sn, float cs)
 {
     const f3 Vh = normalize(f3{alpha * Ve.x, alpha * Ve.y, Ve.z});
     const float lensq = __builtin_fmaf(Vh.y, Vh.y, Vh.x * Vh.x);
@@ -622,10 +627,7 @@ PPT_D f3 sample_visible_trowbridge_reitz(f3 Ve, float alpha, f2 Us)
     else
         T1 = f3{1.0f, 0.0f, 0.0f};
     const f3 T2 = cross(Vh, T1);
-    const float r = sqrt_(Us.x);
-    const float phi = kTwoPi * Us.y;
-    float sn, cs;
-    sincos_(phi, sn, cs);
+    const float r = sqrt_(ux);
     const float t1 = r * cs;
     float t2 = r * sn;
     const float s = 0.5f * (1.0f + Vh.z);
@@ -637,6 +639,12 @@ PPT_D f3 sample_visible_trowbridge_reitz(f3 Ve, float alpha, f2 Us)
                      __builtin_fmaf(Vh.z, k, __builtin_fmaf(T2.z, t2, T1.z * t1))};
     const f3 Ne = normalize(f3{alpha * Nh.x, alpha * Nh.y, fmax_(0.0f, Nh.z)});
     return reflect(-Ve, Ne);
+}
+PPT_D f3 sample_visible_trowbridge_reitz(f3 Ve, float alpha, f2 Us)
+{
+    float sn, cs;
+    sincos_(kTwoPi * Us.y, sn, cs);
+    return sample_visible_trowbridge_reitz(Ve, alpha, Us.x, sn, cs);
 }
 
 // sampling.glsl:81-93
@@ -700,21 +708,62 @@ PPT_D bool sample_light(const DeviceScene &s, f3 surfacePos, uint32_t lightIndex
         return false;
     }
     lightIndex -= 1;
-    if (lightIndex < s.pointLightCount)
+    const bool isPoint = lightIndex < s.pointLightCount;
+    const uint32_t spotIndex = lightIndex - s.pointLightCount;
+    if (!isPoint && !(spotIndex < s.spotLightCount))
     {
-        eval_point_light(s.pointLights->lights[lightIndex], surfacePos, l, d, irradiance);
+        l = f3{0.0f, 1.0f, 0.0f};
+        d = 1.0f;
+        irradiance = f3{0.0f, 0.0f, 0.0f};
         return false;
     }
-    lightIndex -= s.pointLightCount;
-    if (lightIndex < s.spotLightCount)
+    // Point and spot lights (eval_point_light / eval_spot_light above, lighting.glsl:15-56) run the same
+    // arithmetic for the direction, the distance and the inverse-square term: a wave that holds both kinds
+    // does that part once and only the attenuation under the branch - operation for operation what the two
+    // functions compute.
+    f3 pos, radiance;
+    float w0;      // radius | angle scale
+    float offset;  // - | angle offset
+    f3 direction;  // - | spot direction
+    if (isPoint)
     {
-        eval_spot_light(s.spotLights->lights[lightIndex], surfacePos, l, d, irradiance);
-        return true;
+        const prosper_PointLight light = s.pointLights->lights[lightIndex];
+        pos = f3{light.position.x, light.position.y, light.position.z};
+        radiance = f3{light.radianceAndRadius.x, light.radianceAndRadius.y, light.radianceAndRadius.z};
+        w0 = light.radianceAndRadius.w;
+        offset = 0.0f;
+        direction = f3{0.0f, 0.0f, 0.0f};
     }
-    l = f3{0.0f, 1.0f, 0.0f};
-    d = 1.0f;
-    irradiance = f3{0.0f, 0.0f, 0.0f};
-    return false;
+    else
+    {
+        const prosper_SpotLight light = s.spotLights->lights[spotIndex];
+        pos = f3{light.positionAndAngleOffset.x, light.positionAndAngleOffset.y, light.positionAndAngleOffset.z};
+        radiance = f3{light.radianceAndAngleScale.x, light.radianceAndAngleScale.y, light.radianceAndAngleScale.z};
+        w0 = light.radianceAndAngleScale.w;
+        offset = light.positionAndAngleOffset.w;
+        direction = f3{light.direction.x, light.direction.y, light.direction.z};
+    }
+    const f3 toLight = pos - surfacePos;
+    const float d2 = dot(toLight, toLight);
+    d = sqrt_(d2);
+    l = toLight / d;
+    float att;
+    if (isPoint)
+    {
+        const float dPerR = d / w0;
+        const float dPerR2 = dPerR * dPerR;
+        const float dPerR4 = dPerR2 * dPerR2;
+        att = fmax_(fmin_(1.0f - dPerR4, 1.0f), 0.0f);
+    }
+    else
+    {
+        const f3 negDir = f3{-direction.x, -direction.y, -direction.z};
+        const float cd = dot(negDir, l);
+        att = saturate(__builtin_fmaf(cd, w0, offset));
+        att *= att;
+    }
+    irradiance = (radiance * att) / d2;
+    return !isPoint;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1269,12 +1318,14 @@ PPT_D void importance_sample_bounce(const Surface &sf, Rng &rng, f3 &throughput,
     const float alpha = sf.material.roughness * sf.material.roughness;
     const bool pickDiffuse = rng.rnd01() < diffuseWeight;
     const f2 u = rng.rnd2d01();
+    float sinPhi, cosPhi; // phi = 2 pi u.y in cosineSampleHemisphere and in sampleVisibleTrowbridgeReitz alike
+    sincos_(kTwoPi * u.y, sinPhi, cosPhi);
     f3 brdf;
     float NoL;
     float pdf;
     if (pickDiffuse)
     {
-        rd = cosine_sample_hemisphere(sf.normalWS, u);
+        rd = cosine_sample_hemisphere(sf.normalWS, u.x, sinPhi, cosPhi);
         NoL = saturate(dot(sf.normalWS, rd));
         brdf = lambert_brdf(sf.material.albedo);
         pdf = NoL * kInvPi; // sampling.glsl:35
@@ -1282,7 +1333,7 @@ PPT_D void importance_sample_bounce(const Surface &sf, Rng &rng, f3 &throughput,
     }
     else
     {
-        rd = sample_visible_trowbridge_reitz(vInBasis, alpha, u);
+        rd = sample_visible_trowbridge_reitz(vInBasis, alpha, u.x, sinPhi, cosPhi);
         rd = basis.to_world(rd);
         NoL = saturate(dot(sf.normalWS, rd));
         const f3 h = normalize(sf.invViewRayWS + rd);
