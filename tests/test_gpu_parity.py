@@ -2,6 +2,8 @@
 
 All calls go through the C-ABI (libprosper_pt.so); the oracle is only the checker.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -745,3 +747,17 @@ def test_full_sponza_class_scene_parity(gpu_ctx, oracle):
     got = gpu_ctx.read_hdr()
     ok = same_bits(got, want).all(axis=2)
     assert ok.all(), "%d of %d pixels differ" % ((~ok).sum(), ok.size)
+
+
+def test_random_configurations_bit_exact():
+    """A fixed-seed slice of scripts/parity_fuzz.py (random poses, flags, bounces, frame counts, extents and rank
+    tiles over five scenes); profiles/r01_parity_fuzz.txt keeps an 860-case run."""
+    import importlib.util
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scripts", "parity_fuzz.py")
+    spec = importlib.util.spec_from_file_location("parity_fuzz", path)
+    fuzz = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(fuzz)
+    lines = []
+    bad, pixels = fuzz.run(25, 11, ["cornell", "sponza", "foliage", "wall", "zoo"], log=lines.append)
+    assert bad == 0, "\n".join(l for l in lines if "DIFFER" in l)
+    assert pixels > 100000
