@@ -200,6 +200,8 @@ def main():
     ap.add_argument("--persistent", action="store_true", help="use the persistent path-regeneration kernel (A/B)")
     ap.add_argument("--single-chain", action="store_true",
                     help="one chain of launches on one stream instead of two overlapping half-batches (A/B)")
+    ap.add_argument("--in-order", action="store_true",
+                    help="no frames in flight: every step starts after the previous one has finished (A/B)")
     args = ap.parse_args()
 
     import torch
@@ -250,6 +252,8 @@ def main():
     overlap = [True]
     full = None
 
+    render_flags = 0 if (args.in_order or args.single_chain or args.megakernel or args.persistent) else S.RENDER_PIPELINED
+
     def gather_sync(t):
         """Rehearsal path (gloo, through host memory)."""
         torch.cuda.synchronize()
@@ -277,7 +281,9 @@ def main():
         pc = make_pc(focal, 1, max_bounces, ibl, True)
         if record:
             record[0].record()
-        ctx.render(pc, cam, width, height, tile=tile, frames=spp, stream=stream)
+        # two frames in flight (the reference's own frames-in-flight count): the path stages of step i + 1 overlap
+        # the tail of step i; the accumulate kernel and the gather stay in stream order
+        ctx.render(pc, cam, width, height, tile=tile, frames=spp, stream=stream, flags=render_flags)
         if record:
             record[1].record()
         if world_size == 1:
@@ -399,7 +405,9 @@ def main():
                 "bvh_nodes": int(stats.nodeCount),
                 "parallelism": "image stripes x%d%s" % (world_size, " + RCCL gather" if world_size > 1 else ""),
                 "pipeline": "megakernel" if args.megakernel else ("persistent" if args.persistent else (
-                    "wavefront, 1 launch chain" if args.single_chain else "wavefront, 2 concurrent launch chains")),
+                    "wavefront, 1 launch chain" if args.single_chain else (
+                        "wavefront, 2 frames in flight (one launch chain each)" if render_flags
+                        else "wavefront, 2 concurrent launch chains"))),
             },
             "roofline": {
                 "bound": "hbm",
@@ -420,6 +428,7 @@ def main():
                 # duration (hipEvents, = rocprofv3's) includes the time it shares the GPU with the other chain's
                 # launch, so sum(kernel time) > wall time and `frac` is a per-launch, not a whole-GPU, figure
                 "concurrent_chains": 1 if (args.single_chain or args.megakernel or args.persistent) else 2,
+                "frames_in_flight": 2 if render_flags else 1,
                 "kernel_ms_exclusive": kernels[dominant]["ms_per_launch"] * exclusive_scale,
                 "frac_exclusive": achieved / exclusive_scale / HBM_PEAK_GBS,
             },

@@ -226,6 +226,15 @@ typedef struct prosper_pt_scene_stats
 enum
 {
     PROSPER_PT_RENDER_COUNT_WORK = 1u << 0, /* run the instrumented kernels (slower, same pixels) */
+    /* Frames in flight, the role of `nextFrame` / the per-frame descriptor sets in RtReference::record
+     * (src/render/RtReference.cpp:161-168; prosper keeps 2 frames in flight): the path stages of this render use the
+     * context's OTHER workspace and may start before work enqueued earlier on `stream` - including the previous
+     * render - has finished; they wait only for the render of two calls ago.  The accumulate kernel (history read,
+     * output write) runs on `stream`, in order, so the image and everything enqueued after this call behave as
+     * without the flag.  The caller promises that no input of this render (scene, lights) is produced by work still
+     * pending on `stream`: uploads through this API are synchronous, so that holds unless the caller writes the
+     * library's buffers itself.  Same pixels (tested); ignored with PROSPER_PT_RENDER_COUNT_WORK. */
+    PROSPER_PT_RENDER_PIPELINED = 1u << 1,
 };
 
 const char *prosper_pt_last_error(void);

@@ -74,10 +74,6 @@ struct prosper_pt_ctx
     uint32_t *dWorkCounter = nullptr;        // work-distribution counter of the persistent kernel
     // wavefront workspace (one allocation, carved into the WavefrontBuffers arrays)
     // global overflow of the traversal stacks (only for trees whose stack bound exceeds the LDS stack)
-    int32_t *stackOverflow = nullptr;
-    size_t stackOverflowBytes = 0;
-    void *wfBlock = nullptr;
-    size_t wfBytes = 0;
     uint64_t wfSlots = 0;
 
     bool kernelTiming = false;
@@ -94,14 +90,30 @@ struct prosper_pt_ctx
     void *toneScratch = nullptr; // RGBA8 output when the caller only wants a host copy
     size_t toneScratchBytes = 0;
 
-    // the two launch chains of the wavefront pipeline (pt_kernels.hpp WavefrontChains)
-    hipStream_t chainStreams[2] = {};
+    // Everything a render has in flight between its first launch and its accumulate kernel: the wavefront
+    // workspace, the stack-overflow array and the two launch chains (pt_kernels.hpp WavefrontChains) with their
+    // timing events.  Two slots = two frames in flight (PROSPER_PT_RENDER_PIPELINED), the role `nextFrame` and
+    // the per-frame descriptor sets play in RtReference::record; everything else uses slot 0.
+    struct RenderSlot
+    {
+        int32_t *stackOverflow = nullptr;
+        size_t stackOverflowBytes = 0;
+        void *wfBlock = nullptr;
+        size_t wfBytes = 0;
+        hipStream_t chainStreams[2] = {};
+        hipEvent_t chainJoin[2] = {};
+        hipEvent_t chainEvents[2][kMaxTimedLaunches + 1] = {};
+        uint32_t chainStage[2][kMaxTimedLaunches] = {};
+        uint32_t chainLaunches[2] = {};
+        hipEvent_t free = nullptr; // recorded after the accumulate kernel of the slot's last render
+        bool freeRecorded = false;
+    };
+    static constexpr uint32_t kRenderSlots = 2; // prosper keeps two frames in flight; a third slot measured +1.5 %
+    RenderSlot slots[kRenderSlots];
+    uint32_t lastSlot = 0; // of the last render (timing readout)
     hipEvent_t chainFork = nullptr;
-    hipEvent_t chainJoin[2] = {};
-    hipEvent_t chainEvents[2][kMaxTimedLaunches + 1] = {};
-    uint32_t chainStage[2][kMaxTimedLaunches] = {};
-    uint32_t chainLaunches[2] = {};
 };
+using RenderSlot = prosper_pt_ctx::RenderSlot;
 constexpr uint32_t kStageChains = 4; // unnamed interval of the caller's stream: fork .. join of the chains
 
 namespace
@@ -424,9 +436,20 @@ int upload_scene_impl(prosper_pt_ctx *ctx, const prosper_pt_scene_view *v)
     return PROSPER_PT_OK;
 }
 
+// A slot's workspace may be reused once the kernels of its previous user are done: `free` is recorded behind them.
+void wait_for_slot(RenderSlot &slot, hipStream_t stream)
+{
+    if (slot.freeRecorded) (void)hipStreamWaitEvent(stream, slot.free, 0);
+}
+void release_slot(RenderSlot &slot, hipStream_t stream)
+{
+    (void)hipEventRecord(slot.free, stream);
+    slot.freeRecorded = true;
+}
+
 // Sizes and carves the wavefront workspace for `frames` x (tilesX*tilesY*64) path slots.
 int ensure_wavefront_workspace(
-    prosper_pt_ctx *ctx, uint32_t tilesX, uint32_t tilesY, uint32_t frames, hipStream_t stream, WavefrontBuffers *out)
+    prosper_pt_ctx *ctx, RenderSlot &slot, uint32_t tilesX, uint32_t tilesY, uint32_t frames, WavefrontBuffers *out)
 {
     const uint64_t pixelsPadded = (uint64_t)tilesX * tilesY * 64u;
     const uint64_t slots = pixelsPadded * frames;
@@ -465,16 +488,16 @@ int ensure_wavefront_workspace(
     const uint64_t padded = nSeg * segLen;
     // per slot: 8 x 16 B ping-pong state, hit 16 + idx 4, shadow 48, colour 16; + 3 counters per segment
     const size_t bytes = (size_t)padded * (8u * 16u + 16u + 4u + 48u + 16u) + (size_t)nSeg * 12u + 4096u;
-    if (bytes > ctx->wfBytes)
+    if (bytes > slot.wfBytes)
     {
-        PPT_HIP(hipStreamSynchronize(stream));
-        if (ctx->wfBlock) PPT_HIP(hipFree(ctx->wfBlock));
-        ctx->wfBlock = nullptr;
-        ctx->wfBytes = 0;
-        PPT_HIP(hipMalloc(&ctx->wfBlock, bytes));
-        ctx->wfBytes = bytes;
+        PPT_HIP(hipDeviceSynchronize()); // the other slot's render may be in flight on its own streams
+        if (slot.wfBlock) PPT_HIP(hipFree(slot.wfBlock));
+        slot.wfBlock = nullptr;
+        slot.wfBytes = 0;
+        PPT_HIP(hipMalloc(&slot.wfBlock, bytes));
+        slot.wfBytes = bytes;
     }
-    uint8_t *cursor = static_cast<uint8_t *>(ctx->wfBlock);
+    uint8_t *cursor = static_cast<uint8_t *>(slot.wfBlock);
     auto carve = [&](size_t n) {
         void *r = cursor;
         cursor += (n + 255u) & ~(size_t)255u;
@@ -502,17 +525,17 @@ int ensure_wavefront_workspace(
     w.pixelsPadded = (uint32_t)pixelsPadded;
     w.tilesX = tilesX;
     w.tilesY = tilesY;
-    if ((size_t)(cursor - static_cast<uint8_t *>(ctx->wfBlock)) > ctx->wfBytes + 0u)
+    if ((size_t)(cursor - static_cast<uint8_t *>(slot.wfBlock)) > slot.wfBytes + 0u)
     {
         // carve() rounds every array up to 256 B: re-allocate with the exact carved size
-        const size_t need = (size_t)(cursor - static_cast<uint8_t *>(ctx->wfBlock));
-        PPT_HIP(hipStreamSynchronize(stream));
-        PPT_HIP(hipFree(ctx->wfBlock));
-        ctx->wfBlock = nullptr;
-        ctx->wfBytes = 0;
-        PPT_HIP(hipMalloc(&ctx->wfBlock, need));
-        ctx->wfBytes = need;
-        return ensure_wavefront_workspace(ctx, tilesX, tilesY, frames, stream, out);
+        const size_t need = (size_t)(cursor - static_cast<uint8_t *>(slot.wfBlock));
+        PPT_HIP(hipDeviceSynchronize()); // the other slot's render may be in flight on its own streams
+        PPT_HIP(hipFree(slot.wfBlock));
+        slot.wfBlock = nullptr;
+        slot.wfBytes = 0;
+        PPT_HIP(hipMalloc(&slot.wfBlock, need));
+        slot.wfBytes = need;
+        return ensure_wavefront_workspace(ctx, slot, tilesX, tilesY, frames, out);
     }
     *out = w;
     return PROSPER_PT_OK;
@@ -520,22 +543,24 @@ int ensure_wavefront_workspace(
 
 // Makes sure the global stack-overflow array covers `gridBlocks` workgroups of 256 lanes for a kernel
 // whose LDS stack holds `ldsEntries` entries; returns nullptr when the tree never needs more.
-int ensure_stack_overflow(prosper_pt_ctx *ctx, uint32_t ldsEntries, uint32_t gridBlocks, hipStream_t stream, int32_t **out)
+int ensure_stack_overflow(
+    prosper_pt_ctx *ctx, RenderSlot &slot, uint32_t ldsEntries, uint32_t gridBlocks, hipStream_t stream, int32_t **out)
 {
     *out = nullptr;
     const uint32_t bound = ctx->stats.maxDepth;
     if (bound <= ldsEntries) return PROSPER_PT_OK;
     const size_t bytes = (size_t)(bound - ldsEntries) * gridBlocks * 256u * sizeof(int32_t);
-    if (bytes > ctx->stackOverflowBytes)
+    if (bytes > slot.stackOverflowBytes)
     {
-        PPT_HIP(hipStreamSynchronize(stream));
-        if (ctx->stackOverflow) PPT_HIP(hipFree(ctx->stackOverflow));
-        ctx->stackOverflow = nullptr;
-        ctx->stackOverflowBytes = 0;
-        PPT_HIP(hipMalloc((void **)&ctx->stackOverflow, bytes));
-        ctx->stackOverflowBytes = bytes;
+        (void)stream;
+        PPT_HIP(hipDeviceSynchronize());
+        if (slot.stackOverflow) PPT_HIP(hipFree(slot.stackOverflow));
+        slot.stackOverflow = nullptr;
+        slot.stackOverflowBytes = 0;
+        PPT_HIP(hipMalloc((void **)&slot.stackOverflow, bytes));
+        slot.stackOverflowBytes = bytes;
     }
-    *out = ctx->stackOverflow;
+    *out = slot.stackOverflow;
     return PROSPER_PT_OK;
 }
 
@@ -579,11 +604,15 @@ int prosper_pt_create(const prosper_pt_device_desc *desc, prosper_pt_ctx **out_c
     ctx->flags = desc->flags;
     bool eventsOk = true;
     for (auto &e : ctx->events) eventsOk = eventsOk && hipEventCreate(&e) == hipSuccess;
-    for (int i = 0; i < 2; ++i)
+    for (RenderSlot &slot : ctx->slots)
     {
-        eventsOk = eventsOk && hipStreamCreateWithFlags(&ctx->chainStreams[i], hipStreamNonBlocking) == hipSuccess;
-        eventsOk = eventsOk && hipEventCreateWithFlags(&ctx->chainJoin[i], hipEventDisableTiming) == hipSuccess;
-        for (auto &e : ctx->chainEvents[i]) eventsOk = eventsOk && hipEventCreate(&e) == hipSuccess;
+        for (int i = 0; i < 2; ++i)
+        {
+            eventsOk = eventsOk && hipStreamCreateWithFlags(&slot.chainStreams[i], hipStreamNonBlocking) == hipSuccess;
+            eventsOk = eventsOk && hipEventCreateWithFlags(&slot.chainJoin[i], hipEventDisableTiming) == hipSuccess;
+            for (auto &e : slot.chainEvents[i]) eventsOk = eventsOk && hipEventCreate(&e) == hipSuccess;
+        }
+        eventsOk = eventsOk && hipEventCreateWithFlags(&slot.free, hipEventDisableTiming) == hipSuccess;
     }
     eventsOk = eventsOk && hipEventCreateWithFlags(&ctx->chainFork, hipEventDisableTiming) == hipSuccess;
     if (!eventsOk || hipMalloc((void **)&ctx->dCounters, kStageCount * 16 * sizeof(unsigned long long)) != hipSuccess ||
@@ -606,19 +635,26 @@ void prosper_pt_destroy(prosper_pt_ctx *ctx)
     if (ctx->ownedHdr) (void)hipFree(ctx->ownedHdr);
     if (ctx->dCounters) (void)hipFree(ctx->dCounters);
     if (ctx->dWorkCounter) (void)hipFree(ctx->dWorkCounter);
-    if (ctx->wfBlock) (void)hipFree(ctx->wfBlock);
-    if (ctx->stackOverflow) (void)hipFree(ctx->stackOverflow);
+    for (RenderSlot &slot : ctx->slots)
+    {
+        if (slot.wfBlock) (void)hipFree(slot.wfBlock);
+        if (slot.stackOverflow) (void)hipFree(slot.stackOverflow);
+    }
     if (ctx->restirScratch) (void)hipFree(ctx->restirScratch);
     if (ctx->toneLut) (void)hipFree(ctx->toneLut);
     if (ctx->toneScratch) (void)hipFree(ctx->toneScratch);
     for (auto &e : ctx->events)
         if (e) (void)hipEventDestroy(e);
-    for (int i = 0; i < 2; ++i)
+    for (RenderSlot &slot : ctx->slots)
     {
-        for (auto &e : ctx->chainEvents[i])
-            if (e) (void)hipEventDestroy(e);
-        if (ctx->chainJoin[i]) (void)hipEventDestroy(ctx->chainJoin[i]);
-        if (ctx->chainStreams[i]) (void)hipStreamDestroy(ctx->chainStreams[i]);
+        for (int i = 0; i < 2; ++i)
+        {
+            for (auto &e : slot.chainEvents[i])
+                if (e) (void)hipEventDestroy(e);
+            if (slot.chainJoin[i]) (void)hipEventDestroy(slot.chainJoin[i]);
+            if (slot.chainStreams[i]) (void)hipStreamDestroy(slot.chainStreams[i]);
+        }
+        if (slot.free) (void)hipEventDestroy(slot.free);
     }
     if (ctx->chainFork) (void)hipEventDestroy(ctx->chainFork);
     delete ctx;
@@ -752,18 +788,22 @@ int prosper_pt_render_frames(
     if (ctx->flags & PROSPER_PT_CREATE_MEGAKERNEL)
     {
         int32_t *ovf = nullptr;
-        const int orc = ensure_stack_overflow(ctx, kTraversalStackDepth, megakernel_grid_blocks(p), s, &ovf);
+        const int orc = ensure_stack_overflow(ctx, ctx->slots[0], kTraversalStackDepth, megakernel_grid_blocks(p), s, &ovf);
         if (orc != PROSPER_PT_OK) return orc;
+        wait_for_slot(ctx->slots[0], s);
         if (tp) tp->mark(kStageGenerate, s);
         launch_render_megakernel(ctx->scene, p, ctx->hdr, ctx->dCounters, ovf, countWork, s);
+        release_slot(ctx->slots[0], s);
     }
     else if (ctx->flags & PROSPER_PT_CREATE_PERSISTENT)
     {
         int32_t *ovf = nullptr;
-        const int orc = ensure_stack_overflow(ctx, kTraversalStackDepth, persistent_grid_blocks(), s, &ovf);
+        const int orc = ensure_stack_overflow(ctx, ctx->slots[0], kTraversalStackDepth, persistent_grid_blocks(), s, &ovf);
         if (orc != PROSPER_PT_OK) return orc;
+        wait_for_slot(ctx->slots[0], s);
         if (tp) tp->mark(kStageGenerate, s);
         launch_render_persistent(ctx->scene, p, ctx->hdr, ctx->dCounters, ctx->dWorkCounter, ovf, countWork, s);
+        release_slot(ctx->slots[0], s);
     }
     else
     {
@@ -775,25 +815,36 @@ int prosper_pt_render_frames(
         if (pixelsPadded > kMaxWavefrontSlots) return fail(PROSPER_PT_ERR_UNSUPPORTED, "image too large for the wavefront workspace");
         uint32_t framesPerChunk = (uint32_t)(kMaxWavefrontSlots / pixelsPadded);
         if (framesPerChunk > frame_count) framesPerChunk = frame_count;
+        // Frames in flight.  Default: the chains fork from the caller's stream, i.e. after everything enqueued on
+        // it so far, and use slot 0.  PROSPER_PT_RENDER_PIPELINED: the path stages (generate / shade / trace) of
+        // this render run as ONE chain on the other slot's stream and wait only for that slot's previous render,
+        // so they overlap the previous render's remaining work - a 2 M-path batch alone fills 55 % of the GPU,
+        // two of them 80 % (profiles/r01_pipelined.txt).  The accumulate kernel stays on the caller's stream, in
+        // order: history reads, output writes and everything the caller enqueues later see finished frames.
+        const bool pipelined = (render_flags & PROSPER_PT_RENDER_PIPELINED) != 0 && !countWork;
+        const uint32_t slotIndex = pipelined ? (ctx->lastSlot + 1u) % prosper_pt_ctx::kRenderSlots : 0u;
+        RenderSlot &slot = ctx->slots[slotIndex];
+        ctx->lastSlot = slotIndex;
         WavefrontChains chains;
         LaunchTimer chainTimers[2];
-        chains.count = (ctx->flags & PROSPER_PT_CREATE_SINGLE_CHAIN) ? 1u : 2u;
+        chains.count = (pipelined || (ctx->flags & PROSPER_PT_CREATE_SINGLE_CHAIN)) ? 1u : 2u;
+        chains.detached = pipelined;
         chains.fork = ctx->chainFork;
         for (int i = 0; i < 2; ++i)
         {
-            chains.streams[i] = ctx->chainStreams[i];
-            chains.join[i] = ctx->chainJoin[i];
-            chainTimers[i].events = ctx->chainEvents[i];
-            chainTimers[i].stage = ctx->chainStage[i];
+            chains.streams[i] = slot.chainStreams[i];
+            chains.join[i] = slot.chainJoin[i];
+            chainTimers[i].events = slot.chainEvents[i];
+            chainTimers[i].stage = slot.chainStage[i];
             chainTimers[i].capacity = prosper_pt_ctx::kMaxTimedLaunches;
             chains.timers[i] = tp ? &chainTimers[i] : nullptr;
-            ctx->chainLaunches[i] = 0;
+            slot.chainLaunches[i] = 0;
         }
         for (uint32_t f0 = 0; f0 < frame_count; f0 += framesPerChunk)
         {
             const uint32_t frames = (frame_count - f0 < framesPerChunk) ? frame_count - f0 : framesPerChunk;
             WavefrontBuffers w = {};
-            const int rc = ensure_wavefront_workspace(ctx, tilesX, tilesY, frames, s, &w);
+            const int rc = ensure_wavefront_workspace(ctx, slot, tilesX, tilesY, frames, &w);
             if (rc != PROSPER_PT_OK) return rc;
             RenderParams pp = p;
             pp.frameCount = frames;
@@ -801,15 +852,20 @@ int prosper_pt_render_frames(
             if (f0 > 0) pp.pc.flags &= ~(uint32_t)PROSPER_PC_FLAG_SKIP_HISTORY;
             const uint32_t ldsEntries = wavefront_lds_stack_entries(ctx->stats.maxDepth);
             int32_t *ovf = nullptr;
-            const int orc = ensure_stack_overflow(ctx, ldsEntries, wavefront_grid_blocks(w), s, &ovf);
+            const int orc = ensure_stack_overflow(ctx, slot, ldsEntries, wavefront_grid_blocks(w), s, &ovf);
             if (orc != PROSPER_PT_OK) return orc;
             const uint32_t overflowEntries = ctx->stats.maxDepth > ldsEntries ? ctx->stats.maxDepth - ldsEntries : 0u;
+            // the slot's previous user (a render of two calls ago, or the previous chunk of this one) must be done
+            // with the workspace: detached chains wait for that on their own stream, the others on the caller's
+            chains.after = slot.freeRecorded ? slot.free : nullptr;
+            if (!pipelined) wait_for_slot(slot, s);
             if (tp) tp->mark(kStageChains, s);
             launch_render_wavefront(
                 ctx->scene, pp, ctx->hdr, ctx->dCounters, w, ldsEntries, ovf, overflowEntries, (uint32_t)ctx->stats.nodeCount,
                 (uint32_t)ctx->stats.triangleCount, countWork, tp, chains, s);
+            release_slot(slot, s);
         }
-        for (int i = 0; i < 2; ++i) ctx->chainLaunches[i] = chainTimers[i].count;
+        for (int i = 0; i < 2; ++i) slot.chainLaunches[i] = chainTimers[i].count;
     }
     PPT_HIP(hipGetLastError());
     if (tp)
@@ -937,13 +993,15 @@ int prosper_pt_restir_di_trace(
         depth = reinterpret_cast<const float *>(base + pixels * 40u);
     }
     int32_t *ovf = nullptr;
-    const int orc = ensure_stack_overflow(ctx, kTraversalStackDepth, restir_grid_blocks(width, height), s, &ovf);
+    const int orc = ensure_stack_overflow(ctx, ctx->slots[0], kTraversalStackDepth, restir_grid_blocks(width, height), s, &ovf);
     if (orc != PROSPER_PT_OK) return orc;
+    wait_for_slot(ctx->slots[0], s);
     const float eye[3] = {camera->eye.x, camera->eye.y, camera->eye.z};
     float c2w[16];
     std::memcpy(c2w, &camera->clipToWorld, 64);
     launch_restir_di_trace(
         ctx->scene, pc->drawType, pc->frameIndex, pc->flags, width, height, eye, c2w, ar, nm, depth, res, ctx->hdr, ovf, s);
+    release_slot(ctx->slots[0], s);
     PPT_HIP(hipGetLastError());
     return PROSPER_PT_OK;
 }
@@ -1089,13 +1147,14 @@ int prosper_pt_get_last_render_timing(
     if (perStage[kStageChains] > 0.0f || launches[kStageChains] > 0)
     {
         bool any = false;
+        const RenderSlot &slot = ctx->slots[ctx->lastSlot];
         for (int c = 0; c < 2; ++c)
-            for (uint32_t i = 0; i < ctx->chainLaunches[c]; ++i)
+            for (uint32_t i = 0; i < slot.chainLaunches[c]; ++i)
             {
                 float ms = 0.0f;
-                PPT_HIP(hipEventElapsedTime(&ms, ctx->chainEvents[c][i], ctx->chainEvents[c][i + 1]));
-                perStage[ctx->chainStage[c][i]] += ms;
-                launches[ctx->chainStage[c][i]] += 1;
+                PPT_HIP(hipEventElapsedTime(&ms, slot.chainEvents[c][i], slot.chainEvents[c][i + 1]));
+                perStage[slot.chainStage[c][i]] += ms;
+                launches[slot.chainStage[c][i]] += 1;
                 any = true;
             }
         if (any)

@@ -69,9 +69,13 @@ void launch_render_persistent(
 // shade/trace per bounce), chain i on streams[i] with its own launch timer, forked from and joined back
 // into the caller's stream around them; the accumulate kernel follows on the caller's stream.  With
 // count == 1 (or a batch too small to split) everything runs on the caller's stream.
+// `detached`: the (single) chain runs on streams[0] without forking from the caller's stream - it waits only
+// for `after` (the previous use of its workspace) - and is joined back before the accumulate kernel.
 struct WavefrontChains
 {
     uint32_t count = 1;
+    bool detached = false;
+    hipEvent_t after = nullptr;
     hipStream_t streams[2] = {};
     hipEvent_t fork = nullptr;
     hipEvent_t join[2] = {};

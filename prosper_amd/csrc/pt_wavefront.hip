@@ -693,7 +693,8 @@ void launch_render_wavefront(
     static_assert(kTraversalStackDepth == 32, "largest LDS stack variant");
     const uint32_t groups = (w.nSeg + 3u) / 4u;
     // Two chains only pay when each still fills the machine a few times over (>= 1024 workgroups each).
-    const uint32_t parts = (chains.count >= 2u && groups >= 512u) ? 2u : 1u;
+    const uint32_t parts = (!chains.detached && chains.count >= 2u && groups >= 512u) ? 2u : 1u;
+    const bool ownStreams = parts > 1u || chains.detached;
     const uint32_t per = (groups + parts - 1u) / parts;
     if (parts > 1u) (void)hipEventRecord(chains.fork, stream);
     uint32_t blocksBefore = 0;
@@ -702,9 +703,10 @@ void launch_render_wavefront(
         WavefrontBuffers part = w;
         part.groupBase = i * per;
         part.groupCount = (part.groupBase + per <= groups) ? per : groups - part.groupBase;
-        hipStream_t cs = parts > 1u ? chains.streams[i] : stream;
-        LaunchTimer *ct = parts > 1u ? chains.timers[i] : timer;
+        hipStream_t cs = ownStreams ? chains.streams[i] : stream;
+        LaunchTimer *ct = ownStreams ? chains.timers[i] : timer;
         if (parts > 1u) (void)hipStreamWaitEvent(cs, chains.fork, 0);
+        if (chains.detached && chains.after) (void)hipStreamWaitEvent(cs, chains.after, 0);
         // every chain gets its own region of the stack-overflow array: its kernels index it by their own
         // blockIdx / gridDim (TraversalStack), and the chains run concurrently
         int32_t *ovf = stackOverflow ? stackOverflow + (size_t)blocksBefore * 256u * overflowEntries : nullptr;
@@ -713,7 +715,7 @@ void launch_render_wavefront(
         else
             enqueue_for_stack<false>(s, p, counters, part, ldsStackEntries, ovf, nodeCount, triCount, ct, cs);
         blocksBefore += ((part.groupCount + 7u) / 8u) * 8u;
-        if (parts > 1u)
+        if (ownStreams)
         {
             if (ct) ct->close(cs);
             (void)hipEventRecord(chains.join[i], cs);

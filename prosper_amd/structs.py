@@ -156,6 +156,7 @@ CREATE_MEGAKERNEL = 1 << 0
 CREATE_PERSISTENT = 1 << 1
 CREATE_SINGLE_CHAIN = 1 << 2
 RENDER_COUNT_WORK = 1 << 0
+RENDER_PIPELINED = 1 << 1
 MAX_KERNELS = 8
 
 

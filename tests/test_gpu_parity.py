@@ -603,6 +603,59 @@ def test_two_launch_chains_equal_one_chain(gpu_ctx, oracle, sponza_small, monkey
         single.close()
 
 
+def test_pipelined_renders_equal_in_order_renders(gpu_ctx, oracle, sponza_small, monkeypatch):
+    """PROSPER_PT_RENDER_PIPELINED (two frames in flight: the path stages of a render overlap the previous render,
+    alternating between two workspaces): an accumulation sequence - every frame reads the previous frame's image
+    as history - and a sequence of independent frames into alternating output buffers give the same bits as the
+    in-order default, also with spilled traversal stacks and with per-launch timing events on."""
+    import ctypes
+    hip = ctypes.CDLL("libamdhip64.so")  # the runtime the library already uses (torch would bring a second one)
+    w, h = 640, 360
+    nbytes = w * h * 16
+    cam, fl = _camera(oracle, sponza_small, w, h)
+    gpu_ctx.upload_scene(sponza_small)
+    bufs = []
+    for _ in range(2):
+        ptr = ctypes.c_void_p()
+        assert hip.hipMalloc(ctypes.byref(ptr), ctypes.c_size_t(nbytes)) == 0
+        bufs.append(ptr)
+
+    def download(ptr):
+        out = np.empty((h, w, 4), np.float32)
+        assert hip.hipMemcpy(ctypes.c_void_p(out.ctypes.data), ptr, ctypes.c_size_t(nbytes), 2) == 0  # device to host
+        return out
+    for forced in (None, "16"):
+        if forced:
+            monkeypatch.setenv("PROSPER_PT_DEBUG_STACK", forced)
+        results = []
+        for flags in (0, S.RENDER_PIPELINED):
+            gpu_ctx.set_kernel_timing(flags != 0)
+            # (1) accumulation: frames 1..6, the first skips history
+            for f in range(1, 7):
+                pc = default_pc(S, fl, frame_index=f, max_bounces=3, ibl=True, skip_history=(f == 1))
+                gpu_ctx.render(pc, cam, w, h, frames=1 + (f % 2), flags=flags)
+            acc = gpu_ctx.read_hdr()
+            # (2) independent frames into two caller-owned buffers, used alternately, no sync in between
+            for f in range(8):
+                gpu_ctx.set_output_buffer(bufs[f % 2].value, nbytes)
+                pc = default_pc(S, fl, frame_index=10 + f, max_bounces=2 + f % 3, ibl=True)
+                gpu_ctx.render(pc, cam, w, h, flags=flags)
+            assert hip.hipDeviceSynchronize() == 0
+            results.append((acc, download(bufs[0]), download(bufs[1])))
+            gpu_ctx.set_output_buffer(None, 0)
+            gpu_ctx.set_kernel_timing(False)
+        for a, b in zip(*results):
+            assert same_bits(a, b).all(), forced
+        assert (results[0][0][..., 3] == 9.0).all()  # 2+1+2+1+2+1 accumulated samples
+    monkeypatch.delenv("PROSPER_PT_DEBUG_STACK", raising=False)
+    for ptr in bufs:
+        hip.hipFree(ptr)
+    # and the last pipelined frame equals the oracle's
+    pc = default_pc(S, fl, frame_index=17, max_bounces=2 + 7 % 3, ibl=True)
+    want, _ = oracle.OracleScene(sponza_small).render(pc, cam, w, h)
+    assert same_bits(results[1][2], want).all()
+
+
 @pytest.mark.parametrize("draw_type", ["Default", "Albedo", "ShadingNormal", "MaterialID"])
 def test_gltf_scene_bit_exact(gpu_ctx, oracle, draw_type):
     """A scene that came in through the glTF ingest (tests/golden/tiny_scene.gltf: MASK + BLEND materials, a
