@@ -416,9 +416,10 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
-                # the PMC passes were taken on whole-frame (N = 1, two-chain) launches: no figure for a rank's share
-                "traffic": measured_traffic(args.config, dominant) if world_size == 1 and not (
-                    args.single_chain or args.megakernel or args.persistent) else None,
+                # the PMC passes were taken on whole-batch launches of a whole frame (N = 1; the pipelined default and
+                # --single-chain launch that shape): no figure for half-batch launches or for a rank's share
+                "traffic": measured_traffic(args.config, dominant) if world_size == 1 and (
+                    render_flags or args.single_chain) else None,
                 "issue": measured_issue(args.config, dominant),
                 "algorithmic_bytes_per_launch": kernels[dominant]["algorithmic_bytes_per_launch"],
                 "kernel_ms": kernels[dominant]["ms_per_launch"],

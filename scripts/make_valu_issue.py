@@ -14,8 +14,9 @@ import json
 import sys
 
 NOTE = ("rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_INSTS_VMEM SQ_INSTS_SALU "
-        "SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE over scripts/quick_bench.py --config <c> --small-textures --steps 1 (PMC "
-        "collection serialises the dispatches, so each launch - half a batch - runs alone); valu_busy = "
+        "SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE over scripts/quick_bench.py --config <c> --small-textures --single-chain "
+        "--steps 1: whole-batch launches, the launch shape of the default pipelined mode (PMC collection serialises the "
+        "dispatches, so each launch runs alone); valu_busy = "
         "SQ_ACTIVE_INST_VALU / (256 CUs * GRBM_GUI_ACTIVE/8 XCDs) (quad-cycles per SIMD-quad), lane_util = "
         "SQ_THREAD_CYCLES_VALU / (64*SQ_INSTS_VALU); mean per launch")
 
