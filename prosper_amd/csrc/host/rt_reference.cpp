@@ -132,7 +132,9 @@ RtReference::Output RtReference::record(
 {
     PROSPER_ASSERT(m_initialized);
     PROSPER_ASSERT(frameCount >= 1);
-    (void)nextFrame; // selects per-frame descriptor sets in the original; nothing to select here
+    // The original selects per-frame descriptor sets with it (two frames in flight).  The library alternates its two
+    // render slots by itself: pass PROSPER_PT_RENDER_PIPELINED in renderFlags for the same overlap of frames.
+    (void)nextFrame;
     // the caller has run World::buildAccelerationStructures (App.cpp:573-578)
     PROSPER_ASSERT(world.uploadedTo(m_ctx));
 
