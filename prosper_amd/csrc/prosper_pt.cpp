@@ -449,7 +449,8 @@ void release_slot(RenderSlot &slot, hipStream_t stream)
 
 // Sizes and carves the wavefront workspace for `frames` x (tilesX*tilesY*64) path slots.
 int ensure_wavefront_workspace(
-    prosper_pt_ctx *ctx, RenderSlot &slot, uint32_t tilesX, uint32_t tilesY, uint32_t frames, WavefrontBuffers *out)
+    prosper_pt_ctx *ctx, RenderSlot &slot, uint32_t tilesX, uint32_t tilesY, uint32_t frames, bool pipelined,
+    WavefrontBuffers *out)
 {
     const uint64_t pixelsPadded = (uint64_t)tilesX * tilesY * 64u;
     const uint64_t slots = pixelsPadded * frames;
@@ -458,7 +459,8 @@ int ensure_wavefront_workspace(
     // count is about one round of resident waves for each of the two launch chains plus a little, ~11 500 segments (swept:
     // profiles/r01_seglen_sweep.txt).  The length is an ODD multiple of 64 slots: at even multiples the waves'
     // concurrent accesses to their segments' records, `segLen * 16` bytes apart, pile onto a few HBM channels.
-    uint64_t target = 11500u;
+    // (two frames in flight, one chain each: the same total, half of it per frame - 5 500)
+    uint64_t target = pipelined ? 5500u : 11500u;
     if (const char *forced = std::getenv("PROSPER_PT_DEBUG_SEGMENTS")) // tuning hook
     {
         const uint64_t v = (uint64_t)std::atoll(forced);
@@ -535,7 +537,7 @@ int ensure_wavefront_workspace(
         slot.wfBytes = 0;
         PPT_HIP(hipMalloc(&slot.wfBlock, need));
         slot.wfBytes = need;
-        return ensure_wavefront_workspace(ctx, slot, tilesX, tilesY, frames, out);
+        return ensure_wavefront_workspace(ctx, slot, tilesX, tilesY, frames, pipelined, out);
     }
     *out = w;
     return PROSPER_PT_OK;
@@ -844,7 +846,7 @@ int prosper_pt_render_frames(
         {
             const uint32_t frames = (frame_count - f0 < framesPerChunk) ? frame_count - f0 : framesPerChunk;
             WavefrontBuffers w = {};
-            const int rc = ensure_wavefront_workspace(ctx, slot, tilesX, tilesY, frames, &w);
+            const int rc = ensure_wavefront_workspace(ctx, slot, tilesX, tilesY, frames, pipelined, &w);
             if (rc != PROSPER_PT_OK) return rc;
             RenderParams pp = p;
             pp.frameCount = frames;
