@@ -5,7 +5,10 @@ A step = one pass of the hot path over one batch: the 1920x1080 S-cornell frame 
 8 spp with maxBounces 4 (BASELINE.json configs[1]), inputs resident in HBM.  With
 N > 1 GPUs the image is cut into interleaved 16-pixel stripes, one stripe set per rank, and the
 per-rank RGBA32F tiles are gathered to rank 0 over RCCL inside the timed region (strong scaling:
-the total work is fixed).
+the total work is fixed).  Steps are enqueued back to back with two frames in flight
+(PROSPER_PT_RENDER_PIPELINED, prosper's own frames-in-flight count; --in-order for A/B): every step's kernels,
+its accumulate and its gather complete inside the timed region, which is bracketed by barrier + synchronize.
+Before the W warm-up steps the device is woken with PREHEAT_STEPS untimed steps (clock ramp, see below).
 
     python bench.py --gpus 1 --steps 20 --warmup 3
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
@@ -49,6 +52,9 @@ def algorithmic_bytes(c, stats):
     return (c["nodeVisits"] * float(stats.nodeBytes) + c["shortIndexTriangleTests"] * 30.0 + tri_long * 36.0 + chit +
             ahit + c["lightSamples"] * 36.0 + c["spotLightSamples"] * 52.0 + c["skyLookups"] * 32.0 +
             c["pixelsWritten"] * 16.0 + c["historyReads"] * 16.0)
+
+
+PREHEAT_STEPS = 24
 
 
 def measured_traffic(config, kernel):
@@ -332,6 +338,14 @@ def main():
     # the step time itself comes from the two events around every step.
     ctx.set_kernel_timing(True)
 
+    # Device wake-up: the clocks of an idle MI355X take ~40 ms of load to ramp (the first ten 2.5 ms steps after idle
+    # run 5-10 % slower, in every pipeline mode).  A renderer is past that after its first frames; so that the W
+    # warm-up steps and the K timed steps measure the steady state whatever W the caller picks, PREHEAT_STEPS steps
+    # run first (the same count on every rank: they gather).  Untimed, reported as `preheat_steps`; the timed region
+    # is untouched.
+    for _ in range(PREHEAT_STEPS):
+        step()
+    drain()
     for _ in range(args.warmup):
         step()
     drain()
@@ -353,6 +367,8 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     kernel_ms = sum(s.elapsed_time(e) for s, e in zip(starts, stops)) / max(1, args.steps)
+    if os.environ.get("PROSPER_BENCH_STEP_TIMES") and rank == 0:
+        print("step ms: " + " ".join("%.3f" % (starts[i].elapsed_time(starts[i + 1])) for i in range(args.steps - 1)), file=sys.stderr)
     # per-kernel split of the LAST timed step, from the hipEvents recorded around every launch
     _, per_kernel = ctx.last_render_timing()
 
@@ -430,6 +446,7 @@ def main():
                 # launch, so sum(kernel time) > wall time and `frac` is a per-launch, not a whole-GPU, figure
                 "concurrent_chains": 1 if (args.single_chain or args.megakernel or args.persistent) else 2,
                 "frames_in_flight": 2 if render_flags else 1,
+                "preheat_steps": PREHEAT_STEPS,
                 "kernel_ms_exclusive": kernels[dominant]["ms_per_launch"] * exclusive_scale,
                 "frac_exclusive": achieved / exclusive_scale / HBM_PEAK_GBS,
             },
