@@ -262,10 +262,12 @@ int upload_scene_impl(prosper_pt_ctx *ctx, const prosper_pt_scene_view *v)
     // cache line each (pt_scene.hpp DeviceTexture), + descriptor table
     std::vector<DeviceTexture> textures(v->textureCount ? v->textureCount : 1);
     std::vector<uint32_t> tiled;
+    uint64_t texelBytes = 0;
     for (uint32_t i = 0; i < v->textureCount; ++i)
     {
         const prosper_pt_texture_desc &t = v->textures[i];
         const uint32_t tilesX = (t.width + kTexTileW - 1u) / kTexTileW, tilesY = (t.height + kTexTileH - 1u) / kTexTileH;
+        texelBytes += (uint64_t)t.width * t.height * 4u;
         if (t.format == PROSPER_PT_FORMAT_BC7_UNORM)
         {
             // the blocks go up as they are and a kernel decodes them into the tiles (pt_bc7.hpp)
@@ -301,6 +303,10 @@ int upload_scene_impl(prosper_pt_ctx *ctx, const prosper_pt_scene_view *v)
     }
     if ((rc = upload(ctx, textures.data(), textures.size() * sizeof(DeviceTexture), &d))) return rc;
     s.textures = static_cast<const DeviceTexture *>(d);
+    // beyond the 8 x 4 MB of L2 the texels of a hit come from the Infinity Cache or HBM: overlap their fetches
+    // (PROSPER_PT_DEBUG_BATCHED_TEXTURES = 0 / 1 forces either path: same pixels, tested)
+    s.batchedTextures = texelBytes > (32ull << 20) ? 1u : 0u;
+    if (const char *forced = std::getenv("PROSPER_PT_DEBUG_BATCHED_TEXTURES")) s.batchedTextures = std::atoi(forced) ? 1u : 0u;
 
     // lights
     if ((rc = upload(ctx, v->directionalLight, sizeof(prosper_DirectionalLightParameters), &d))) return rc;

@@ -266,39 +266,80 @@ PPT_D void wrap_pair(int32_t i, int32_t size, uint32_t mode, int32_t &c0, int32_
     c1 = i < -1 ? 0 : (i >= size - 1 ? size - 1 : i + 1);
 }
 
-PPT_D f4 fetch_rgba8(const DeviceTexture &t, int32_t i, int32_t j)
+// word offset of texel (i, j) in the tiled image
+PPT_D uint32_t texel_offset(const DeviceTexture &t, int32_t i, int32_t j)
 {
     const uint32_t tile = ((uint32_t)j >> 2) * t.tilesPerRow + ((uint32_t)i >> 3);
-    const uint32_t p = ((global_u32_ptr)t.texels)[(size_t)tile * 32u + ((((uint32_t)j & 3u) << 3) | ((uint32_t)i & 7u))];
+    return tile * 32u + ((((uint32_t)j & 3u) << 3) | ((uint32_t)i & 7u));
+}
+PPT_D f4 unpack_rgba8(uint32_t p)
+{
     const float k = 1.0f / 255.0f;
     return f4{(float)(p & 0xFFu) * k, (float)((p >> 8) & 0xFFu) * k, (float)((p >> 16) & 0xFFu) * k, (float)(p >> 24) * k};
 }
-
-PPT_D f4 sample_texture(const DeviceScene &s, uint32_t tex, uint32_t smp, f2 uv)
+PPT_D f4 fetch_rgba8(const DeviceTexture &t, int32_t i, int32_t j)
 {
-    const DeviceTexture t = s.textures[tex];
-    const prosper_pt_sampler_desc sd = s.samplers[smp];
+    return unpack_rgba8(((global_u32_ptr)t.texels)[texel_offset(t, i, j)]);
+}
+
+// One LOD-0 sample in three steps, so that a caller with several textures can compute all coordinates, then have
+// all texel loads in flight together, then filter (sample_material: three dependent round trips become one):
+//   texel_taps  - wrap + filter footprint: four texel offsets and the bilinear weights (no memory access);
+//                 a nearest-filter sample is the footprint (i, j) x 4 with weights (1, 0, 0, 0) - the weighted
+//                 sum below then returns that texel's value exactly (texels are finite, 0 * t = 0, x + 0 = x)
+//   fetch_taps  - the four loads
+//   filter_taps - unpack + weighted sum, the same fma chain as ever
+struct TexelTaps
+{
+    global_u32_ptr texels;
+    uint32_t o00, o10, o01, o11;
+    float a, b;
+};
+PPT_D TexelTaps texel_taps(const DeviceTexture &t, const prosper_pt_sampler_desc &sd, f2 uv)
+{
     const int32_t w = (int32_t)t.width;
     const int32_t h = (int32_t)t.height;
+    TexelTaps k;
+    k.texels = (global_u32_ptr)t.texels;
     if (sd.magFilter == PROSPER_PT_FILTER_NEAREST)
     {
         const int32_t i = wrap_coord(f2i(__builtin_floorf(uv.x * (float)w)), w, sd.wrapS);
         const int32_t j = wrap_coord(f2i(__builtin_floorf(uv.y * (float)h)), h, sd.wrapT);
-        return fetch_rgba8(t, i, j);
+        k.o00 = k.o10 = k.o01 = k.o11 = texel_offset(t, i, j);
+        k.a = 0.0f;
+        k.b = 0.0f;
+        return k;
     }
     const float u = __builtin_fmaf(uv.x, (float)w, -0.5f);
     const float v = __builtin_fmaf(uv.y, (float)h, -0.5f);
     const float fu = __builtin_floorf(u);
     const float fv = __builtin_floorf(v);
-    const float a = u - fu;
-    const float b = v - fv;
+    k.a = u - fu;
+    k.b = v - fv;
     int32_t i0, i1, j0, j1;
     wrap_pair(f2i(fu), w, sd.wrapS, i0, i1);
     wrap_pair(f2i(fv), h, sd.wrapT, j0, j1);
-    const f4 t00 = fetch_rgba8(t, i0, j0);
-    const f4 t10 = fetch_rgba8(t, i1, j0);
-    const f4 t01 = fetch_rgba8(t, i0, j1);
-    const f4 t11 = fetch_rgba8(t, i1, j1);
+    k.o00 = texel_offset(t, i0, j0);
+    k.o10 = texel_offset(t, i1, j0);
+    k.o01 = texel_offset(t, i0, j1);
+    k.o11 = texel_offset(t, i1, j1);
+    return k;
+}
+struct RawTaps
+{
+    uint32_t p00, p10, p01, p11;
+};
+PPT_D RawTaps fetch_taps(const TexelTaps &k)
+{
+    return RawTaps{k.texels[k.o00], k.texels[k.o10], k.texels[k.o01], k.texels[k.o11]};
+}
+PPT_D f4 filter_taps(const TexelTaps &k, const RawTaps &r)
+{
+    const f4 t00 = unpack_rgba8(r.p00);
+    const f4 t10 = unpack_rgba8(r.p10);
+    const f4 t01 = unpack_rgba8(r.p01);
+    const f4 t11 = unpack_rgba8(r.p11);
+    const float a = k.a, b = k.b;
     const float w00 = (1.0f - a) * (1.0f - b);
     const float w10 = a * (1.0f - b);
     const float w01 = (1.0f - a) * b;
@@ -307,6 +348,22 @@ PPT_D f4 sample_texture(const DeviceScene &s, uint32_t tex, uint32_t smp, f2 uv)
               __builtin_fmaf(w11, t11.y, __builtin_fmaf(w01, t01.y, __builtin_fmaf(w10, t10.y, w00 * t00.y))),
               __builtin_fmaf(w11, t11.z, __builtin_fmaf(w01, t01.z, __builtin_fmaf(w10, t10.z, w00 * t00.z))),
               __builtin_fmaf(w11, t11.w, __builtin_fmaf(w01, t01.w, __builtin_fmaf(w10, t10.w, w00 * t00.w)))};
+}
+
+PPT_D f4 sample_texture(const DeviceScene &s, uint32_t tex, uint32_t smp, f2 uv)
+{
+    const DeviceTexture t = s.textures[tex];
+    const prosper_pt_sampler_desc sd = s.samplers[smp];
+    if (sd.magFilter == PROSPER_PT_FILTER_NEAREST)
+    {
+        const int32_t w = (int32_t)t.width;
+        const int32_t h = (int32_t)t.height;
+        const int32_t i = wrap_coord(f2i(__builtin_floorf(uv.x * (float)w)), w, sd.wrapS);
+        const int32_t j = wrap_coord(f2i(__builtin_floorf(uv.y * (float)h)), h, sd.wrapT);
+        return fetch_rgba8(t, i, j);
+    }
+    const TexelTaps k = texel_taps(t, sd, uv);
+    return filter_taps(k, fetch_taps(k));
 }
 
 // Cube face selection per Vulkan 1.3 §16.5.4 (faces +X,-X,+Y,-Y,+Z,-Z)
@@ -425,6 +482,9 @@ PPT_D float srgb_to_linear(float x)
 }
 
 // materials.glsl:47-119
+// BATCHED: all texel loads of the three textures in flight together (costs ~13 more VGPRs: the shade kernel then
+// sits at its 128-register limit with a 16-byte spill, which a scene without big textures does not get back)
+template <bool BATCHED>
 PPT_D Material sample_material(const DeviceScene &s, uint32_t index, f2 uv)
 {
     const prosper_MaterialData data = s.materials[index];
@@ -434,13 +494,55 @@ PPT_D Material sample_material(const DeviceScene &s, uint32_t index, f2 uv)
     ret.roughness = 0.0f;
     ret.metallic = 0.0f;
 
-    f4 base = f4{1.0f, 1.0f, 1.0f, 1.0f};
+    // The three texture samples do not depend on one another: descriptors first, then all footprints, then all
+    // twelve texel loads in flight together, then the filtering - one memory round trip per stage instead of one
+    // per texture (the texels of a 315 MB texture set mostly come from HBM).  On a failed alpha mask the
+    // reference returns before the other two samples; their values are simply not used then.
     const uint32_t baseTex = data.baseColorTextureSampler & 0xFFFFFFu;
-    if (baseTex > 0)
+    const uint32_t mrTex = data.metallicRoughnessTextureSampler & 0xFFFFFFu;
+    const uint32_t nTex = data.normalTextureSampler & 0xFFFFFFu;
+    f4 sBaseT = f4{1.0f, 1.0f, 1.0f, 1.0f}, sMrT = f4{0.0f, 0.0f, 0.0f, 0.0f}, sNT = f4{0.0f, 0.0f, 0.0f, 0.0f};
+    if constexpr (!BATCHED)
     {
-        const f4 t = sample_texture(s, baseTex, data.baseColorTextureSampler >> 24, uv);
-        base = f4{srgb_to_linear(t.x), srgb_to_linear(t.y), srgb_to_linear(t.z), t.w};
+        // one texture after the other: fewer live registers
+        if (baseTex > 0) sBaseT = sample_texture(s, baseTex, data.baseColorTextureSampler >> 24, uv);
+        if (mrTex > 0) sMrT = sample_texture(s, mrTex, data.metallicRoughnessTextureSampler >> 24, uv);
+        if (nTex > 0) sNT = sample_texture(s, nTex, data.normalTextureSampler >> 24, uv);
     }
+    else if ((baseTex | mrTex | nTex) != 0u) // untextured materials skip the block as a whole
+    {
+        DeviceTexture tBase, tMr, tN;
+        prosper_pt_sampler_desc sBase, sMr, sN;
+        if (baseTex > 0)
+        {
+            tBase = s.textures[baseTex];
+            sBase = s.samplers[data.baseColorTextureSampler >> 24];
+        }
+        if (mrTex > 0)
+        {
+            tMr = s.textures[mrTex];
+            sMr = s.samplers[data.metallicRoughnessTextureSampler >> 24];
+        }
+        if (nTex > 0)
+        {
+            tN = s.textures[nTex];
+            sN = s.samplers[data.normalTextureSampler >> 24];
+        }
+        TexelTaps kBase, kMr, kN;
+        if (baseTex > 0) kBase = texel_taps(tBase, sBase, uv);
+        if (mrTex > 0) kMr = texel_taps(tMr, sMr, uv);
+        if (nTex > 0) kN = texel_taps(tN, sN, uv);
+        RawTaps rBase, rMr, rN;
+        if (baseTex > 0) rBase = fetch_taps(kBase);
+        if (mrTex > 0) rMr = fetch_taps(kMr);
+        if (nTex > 0) rN = fetch_taps(kN);
+        if (baseTex > 0) sBaseT = filter_taps(kBase, rBase);
+        if (mrTex > 0) sMrT = filter_taps(kMr, rMr);
+        if (nTex > 0) sNT = filter_taps(kN, rN);
+    }
+
+    f4 base = f4{1.0f, 1.0f, 1.0f, 1.0f};
+    if (baseTex > 0) base = f4{srgb_to_linear(sBaseT.x), srgb_to_linear(sBaseT.y), srgb_to_linear(sBaseT.z), sBaseT.w};
     base.x *= data.baseColorFactor.x;
     base.y *= data.baseColorFactor.y;
     base.z *= data.baseColorFactor.z;
@@ -459,12 +561,10 @@ PPT_D Material sample_material(const DeviceScene &s, uint32_t index, f2 uv)
     }
     ret.albedo = f3{base.x, base.y, base.z};
 
-    const uint32_t mrTex = data.metallicRoughnessTextureSampler & 0xFFFFFFu;
     if (mrTex > 0)
     {
-        const f4 mr = sample_texture(s, mrTex, data.metallicRoughnessTextureSampler >> 24, uv);
-        ret.roughness = mr.y * data.roughnessFactor;
-        ret.metallic = mr.z * data.metallicFactor;
+        ret.roughness = sMrT.y * data.roughnessFactor;
+        ret.metallic = sMrT.z * data.metallicFactor;
     }
     else
     {
@@ -473,12 +573,8 @@ PPT_D Material sample_material(const DeviceScene &s, uint32_t index, f2 uv)
     }
     ret.roughness = fmax_(ret.roughness, 0.05f);
 
-    const uint32_t nTex = data.normalTextureSampler & 0xFFFFFFu;
     if (nTex > 0)
-    {
-        const f4 tn = sample_texture(s, nTex, data.normalTextureSampler >> 24, uv);
-        ret.normal = f3{__builtin_fmaf(tn.x, 2.0f, -1.0f), __builtin_fmaf(tn.y, 2.0f, -1.0f), __builtin_fmaf(tn.z, 2.0f, -1.0f)};
-    }
+        ret.normal = f3{__builtin_fmaf(sNT.x, 2.0f, -1.0f), __builtin_fmaf(sNT.y, 2.0f, -1.0f), __builtin_fmaf(sNT.z, 2.0f, -1.0f)};
     else
         ret.normal = f3{-2.0f, -2.0f, -2.0f};
     return ret;
@@ -1238,7 +1334,7 @@ PPT_D f3 mapped_normal(f3 tsn, f3 normal, f3 tangent, float sgn)
     return normalize(((tangent * tsn.x) + (vB * tsn.y)) + (normal * tsn.z));
 }
 
-template <bool COUNT>
+template <bool COUNT, bool BATCHED_TEXTURES = false>
 PPT_D Surface evaluate_surface(const DeviceScene &s, f3 rayDir, const Hit &hit, LaneCounters &cnt)
 {
     // loadVertexThroughIndexBuffer x 3 (geometry.glsl:220-244) from the triangle's precomputed record
@@ -1270,7 +1366,7 @@ PPT_D Surface evaluate_surface(const DeviceScene &s, f3 rayDir, const Hit &hit, 
     sf.positionWS = v.position;
     sf.invViewRayWS = -rayDir;
     sf.uv = v.uv;
-    sf.material = sample_material(s, inst.materialIndex, v.uv);
+    sf.material = sample_material<BATCHED_TEXTURES>(s, inst.materialIndex, v.uv);
     if (sf.material.normal.x != -2.0f && v.tangent.w != 0.0f)
         sf.normalWS = mapped_normal(sf.material.normal, v.normal, f3{v.tangent.x, v.tangent.y, v.tangent.z}, v.tangent.w);
     else

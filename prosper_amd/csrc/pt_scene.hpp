@@ -111,6 +111,9 @@ struct DeviceScene
     uint32_t materialCount; // table sizes, for staging the tables in LDS (wf_shade)
     uint32_t drawInstanceCount;
     uint32_t modelInstanceCount;
+    // texel loads of a hit's three textures issued together (sample_material<true>): set for texture sets too big
+    // for the caches, where the three dependent HBM round trips per hit are what the shade kernel waits for
+    uint32_t batchedTextures;
 };
 
 // Per-launch constants: push constants, the camera terms the path reads, extent and tile.

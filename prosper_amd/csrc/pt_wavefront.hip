@@ -344,7 +344,7 @@ __device__ __forceinline__ const void *stage_table(uint32_t *lds, uint32_t &offs
     return dst;
 }
 
-template <bool COUNT, bool LDS_TABLES>
+template <bool COUNT, bool LDS_TABLES, bool BATCHED_TEXTURES>
 __global__ __launch_bounds__(256, PPT_SHADE_WPE) void wf_shade(
     DeviceScene s, RenderParams p, WavefrontBuffers w, uint32_t bounce, uint32_t cur, uint32_t lastBounce,
     unsigned long long *__restrict__ counters)
@@ -405,7 +405,7 @@ __global__ __launch_bounds__(256, PPT_SHADE_WPE) void wf_shade(
             hit.primitive = h.y;
             hit.bary = f2{asf(h.z), asf(h.w)};
             hit.t = 0.0f;
-            const Surface sf = evaluate_surface<COUNT>(s, xyz(b), hit, cnt);
+            const Surface sf = evaluate_surface<COUNT, BATCHED_TEXTURES>(s, xyz(b), hit, cnt);
             if (debugDraw)
             {
                 const f3 c = debug_color(s, p.pc.drawType, hit, sf);
@@ -630,10 +630,12 @@ static void enqueue_wavefront(
         const uint32_t cur = b & 1u;
         const uint32_t last = (b + 1u == bounces) ? 1u : 0u;
         mark(kStageShade);
-        if (shade_table_bytes(s) <= kLdsTableBytes && !std::getenv("PROSPER_PT_DEBUG_NO_LDS_TABLES"))
-            hipLaunchKernelGGL((wf_shade<COUNT, true>), grid, block, 0, stream, s, p, w, b, cur, last, cShade);
+        const bool ldsTables = shade_table_bytes(s) <= kLdsTableBytes && !std::getenv("PROSPER_PT_DEBUG_NO_LDS_TABLES");
+        auto shade = [&](auto kernel) { hipLaunchKernelGGL(kernel, grid, block, 0, stream, s, p, w, b, cur, last, cShade); };
+        if (s.batchedTextures)
+            ldsTables ? shade(wf_shade<COUNT, true, true>) : shade(wf_shade<COUNT, false, true>);
         else
-            hipLaunchKernelGGL((wf_shade<COUNT, false>), grid, block, 0, stream, s, p, w, b, cur, last, cShade);
+            ldsTables ? shade(wf_shade<COUNT, true, false>) : shade(wf_shade<COUNT, false, false>);
         if (!debugDraw)
         {
             mark(kStageTrace);

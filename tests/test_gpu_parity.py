@@ -746,6 +746,32 @@ def test_lds_staged_tables_equal_global_memory_tables(gpu_ctx, oracle, sponza_sm
     assert same_bits(gpu_ctx.read_hdr(), base).all()
 
 
+def test_batched_texture_fetches_equal_sequential_ones(gpu_ctx, oracle, sponza_small, monkeypatch):
+    """sample_material<true> (big texture sets: the twelve texel loads of a hit's three textures in flight together)
+    against the one-texture-after-the-other path, forced either way on the texture-addressing wall (every wrap mode
+    and filter, odd sizes) and on the small S-sponza-class scene: same bits, and the wall equals the oracle."""
+    for world, extent, kw in ((scenes.texture_wall(), (384, 256), dict(max_bounces=2)),
+                              (sponza_small, (480, 270), dict(max_bounces=3, ibl=True))):
+        w, h = extent
+        cam, fl = _camera(oracle, world, w, h)
+        pc = default_pc(S, fl, **kw)
+        images = []
+        for forced in ("0", "1"):
+            monkeypatch.setenv("PROSPER_PT_DEBUG_BATCHED_TEXTURES", forced)
+            gpu_ctx.upload_scene(world)
+            gpu_ctx.render(pc, cam, w, h, frames=2)
+            images.append(gpu_ctx.read_hdr())
+        monkeypatch.delenv("PROSPER_PT_DEBUG_BATCHED_TEXTURES")
+        assert same_bits(images[0], images[1]).all()
+        if world is not sponza_small:
+            want = None
+            osc = oracle.OracleScene(world, brute_force=True)
+            for f in range(2):
+                p2 = default_pc(S, fl, frame_index=1 + f, skip_history=(f == 0), **kw)
+                want, _ = osc.render(p2, cam, w, h, history=want)
+            assert same_bits(images[1], want).all()
+
+
 def test_hits_do_not_depend_on_the_hierarchy(gpu_ctx, oracle, sponza_small, monkeypatch):
     """Hit contract: the box guard bounds where a triangle can be hit, so fatter BVH boxes (a different
     tree: other culling, other traversal order) must give the same bits."""
