@@ -5,8 +5,8 @@ A step = one pass of the hot path over one batch: the 1920x1080 S-cornell frame 
 8 spp with maxBounces 4 (BASELINE.json configs[1]), inputs resident in HBM.  With
 N > 1 GPUs the image is cut into interleaved 16-pixel stripes, one stripe set per rank, and the
 per-rank RGBA32F tiles are gathered to rank 0 over RCCL inside the timed region (strong scaling:
-the total work is fixed).  Steps are enqueued back to back with two frames in flight
-(PROSPER_PT_RENDER_PIPELINED, prosper's own frames-in-flight count; --in-order for A/B): every step's kernels,
+the total work is fixed).  Steps are enqueued back to back with up to three frames in flight
+(PROSPER_PT_RENDER_PIPELINED, prosper's frames-in-flight idea; --in-order for A/B): every step's kernels,
 its accumulate and its gather complete inside the timed region, which is bracketed by barrier + synchronize.
 Before the W warm-up steps the device is woken with PREHEAT_STEPS untimed steps (clock ramp, see below).
 
@@ -287,8 +287,8 @@ def main():
         pc = make_pc(focal, 1, max_bounces, ibl, True)
         if record:
             record[0].record()
-        # two frames in flight (the reference's own frames-in-flight count): the path stages of step i + 1 overlap
-        # the tail of step i; the accumulate kernel and the gather stay in stream order
+        # frames in flight (as the reference keeps frames in flight): the path stages of steps i + 1 and i + 2 overlap
+        # step i; the accumulate kernel and the gather stay in stream order
         ctx.render(pc, cam, width, height, tile=tile, frames=spp, stream=stream, flags=render_flags)
         if record:
             record[1].record()
@@ -333,9 +333,9 @@ def main():
     bytes_per_launch = algorithmic_bytes(counters, stats)
     stage_bytes = [algorithmic_bytes(ctx.stage_counters(i, stream).as_dict(), stats) for i in range(4)]
     # Per-launch hipEvents (on the launch streams) cost ~35 us per render - 1 % of a full frame, 5 % of a rank's
-    # share at N = 8 - and only the last render's are kept by the library: they are switched on for the warm-up
-    # (same code path exercised) and for the LAST timed step, whose per-launch durations the roofline object uses;
-    # the step time itself comes from the two events around every step.
+    # share at N = 8 - and only one render's are kept by the library: they are switched on for the warm-up
+    # (same code path exercised) and for ONE timed step (`timed_step` below), whose per-launch durations the roofline
+    # object uses; the step time itself comes from the two events around every step.
     ctx.set_kernel_timing(True)
 
     # Device wake-up: the clocks of an idle MI355X take ~40 ms of load to ramp (the first ten 2.5 ms steps after idle
@@ -355,12 +355,15 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # per-launch events on ONE step: with frames in flight the third-last (two steps follow it, so its launches share
+    # the GPU like any steady-state step's; the last steps drain the pipeline and run faster), else the last
+    timed_step = args.steps - 3 if (render_flags and args.steps >= 4) else args.steps - 1
     starts = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
     stops = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
     barrier()
     t0 = time.perf_counter()
     for i in range(args.steps):
-        ctx.set_kernel_timing(i + 1 == args.steps)
+        ctx.set_kernel_timing(i == timed_step)
         # kernel-only time: events on the stream the render kernels are launched on
         step((starts[i], stops[i]))
     drain()
@@ -422,7 +425,7 @@ def main():
                 "parallelism": "image stripes x%d%s" % (world_size, " + RCCL gather" if world_size > 1 else ""),
                 "pipeline": "megakernel" if args.megakernel else ("persistent" if args.persistent else (
                     "wavefront, 1 launch chain" if args.single_chain else (
-                        "wavefront, 2 frames in flight (one launch chain each)" if render_flags
+                        "wavefront, 3 frames in flight (one launch chain each)" if render_flags
                         else "wavefront, 2 concurrent launch chains"))),
             },
             "roofline": {
@@ -439,13 +442,13 @@ def main():
                 "issue": measured_issue(args.config, dominant),
                 "algorithmic_bytes_per_launch": kernels[dominant]["algorithmic_bytes_per_launch"],
                 "kernel_ms": kernels[dominant]["ms_per_launch"],
-                "kernel_ms_source": "hipEvents around every launch of the last timed step",
+                "kernel_ms_source": "hipEvents around every launch of timed step %d of %d" % (timed_step + 1, args.steps),
                 "launches_per_step": kernels[dominant]["launches_per_step"],
                 # the default pipeline runs two half-batches as two chains of launches on two streams: a launch's
                 # duration (hipEvents, = rocprofv3's) includes the time it shares the GPU with the other chain's
                 # launch, so sum(kernel time) > wall time and `frac` is a per-launch, not a whole-GPU, figure
                 "concurrent_chains": 1 if (args.single_chain or args.megakernel or args.persistent) else 2,
-                "frames_in_flight": 2 if render_flags else 1,
+                "frames_in_flight": 3 if render_flags else 1,
                 "preheat_steps": PREHEAT_STEPS,
                 "kernel_ms_exclusive": kernels[dominant]["ms_per_launch"] * exclusive_scale,
                 "frac_exclusive": achieved / exclusive_scale / HBM_PEAK_GBS,

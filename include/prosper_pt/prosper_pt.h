@@ -228,8 +228,8 @@ enum
     PROSPER_PT_RENDER_COUNT_WORK = 1u << 0, /* run the instrumented kernels (slower, same pixels) */
     /* Frames in flight, the role of `nextFrame` / the per-frame descriptor sets in RtReference::record
      * (src/render/RtReference.cpp:161-168; prosper keeps 2 frames in flight): the path stages of this render use the
-     * context's OTHER workspace and may start before work enqueued earlier on `stream` - including the previous
-     * render - has finished; they wait only for the render of two calls ago.  The accumulate kernel (history read,
+     * context's NEXT workspace (it owns three) and may start before work enqueued earlier on `stream` - including the
+     * two previous renders - has finished; they wait only for the render of three calls ago.  The accumulate kernel (history read,
      * output write) runs on `stream`, in order, so the image and everything enqueued after this call behave as
      * without the flag.  The caller promises that no input of this render (scene, lights) is produced by work still
      * pending on `stream`: uploads through this API are synchronous, so that holds unless the caller writes the
@@ -342,7 +342,9 @@ int prosper_pt_get_last_render_timing(
     prosper_pt_ctx *ctx, float *total_ms, float kernel_ms[PROSPER_PT_MAX_KERNELS],
     uint32_t kernel_launches[PROSPER_PT_MAX_KERNELS]);
 const char *prosper_pt_kernel_name(uint32_t index);
-/* Enables per-kernel hipEvent timing for subsequent renders (off by default: events add launches). */
+/* Enables per-kernel hipEvent timing for subsequent renders (off by default: events add launches).  The readout
+ * functions above report the last render that ran with timing on, also after timing has been switched off again
+ * and further (untimed) renders have followed - up to two of them with PROSPER_PT_RENDER_PIPELINED. */
 int prosper_pt_set_kernel_timing(prosper_pt_ctx *ctx, int enabled);
 
 enum

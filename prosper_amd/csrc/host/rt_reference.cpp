@@ -132,7 +132,7 @@ RtReference::Output RtReference::record(
 {
     PROSPER_ASSERT(m_initialized);
     PROSPER_ASSERT(frameCount >= 1);
-    // The original selects per-frame descriptor sets with it (two frames in flight).  The library alternates its two
+    // The original selects per-frame descriptor sets with it (two frames in flight).  The library cycles through its
     // render slots by itself: pass PROSPER_PT_RENDER_PIPELINED in renderFlags for the same overlap of frames.
     (void)nextFrame;
     // the caller has run World::buildAccelerationStructures (App.cpp:573-578)

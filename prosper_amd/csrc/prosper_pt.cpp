@@ -92,7 +92,7 @@ struct prosper_pt_ctx
 
     // Everything a render has in flight between its first launch and its accumulate kernel: the wavefront
     // workspace, the stack-overflow array and the two launch chains (pt_kernels.hpp WavefrontChains) with their
-    // timing events.  Two slots = two frames in flight (PROSPER_PT_RENDER_PIPELINED), the role `nextFrame` and
+    // timing events.  kRenderSlots slots = that many frames in flight (PROSPER_PT_RENDER_PIPELINED), the role `nextFrame` and
     // the per-frame descriptor sets play in RtReference::record; everything else uses slot 0.
     struct RenderSlot
     {
@@ -100,7 +100,6 @@ struct prosper_pt_ctx
         size_t stackOverflowBytes = 0;
         void *wfBlock = nullptr;
         size_t wfBytes = 0;
-        hipStream_t chainStreams[2] = {};
         hipEvent_t chainJoin[2] = {};
         hipEvent_t chainEvents[2][kMaxTimedLaunches + 1] = {};
         uint32_t chainStage[2][kMaxTimedLaunches] = {};
@@ -108,9 +107,16 @@ struct prosper_pt_ctx
         hipEvent_t free = nullptr; // recorded after the accumulate kernel of the slot's last render
         bool freeRecorded = false;
     };
-    static constexpr uint32_t kRenderSlots = 2; // prosper keeps two frames in flight; a third slot measured +1.5 %
+    // prosper keeps two frames in flight; a third one fills the machine better at the batch sizes of a multi-GPU
+    // rank share (1/4 share 0.71 -> 0.66 ms, C3 19.3 -> 18.9 ms; profiles/r01_pipelined.txt)
+    static constexpr uint32_t kRenderSlots = 3;
+    // The internal streams, three in all (+ the caller's = the four hardware queues of the device; more streams
+    // share queues and serialise): a pipelined render's chain runs on workStreams[slot], the two chains of an
+    // in-order render on workStreams[0] and [1].  All ordering between them goes through events.
+    hipStream_t workStreams[kRenderSlots] = {};
     RenderSlot slots[kRenderSlots];
-    uint32_t lastSlot = 0; // of the last render (timing readout)
+    uint32_t lastSlot = 0;  // of the last render
+    uint32_t timedSlot = 0; // of the last render that ran with kernel timing on (timing readout)
     hipEvent_t chainFork = nullptr;
 };
 using RenderSlot = prosper_pt_ctx::RenderSlot;
@@ -465,8 +471,8 @@ int ensure_wavefront_workspace(
     // count is about one round of resident waves for each of the two launch chains plus a little, ~11 500 segments (swept:
     // profiles/r01_seglen_sweep.txt).  The length is an ODD multiple of 64 slots: at even multiples the waves'
     // concurrent accesses to their segments' records, `segLen * 16` bytes apart, pile onto a few HBM channels.
-    // (two frames in flight, one chain each: the same total, half of it per frame - 5 500)
-    uint64_t target = pipelined ? 5500u : 11500u;
+    // (frames in flight, one chain each: the same total split over the kRenderSlots frames - 3 700)
+    uint64_t target = pipelined ? 3700u : 11500u;
     if (const char *forced = std::getenv("PROSPER_PT_DEBUG_SEGMENTS")) // tuning hook
     {
         const uint64_t v = (uint64_t)std::atoll(forced);
@@ -612,11 +618,11 @@ int prosper_pt_create(const prosper_pt_device_desc *desc, prosper_pt_ctx **out_c
     ctx->flags = desc->flags;
     bool eventsOk = true;
     for (auto &e : ctx->events) eventsOk = eventsOk && hipEventCreate(&e) == hipSuccess;
+    for (auto &ws : ctx->workStreams) eventsOk = eventsOk && hipStreamCreateWithFlags(&ws, hipStreamNonBlocking) == hipSuccess;
     for (RenderSlot &slot : ctx->slots)
     {
         for (int i = 0; i < 2; ++i)
         {
-            eventsOk = eventsOk && hipStreamCreateWithFlags(&slot.chainStreams[i], hipStreamNonBlocking) == hipSuccess;
             eventsOk = eventsOk && hipEventCreateWithFlags(&slot.chainJoin[i], hipEventDisableTiming) == hipSuccess;
             for (auto &e : slot.chainEvents[i]) eventsOk = eventsOk && hipEventCreate(&e) == hipSuccess;
         }
@@ -660,10 +666,11 @@ void prosper_pt_destroy(prosper_pt_ctx *ctx)
             for (auto &e : slot.chainEvents[i])
                 if (e) (void)hipEventDestroy(e);
             if (slot.chainJoin[i]) (void)hipEventDestroy(slot.chainJoin[i]);
-            if (slot.chainStreams[i]) (void)hipStreamDestroy(slot.chainStreams[i]);
         }
         if (slot.free) (void)hipEventDestroy(slot.free);
     }
+    for (auto &ws : ctx->workStreams)
+        if (ws) (void)hipStreamDestroy(ws);
     if (ctx->chainFork) (void)hipEventDestroy(ctx->chainFork);
     delete ctx;
 }
@@ -840,7 +847,7 @@ int prosper_pt_render_frames(
         chains.fork = ctx->chainFork;
         for (int i = 0; i < 2; ++i)
         {
-            chains.streams[i] = slot.chainStreams[i];
+            chains.streams[i] = ctx->workStreams[pipelined ? slotIndex : (uint32_t)i];
             chains.join[i] = slot.chainJoin[i];
             chainTimers[i].events = slot.chainEvents[i];
             chainTimers[i].stage = slot.chainStage[i];
@@ -874,6 +881,7 @@ int prosper_pt_render_frames(
             release_slot(slot, s);
         }
         for (int i = 0; i < 2; ++i) slot.chainLaunches[i] = chainTimers[i].count;
+        if (tp) ctx->timedSlot = slotIndex;
     }
     PPT_HIP(hipGetLastError());
     if (tp)
@@ -1111,8 +1119,9 @@ int prosper_pt_reset_counters(prosper_pt_ctx *ctx, void *stream)
 int prosper_pt_set_kernel_timing(prosper_pt_ctx *ctx, int enabled)
 {
     if (!ctx) return fail(PROSPER_PT_ERR_INVALID_ARGUMENT, "prosper_pt_set_kernel_timing: null context");
+    // switching it off keeps the figures of the last timed render readable (later untimed renders record no events)
+    if (enabled && !ctx->kernelTiming) ctx->timingValid = false;
     ctx->kernelTiming = enabled != 0;
-    ctx->timingValid = false;
     return PROSPER_PT_OK;
 }
 
@@ -1133,8 +1142,8 @@ int prosper_pt_get_last_render_timing(
     uint32_t kernel_launches[PROSPER_PT_MAX_KERNELS])
 {
     if (!ctx || !total_ms) return fail(PROSPER_PT_ERR_INVALID_ARGUMENT, "prosper_pt_get_last_render_timing: null argument");
-    if (!ctx->kernelTiming || !ctx->timingValid)
-        return fail(PROSPER_PT_ERR_INVALID_ARGUMENT, "kernel timing is not enabled or nothing was rendered since enabling it");
+    if (!ctx->timingValid)
+        return fail(PROSPER_PT_ERR_INVALID_ARGUMENT, "no render has run with kernel timing enabled (prosper_pt_set_kernel_timing)");
     PPT_HIP(hipSetDevice(ctx->device));
     PPT_HIP(hipEventSynchronize(ctx->events[ctx->timedLaunches]));
     float perStage[PROSPER_PT_MAX_KERNELS] = {};
@@ -1155,7 +1164,7 @@ int prosper_pt_get_last_render_timing(
     if (perStage[kStageChains] > 0.0f || launches[kStageChains] > 0)
     {
         bool any = false;
-        const RenderSlot &slot = ctx->slots[ctx->lastSlot];
+        const RenderSlot &slot = ctx->slots[ctx->timedSlot];
         for (int c = 0; c < 2; ++c)
             for (uint32_t i = 0; i < slot.chainLaunches[c]; ++i)
             {
