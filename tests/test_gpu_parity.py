@@ -630,10 +630,12 @@ def test_pipelined_renders_equal_in_order_renders(gpu_ctx, oracle, sponza_small,
         results = []
         for flags in (0, S.RENDER_PIPELINED):
             gpu_ctx.set_kernel_timing(flags != 0)
-            # (1) accumulation: frames 1..6, the first skips history
+            # (1) accumulation: frames 1..6, the first skips history; the pipelined pass mixes in an in-order and a
+            # counted render (the flag is ignored with PROSPER_PT_RENDER_COUNT_WORK) between pipelined ones
+            mixed = [flags, flags, 0, flags, flags | S.RENDER_COUNT_WORK, flags]
             for f in range(1, 7):
                 pc = default_pc(S, fl, frame_index=f, max_bounces=3, ibl=True, skip_history=(f == 1))
-                gpu_ctx.render(pc, cam, w, h, frames=1 + (f % 2), flags=flags)
+                gpu_ctx.render(pc, cam, w, h, frames=1 + (f % 2), flags=mixed[f - 1] if flags else 0)
             acc = gpu_ctx.read_hdr()
             # (2) independent frames into two caller-owned buffers, used alternately, no sync in between
             for f in range(8):
