@@ -748,6 +748,24 @@ def test_lds_staged_tables_equal_global_memory_tables(gpu_ctx, oracle, sponza_sm
     assert same_bits(gpu_ctx.read_hdr(), base).all()
 
 
+def test_pipelined_renders_survive_changing_extents(gpu_ctx, oracle, cornell_world):
+    """Frames in flight while the image extent (and with it every slot's workspace size) changes from call to call,
+    growing and shrinking: each image equals the in-order render of the same call."""
+    gpu_ctx.upload_scene(cornell_world)
+    extents = [(64, 64), (320, 200), (96, 48), (640, 360), (640, 360), (33, 17), (512, 288), (128, 128)]
+    images = {}
+    for flags in (0, S.RENDER_PIPELINED):
+        out = []
+        for k, (w, h) in enumerate(extents):
+            cam, fl = _camera(oracle, cornell_world, w, h)
+            pc = default_pc(S, fl, frame_index=1 + k, max_bounces=2 + k % 3)
+            gpu_ctx.render(pc, cam, w, h, frames=1 + k % 2, flags=flags)
+            out.append(gpu_ctx.read_hdr())
+        images[flags] = out
+    for a, b in zip(images[0], images[S.RENDER_PIPELINED]):
+        assert same_bits(a, b).all()
+
+
 def test_batched_texture_fetches_equal_sequential_ones(gpu_ctx, oracle, sponza_small, monkeypatch):
     """sample_material<true> (big texture sets: the twelve texel loads of a hit's three textures in flight together)
     against the one-texture-after-the-other path, forced either way on the texture-addressing wall (every wrap mode
