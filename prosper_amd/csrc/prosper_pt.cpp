@@ -100,10 +100,10 @@ struct prosper_pt_ctx
         size_t stackOverflowBytes = 0;
         void *wfBlock = nullptr;
         size_t wfBytes = 0;
-        hipEvent_t chainJoin[2] = {};
-        hipEvent_t chainEvents[2][kMaxTimedLaunches + 1] = {};
-        uint32_t chainStage[2][kMaxTimedLaunches] = {};
-        uint32_t chainLaunches[2] = {};
+        hipEvent_t chainJoin[kMaxChains] = {};
+        hipEvent_t chainEvents[kMaxChains][kMaxTimedLaunches + 1] = {};
+        uint32_t chainStage[kMaxChains][kMaxTimedLaunches] = {};
+        uint32_t chainLaunches[kMaxChains] = {};
         hipEvent_t free = nullptr; // recorded after the accumulate kernel of the slot's last render
         bool freeRecorded = false;
     };
@@ -621,7 +621,7 @@ int prosper_pt_create(const prosper_pt_device_desc *desc, prosper_pt_ctx **out_c
     for (auto &ws : ctx->workStreams) eventsOk = eventsOk && hipStreamCreateWithFlags(&ws, hipStreamNonBlocking) == hipSuccess;
     for (RenderSlot &slot : ctx->slots)
     {
-        for (int i = 0; i < 2; ++i)
+        for (uint32_t i = 0; i < kMaxChains; ++i)
         {
             eventsOk = eventsOk && hipEventCreateWithFlags(&slot.chainJoin[i], hipEventDisableTiming) == hipSuccess;
             for (auto &e : slot.chainEvents[i]) eventsOk = eventsOk && hipEventCreate(&e) == hipSuccess;
@@ -661,7 +661,7 @@ void prosper_pt_destroy(prosper_pt_ctx *ctx)
         if (e) (void)hipEventDestroy(e);
     for (RenderSlot &slot : ctx->slots)
     {
-        for (int i = 0; i < 2; ++i)
+        for (uint32_t i = 0; i < kMaxChains; ++i)
         {
             for (auto &e : slot.chainEvents[i])
                 if (e) (void)hipEventDestroy(e);
@@ -841,13 +841,15 @@ int prosper_pt_render_frames(
         RenderSlot &slot = ctx->slots[slotIndex];
         ctx->lastSlot = slotIndex;
         WavefrontChains chains;
-        LaunchTimer chainTimers[2];
+        LaunchTimer chainTimers[kMaxChains];
         chains.count = (pipelined || (ctx->flags & PROSPER_PT_CREATE_SINGLE_CHAIN)) ? 1u : 2u;
+        if (const char *forced = std::getenv("PROSPER_PT_DEBUG_CHAINS")) // tuning hook (in-order mode)
+            if (!pipelined && std::atoi(forced) >= 1 && std::atoi(forced) <= (int)kMaxChains) chains.count = (uint32_t)std::atoi(forced);
         chains.detached = pipelined;
         chains.fork = ctx->chainFork;
-        for (int i = 0; i < 2; ++i)
+        for (uint32_t i = 0; i < kMaxChains; ++i)
         {
-            chains.streams[i] = ctx->workStreams[pipelined ? slotIndex : (uint32_t)i];
+            chains.streams[i] = ctx->workStreams[pipelined ? slotIndex : i];
             chains.join[i] = slot.chainJoin[i];
             chainTimers[i].events = slot.chainEvents[i];
             chainTimers[i].stage = slot.chainStage[i];
@@ -880,7 +882,7 @@ int prosper_pt_render_frames(
                 (uint32_t)ctx->stats.triangleCount, countWork, tp, chains, s);
             release_slot(slot, s);
         }
-        for (int i = 0; i < 2; ++i) slot.chainLaunches[i] = chainTimers[i].count;
+        for (uint32_t i = 0; i < kMaxChains; ++i) slot.chainLaunches[i] = chainTimers[i].count;
         if (tp) ctx->timedSlot = slotIndex;
     }
     PPT_HIP(hipGetLastError());
@@ -1165,7 +1167,7 @@ int prosper_pt_get_last_render_timing(
     {
         bool any = false;
         const RenderSlot &slot = ctx->slots[ctx->timedSlot];
-        for (int c = 0; c < 2; ++c)
+        for (uint32_t c = 0; c < kMaxChains; ++c)
             for (uint32_t i = 0; i < slot.chainLaunches[c]; ++i)
             {
                 float ms = 0.0f;

@@ -71,15 +71,16 @@ void launch_render_persistent(
 // count == 1 (or a batch too small to split) everything runs on the caller's stream.
 // `detached`: the (single) chain runs on streams[0] without forking from the caller's stream - it waits only
 // for `after` (the previous use of its workspace) - and is joined back before the accumulate kernel.
+constexpr uint32_t kMaxChains = 3;
 struct WavefrontChains
 {
     uint32_t count = 1;
     bool detached = false;
     hipEvent_t after = nullptr;
-    hipStream_t streams[2] = {};
+    hipStream_t streams[kMaxChains] = {};
     hipEvent_t fork = nullptr;
-    hipEvent_t join[2] = {};
-    LaunchTimer *timers[2] = {};
+    hipEvent_t join[kMaxChains] = {};
+    LaunchTimer *timers[kMaxChains] = {};
 };
 // `overflowEntries`: ints per lane in `stackOverflow` (stack bound - LDS entries), 0 when unused
 void launch_render_wavefront(

@@ -649,7 +649,7 @@ static void enqueue_wavefront(
 uint32_t wavefront_grid_blocks(const WavefrontBuffers &w)
 {
     const uint32_t groups = (w.nSeg + 3u) / 4u;
-    return ((groups + 7u) / 8u) * 8u + 16u; // + the per-chain rounding of a split launch
+    return ((groups + 7u) / 8u) * 8u + 8u * kMaxChains; // + the per-chain rounding of a split launch
 }
 
 uint32_t wavefront_lds_stack_entries(uint32_t stackBound)
@@ -695,7 +695,8 @@ void launch_render_wavefront(
     static_assert(kTraversalStackDepth == 32, "largest LDS stack variant");
     const uint32_t groups = (w.nSeg + 3u) / 4u;
     // Two chains only pay when each still fills the machine a few times over (>= 1024 workgroups each).
-    const uint32_t parts = (!chains.detached && chains.count >= 2u && groups >= 512u) ? 2u : 1u;
+    uint32_t parts = chains.detached ? 1u : (chains.count < kMaxChains ? chains.count : kMaxChains);
+    while (parts > 1u && groups < 256u * parts) --parts;
     const bool ownStreams = parts > 1u || chains.detached;
     const uint32_t per = (groups + parts - 1u) / parts;
     if (parts > 1u) (void)hipEventRecord(chains.fork, stream);
