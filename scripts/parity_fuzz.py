@@ -84,11 +84,12 @@ def run(cases, seed, scene_names, log=print):
             pcs.append(S.ReferencePC(draw, fl_flags, (first + f - 1) % 4096 + 0, aperture, focus, fl, roulette, bounces))
         # GPU: either one batched call or frame by frame (both are the reference's accumulation)
         batched = frames > 1 and rng.random() < 0.5 and all(p.frameIndex == (pcs[0].frameIndex + i) % 4096 for i, p in enumerate(pcs))
+        pipelined = S.RENDER_PIPELINED if rng.random() < 0.5 else 0  # frames in flight: same pixels
         if batched:
-            ctx.render(pcs[0], cam, w, h, frames=frames, tile=tile)
+            ctx.render(pcs[0], cam, w, h, frames=frames, tile=tile, flags=pipelined)
         else:
             for p in pcs:
-                ctx.render(p, cam, w, h, tile=tile)
+                ctx.render(p, cam, w, h, tile=tile, flags=pipelined)
         got = ctx.read_hdr()
         for p in pcs:
             want, _ = oracles[name].render(p, cam, w, h, history=want)
@@ -101,7 +102,7 @@ def run(cases, seed, scene_names, log=print):
         total_px += ok.size
         nan = int(np.isnan(got[..., :3]).any(axis=2).sum())
         log("case %3d %-8s %3dx%-3d draw %2d flags %02x bounces %d rr %d frames %d%s%s  eye-dist %.2g fov %3.0f  -> %s (%d NaN px)" % (
-            case, name, w, h, draw, flags, bounces, roulette, frames, " batched" if batched else "",
+            case, name, w, h, draw, flags, bounces, roulette, frames, (" batched" if batched else "") + (" pipelined" if pipelined else ""),
             " tile %d/%d" % (tile.stripeIndex, tile.stripeCount) if tile is not None else "", r, math.degrees(fov),
             "ok" if nbad == 0 else "%d PIXELS DIFFER" % nbad, nan))
     ctx.close()
