@@ -346,6 +346,18 @@ struct Emitter
                 kids[k++] = tmp[open].right;
             }
         }
+        // Storage order = the order an any-hit (shadow) ray tries the children it enters (descend_any): smallest box
+        // first.  A small subtree is cheap to rule out and ends the ray if it occludes; measured on S-sponza-class
+        // (shadow + bounce rays, node visits per step): distance-sorted 1235 M, build order 1211 M, largest first
+        // 1192 M, most triangles first 1219 M, smallest first 1138 M.  Closest-hit rays sort by distance anyway.
+        // PROSPER_PT_DEBUG_CHILD_ORDER=0 keeps the build order (hierarchy-independence tests).
+        {
+            const char *order = std::getenv("PROSPER_PT_DEBUG_CHILD_ORDER");
+            if (!order || std::atoi(order) != 0)
+                std::stable_sort(kids, kids + k, [&](int32_t a, int32_t b) {
+                    return tmp[a].box.half_area() < tmp[b].box.half_area();
+                });
+        }
         BvhNode node;
         node.reserved = 0;
         // unused slots: lo = hi = +inf (half 0x7C00) can never be entered (see build_bvh)

@@ -1188,6 +1188,9 @@ PPT_D RaySlabs make_ray_slabs(f3 invd)
 // Per axis the near planes are the lo planes when the ray travels in + and the hi planes otherwise, so
 // the dwords (two children each) are swapped up front (12 v_cndmask) instead of taking min/max of the
 // 24 products; 24 v_fma_mix_f32 + 12 v_pk_mul_f32 then produce the distances.
+// SORTED = false leaves the four (entry, child) pairs in storage order: enough for an any-hit ray, whose answer
+// does not depend on the order its candidates are met in (descend_any below).
+template <bool SORTED = true>
 PPT_D void intersect_node4(const NodeData &n, f3 o, const RaySlabs &rs, float tMin, float tMax, float e[4], int32_t ref[4])
 {
     // the ray origin relative to the node (one rounding of 2^-24 |o - origin|, inside the builder's slack)
@@ -1227,12 +1230,37 @@ PPT_D void intersect_node4(const NodeData &n, f3 o, const RaySlabs &rs, float tM
         ref[j] = sw ? ref[i] : ref[j];                                                                                 \
         ref[i] = tr;                                                                                                   \
     }
-    PPT_CSWAP(0, 1)
-    PPT_CSWAP(2, 3)
-    PPT_CSWAP(0, 2)
-    PPT_CSWAP(1, 3)
-    PPT_CSWAP(1, 2)
+    if constexpr (SORTED)
+    {
+        PPT_CSWAP(0, 1)
+        PPT_CSWAP(2, 3)
+        PPT_CSWAP(0, 2)
+        PPT_CSWAP(1, 3)
+        PPT_CSWAP(1, 2)
+    }
 #undef PPT_CSWAP
+}
+
+// Any-hit rays (shadow(): terminate on the first accepted hit) take the children a node test reports in storage
+// order: the first one entered becomes the next node, the others go on the stack.  Whether the ray is occluded does
+// not depend on the order - every candidate's acceptance is a function of the ray and the candidate alone - so the
+// 25-instruction distance sort is left out.  Returns false when no child was entered.
+PPT_D bool descend_any(const float e[4], const int32_t ref[4], const TraversalStack &stack, int32_t &sp, int32_t &node)
+{
+    bool found = false;
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+        if (e[k] < kInf)
+        {
+            if (found)
+                stack.push(sp, ref[k]);
+            else
+            {
+                node = ref[k];
+                found = true;
+            }
+        }
+    return found;
 }
 
 // Shared driver of traceClosest (ANY = false, main.rgen:62-81) and shadow (ANY = true,
@@ -1264,12 +1292,23 @@ PPT_D bool trace_in(
             if constexpr (COUNT) cnt.nodeVisits++;
             float e[4];
             int32_t ref[4];
-            intersect_node4(nd, o, rs, tMin, hit.t, e, ref);
-            if (e[3] < kInf) stack.push(sp, ref[3]);
-            if (e[2] < kInf) stack.push(sp, ref[2]);
-            if (e[1] < kInf) stack.push(sp, ref[1]);
-            if (e[0] < kInf)
-                node = ref[0];
+            bool entered;
+            if constexpr (ANY)
+            {
+                intersect_node4<false>(nd, o, rs, tMin, hit.t, e, ref);
+                entered = descend_any(e, ref, stack, sp, node);
+            }
+            else
+            {
+                intersect_node4(nd, o, rs, tMin, hit.t, e, ref);
+                if (e[3] < kInf) stack.push(sp, ref[3]);
+                if (e[2] < kInf) stack.push(sp, ref[2]);
+                if (e[1] < kInf) stack.push(sp, ref[1]);
+                entered = e[0] < kInf;
+                if (entered) node = ref[0];
+            }
+            if (entered)
+                ;
             else if (sp == 0)
                 alive = false;
             else

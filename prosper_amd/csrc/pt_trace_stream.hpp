@@ -149,13 +149,23 @@ PPT_D void trace_stream(
                     if constexpr (COUNT) cnt.nodeVisits++;
                     float e[4];
                     int32_t ref[4];
-                    intersect_node4(nd, o, make_ray_slabs(invd), tMin, hit.t, e, ref);
-                    if (e[3] < kInf) stack.push(sp, ref[3]);
-                    if (e[2] < kInf) stack.push(sp, ref[2]);
-                    if (e[1] < kInf) stack.push(sp, ref[1]);
-                    if (e[0] < kInf)
+                    bool entered;
+                    if constexpr (ANY)
                     {
-                        node = ref[0];
+                        intersect_node4<false>(nd, o, make_ray_slabs(invd), tMin, hit.t, e, ref);
+                        entered = descend_any(e, ref, stack, sp, node);
+                    }
+                    else
+                    {
+                        intersect_node4(nd, o, make_ray_slabs(invd), tMin, hit.t, e, ref);
+                        if (e[3] < kInf) stack.push(sp, ref[3]);
+                        if (e[2] < kInf) stack.push(sp, ref[2]);
+                        if (e[1] < kInf) stack.push(sp, ref[1]);
+                        entered = e[0] < kInf;
+                        if (entered) node = ref[0];
+                    }
+                    if (entered)
+                    {
                         if (node < 0)
                         {
                             const uint32_t leaf = (uint32_t)~node;

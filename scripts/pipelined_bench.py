@@ -16,6 +16,8 @@ from prosper_amd import capi, scenes, structs as S, tiling  # noqa: E402
 from prosper_amd.rt_reference import Camera  # noqa: E402
 
 SPP = int(os.environ.get("SPP", "8"))
+if os.environ.get("LIB"):  # A/B against another build of the library
+    capi.LIB_PATH = os.path.abspath(os.environ["LIB"])
 CONFIGS = {
     "c2": (scenes.cornell, False),
     "c3": (lambda: scenes.sponza_class(), True),
