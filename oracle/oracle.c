@@ -1431,6 +1431,9 @@ static ora_v3 trace_path(ora_path_ctx *c, uint32_t px, uint32_t py, uint32_t wid
         add_bounce(pc, &color, evaluate_direct_lighting(c, &sf, throughput), bounce);
         ora_v3 rd;
         importance_sample_bounce(c, &sf, &throughput, &rd);
+        /* arithmetic contract: a path with throughput exactly (0,0,0) ends here - all its later terms are
+         * throughput * X = +0 for finite X (NaN components compare unequal and keep the path going) */
+        if (throughput.x == 0.0f && throughput.y == 0.0f && throughput.z == 0.0f) break;
         if (bounce > pc->rouletteStartBounce)
         {
             if (rnd01(&c->rng) < ora_max(0.05f, 1.0f - ora_max3(throughput))) break;

@@ -1482,6 +1482,12 @@ PPT_D void importance_sample_bounce(const Surface &sf, Rng &rng, f3 &throughput,
     throughput = f3{throughput.x * fmax_(w.x, 0.0f), throughput.y * fmax_(w.y, 0.0f), throughput.z * fmax_(w.z, 0.0f)};
 }
 
+// A path whose throughput is exactly (0, 0, 0) after importanceSampleBounce ends there (arithmetic contract,
+// DESIGN.md): every later term of main.rgen:241-283 is throughput * X, i.e. +0 for any finite X - and a quarter
+// to a half of all bounce rays carry such a throughput (a sampled direction at or below the shading horizon has
+// NoL = 0).  NaN components compare unequal to zero: such a path goes on and poisons its pixel as in the GLSL.
+PPT_D bool throughput_is_zero(f3 t) { return t.x == 0.0f && t.y == 0.0f && t.z == 0.0f; }
+
 // First half of evaluateDirectLighting (main.rgen:195-214): pick a light, evaluate it.  Returns
 // true when a shadow ray towards `l` of length `d` must be traced; `contribution` is then
 // throughput * irradiance * lightCount * BRDF (everything but the visibility term).
