@@ -792,6 +792,10 @@ int prosper_pt_render_frames(
     p.stripeCount = tiled ? tile->stripeCount : 1;
     p.localWidth = localWidth;
     p.frameCount = frame_count;
+    {
+        const char *audit = std::getenv("PROSPER_PT_DEBUG_TRACE_DEAD_PATHS");
+        p.traceDeadPaths = (audit && std::atoi(audit) != 0) ? 1u : 0u;
+    }
 
     if (localWidth == 0) return PROSPER_PT_OK;
     const bool countWork = (render_flags & PROSPER_PT_RENDER_COUNT_WORK) != 0;

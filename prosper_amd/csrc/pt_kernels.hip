@@ -188,7 +188,7 @@ __device__ f3 trace_path(
         }
         f3 rd;
         importance_sample_bounce(sf, rng, throughput, rd);
-        if (throughput_is_zero(throughput)) break;
+        if (!p.traceDeadPaths && throughput_is_zero(throughput)) break;
         if (bounce > p.pc.rouletteStartBounce)
         {
             if (rng.rnd01() < fmax_(0.05f, 1.0f - max3(throughput))) break;
@@ -339,7 +339,7 @@ __device__ __forceinline__ bool path_bounce(
     }
     f3 rd;
     importance_sample_bounce(sf, st.rng, st.throughput, rd);
-    if (throughput_is_zero(st.throughput)) return true;
+    if (!p.traceDeadPaths && throughput_is_zero(st.throughput)) return true;
     if (st.bounce > p.pc.rouletteStartBounce)
     {
         if (st.rng.rnd01() < fmax_(0.05f, 1.0f - max3(st.throughput))) return true;

@@ -135,7 +135,9 @@ struct RenderParams
     uint32_t stripeCount;
     uint32_t localWidth;
     uint32_t frameCount; // consecutive accumulated frames rendered by this launch
-    uint32_t pad;
+    // audit switch (PROSPER_PT_DEBUG_TRACE_DEAD_PATHS=1): keep tracing paths whose throughput is exactly zero, as the
+    // GLSL does; the images must not differ (arithmetic contract)
+    uint32_t traceDeadPaths;
 };
 
 // Workspace of the wavefront pipeline (pt_wavefront.hip).  Paths live in fixed-length SEGMENTS of

@@ -437,7 +437,7 @@ __global__ __launch_bounds__(256, PPT_SHADE_WPE) void wf_shade(
                     f3 rd;
                     f3 tp = throughput;
                     importance_sample_bounce(sf, rng, tp, rd);
-                    bool alive = !throughput_is_zero(tp);
+                    bool alive = p.traceDeadPaths || !throughput_is_zero(tp);
                     if (alive && bounce > p.pc.rouletteStartBounce)
                         alive = !(rng.rnd01() < fmax_(0.05f, 1.0f - max3(tp)));
                     if (alive)

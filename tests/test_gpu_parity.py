@@ -766,6 +766,34 @@ def test_pipelined_renders_survive_changing_extents(gpu_ctx, oracle, cornell_wor
         assert same_bits(a, b).all()
 
 
+def test_zero_throughput_rule_does_not_change_the_image(gpu_ctx, oracle, sponza_small, monkeypatch):
+    """Arithmetic contract: a path whose throughput is exactly (0, 0, 0) ends.  With PROSPER_PT_DEBUG_TRACE_DEAD_PATHS=1
+    the kernels keep tracing such paths like the GLSL does: more rays (the counters say how many), the same bits in
+    every pixel - on the small S-sponza-class scene with lights, foliage and IBL and on S-cornell, all three pipelines."""
+    from prosper_amd import capi
+    for world, kw in ((sponza_small, dict(max_bounces=5, ibl=True, roulette=6)),
+                      (scenes.cornell(with_skybox=True), dict(max_bounces=6, ibl=True, roulette=2))):
+        w, h = 480, 270
+        cam, fl = _camera(oracle, world, w, h)
+        pc = default_pc(S, fl, **kw)
+        for create in (0, S.CREATE_MEGAKERNEL, S.CREATE_PERSISTENT):
+            ctx = capi.Context(device=0, flags=create)
+            try:
+                ctx.upload_scene(world)
+                out = []
+                for audit in ("0", "1"):
+                    monkeypatch.setenv("PROSPER_PT_DEBUG_TRACE_DEAD_PATHS", audit)
+                    ctx.reset_counters()
+                    ctx.render(pc, cam, w, h, frames=2, flags=S.RENDER_COUNT_WORK)
+                    out.append((ctx.read_hdr(), ctx.counters().as_dict()))
+                monkeypatch.delenv("PROSPER_PT_DEBUG_TRACE_DEAD_PATHS")
+            finally:
+                ctx.close()
+            assert same_bits(out[0][0], out[1][0]).all(), create
+            assert out[1][1]["closestRays"] > out[0][1]["closestRays"] * 1.1, create  # the dead paths are many
+            assert out[1][1]["paths"] == out[0][1]["paths"]
+
+
 def test_batched_texture_fetches_equal_sequential_ones(gpu_ctx, oracle, sponza_small, monkeypatch):
     """sample_material<true> (big texture sets: the twelve texel loads of a hit's three textures in flight together)
     against the one-texture-after-the-other path, forced either way on the texture-addressing wall (every wrap mode
