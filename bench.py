@@ -38,6 +38,8 @@ CONFIGS = {
     "c3": ("S-sponza-class 1920x1080 8spp maxBounces 4 IBL", lambda: scenes.sponza_class(), 1920, 1080, 8, 4, True),
     "c4": ("S-sponza-class + 1024 lights + foliage 1920x1080 8spp maxBounces 4 IBL",
            lambda: scenes.sponza_class(lights=True, foliage=True), 1920, 1080, 8, 4, True),
+    # BASELINE.json configs[4]: meant for 8 GPUs (a rank then renders 1/8 of the stripes); runs on one as well
+    "c5": ("S-sponza-class 3840x2160 64spp maxBounces 4 IBL", lambda: scenes.sponza_class(), 3840, 2160, 64, 4, True),
     "c1": ("S-cornell 256x256 1spp maxBounces 1", lambda: scenes.cornell(), 256, 256, 1, 1, False),
 }
 
@@ -340,10 +342,11 @@ def main():
 
     # Device wake-up: the clocks of an idle MI355X take ~40 ms of load to ramp (the first ten 2.5 ms steps after idle
     # run 5-10 % slower, in every pipeline mode).  A renderer is past that after its first frames; so that the W
-    # warm-up steps and the K timed steps measure the steady state whatever W the caller picks, PREHEAT_STEPS steps
-    # run first (the same count on every rank: they gather).  Untimed, reported as `preheat_steps`; the timed region
+    # warm-up steps and the K timed steps measure the steady state whatever W the caller picks, up to PREHEAT_STEPS steps
+    # run first (fewer for the very large configurations; the same count on every rank: they gather).  Untimed, reported as `preheat_steps`; the timed region
     # is untouched.
-    for _ in range(PREHEAT_STEPS):
+    preheat_steps = max(2, min(PREHEAT_STEPS, int(round(4e8 / (width * height * spp / world_size)))))
+    for _ in range(preheat_steps):
         step()
     drain()
     for _ in range(args.warmup):
@@ -449,7 +452,7 @@ def main():
                 # launch, so sum(kernel time) > wall time and `frac` is a per-launch, not a whole-GPU, figure
                 "concurrent_chains": 1 if (args.single_chain or args.megakernel or args.persistent) else 2,
                 "frames_in_flight": 3 if render_flags else 1,
-                "preheat_steps": PREHEAT_STEPS,
+                "preheat_steps": preheat_steps,
                 "kernel_ms_exclusive": kernels[dominant]["ms_per_launch"] * exclusive_scale,
                 "frac_exclusive": achieved / exclusive_scale / HBM_PEAK_GBS,
             },
