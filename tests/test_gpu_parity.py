@@ -769,7 +769,8 @@ def test_pipelined_renders_survive_changing_extents(gpu_ctx, oracle, cornell_wor
 def test_zero_throughput_rule_does_not_change_the_image(gpu_ctx, oracle, sponza_small, monkeypatch):
     """Arithmetic contract: a path whose throughput is exactly (0, 0, 0) ends.  With PROSPER_PT_DEBUG_TRACE_DEAD_PATHS=1
     the kernels keep tracing such paths like the GLSL does: more rays (the counters say how many), the same bits in
-    every pixel - on the small S-sponza-class scene with lights, foliage and IBL and on S-cornell, all three pipelines."""
+    every pixel with clampIndirect on, the reference's default (without it the traced paths' NaN sky terms survive:
+    DESIGN.md section 3) - on the small S-sponza-class scene with lights, foliage and IBL and on S-cornell, all three pipelines."""
     from prosper_amd import capi
     for world, kw in ((sponza_small, dict(max_bounces=5, ibl=True, roulette=6)),
                       (scenes.cornell(with_skybox=True), dict(max_bounces=6, ibl=True, roulette=2))):
