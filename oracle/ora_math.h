@@ -16,7 +16,10 @@
  *   - sin/cos/exp2/log2/pow are the fixed polynomial kernels in this file (a few ulp, far inside
  *     Vulkan's precision bounds for GLSL.std.450 Sin/Cos/Pow);
  *   - min/max follow IEEE minNum/maxNum (a NaN operand loses), as GPU hardware does; GLSL leaves
- *     the NaN case undefined (GLSL 4.60 §8.3).
+ *     the NaN case undefined (GLSL 4.60 §8.3);
+ *   - (integrator, oracle.c trace_path) a path whose throughput is exactly (0,0,0) after
+ *     importanceSampleBounce ends: its later terms are 0 * X, and the ray the GLSL would go on to trace
+ *     usually has a NaN direction (undefined per Vulkan); DESIGN.md section 3.
  *
  * Reference text restated here: res/shader/common/math.glsl:4-13 (PI, saturate, max3).
  */
