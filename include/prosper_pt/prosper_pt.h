@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define PROSPER_PT_ABI_VERSION 1
+#define PROSPER_PT_ABI_VERSION 2
 
 enum
 {
@@ -218,10 +218,22 @@ typedef struct prosper_pt_scene_stats
     uint32_t nodeBytes;     /* S_node: bytes fetched per node visit */
     uint32_t triangleBytes; /* bytes fetched per ray/triangle test */
     uint32_t maxDepth;
-    uint32_t reserved;
+    uint32_t variantFlags;  /* PROSPER_PT_VARIANT_*: the kernel variants the next render of this scene takes */
     uint64_t deviceBytes;   /* HBM resident bytes for the scene */
-    double buildSeconds;    /* host+device time spent in prosper_pt_upload_scene building the BVH */
+    double buildSeconds;    /* acceleration structure: flatten kernel + host BVH build + node/triangle upload */
+    /* (ABI 2) where prosper_pt_upload_scene spent its time: the whole call, the host-side BVH construction alone
+     * (the part a moved instance would pay again), and the texture re-tiling / BC7 decode + copies */
+    double uploadSeconds;
+    double bvhBuildSeconds;
+    double textureSeconds;
 } prosper_pt_scene_stats;
+enum
+{
+    PROSPER_PT_VARIANT_LDS_SCENE = 1u << 0,       /* BVH + triangles staged in LDS by the traversal kernels */
+    PROSPER_PT_VARIANT_LDS_TABLES = 1u << 1,      /* wf_shade stages instances/transforms/materials/lights in LDS */
+    PROSPER_PT_VARIANT_BATCHED_TEXTURES = 1u << 2, /* the twelve texel loads of a hit issued together */
+    PROSPER_PT_VARIANT_STACK_SHIFT = 8,           /* bits 8..15: LDS traversal-stack entries (16/24/32) */
+};
 
 enum
 {

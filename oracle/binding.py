@@ -51,6 +51,8 @@ def lib():
         L.ora_scene_destroy.argtypes = [C.c_void_p]
         L.ora_scene_triangle_count.restype = C.c_uint64
         L.ora_scene_triangle_count.argtypes = [C.c_void_p]
+        L.ora_scene_set_literal_glsl.restype = None
+        L.ora_scene_set_literal_glsl.argtypes = [C.c_void_p, C.c_int]
         L.ora_render.argtypes = [
             C.c_void_p, C.POINTER(S.ReferencePC), C.POINTER(S.CameraUniforms), C.c_uint32, C.c_uint32,
             C.POINTER(S.TileDesc), C.c_void_p, C.c_int, C.POINTER(OraCounters)]
@@ -103,6 +105,10 @@ class OracleScene:
             self.close()
         except Exception:
             pass
+
+    def set_literal_glsl(self, on):
+        """main.rgen:241-283 as written: no zero-throughput rule (oracle.h ora_scene_set_literal_glsl)."""
+        lib().ora_scene_set_literal_glsl(self._h, 1 if on else 0)
 
     @property
     def triangle_count(self):

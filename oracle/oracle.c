@@ -106,6 +106,7 @@ struct ora_scene
     ora_node *nodes;
     uint32_t nodeCount;
     int bruteForce;
+    int literalGlsl; /* ora_scene_set_literal_glsl: main.rgen:241-283 as written, no zero-throughput rule */
 };
 
 /* ------------------------------------------------------------------------------------------
@@ -1203,6 +1204,7 @@ void ora_scene_destroy(ora_scene *s)
 }
 
 uint64_t ora_scene_triangle_count(const ora_scene *s) { return s->triCount; }
+void ora_scene_set_literal_glsl(ora_scene *s, int on) { s->literalGlsl = on ? 1 : 0; }
 
 int ora_trace_closest(
     const ora_scene *s, const float origin[3], const float dir[3], float tMin, float tMax, uint32_t randomSeed,
@@ -1432,8 +1434,10 @@ static ora_v3 trace_path(ora_path_ctx *c, uint32_t px, uint32_t py, uint32_t wid
         ora_v3 rd;
         importance_sample_bounce(c, &sf, &throughput, &rd);
         /* arithmetic contract: a path with throughput exactly (0,0,0) ends here - all its later terms are
-         * throughput * X = +0 for finite X (NaN components compare unequal and keep the path going) */
-        if (throughput.x == 0.0f && throughput.y == 0.0f && throughput.z == 0.0f) break;
+         * throughput * X = +0 for finite X (NaN components compare unequal and keep the path going).
+         * The GLSL has no such line: the literal mode (ora_scene_set_literal_glsl) leaves it out and goes on
+         * exactly as main.rgen:269-283 is written, 0 * inf = NaN and NaN ray directions included. */
+        if (!c->scene->literalGlsl && throughput.x == 0.0f && throughput.y == 0.0f && throughput.z == 0.0f) break;
         if (bounce > pc->rouletteStartBounce)
         {
             if (rnd01(&c->rng) < ora_max(0.05f, 1.0f - ora_max3(throughput))) break;

@@ -53,6 +53,12 @@ typedef struct ora_counters
 ora_scene *ora_scene_create(const prosper_pt_scene_view *view, int brute_force);
 void ora_scene_destroy(ora_scene *scene);
 uint64_t ora_scene_triangle_count(const ora_scene *scene);
+/* The ONE place ora_render departs from the text of main.rgen:241-283 is the arithmetic contract's rule "a path whose
+ * throughput is exactly (0,0,0) after importanceSampleBounce ends there" (DESIGN.md section 3).  on != 0 removes
+ * the rule: the loop then runs exactly as written - zero-throughput paths go on bouncing, 0 * inf and 0 * NaN
+ * terms are added, rays with NaN directions are traced (they miss everything here; the Vulkan specification
+ * leaves them undefined).  tests/test_literal_glsl.py measures, pixel by pixel, where the two modes differ. */
+void ora_scene_set_literal_glsl(ora_scene *scene, int on);
 
 /* One accumulated frame of the whole image (or of the tile's pixels, same compact layout as
  * prosper_pt_render).  `rgba` holds the history on entry and the new image on return

@@ -240,6 +240,10 @@ int upload_scene_impl(prosper_pt_ctx *ctx, const prosper_pt_scene_view *v)
 {
     DeviceScene &s = ctx->scene;
     int rc;
+    const auto tUpload = std::chrono::steady_clock::now();
+    auto seconds_since = [](std::chrono::steady_clock::time_point t) {
+        return std::chrono::duration<double>(std::chrono::steady_clock::now() - t).count();
+    };
 
     // bindless geometry buffers + pointer table
     std::vector<const void *> bufferPtrs(v->geometryBufferCount ? v->geometryBufferCount : 1, nullptr);
@@ -266,6 +270,7 @@ int upload_scene_impl(prosper_pt_ctx *ctx, const prosper_pt_scene_view *v)
 
     // textures: one allocation each (256-B aligned by hipMalloc), re-laid out in 8x4-texel tiles of one
     // cache line each (pt_scene.hpp DeviceTexture), + descriptor table
+    const auto tTextures = std::chrono::steady_clock::now();
     std::vector<DeviceTexture> textures(v->textureCount ? v->textureCount : 1);
     std::vector<uint32_t> tiled;
     uint64_t texelBytes = 0;
@@ -313,6 +318,7 @@ int upload_scene_impl(prosper_pt_ctx *ctx, const prosper_pt_scene_view *v)
     // (PROSPER_PT_DEBUG_BATCHED_TEXTURES = 0 / 1 forces either path: same pixels, tested)
     s.batchedTextures = texelBytes > (32ull << 20) ? 1u : 0u;
     if (const char *forced = std::getenv("PROSPER_PT_DEBUG_BATCHED_TEXTURES")) s.batchedTextures = std::atoi(forced) ? 1u : 0u;
+    const double textureSeconds = seconds_since(tTextures);
 
     // lights
     if ((rc = upload(ctx, v->directionalLight, sizeof(prosper_DirectionalLightParameters), &d))) return rc;
@@ -399,6 +405,7 @@ int upload_scene_impl(prosper_pt_ctx *ctx, const prosper_pt_scene_view *v)
     }
 
     BvhBuildResult bvh;
+    const auto tBuild = std::chrono::steady_clock::now();
     try
     {
         bvh = build_bvh(flat.data(), total);
@@ -409,6 +416,7 @@ int upload_scene_impl(prosper_pt_ctx *ctx, const prosper_pt_scene_view *v)
         return fail(PROSPER_PT_ERR_UNSUPPORTED, std::string("BVH build failed: ") + ex.what());
     }
 
+    const double bvhBuildSeconds = seconds_since(tBuild);
     if ((rc = upload(ctx, bvh.nodes.data(), bvh.nodes.size() * sizeof(BvhNode), &d)))
     {
         cleanupTemp();
@@ -445,6 +453,9 @@ int upload_scene_impl(prosper_pt_ctx *ctx, const prosper_pt_scene_view *v)
     ctx->stats.maxDepth = bvh.maxDepth;
     ctx->stats.deviceBytes = ctx->sceneBytes;
     ctx->stats.buildSeconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    ctx->stats.bvhBuildSeconds = bvhBuildSeconds;
+    ctx->stats.textureSeconds = textureSeconds;
+    ctx->stats.uploadSeconds = seconds_since(tUpload);
     return PROSPER_PT_OK;
 }
 
@@ -717,6 +728,15 @@ int prosper_pt_get_scene_stats(prosper_pt_ctx *ctx, prosper_pt_scene_stats *out)
     if (!ctx || !out) return fail(PROSPER_PT_ERR_INVALID_ARGUMENT, "prosper_pt_get_scene_stats: null argument");
     if (!ctx->haveScene) return fail(PROSPER_PT_ERR_NO_SCENE, "no scene uploaded");
     *out = ctx->stats;
+    // the variants depend on tuning/test hooks read from the environment at launch time: report what a render
+    // started now would take
+    const uint32_t ldsEntries = wavefront_lds_stack_entries(ctx->stats.maxDepth);
+    out->variantFlags =
+        (wavefront_scene_in_lds(ldsEntries, (uint32_t)ctx->stats.nodeCount, (uint32_t)ctx->stats.triangleCount)
+             ? PROSPER_PT_VARIANT_LDS_SCENE
+             : 0u) |
+        (wavefront_shade_tables_in_lds(ctx->scene) ? PROSPER_PT_VARIANT_LDS_TABLES : 0u) |
+        (ctx->scene.batchedTextures ? PROSPER_PT_VARIANT_BATCHED_TEXTURES : 0u) | (ldsEntries << PROSPER_PT_VARIANT_STACK_SHIFT);
     return PROSPER_PT_OK;
 }
 

@@ -89,6 +89,9 @@ void launch_render_wavefront(
     bool countWork, LaunchTimer *timer, const WavefrontChains &chains, hipStream_t stream);
 // LDS stack entries (16/24/32) the wavefront traversal kernels use for a tree with this stack bound
 uint32_t wavefront_lds_stack_entries(uint32_t stackBound);
+// kernel variants a render takes: wf_shade with the scene tables staged in LDS; traversal out of an LDS copy of the scene
+bool wavefront_shade_tables_in_lds(const DeviceScene &s);
+bool wavefront_scene_in_lds(uint32_t ldsStackEntries, uint32_t nodeCount, uint32_t triCount);
 void launch_blit_rgba16f(const float4 *in, void *out, uint32_t count, hipStream_t stream);
 // BC7 blocks of one level (row-major, 16 B each; width and height multiples of 4) -> RGBA8 texels in the tiled
 // layout of DeviceTexture

@@ -630,7 +630,7 @@ static void enqueue_wavefront(
         const uint32_t cur = b & 1u;
         const uint32_t last = (b + 1u == bounces) ? 1u : 0u;
         mark(kStageShade);
-        const bool ldsTables = shade_table_bytes(s) <= kLdsTableBytes && !std::getenv("PROSPER_PT_DEBUG_NO_LDS_TABLES");
+        const bool ldsTables = wavefront_shade_tables_in_lds(s);
         auto shade = [&](auto kernel) { hipLaunchKernelGGL(kernel, grid, block, 0, stream, s, p, w, b, cur, last, cShade); };
         if (s.batchedTextures)
             ldsTables ? shade(wf_shade<COUNT, true, true>) : shade(wf_shade<COUNT, false, true>);
@@ -667,6 +667,18 @@ uint32_t wavefront_lds_stack_entries(uint32_t stackBound)
     return stackBound <= 16u ? 16u : 24u;
 }
 
+// Which kernel variants a render of this scene takes (also reported by prosper_pt_get_scene_stats, so that a
+// test of a variant can assert it is the one that ran).
+bool wavefront_shade_tables_in_lds(const DeviceScene &s)
+{
+    return shade_table_bytes(s) <= kLdsTableBytes && !std::getenv("PROSPER_PT_DEBUG_NO_LDS_TABLES");
+}
+bool wavefront_scene_in_lds(uint32_t ldsStackEntries, uint32_t nodeCount, uint32_t triCount)
+{
+    return ldsStackEntries == 16u && nodeCount * kLdsNodeStride + triCount * 3u <= kLdsSceneFloat4s &&
+           !std::getenv("PROSPER_PT_DEBUG_NO_LDS_SCENE");
+}
+
 template <bool COUNT>
 static void enqueue_for_stack(
     const DeviceScene &s, const RenderParams &p, unsigned long long *counters, const WavefrontBuffers &w,
@@ -674,8 +686,7 @@ static void enqueue_for_stack(
     hipStream_t stream)
 {
     // a scene of a few KB is traversed out of LDS
-    const bool ldsScene = ldsStackEntries == 16u && nodeCount * kLdsNodeStride + triCount * 3u <= kLdsSceneFloat4s &&
-                          !std::getenv("PROSPER_PT_DEBUG_NO_LDS_SCENE");
+    const bool ldsScene = wavefront_scene_in_lds(ldsStackEntries, nodeCount, triCount);
     if (ldsScene)
         enqueue_wavefront<COUNT, 16, true>(s, p, counters, w, nodeCount, triCount, stackOverflow, timer, stream);
     else if (ldsStackEntries == 16u)

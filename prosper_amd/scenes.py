@@ -456,7 +456,9 @@ def sponza_class(lights=False, foliage=False, texture_size=1024, sky_size=512, d
     if foliage:
         _add_foliage(w, 20000)
     if lights:
-        _add_lights(w, 512, 512, lo=(-L / 2 + 0.5, 0.5, -W / 2 + 0.5), hi=(L / 2 - 0.5, H - 0.5, W / 2 - 0.5))
+        # lights=True: the 512 + 512 of BASELINE C4; lights=(n_point, n_spot): the first n of the same sequences
+        n_point, n_spot = (512, 512) if lights is True else lights
+        _add_lights(w, n_point, n_spot, lo=(-L / 2 + 0.5, 0.5, -W / 2 + 0.5), hi=(L / 2 - 0.5, H - 0.5, W / 2 - 0.5))
 
     w.set_directional_light((1.0, 1.0, 1.0), 2.0, (-1.0, -1.0, -1.0)) if not lights else None
     if lights:

@@ -259,10 +259,19 @@ class SceneStats(C.Structure):
         ("nodeBytes", C.c_uint32),
         ("triangleBytes", C.c_uint32),
         ("maxDepth", C.c_uint32),
-        ("reserved", C.c_uint32),
+        ("variantFlags", C.c_uint32),
         ("deviceBytes", C.c_uint64),
         ("buildSeconds", C.c_double),
+        ("uploadSeconds", C.c_double),
+        ("bvhBuildSeconds", C.c_double),
+        ("textureSeconds", C.c_double),
     ]
+
+
+VARIANT_LDS_SCENE = 1
+VARIANT_LDS_TABLES = 2
+VARIANT_BATCHED_TEXTURES = 4
+VARIANT_STACK_SHIFT = 8
 
 
 def as_numpy(struct_array, dtype=np.uint8):

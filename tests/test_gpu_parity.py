@@ -571,6 +571,55 @@ def test_c5_rank_tile_chunked_batch_properties(gpu_ctx, oracle, cornell_world):
     assert same_bits(t2, full[:, cols]).all()
 
 
+@pytest.fixture(scope="module")
+def sponza_full():
+    """S-sponza-class as BASELINE C3/C5 name it: 262 k triangles, 75 x 1024^2 textures, 512^2 sky."""
+    return scenes.sponza_class()
+
+
+def test_c5_own_workload_rank_tile(gpu_ctx, oracle, sponza_full):
+    """BASELINE C5 on its OWN scene, as one of its 8 ranks sees it: S-sponza-class (full detail, 1024^2 textures, IBL),
+    3840x2160, stripe set 3 of 8.  2 spp of the rank tile against the oracle, bit for bit; then the 64-spp batch
+    (66 M path slots: two workspace chunks) against the same 64 frames accumulated 16 at a time, and the tile's columns
+    against an untiled render."""
+    from prosper_amd import tiling
+    w, h, spp = 3840, 2160, 64
+    cam, fl = _camera(oracle, sponza_full, w, h)
+    gpu_ctx.upload_scene(sponza_full)
+    st = gpu_ctx.scene_stats()
+    assert st.triangleCount == sponza_full.triangle_count() and abs(st.triangleCount - 262144) < 2622
+    tile = tiling.tile_for_rank(3, 8)
+    lw = tiling.local_width(w, 3, 8)
+    osc = oracle.OracleScene(sponza_full)
+    want = None
+    for frame in (1, 2):
+        pc = default_pc(S, fl, frame_index=frame, max_bounces=4, ibl=True, skip_history=(frame == 1))
+        want, _ = osc.render(pc, cam, w, h, history=want, tile=tile)
+    pc = default_pc(S, fl, max_bounces=4, ibl=True)
+    gpu_ctx.render(pc, cam, w, h, tile=tile, frames=2)
+    t2 = gpu_ctx.read_hdr()
+    assert t2.shape == (h, lw, 4)
+    ok = same_bits(t2, want).all(axis=2)
+    assert ok.all(), "%d of %d pixels of the rank tile differ from the oracle" % ((~ok).sum(), ok.size)
+    # the same 2 spp untiled: stripe 3 = columns 48..63, 176..191, ...
+    gpu_ctx.render(pc, cam, w, h, frames=2)
+    full = gpu_ctx.read_hdr()
+    cols = np.concatenate([np.arange(16) + 16 * (3 + 8 * j) for j in range(lw // 16)])
+    assert same_bits(t2, full[:, cols]).all()
+    del full
+    # 64 spp: one call (two chunks) == four calls of 16 frames
+    gpu_ctx.reset_counters()
+    gpu_ctx.render(pc, cam, w, h, tile=tile, frames=spp, flags=S.RENDER_COUNT_WORK)
+    a = gpu_ctx.read_hdr()
+    assert np.isfinite(a).all() and (a[..., 3] == spp).all()
+    c = gpu_ctx.counters().as_dict()
+    assert c["paths"] == lw * h * spp and c["historyReads"] == lw * h * (spp - 1)
+    for k in range(4):
+        p = default_pc(S, fl, frame_index=1 + 16 * k, max_bounces=4, ibl=True, skip_history=(k == 0))
+        gpu_ctx.render(p, cam, w, h, tile=tile, frames=16, flags=S.RENDER_PIPELINED)
+    assert same_bits(gpu_ctx.read_hdr(), a).all()
+
+
 def test_two_launch_chains_equal_one_chain(gpu_ctx, oracle, sponza_small, monkeypatch):
     """The default pipeline runs the segment groups as two chains of launches on two internal streams
     (tails of one overlap the other); PROSPER_PT_CREATE_SINGLE_CHAIN runs one chain on the caller's stream.
@@ -604,8 +653,8 @@ def test_two_launch_chains_equal_one_chain(gpu_ctx, oracle, sponza_small, monkey
 
 
 def test_pipelined_renders_equal_in_order_renders(gpu_ctx, oracle, sponza_small, monkeypatch):
-    """PROSPER_PT_RENDER_PIPELINED (two frames in flight: the path stages of a render overlap the previous render,
-    alternating between two workspaces): an accumulation sequence - every frame reads the previous frame's image
+    """PROSPER_PT_RENDER_PIPELINED (up to three frames in flight: the path stages of a render overlap the previous
+    renders, taking the context's three workspaces in turn): an accumulation sequence - every frame reads the previous frame's image
     as history - and a sequence of independent frames into alternating output buffers give the same bits as the
     in-order default, also with spilled traversal stacks and with per-launch timing events on."""
     import ctypes
@@ -733,19 +782,35 @@ def test_lds_stack_variants_agree(gpu_ctx, oracle, sponza_small, monkeypatch):
     monkeypatch.delenv("PROSPER_PT_DEBUG_STACK")
 
 
-def test_lds_staged_tables_equal_global_memory_tables(gpu_ctx, oracle, sponza_small, monkeypatch):
-    """wf_shade stages draw instances, transforms, materials and lights in LDS when they fit in 16 KB
-    (sponza_small: 64 lights, 40 instances); PROSPER_PT_DEBUG_NO_LDS_TABLES reads them from global memory."""
+def test_lds_staged_tables_equal_global_memory_tables(gpu_ctx, oracle, monkeypatch):
+    """wf_shade stages draw instances, transforms, materials and lights in LDS when they fit in 16 KB.  The scene
+    here is S-sponza-class with the first 24 + 24 lights of C4's sequences (about 8 KB of tables: the LDS variant
+    is the one that runs - asserted through prosper_pt_scene_stats.variantFlags);
+    PROSPER_PT_DEBUG_NO_LDS_TABLES reads the tables from global memory.  Same bits, and the oracle's."""
+    world = scenes.sponza_class(lights=(24, 24), foliage=True, texture_size=64, sky_size=32, detail=0.25)
+    assert world.point_lights.count == 24 and world.spot_lights.count == 24
     w, h = 200, 120
-    cam, fl = _camera(oracle, sponza_small, w, h)
+    cam, fl = _camera(oracle, world, w, h)
     pc = default_pc(S, fl, max_bounces=4, ibl=True)
-    gpu_ctx.upload_scene(sponza_small)
+    gpu_ctx.upload_scene(world)
+    assert gpu_ctx.scene_stats().variantFlags & S.VARIANT_LDS_TABLES
     gpu_ctx.render(pc, cam, w, h, frames=2)
     base = gpu_ctx.read_hdr()
     monkeypatch.setenv("PROSPER_PT_DEBUG_NO_LDS_TABLES", "1")
+    assert not (gpu_ctx.scene_stats().variantFlags & S.VARIANT_LDS_TABLES)
     gpu_ctx.render(pc, cam, w, h, frames=2)
     monkeypatch.delenv("PROSPER_PT_DEBUG_NO_LDS_TABLES")
     assert same_bits(gpu_ctx.read_hdr(), base).all()
+    osc = oracle.OracleScene(world)
+    want = None
+    for frame in (1, 2):
+        want, _ = osc.render(default_pc(S, fl, frame_index=frame, max_bounces=4, ibl=True, skip_history=(frame == 1)),
+                             cam, w, h, history=want)
+    assert same_bits(base, want).all()
+    # and C4's 1024 lights (40 KB of light tables) take the global-memory variant
+    big = scenes.sponza_class(lights=True, foliage=False, texture_size=64, sky_size=32, detail=0.25)
+    gpu_ctx.upload_scene(big)
+    assert not (gpu_ctx.scene_stats().variantFlags & S.VARIANT_LDS_TABLES)
 
 
 def test_pipelined_renders_survive_changing_extents(gpu_ctx, oracle, cornell_world):

@@ -1,0 +1,217 @@
+"""An integrator-level known answer that does not go through oracle/oracle.c ("Next 1d").
+
+Scene: one Lambert-ish quad (metallic 0, roughness 1) in the plane y = 0, one point light, one spot light, no sun
+irradiance, maxBounces 1, one frame.  Every pixel's radiance is then a closed-form function of its jittered primary
+ray, evaluated HERE in NumPy float64 straight from the shader text:
+
+    res/shader/common/random.glsl:17-28,42-63   pcg3d, rngTo01 (the jitter and the light pick are integer arithmetic)
+    res/shader/rt/ray.glsl:15-43                pinholeCameraRay (Y-flipped projection: SURVEY section 8a, F6)
+    res/shader/rt/reference/main.rgen:195-223   evaluateDirectLighting: uniform pick of 1 + P + S lights, x lightCount
+    res/shader/scene/lighting.glsl:15-56        point / spot light irradiance
+    res/shader/brdf.glsl:9-87                   evalBRDFTimesNoL
+
+The oracle must agree within 1e-5 relative, plus - for pixels in the spot cone's falloff zone only - the amplification
+of cd's fp32 rounding by att = saturate(cd * scale + offset)^2 (2 * scale / x relative, 1e-5..1e-4 there), plus an
+absolute floor of 1e-6 of the brightest pixel; the HIP path must agree with the oracle bit for bit.  The camera basis is recomputed here from
+eye / target / up / fov as well, so the host camera code is cross-checked too.
+"""
+import math
+
+import numpy as np
+import pytest
+
+from conftest import default_pc, same_bits
+from prosper_amd import scenes, structs as S
+from prosper_amd.world import World
+
+W, H = 160, 120
+RTOL, ATOL_OF_MAX = 1e-5, 1e-6
+
+
+def build_world():
+    w = World()
+    mat = w.add_material(base_color=(0.8, 0.7, 0.6, 1.0), metallic=0.0, roughness=1.0)
+    mesh = scenes._add(w, scenes.quad((-40, 0, 40), (40, 0, 40), (40, 0, -40), (-40, 0, -40)), mat)
+    w.add_instance(w.add_model([(mesh, mat)]))
+    w.add_point_light((1.0, 0.9, 0.8), 200.0, (1.0, 3.0, 0.5))
+    d = np.array([0.3, -1.0, -0.2])
+    w.add_spot_light((0.7, 0.8, 1.0), 300.0, (-2.0, 4.0, 1.0), d / np.linalg.norm(d), math.radians(20.0), math.radians(35.0))
+    w.camera = dict(eye=(0.0, 2.0, 4.0), target=(0.0, 0.0, 0.0), up=(0.0, 1.0, 0.0), fov=math.radians(40.0), zN=0.1, zF=100.0)
+    return w
+
+
+def pcg3d(v):
+    """random.glsl:17-28 on uint32 arrays [..., 3]."""
+    v = (v.astype(np.uint64) * 1664525 + 1013904223) & 0xFFFFFFFF
+    x, y, z = v[..., 0], v[..., 1], v[..., 2]
+    x = (x + y * z) & 0xFFFFFFFF
+    y = (y + z * x) & 0xFFFFFFFF
+    z = (z + x * y) & 0xFFFFFFFF
+    x, y, z = x ^ (x >> 16), y ^ (y >> 16), z ^ (z >> 16)
+    x = (x + y * z) & 0xFFFFFFFF
+    y = (y + z * x) & 0xFFFFFFFF
+    z = (z + x * y) & 0xFFFFFFFF
+    return np.stack([x, y, z], axis=-1)
+
+
+def rng_to_01(u):
+    """random.glsl:42: u / float(0xFFFFFFFFu); both conversions round to fp32 (float(0xFFFFFFFF) = 2^32)."""
+    return (u.astype(np.float32) / np.float32(4294967296.0)).astype(np.float32)
+
+
+def saturate(x):
+    return np.clip(x, 0.0, 1.0)
+
+
+def normalize(v):
+    return v / np.linalg.norm(v, axis=-1, keepdims=True)
+
+
+def eval_brdf_times_nol(l, n, v, albedo, roughness, metallic):
+    """brdf.glsl:67-87 and the functions it calls, float64."""
+    h = normalize(v + l)
+    NoL = saturate((n * l).sum(-1))
+    NoH = saturate((n * h).sum(-1))
+    VoH = saturate((v * h).sum(-1))
+    NoV = saturate((n * v).sum(-1))
+    f0 = 0.04 * (1.0 - metallic) + albedo * metallic
+    c_diff = albedo * (1.0 - 0.04) * (1.0 - metallic)
+    alpha = roughness * roughness
+    a2 = alpha * alpha
+    denom = NoH * NoH * (a2 - 1.0) + 1.0
+    D = a2 / (math.pi * denom * denom)
+    F = f0 + (1.0 - f0) * ((1.0 - VoH) ** 5.0)[..., None]
+    k = max(alpha * 0.5, 0.0001)
+    G = (NoL / (NoL * (1.0 - k) + k)) * (NoV / (NoV * (1.0 - k) + k))
+    spec = F * (D * G / (4.0 * NoL * NoV + 0.0001))[..., None]
+    return (c_diff / math.pi + spec) * NoL[..., None]
+
+
+def numpy_radiance(world, frame_index=1):
+    f = world.freeze()
+    cam = world.camera
+    eye, target, up = (np.array(cam[k], np.float64) for k in ("eye", "target", "up"))
+    fwd = normalize(target - eye)
+    right = normalize(np.cross(fwd, up))
+    upv = np.cross(right, fwd)
+    tan_half = math.tan(cam["fov"] * 0.5)
+    aspect = W / H
+
+    py, px = np.meshgrid(np.arange(H, dtype=np.uint32), np.arange(W, dtype=np.uint32), indexing="ij")
+    state = np.stack([px, py, np.full_like(px, frame_index)], axis=-1)
+    state = pcg3d(state)                                   # main.rgen:229-231: rnd2d01 jitter
+    jitter = rng_to_01(state[..., :2]).astype(np.float64)
+    uv = (np.stack([px, py], axis=-1).astype(np.float64) + jitter) / np.array([W, H], np.float64)
+    nd = uv * 2.0 - 1.0
+    # ray.glsl:21-24 with Camera::perspective's Y flip: cameraToClip[1][1] < 0, so aspect and tanHalfFovY are both
+    # negative - their product (the x term) is positive, the y term changes sign
+    d = normalize(nd[..., :1] * right * (tan_half * aspect) - nd[..., 1:] * upv * tan_half + fwd)
+    assert (d[..., 1] < 0).all(), "every primary ray must reach the plane"
+    t = -eye[1] / d[..., 1]
+    p = eye + t[..., None] * d
+    assert (np.abs(p[..., 0]) < 40).all() and (np.abs(p[..., 2]) < 40).all()
+    n = np.array([0.0, 1.0, 0.0])
+    v = -d
+
+    state = pcg3d(state)                                   # main.rgen:205: rnd01 light pick, fp32 as written
+    light_count = 1 + world.point_lights.count + world.spot_lights.count
+    assert light_count == 3
+    pick = np.minimum((rng_to_01(state[..., 0]) * np.float32(light_count)).astype(np.uint32), light_count - 1)
+
+    mat = f["materials"][1]
+    albedo = np.array([mat.baseColorFactor.x, mat.baseColorFactor.y, mat.baseColorFactor.z], np.float64)
+    rough = max(float(mat.roughnessFactor), 0.05)
+    metal = float(mat.metallicFactor)
+
+    pl = world.point_lights.lights[0]
+    sl = world.spot_lights.lights[0]
+    out = np.zeros((H, W, 3), np.float64)
+    # sun (pick 0): WorldData.cpp:1537-1542 zeroes its irradiance in a scene with punctual lights only
+    sun = world.directional.irradiance
+    assert (sun.x, sun.y, sun.z) == (0.0, 0.0, 0.0)
+
+    # point light, lighting.glsl:15-37
+    pos = np.array([pl.position.x, pl.position.y, pl.position.z], np.float64)
+    radiance = np.array([pl.radianceAndRadius.x, pl.radianceAndRadius.y, pl.radianceAndRadius.z], np.float64)
+    radius = float(pl.radianceAndRadius.w)
+    to_light = pos - p
+    d2 = (to_light * to_light).sum(-1)
+    dist = np.sqrt(d2)
+    l = to_light / dist[..., None]
+    att = np.maximum(np.minimum(1.0 - (dist / radius) ** 4, 1.0), 0.0)
+    irr = radiance * (att / d2)[..., None]
+    lit = (l * n).sum(-1) > 0
+    c = irr * light_count * eval_brdf_times_nol(l, n, v, albedo, rough, metal)
+    out = np.where(((pick == 1) & lit)[..., None], c, out)
+
+    # spot light, lighting.glsl:39-56
+    pos = np.array([sl.positionAndAngleOffset.x, sl.positionAndAngleOffset.y, sl.positionAndAngleOffset.z], np.float64)
+    radiance = np.array([sl.radianceAndAngleScale.x, sl.radianceAndAngleScale.y, sl.radianceAndAngleScale.z], np.float64)
+    scale, offset = float(sl.radianceAndAngleScale.w), float(sl.positionAndAngleOffset.w)
+    direction = np.array([sl.direction.x, sl.direction.y, sl.direction.z], np.float64)
+    to_light = pos - p
+    d2 = (to_light * to_light).sum(-1)
+    dist = np.sqrt(d2)
+    l = to_light / dist[..., None]
+    cd = (l * -direction).sum(-1)
+    x = saturate(cd * scale + offset)
+    att = x ** 2
+    irr = radiance * (att / d2)[..., None]
+    lit = (l * n).sum(-1) > 0
+    c = irr * light_count * eval_brdf_times_nol(l, n, v, albedo, rough, metal)
+    out = np.where(((pick == 2) & lit)[..., None], c, out)
+    # conditioning of the spot cone's edge: the fp32 shader's cd = dot(-direction, l) carries a few half-ulps of
+    # rounding (taken as 4 * 2^-24 here), which att = saturate(cd * scale + offset)^2 amplifies by 2 * scale / x
+    cond = np.where((pick == 2) & (x > 0) & (x < 1), 2.0 * scale * 4.0 * 2.0 ** -24 / np.maximum(x, 1e-30), 0.0)
+    return out, pick, cond
+
+
+def _camera(oracle, world):
+    c = world.camera
+    return oracle.camera_uniforms(c["eye"], c["target"], c["up"], c["fov"], c["zN"], c["zF"], W, H)
+
+
+def _check_against_numpy(img, want, pick, cond):
+    assert (img[..., 3] == 1.0).all()
+    scale = want.max()
+    err = np.abs(img[..., :3].astype(np.float64) - want)
+    bound = (RTOL + cond[..., None]) * np.abs(want) + ATOL_OF_MAX * scale
+    bad = err > bound
+    assert not bad.any(), "%d channel values off; worst %g at %s (want %g)" % (
+        bad.sum(), (err / np.maximum(np.abs(want), 1e-300)).max(), np.argwhere(bad)[0], want[tuple(np.argwhere(bad)[0])])
+    # the case is not degenerate: all three picks occur, both punctual lights light thousands of pixels
+    assert all((pick == k).sum() > 1000 for k in (0, 1, 2))
+    assert (cond > 0).sum() > 200 and ((cond > 0) & (cond < 1e-4)).sum() > 0.9 * (cond > 0).sum()  # the falloff zone is small
+    plain = (cond == 0) & (want.sum(-1) > 100 * ATOL_OF_MAX * scale)
+    assert (err[plain] / want[plain]).max() < RTOL  # everywhere else: 1e-5 relative, as stated
+    assert ((want.sum(-1) > 0) & (pick == 1)).sum() > 1000 and ((want.sum(-1) > 0) & (pick == 2)).sum() > 500
+
+
+def test_oracle_matches_the_numpy_float64_integrator(oracle):
+    world = build_world()
+    want, pick, cond = numpy_radiance(world)
+    cam, fl = _camera(oracle, world)
+    osc = oracle.OracleScene(world, brute_force=True)
+    img, counters = osc.render(default_pc(S, fl, max_bounces=1), cam, W, H)
+    _check_against_numpy(img, want, pick, cond)
+    c = counters.as_dict()
+    assert c["closestHits"] == W * H and c["lightSamples"] + c["spotLightSamples"] == W * H
+    assert c["spotLightSamples"] == int((pick == 2).sum())
+    # frame 2 has other jitter and other picks: same agreement
+    want2, pick2, cond2 = numpy_radiance(world, frame_index=2)
+    img2, _ = osc.render(default_pc(S, fl, frame_index=2, max_bounces=1), cam, W, H)
+    _check_against_numpy(img2, want2, pick2, cond2)
+
+
+@pytest.mark.gpu
+def test_hip_path_matches_oracle_bitwise_and_numpy_within_tolerance(gpu_ctx, oracle):
+    world = build_world()
+    want, pick, cond = numpy_radiance(world)
+    cam, fl = _camera(oracle, world)
+    pc = default_pc(S, fl, max_bounces=1)
+    gpu_ctx.upload_scene(world)
+    gpu_ctx.render(pc, cam, W, H)
+    got = gpu_ctx.read_hdr()
+    ref, _ = oracle.OracleScene(world, brute_force=True).render(pc, cam, W, H)
+    assert same_bits(got, ref).all()
+    _check_against_numpy(got, want, pick, cond)
