@@ -1,14 +1,23 @@
 #!/usr/bin/env python3
 """bench.py — Mpaths/s and HDR frames/s of the path-tracing reference pass on MI355X.
 
-A step = one pass of the hot path over one batch: the 1920x1080 S-cornell frame accumulated to
-8 spp with maxBounces 4 (BASELINE.json configs[1]), inputs resident in HBM.  With
-N > 1 GPUs the image is cut into interleaved 16-pixel stripes, one stripe set per rank, and the
-per-rank RGBA32F tiles are gathered to rank 0 over RCCL inside the timed region (strong scaling:
-the total work is fixed).  Steps are enqueued back to back with up to three frames in flight
-(PROSPER_PT_RENDER_PIPELINED, prosper's frames-in-flight idea; --in-order for A/B): every step's kernels,
-its accumulate and its gather complete inside the timed region, which is bracketed by barrier + synchronize.
-Before the W warm-up steps the device is woken with PREHEAT_STEPS untimed steps (clock ramp, see below).
+A step = one pass of the hot path over one batch: the 1920x1080 S-cornell frame accumulated to 8 spp with maxBounces 4
+(BASELINE.json configs[1]), inputs resident in HBM.  With N > 1 GPUs the image is cut into interleaved
+16-pixel stripes, one stripe set per rank, and the per-rank RGBA32F tiles are gathered to rank 0 inside the timed
+region by the PRODUCT: prosper_pt_gather_tiles = ncclGather over RCCL/xGMI + a HIP de-interleave kernel on the root
+(strong scaling: the total work is fixed).  torch.distributed only carries the rendezvous (communicator id, barrier,
+max-over-ranks of the wall time).  Steps are enqueued back to back with up to three frames in flight
+(PROSPER_PT_RENDER_PIPELINED, prosper's frames-in-flight idea; --in-order for A/B): every step's kernels, its
+accumulate and its gather complete inside the timed region, which is bracketed by barrier + synchronize.
+
+What the one JSON line carries besides the contract fields:
+  roofline   the roof that binds the dominant kernel: VALU issue.  achieved = wave-instructions/s of that kernel
+             (SQ_INSTS_VALU per launch, measured IN THIS RUN by rocprofv3 child passes over the same launch shape, /
+             the kernel's exclusive share of the step time), peak = the chip's measured v_fma_f32 issue rate
+             (profiles/r02_valu_calibration.json), lane_util beside it; hbm_measured = PMC bytes / that time / 8 TB/s
+  configs    C3 and C4 (the configurations where bytes matter), each with ms/step, Mpaths/s, dominant kernel,
+             upload and BVH build time, measured / algorithmic traffic
+  cpu_baseline  the oracle (a scalar port) on this box's host cores, bounded sample
 
     python bench.py --gpus 1 --steps 20 --warmup 3
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
@@ -23,17 +32,21 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "scripts"))
 
 import numpy as np  # noqa: E402
 
 from prosper_amd import capi, scenes, structs as S, tiling  # noqa: E402
 from prosper_amd.rt_reference import Camera  # noqa: E402
 
+import pmc_tools  # noqa: E402  (scripts/: measurement tooling)
+
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md, chip-level parameters)
 STRIPE_WIDTH = tiling.STRIPE_WIDTH
+PREHEAT_STEPS = 24
 
 CONFIGS = {
-    # name: (scene builder, width, height, spp, maxBounces, ibl)
+    # name: (workload, scene builder, width, height, spp, maxBounces, ibl)
     "c2": ("S-cornell 1920x1080 8spp maxBounces 4", lambda: scenes.cornell(), 1920, 1080, 8, 4, False),
     "c3": ("S-sponza-class 1920x1080 8spp maxBounces 4 IBL", lambda: scenes.sponza_class(), 1920, 1080, 8, 4, True),
     "c4": ("S-sponza-class + 1024 lights + foliage 1920x1080 8spp maxBounces 4 IBL",
@@ -41,11 +54,18 @@ CONFIGS = {
     # BASELINE.json configs[4]: meant for 8 GPUs (a rank then renders 1/8 of the stripes); runs on one as well
     "c5": ("S-sponza-class 3840x2160 64spp maxBounces 4 IBL", lambda: scenes.sponza_class(), 3840, 2160, 64, 4, True),
     "c1": ("S-cornell 256x256 1spp maxBounces 1", lambda: scenes.cornell(), 256, 256, 1, 1, False),
+    # the reference's one bundled asset (src/main.cpp:32-33), from the packed fixture (tests/golden/flight_helmet.npz)
+    "helmet": ("FlightHelmet 1920x1080 8spp maxBounces 4 IBL", lambda: helmet_world(), 1920, 1080, 8, 4, True),
 }
 
 
+def helmet_world():
+    from prosper_amd import flight_helmet
+    return flight_helmet.load_fixture()
+
+
 def algorithmic_bytes(c, stats):
-    """B_alg of SURVEY §8d from the deterministic work counters of one launch."""
+    """B_alg of SURVEY 8d from the deterministic work counters of one launch."""
     tri_long = c["triangleTests"] - c["shortIndexTriangleTests"]
     hits = c["closestHits"] + c["anyHitCalls"]
     short_share = (c["shortIndexHits"] / hits) if hits else 0.0
@@ -56,29 +76,17 @@ def algorithmic_bytes(c, stats):
             c["pixelsWritten"] * 16.0 + c["historyReads"] * 16.0)
 
 
-PREHEAT_STEPS = 24
-
-
-def measured_traffic(config, kernel):
-    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (FETCH_SIZE doubled as the
-    gfx950 guide prescribes, + WRITE_SIZE), or None if that config/kernel has not been measured."""
-    path = os.path.join(ROOT, "profiles", "r01_%s_traffic.json" % config)
+def valu_peak():
+    """The chip's measured issue rate of independent v_fma_f32 (wave-instructions/s, best over the occupancies the
+    calibration ran): profiles/r02_valu_calibration.json, scripts/valu_calibration.hip."""
     try:
-        with open(path) as f:
-            return json.load(f)["kernels"][kernel]["hbm_bytes_per_launch"]
+        with open(os.path.join(ROOT, "profiles", "r02_valu_calibration.json")) as f:
+            rows = json.load(f)["results"]
+        best = max(r["wave_insts_per_s_chip"] for r in rows if r["inst"] in ("fma_f32", "v_fma_f32"))
+        return best, "profiles/r02_valu_calibration.json (v_fma_f32, best occupancy)"
     except (OSError, KeyError, ValueError):
-        return None
-
-
-def measured_issue(config, kernel):
-    """Vector-ALU issue-slot occupancy and lane utilisation of `kernel` from the committed PMC pass
-    (profiles/r01_valu_issue.json): what actually bounds the traversal kernels."""
-    try:
-        with open(os.path.join(ROOT, "profiles", "r01_valu_issue.json")) as f:
-            k = json.load(f)["configs"][config][kernel]
-        return {"valu_busy": k["valu_busy"], "lane_util": k["lane_util"], "source": "profiles/r01_valu_issue.json"}
-    except (OSError, KeyError, ValueError):
-        return None
+        # 1024 SIMDs x 2.4 GHz / 2 cycles per wave64 instruction (MI355X_MICROARCH.md, cycle constants)
+        return 1024 * 2.4e9 / 2.0, "1024 SIMDs x 2.4 GHz / 2 cycles (MI355X_MICROARCH.md; no calibration file)"
 
 
 def make_pc(focal, frame_index, max_bounces, ibl, skip_history):
@@ -128,14 +136,14 @@ def cpu_baseline(world, cam, focal, width, height, spp, max_bounces, ibl, budget
         "unit": "Mpaths/s",
         "cores": cores,
         "kind": "port",
-        "sample": "%d of %d spp of the same %dx%d frame (%.1f s, OpenMP over rows)" % (frames, spp, width, height, elapsed),
+        "sample": "%d of %d spp of the same %dx%d frame (%.1f s; 16x16-pixel tiles from a shared counter, one worker per "
+                  "hardware thread, -O3 x86-64-v3, fp contraction off, the oracle's own BVH2)" % (frames, spp, width, height, elapsed),
     }
 
 
 def bench_tone_map(ctx, torch, width, height, stream, repeats=50):
     """The step after the path (not part of `value`): blit + tone_map.comp in one kernel over
     the frame just rendered; 16 B read + 4 B written per pixel, the 442 KB LUT stays in L2."""
-    import numpy as np
     from prosper_amd import dds
     g = np.linspace(0.0, 1.0, 48)
     b, gg, r = np.meshgrid(g, g, g, indexing="ij")
@@ -155,10 +163,9 @@ def bench_tone_map(ctx, torch, width, height, stream, repeats=50):
             "achieved_GBps": nbytes / (ms * 1e-3) / 1e9, "frac_of_hbm_peak": nbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
 
 
-def bench_restir_di(ctx, torch, cam, focal, width, height, stream, repeats=30):
+def bench_restir_di(ctx, torch, world, cam, focal, width, height, stream, repeats=30):
     """A second client of the traversal (not part of `value`): the ReSTIR-DI trace pass over a
     G-buffer made from the product's own debug views of the primary hits, one random light per pixel."""
-    import numpy as np
 
     def view(name):
         pc = S.ReferencePC(S.DrawType[name], S.PC_FLAG_SKIP_HISTORY, 1, 1e-5, 1.0, focal, 3, 1)
@@ -178,7 +185,6 @@ def bench_restir_di(ctx, torch, cam, focal, width, height, stream, repeats=30):
     ar = np.concatenate([alb, np.maximum(rough, 0.05)[..., None]], axis=-1).astype(np.float32)
     nm = np.stack([enc[..., 0], enc[..., 1], metal, enc[..., 2]], axis=-1).astype(np.float32)
     rng = np.random.default_rng(1)
-    world = ctx._world
     lights = 1 + world.point_lights.count + world.spot_lights.count
     idx = rng.integers(0, lights, size=(height, width)).astype(np.int32)
     res = np.stack([idx.view(np.float32), np.ones((height, width), np.float32)], axis=-1)
@@ -197,6 +203,127 @@ def bench_restir_di(ctx, torch, cam, focal, width, height, stream, repeats=30):
             "gbuffer_bytes_per_pixel": 60, "lights": int(lights)}
 
 
+def kernel_table(per_kernel, stage_bytes, ms_per_step, pmc):
+    """Per kernel: launches, raw per-launch duration (hipEvents; launches of frames in flight overlap), its EXCLUSIVE
+    share of the step (raw x ms_per_step / sum of raw: the shares add up to the step time), algorithmic bytes, and -
+    when PMC figures for this launch shape exist - VALU wave-instructions, lane utilisation and HBM bytes."""
+    raw_sum = sum(ms for ms, n in per_kernel.values() if n)
+    scale = min(1.0, ms_per_step / raw_sum) if raw_sum > 0 else 1.0
+    kernels = {}
+    for i, (name, (sum_ms, launches)) in enumerate(per_kernel.items()):
+        if not launches:
+            continue
+        raw = sum_ms / launches
+        k = {"launches_per_step": launches, "ms_per_launch_raw": raw, "ms_per_launch": raw * scale,
+             "algorithmic_bytes_per_launch": stage_bytes[i] / launches}
+        p = (pmc or {}).get("kernels", {}).get(name)
+        if p:
+            t = k["ms_per_launch"] * 1e-3
+            k.update({
+                "valu_insts_per_launch": p["valu_insts_per_launch"],
+                "valu_wave_insts_per_s": p["valu_insts_per_launch"] / t,
+                "lane_util": p["lane_util"],
+                "hbm_bytes_per_launch": p["hbm_bytes_per_launch"],
+                "hbm_GBps": p["hbm_bytes_per_launch"] / t / 1e9,
+                "traffic_over_algorithmic": p["hbm_bytes_per_launch"] / k["algorithmic_bytes_per_launch"]
+                if k["algorithmic_bytes_per_launch"] else None,
+            })
+        kernels[name] = k
+    return kernels, scale
+
+
+def roofline_object(kernels, pmc, pmc_source, peak, peak_source, ms_per_step, timed_note):
+    dominant = max(kernels, key=lambda k: kernels[k]["ms_per_launch"] * kernels[k]["launches_per_step"])
+    d = kernels[dominant]
+    r = {
+        "bound": "valu",
+        "kernel": dominant,
+        "unit": "Gwave-inst/s",
+        "peak": peak / 1e9,
+        "peak_source": peak_source,
+        "kernel_ms": d["ms_per_launch"],
+        "kernel_ms_raw": d["ms_per_launch_raw"],
+        "kernel_ms_source": timed_note,
+        "launches_per_step": d["launches_per_step"],
+        "share_of_step": d["ms_per_launch"] * d["launches_per_step"] / ms_per_step,
+        "algorithmic_bytes_per_launch": d["algorithmic_bytes_per_launch"],
+        "pmc_source": pmc_source,
+    }
+    if "valu_wave_insts_per_s" in d:
+        total_insts = sum(k["valu_insts_per_launch"] * k["launches_per_step"] for k in kernels.values() if "valu_insts_per_launch" in k)
+        r.update({
+            "achieved": d["valu_wave_insts_per_s"] / 1e9,
+            "frac": d["valu_wave_insts_per_s"] / peak,
+            "lane_util": d["lane_util"],
+            "useful_frac": d["valu_wave_insts_per_s"] / peak * d["lane_util"],
+            "traffic": d["hbm_bytes_per_launch"],
+            "hbm_measured": {"bytes_per_launch": d["hbm_bytes_per_launch"], "GBps": d["hbm_GBps"],
+                             "frac_of_peak": d["hbm_GBps"] / HBM_PEAK_GBS, "peak_GBps": HBM_PEAK_GBS},
+            "traffic_over_algorithmic": d["traffic_over_algorithmic"],
+            # the whole step against the same roofs: every kernel's instructions and bytes over the step time
+            "whole_step": {
+                "valu_Gwave_insts_per_s": total_insts / (ms_per_step * 1e-3) / 1e9,
+                "valu_frac": total_insts / (ms_per_step * 1e-3) / peak,
+                "hbm_bytes": sum(k["hbm_bytes_per_launch"] * k["launches_per_step"] for k in kernels.values() if "hbm_bytes_per_launch" in k),
+            },
+        })
+        r["whole_step"]["hbm_frac_of_peak"] = r["whole_step"]["hbm_bytes"] / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS
+    else:
+        r.update({"achieved": None, "frac": None, "lane_util": None, "traffic": None, "hbm_measured": None})
+    return r
+
+
+def time_config(ctx, torch, name, world, width, height, spp, max_bounces, ibl, steps, warmup, stream, render_flags):
+    """A sub-configuration on one GPU (C3, C4): upload, one counted render, preheat, `steps` timed pipelined steps with
+    per-launch events on one of them."""
+    t0 = time.perf_counter()
+    ctx.upload_scene(world)
+    upload_wall = time.perf_counter() - t0
+    stats = ctx.scene_stats()
+    cam, focal = Camera.from_world(world, width, height).update_buffer()
+    pc = make_pc(focal, 1, max_bounces, ibl, True)
+    hdr = torch.zeros((height, width, 4), dtype=torch.float32, device="cuda")
+    ctx.set_output_buffer(hdr.data_ptr(), hdr.numel() * 4)
+    ctx.reset_counters(stream)
+    ctx.render(pc, cam, width, height, frames=spp, flags=S.RENDER_COUNT_WORK, stream=stream)
+    counters = ctx.counters(stream).as_dict()
+    stage_bytes = [algorithmic_bytes(ctx.stage_counters(i, stream).as_dict(), stats) for i in range(4)]
+    ctx.set_kernel_timing(False)
+    preheat = max(2, min(PREHEAT_STEPS, int(round(4e8 / (width * height * spp)))))
+    for _ in range(preheat + warmup):
+        ctx.render(pc, cam, width, height, frames=spp, stream=stream, flags=render_flags)
+    torch.cuda.synchronize()
+    timed_step = steps - 3 if (render_flags and steps >= 4) else steps - 1
+    t0 = time.perf_counter()
+    for i in range(steps):
+        ctx.set_kernel_timing(i == timed_step)
+        ctx.render(pc, cam, width, height, frames=spp, stream=stream, flags=render_flags)
+    torch.cuda.synchronize()
+    ms_per_step = (time.perf_counter() - t0) * 1e3 / steps
+    _, per_kernel = ctx.last_render_timing()
+    ctx.set_kernel_timing(False)
+    pmc = pmc_tools.load_committed(name)
+    kernels, _ = kernel_table(per_kernel, stage_bytes, ms_per_step, pmc)
+    dominant = max(kernels, key=lambda k: kernels[k]["ms_per_launch"] * kernels[k]["launches_per_step"])
+    out = {
+        "ms_per_step": ms_per_step, "Mpaths_per_s": width * height * spp / ms_per_step / 1e3, "steps": steps,
+        "triangles": int(stats.triangleCount), "bvh_nodes": int(stats.nodeCount),
+        "upload_ms": stats.uploadSeconds * 1e3, "bvh_build_ms": stats.bvhBuildSeconds * 1e3,
+        "texture_upload_ms": stats.textureSeconds * 1e3, "upload_wall_ms": upload_wall * 1e3,
+        "scene_device_MB": stats.deviceBytes / 1e6,
+        "dominant_kernel": dominant, "kernels": kernels,
+        "algorithmic_bytes_per_step": algorithmic_bytes(counters, stats),
+        "pmc_source": pmc["source"] if pmc else None,
+        "mean_radiance": float(hdr[..., :3].mean().item()),
+    }
+    if pmc and "hbm_bytes_per_launch" in kernels[dominant]:
+        out["measured_traffic_ratio"] = {k: v.get("traffic_over_algorithmic") for k, v in kernels.items()}
+        out["hbm_bytes_per_step"] = sum(v["hbm_bytes_per_launch"] * v["launches_per_step"] for v in kernels.values() if "hbm_bytes_per_launch" in v)
+        out["lane_util"] = {k: v.get("lane_util") for k, v in kernels.items()}
+    ctx.set_output_buffer(0, 0)
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -204,6 +331,11 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--config", default="c2", choices=sorted(CONFIGS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-pmc", action="store_true", help="skip the rocprofv3 child passes (roofline then quotes the "
+                    "committed profile if it matches the kernel sources, else null)")
+    ap.add_argument("--no-subconfigs", action="store_true", help="skip the C3 / C4 sub-objects")
+    ap.add_argument("--no-extras", action="store_true", help="skip the tone-map and ReSTIR-DI legs")
+    ap.add_argument("--subconfigs", default="c3,c4")
     ap.add_argument("--megakernel", action="store_true", help="use the one-lane-per-pixel kernel (A/B)")
     ap.add_argument("--persistent", action="store_true", help="use the persistent path-regeneration kernel (A/B)")
     ap.add_argument("--single-chain", action="store_true",
@@ -212,9 +344,6 @@ def main():
                     help="no frames in flight: every step starts after the previous one has finished (A/B)")
     args = ap.parse_args()
 
-    import torch
-    import torch.distributed as dist
-
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world_size = int(os.environ.get("WORLD_SIZE", "1"))
@@ -222,129 +351,110 @@ def main():
         if world_size == 1 and args.gpus > 1:
             raise SystemExit("--gpus %d needs torch.distributed.run with --nproc-per-node %d" % (args.gpus, args.gpus))
         raise SystemExit("WORLD_SIZE %d != --gpus %d" % (world_size, args.gpus))
-    # PROSPER_BENCH_REHEARSE=1: every rank on GPU 0 with the gloo backend, to rehearse the N > 1 flow
-    # (stripes, gather, de-interleave, max-over-ranks timing) on a one-GPU box; never a measurement.
+    wavefront = not (args.megakernel or args.persistent)
+
+    # ---- PMC passes of the headline configuration, as child processes, BEFORE this process touches the GPU ----
+    pmc, pmc_source = None, None
+    if world_size == 1 and wavefront and args.config in ("c2", "c3", "c4", "c5", "helmet"):
+        if not args.no_pmc:
+            try:
+                t0 = time.perf_counter()
+                pmc = pmc_tools.collect(args.config, timeout=420)
+                pmc_source = "rocprofv3 --pmc child passes of this run (%.0f s; scripts/pmc_tools.py)" % (time.perf_counter() - t0)
+            except Exception as e:  # no profiler, a refused counter, a timeout: the line says so instead of failing
+                print("bench: live PMC passes unavailable (%s)" % str(e)[:300], file=sys.stderr)
+        if pmc is None:
+            pmc = pmc_tools.load_committed(args.config)
+            pmc_source = pmc["source"] if pmc else "none (no live pass, no committed profile for these kernel sources)"
+
+    import torch
+    import torch.distributed as dist
+
+    # PROSPER_BENCH_REHEARSE=1: every rank on GPU 0, tiles exchanged through host memory over gloo, de-interleaved by
+    # the product's kernel: rehearses the N > 1 flow on a one-GPU box (RCCL refuses two ranks on one device); never a
+    # measurement.
     rehearse = os.environ.get("PROSPER_BENCH_REHEARSE") == "1"
     if rehearse:
         local_rank = 0
     torch.cuda.set_device(local_rank)
     if world_size > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if rehearse:
-            dist.init_process_group("gloo", rank=rank, world_size=world_size)
-        else:
-            dist.init_process_group("nccl", rank=rank, world_size=world_size, device_id=torch.device("cuda", local_rank))
+        # control plane only (communicator id, barriers, max-over-ranks): CPU tensors over gloo.  The data plane - the
+        # gather of the HDR tiles - is the library's own RCCL communicator (prosper_pt_comm_init).
+        dist.init_process_group("gloo", rank=rank, world_size=world_size)
 
     workload, builder, width, height, spp, max_bounces, ibl = CONFIGS[args.config]
-    if not tiling.check_divisible(width, world_size):
-        raise SystemExit("%d stripes do not divide over %d ranks" % (width // STRIPE_WIDTH, world_size))
     world = builder()
-
     camera = Camera.from_world(world, width, height)
     cam, focal = camera.update_buffer()
 
     ctx = capi.Context(device=local_rank, flags=S.CREATE_MEGAKERNEL if args.megakernel else (
         S.CREATE_PERSISTENT if args.persistent else (S.CREATE_SINGLE_CHAIN if args.single_chain else 0)))
+    t0 = time.perf_counter()
     ctx.upload_scene(world)
+    upload_wall = time.perf_counter() - t0
     stats = ctx.scene_stats()
     tile = tiling.tile_for_rank(rank, world_size)
     local_w = tiling.local_width(width, rank, world_size)
-    # Two HDR tiles, used alternately: while the tile of step i is gathered (RCCL's own stream), step i + 1
-    # already renders into the other one.  N = 1 only ever uses the first.
-    tiles = [torch.zeros((height, local_w, 4), dtype=torch.float32, device="cuda") for _ in range(2 if world_size > 1 else 1)]
-    hdr = tiles[0]
+    hdr = torch.zeros((height, local_w, 4), dtype=torch.float32, device="cuda")
     ctx.set_output_buffer(hdr.data_ptr(), hdr.numel() * 4)
     stream = torch.cuda.current_stream().cuda_stream
-    recv = [[torch.empty_like(hdr) for _ in range(world_size)] if (world_size > 1 and rank == 0) else None for _ in tiles]
-    pending = [None for _ in tiles]  # in-flight gather of each tile
-    overlap = [True]
-    full = None
+    full = torch.zeros((height, width, 4), dtype=torch.float32, device="cuda") if (rank == 0 and world_size > 1) else None
 
-    render_flags = 0 if (args.in_order or args.single_chain or args.megakernel or args.persistent) else S.RENDER_PIPELINED
+    gather_mode = "none"
+    if world_size > 1 and not rehearse:
+        ids = [capi.Context.comm_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(ids, src=0)
+        ctx.comm_init(ids[0], rank, world_size)  # ncclCommInitRank: collective over the ranks
+        gather_mode = "prosper_pt_gather_tiles: ncclGather over RCCL + HIP de-interleave on rank 0, on the context's comm stream"
+    elif world_size > 1:
+        gather_mode = "REHEARSAL: gloo through host memory + prosper_pt_deinterleave_tiles"
 
-    def gather_sync(t):
-        """Rehearsal path (gloo, through host memory)."""
+    render_flags = 0 if (args.in_order or args.single_chain or not wavefront) else S.RENDER_PIPELINED
+
+    def gather(step_tile):
+        """The one data-path collective of step i, enqueued behind its render."""
+        if world_size == 1:
+            return
+        if not rehearse:
+            ctx.gather_tiles(root=0, device_ptr=full.data_ptr() if rank == 0 else None,
+                             byte_size=full.numel() * 4 if rank == 0 else 0, stream=stream)
+            return
         torch.cuda.synchronize()
-        host = t.cpu()
+        host = step_tile.cpu()
         parts = [torch.empty_like(host) for _ in range(world_size)] if rank == 0 else None
         dist.gather(host, parts, dst=0)
-        return tiling.deinterleave([p.cuda() for p in parts], width) if rank == 0 else None
+        if rank == 0:
+            staging = torch.cat([p.reshape(-1) for p in parts]).cuda()
+            ctx.deinterleave_tiles(staging.data_ptr(), world_size, STRIPE_WIDTH, width, height, full.data_ptr(), stream=stream)
+            torch.cuda.synchronize()
 
-    def finish_gather(b):
-        """Waits (stream-side) for tile b's gather and de-interleaves it on rank 0."""
-        nonlocal full
-        if pending[b] is not None:
-            pending[b].wait()
-            pending[b] = None
-            if rank == 0:
-                full = tiling.deinterleave(recv[b], width)
-
-    def render_and_gather(i, record=None):
-        """Step i: render the rank's stripes into tile i % 2, start its gather (the one data-path collective:
-        per-rank RGBA32F stripes to rank 0, RCCL over xGMI), then complete the previous step's."""
-        nonlocal full
-        b = i % len(tiles)
-        finish_gather(b)  # the gather that last read this tile (two steps ago)
-        ctx.set_output_buffer(tiles[b].data_ptr(), tiles[b].numel() * 4)
+    def step(record=None):
         pc = make_pc(focal, 1, max_bounces, ibl, True)
         if record:
             record[0].record()
-        # frames in flight (as the reference keeps frames in flight): the path stages of steps i + 1 and i + 2 overlap
-        # step i; the accumulate kernel and the gather stay in stream order
+        # frames in flight: the path stages of steps i + 1 and i + 2 overlap step i and its gather; the accumulate
+        # kernel - the one writer of the tile - waits for the gather of the previous step inside the library
         ctx.render(pc, cam, width, height, tile=tile, frames=spp, stream=stream, flags=render_flags)
         if record:
             record[1].record()
-        if world_size == 1:
-            full = tiles[b]
-        elif rehearse:
-            full = gather_sync(tiles[b])
-        elif overlap[0]:
-            try:
-                pending[b] = dist.gather(tiles[b], recv[b], dst=0, async_op=True)
-            except (RuntimeError, TypeError, ValueError) as e:  # a backend without async gather: plain gather
-                if step_index > 0:
-                    raise
-                print("bench: async gather unavailable (%s); gathering synchronously" % e, file=sys.stderr)
-                overlap[0] = False
-                dist.gather(tiles[b], recv[b], dst=0)
-                if rank == 0:
-                    full = tiling.deinterleave(recv[b], width)
-            else:
-                finish_gather(1 - b)
-        else:
-            dist.gather(tiles[b], recv[b], dst=0)
-            if rank == 0:
-                full = tiling.deinterleave(recv[b], width)
+        gather(hdr)
 
     def drain():
-        for b in range(len(tiles)):
-            finish_gather((b + 1) % len(tiles))
-
-    step_index = 0
-
-    def step(record=None):
-        nonlocal step_index
-        render_and_gather(step_index, record)
-        step_index += 1
+        if world_size > 1 and not rehearse:
+            ctx.gather_wait(stream)
 
     # deterministic work counters of one launch (outside the timed region)
     ctx.reset_counters(stream)
     pc = make_pc(focal, 1, max_bounces, ibl, True)
     ctx.render(pc, cam, width, height, tile=tile, frames=spp, flags=S.RENDER_COUNT_WORK, stream=stream)
     counters = ctx.counters(stream).as_dict()
-    bytes_per_launch = algorithmic_bytes(counters, stats)
+    bytes_per_step = algorithmic_bytes(counters, stats)
     stage_bytes = [algorithmic_bytes(ctx.stage_counters(i, stream).as_dict(), stats) for i in range(4)]
-    # Per-launch hipEvents (on the launch streams) cost ~35 us per render - 1 % of a full frame, 5 % of a rank's
-    # share at N = 8 - and only one render's are kept by the library: they are switched on for the warm-up
-    # (same code path exercised) and for ONE timed step (`timed_step` below), whose per-launch durations the roofline
-    # object uses; the step time itself comes from the two events around every step.
     ctx.set_kernel_timing(True)
 
     # Device wake-up: the clocks of an idle MI355X take ~40 ms of load to ramp (the first ten 2.5 ms steps after idle
-    # run 5-10 % slower, in every pipeline mode).  A renderer is past that after its first frames; so that the W
-    # warm-up steps and the K timed steps measure the steady state whatever W the caller picks, up to PREHEAT_STEPS steps
-    # run first (fewer for the very large configurations; the same count on every rank: they gather).  Untimed, reported as `preheat_steps`; the timed region
-    # is untouched.
+    # run 5-10 % slower, in every pipeline mode).  Untimed, reported as `preheat_steps`; the timed region is untouched.
     preheat_steps = max(2, min(PREHEAT_STEPS, int(round(4e8 / (width * height * spp / world_size)))))
     for _ in range(preheat_steps):
         step()
@@ -367,42 +477,31 @@ def main():
     t0 = time.perf_counter()
     for i in range(args.steps):
         ctx.set_kernel_timing(i == timed_step)
-        # kernel-only time: events on the stream the render kernels are launched on
         step((starts[i], stops[i]))
     drain()
     barrier()
     elapsed = time.perf_counter() - t0
-    kernel_ms = sum(s.elapsed_time(e) for s, e in zip(starts, stops)) / max(1, args.steps)
     if os.environ.get("PROSPER_BENCH_STEP_TIMES") and rank == 0:
         print("step ms: " + " ".join("%.3f" % (starts[i].elapsed_time(starts[i + 1])) for i in range(args.steps - 1)), file=sys.stderr)
-    # per-kernel split of the LAST timed step, from the hipEvents recorded around every launch
     _, per_kernel = ctx.last_render_timing()
+    ctx.set_kernel_timing(False)
 
-    t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if rehearse else "cuda")
+    t = torch.tensor([elapsed], dtype=torch.float64)
     if world_size > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
 
     if rank == 0:
+        if world_size > 1:
+            torch.cuda.synchronize()
+        image = full if world_size > 1 else hdr
         paths_per_step = width * height * spp
         ms_per_step = elapsed * 1e3 / args.steps
-        pass_achieved = bytes_per_launch / (kernel_ms * 1e-3) / 1e9
-        kernels = {}
-        for i, (name, (sum_ms, launches)) in enumerate(per_kernel.items()):
-            if launches:
-                per_launch_ms = sum_ms / launches
-                per_launch_bytes = stage_bytes[i] / launches
-                kernels[name] = {
-                    "launches_per_step": launches, "ms_per_launch": per_launch_ms,
-                    "algorithmic_bytes_per_launch": per_launch_bytes,
-                    "achieved_GBps": per_launch_bytes / (per_launch_ms * 1e-3) / 1e9,
-                }
-        dominant = max(kernels, key=lambda k: kernels[k]["ms_per_launch"] * kernels[k]["launches_per_step"])
-        achieved = kernels[dominant]["achieved_GBps"]
-        # with two concurrent launch chains the per-launch durations overlap in time: the share of the step's
-        # device time a launch accounts for is its duration scaled by (device time per step) / (sum of durations)
-        summed_ms = sum(k["ms_per_launch"] * k["launches_per_step"] for k in kernels.values())
-        exclusive_scale = min(1.0, kernel_ms / summed_ms) if summed_ms > 0 else 1.0
+        peak, peak_source = valu_peak()
+        kernels, scale = kernel_table(per_kernel, stage_bytes, ms_per_step, pmc if world_size == 1 else None)
+        timed_note = ("hipEvents around every launch of timed step %d of %d, scaled by %.3f = ms_per_step / sum of the raw "
+                      "durations (launches of the frames in flight overlap): the exclusive shares add up to the step" % (
+                          timed_step + 1, args.steps, scale))
         result = {
             "metric": "Mpaths/s",
             "value": paths_per_step * args.steps / elapsed / 1e6,
@@ -425,59 +524,45 @@ def main():
                 "max_bounces": max_bounces,
                 "triangles": int(stats.triangleCount),
                 "bvh_nodes": int(stats.nodeCount),
-                "parallelism": "image stripes x%d%s" % (world_size, " + RCCL gather" if world_size > 1 else ""),
+                "parallelism": "image stripes x%d%s" % (world_size, "; " + gather_mode if world_size > 1 else ""),
                 "pipeline": "megakernel" if args.megakernel else ("persistent" if args.persistent else (
                     "wavefront, 1 launch chain" if args.single_chain else (
                         "wavefront, 3 frames in flight (one launch chain each)" if render_flags
                         else "wavefront, 2 concurrent launch chains"))),
-            },
-            "roofline": {
-                "bound": "hbm",
-                "kernel": dominant,
-                "achieved": achieved,
-                "peak": HBM_PEAK_GBS,
-                "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS,
-                # the PMC passes were taken on whole-batch launches of a whole frame (N = 1; the pipelined default and
-                # --single-chain launch that shape): no figure for half-batch launches or for a rank's share
-                "traffic": measured_traffic(args.config, dominant) if world_size == 1 and (
-                    render_flags or args.single_chain) else None,
-                "issue": measured_issue(args.config, dominant),
-                "algorithmic_bytes_per_launch": kernels[dominant]["algorithmic_bytes_per_launch"],
-                "kernel_ms": kernels[dominant]["ms_per_launch"],
-                "kernel_ms_source": "hipEvents around every launch of timed step %d of %d" % (timed_step + 1, args.steps),
-                "launches_per_step": kernels[dominant]["launches_per_step"],
-                # the default pipeline runs two half-batches as two chains of launches on two streams: a launch's
-                # duration (hipEvents, = rocprofv3's) includes the time it shares the GPU with the other chain's
-                # launch, so sum(kernel time) > wall time and `frac` is a per-launch, not a whole-GPU, figure
-                "concurrent_chains": 1 if (args.single_chain or args.megakernel or args.persistent) else 2,
-                "frames_in_flight": 3 if render_flags else 1,
                 "preheat_steps": preheat_steps,
-                "kernel_ms_exclusive": kernels[dominant]["ms_per_launch"] * exclusive_scale,
-                "frac_exclusive": achieved / exclusive_scale / HBM_PEAK_GBS,
             },
+            "roofline": roofline_object(kernels, pmc, pmc_source, peak, peak_source, ms_per_step, timed_note),
             "kernels": kernels,
-            "whole_pass": {
-                "algorithmic_bytes_per_step": bytes_per_launch,
-                "device_ms_per_step": kernel_ms,
-                "achieved_GBps": pass_achieved,
-                "frac_of_hbm_peak": pass_achieved / HBM_PEAK_GBS,
-                "bytes_per_path": bytes_per_launch / max(1, counters["paths"]),
-            },
+            "scene": {"upload_ms": stats.uploadSeconds * 1e3, "bvh_build_ms": stats.bvhBuildSeconds * 1e3,
+                      "texture_upload_ms": stats.textureSeconds * 1e3, "upload_wall_ms": upload_wall * 1e3,
+                      "device_MB": stats.deviceBytes / 1e6, "variant_flags": int(stats.variantFlags)},
+            "whole_pass": {"algorithmic_bytes_per_step": bytes_per_step, "bytes_per_path": bytes_per_step / max(1, counters["paths"])},
             "counters": counters,
-            "mean_radiance": float(full[..., :3].mean().item()),
+            "mean_radiance": float(image[..., :3].mean().item()),
         }
-        if world_size == 1:
-            result["tone_map"] = bench_tone_map(ctx, torch, width, height, stream)
-            result["restir_di_trace"] = bench_restir_di(ctx, torch, cam, focal, width, height, stream)
-        if world_size == 1 and not args.no_cpu_baseline:
-            result["cpu_baseline"] = cpu_baseline(world, cam, focal, width, height, spp, max_bounces, ibl)
-            result["gpu_over_cpu"] = result["value"] / result["cpu_baseline"]["value"]
+        if world_size == 1 and wavefront:
+            if not args.no_extras:
+                result["tone_map"] = bench_tone_map(ctx, torch, width, height, stream)
+                result["restir_di_trace"] = bench_restir_di(ctx, torch, world, cam, focal, width, height, stream)
+            if not args.no_subconfigs and args.config == "c2":
+                result["configs"] = {}
+                for name in [c for c in args.subconfigs.split(",") if c]:
+                    w2, b2, ww, hh, s2, mb2, ibl2 = CONFIGS[name]
+                    try:
+                        sub = time_config(ctx, torch, name, b2(), ww, hh, s2, mb2, ibl2, max(6, args.steps // 2), 2, stream, render_flags)
+                        sub["workload"] = w2
+                        result["configs"][name] = sub
+                    except Exception as e:  # a sub-configuration must never cost the headline line
+                        result["configs"][name] = {"error": str(e)[:300]}
+            if not args.no_cpu_baseline:
+                result["cpu_baseline"] = cpu_baseline(world, cam, focal, width, height, spp, max_bounces, ibl)
+                result["gpu_over_cpu"] = result["value"] / result["cpu_baseline"]["value"]
         print(json.dumps(result))
 
     ctx.set_output_buffer(0, 0)
     ctx.close()
     if world_size > 1:
+        dist.barrier()
         dist.destroy_process_group()
 
 

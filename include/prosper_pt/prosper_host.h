@@ -58,6 +58,25 @@ int prosper_host_rt_reference_record(
     const prosper_host_record_options *options, uint32_t frameCount, const prosper_pt_tile_desc *tile,
     uint32_t renderFlags, void *stream, prosper_ReferencePC *outPushConstants);
 
+/* render::TiledRtReference (host/tiled_rt_reference.hpp): the pass on one rank of a multi-GPU job - RtReference::record
+ * for the rank's interleaved 16-pixel stripes, then the RCCL gather of the ranks' HDR tiles to `root` and the
+ * de-interleave kernel there (prosper_pt_gather_tiles).  No counterpart in the reference, which asserts
+ * renderArea.offset == 0 (src/render/RtReference.cpp:327).  `commId`: prosper_pt_comm_get_unique_id of one rank.
+ * record() returns, on the root, the device pointer of the gathered width*height RGBA32F image; readers enqueue
+ * wait_for_gather on their stream first. */
+typedef struct prosper_host_tiled_rt_reference prosper_host_tiled_rt_reference;
+int prosper_host_tiled_rt_reference_create(
+    int32_t deviceOrdinal, uint32_t rank, uint32_t ranks, const uint8_t commId[PROSPER_PT_COMM_ID_BYTES], uint32_t root,
+    uint32_t createFlags, prosper_host_tiled_rt_reference **out);
+void prosper_host_tiled_rt_reference_destroy(prosper_host_tiled_rt_reference *pass);
+prosper_pt_ctx *prosper_host_tiled_rt_reference_context(prosper_host_tiled_rt_reference *pass);
+int prosper_host_tiled_rt_reference_set_scene(prosper_host_tiled_rt_reference *pass, const prosper_pt_scene_view *view);
+int prosper_host_tiled_rt_reference_record(
+    prosper_host_tiled_rt_reference *pass, prosper_host_camera *camera, uint32_t width, uint32_t height,
+    const prosper_host_record_options *options, uint32_t frameCount, uint32_t renderFlags, void *stream,
+    const float **outIllumination);
+int prosper_host_tiled_rt_reference_wait_for_gather(prosper_host_tiled_rt_reference *pass, void *stream);
+
 /* render::ToneMap (host/tone_map.hpp; reference src/render/ToneMap.hpp:16-52): init with the LUT file
  * (res/texture/tony_mc_mapface.dds) or its texels, drawUi's two sliders, record into caller-owned device memory. */
 typedef struct prosper_host_tone_map prosper_host_tone_map;

@@ -17,6 +17,8 @@
  *   prosper_pt_read_hdr               the RGBA32F "rtIllumination" image           RtReference.cpp:178-187
  *   prosper_pt_blit_rgba16f           blitImage RGBA32F -> RGBA16F                 RtReference.cpp:339-377
  *   prosper_pt_get_counters           (new) deterministic work counters for the roofline model
+ *   prosper_pt_comm_* / _gather_tiles (new) multi-GPU: stripes per rank + one RCCL gather + de-interleave kernel
+ *                                     (the reference asserts renderArea.offset == 0, RtReference.cpp:327)
  *
  * All entry points are `extern "C"`, take PODs / plain pointers and sizes, never throw and return
  * PROSPER_PT_OK (0) or a negative error code; prosper_pt_last_error() returns the message of the
@@ -335,6 +337,50 @@ typedef struct prosper_pt_restir_inputs
 int prosper_pt_restir_di_trace(
     prosper_pt_ctx *ctx, const prosper_pt_restir_trace_pc *pc, const prosper_CameraUniforms *camera, uint32_t width,
     uint32_t height, const prosper_pt_restir_inputs *inputs, void *stream);
+
+/* ---- multi-GPU: image stripes per rank + ONE gather of the per-rank HDR tiles over RCCL + de-interleave ----
+ * (north star: "the image is tiled across the 8 GPUs of one node with an RCCL gather over xGMI of
+ * per-tile HDR buffers".)  The reference renders the whole image on one GPU and asserts renderArea.offset == 0
+ * (src/render/RtReference.cpp:327): these entry points have no counterpart there.  One process (or thread) per GPU,
+ * one context each; rank r renders with prosper_pt_tile_desc{stripeWidth, r, ranks}; pixels are independent
+ * (seed = absolute pixel + frame index, main.rgen:229), so nothing is exchanged while rendering.
+ *
+ * RCCL is loaded on first use (dlopen librccl.so.1); without it these calls fail with PROSPER_PT_ERR_UNSUPPORTED.
+ *   prosper_pt_comm_get_unique_id  ncclGetUniqueId: call on ONE rank, hand the 128 bytes to the others by any means
+ *   prosper_pt_comm_init           ncclCommInitRank on the context's device (collective over the ranks)
+ *   prosper_pt_comm_adopt          use the caller's ncclComm_t instead (borrowed, not destroyed)
+ *   prosper_pt_gather_tiles        after a render with a tile: ncclGather of every rank's localWidth*height RGBA32F
+ *                                  tile to `root` (grouped ncclSend/ncclRecv with per-rank counts when the stripes do
+ *                                  not divide evenly), then on the root a HIP kernel writes the width*height image into
+ *                                  `device_full_rgba32f` (ignored on the other ranks; NULL on the root: a buffer the context owns;
+ *                                  with one rank: a copy).
+ *                                  Enqueue-only.  Default: gather and de-interleave run on a stream the context owns,
+ *                                  after the work queued on `stream` so far, and overlap what the caller enqueues next -
+ *                                  the next render's accumulate kernel (the one writer of the tile) waits for them by
+ *                                  itself; readers of `device_full_rgba32f` call prosper_pt_gather_wait first.
+ *                                  PROSPER_PT_GATHER_IN_STREAM runs everything on `stream` instead.
+ *   prosper_pt_gather_wait         makes `stream` wait for the last gather (+ de-interleave)
+ *   prosper_pt_deinterleave_tiles  the root's kernel alone: `device_tiles` = the ranks' tiles back to back in rank order
+ */
+#define PROSPER_PT_COMM_ID_BYTES 128
+enum
+{
+    PROSPER_PT_GATHER_IN_STREAM = 1u << 0,
+};
+int prosper_pt_comm_get_unique_id(uint8_t id[PROSPER_PT_COMM_ID_BYTES]);
+int prosper_pt_comm_init(prosper_pt_ctx *ctx, const uint8_t id[PROSPER_PT_COMM_ID_BYTES], uint32_t rank, uint32_t ranks);
+int prosper_pt_comm_adopt(prosper_pt_ctx *ctx, void *nccl_comm, uint32_t rank, uint32_t ranks);
+int prosper_pt_comm_destroy(prosper_pt_ctx *ctx);
+int prosper_pt_gather_tiles(
+    prosper_pt_ctx *ctx, uint32_t root, void *device_full_rgba32f, size_t byte_size, uint32_t flags, void *stream);
+int prosper_pt_gather_wait(prosper_pt_ctx *ctx, void *stream);
+/* The root's gathered image: where the last prosper_pt_gather_tiles put it (the caller's buffer, or the context's own
+ * when `device_full_rgba32f` was NULL), and a synchronising copy of it to host memory (width*height RGBA32F). */
+int prosper_pt_get_gathered_device_ptr(prosper_pt_ctx *ctx, void **out_ptr, uint32_t *width, uint32_t *height);
+int prosper_pt_read_gathered(prosper_pt_ctx *ctx, float *rgba32f, size_t byte_size, void *stream);
+int prosper_pt_deinterleave_tiles(
+    prosper_pt_ctx *ctx, const void *device_tiles, uint32_t ranks, uint32_t stripe_width, uint32_t width, uint32_t height,
+    void *device_full_rgba32f, size_t byte_size, void *stream);
 
 int prosper_pt_get_counters(prosper_pt_ctx *ctx, prosper_pt_counters *out, void *stream);
 /* The same counters for one kernel stage (index as in prosper_pt_kernel_name): lets the roofline

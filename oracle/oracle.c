@@ -1486,11 +1486,19 @@ void ora_render(
         ctx.pc = pc;
         ctx.camera = camera;
         ctx.counters = &local;
-#pragma omp for schedule(dynamic, 4)
-        for (int64_t y = 0; y < (int64_t)height; ++y)
+        /* BASELINE.md's CPU plan: one worker per hardware thread pulling 16x16-pixel tiles from a shared counter
+         * (schedule(dynamic, 1) over the tile index is exactly that counter) */
+        const int64_t tilesX = ((int64_t)width + 15) / 16, tilesY = ((int64_t)height + 15) / 16;
+#pragma omp for schedule(dynamic, 1)
+        for (int64_t tileIndex = 0; tileIndex < tilesX * tilesY; ++tileIndex)
         {
-            for (uint32_t x = 0; x < width; ++x)
+            const uint32_t x0 = (uint32_t)(tileIndex % tilesX) * 16u, y0 = (uint32_t)(tileIndex / tilesX) * 16u;
+            for (uint32_t ty = 0; ty < 16u; ++ty)
+            for (uint32_t tx = 0; tx < 16u; ++tx)
             {
+                const uint32_t x = x0 + tx;
+                const int64_t y = (int64_t)y0 + ty;
+                if (x >= width || y >= (int64_t)height) continue;
                 uint32_t lx = x;
                 if (tiled)
                 {

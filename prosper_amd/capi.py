@@ -73,6 +73,16 @@ def lib():
     L.prosper_pt_kernel_name.restype = C.c_char_p
     L.prosper_pt_set_kernel_timing.argtypes = [vp, C.c_int]
     L.prosper_pt_eval_device_fn.argtypes = [vp, u32, vp, u32, vp, u32, u32]
+    # multi-GPU: stripes + RCCL gather + de-interleave
+    L.prosper_pt_comm_get_unique_id.argtypes = [vp]
+    L.prosper_pt_comm_init.argtypes = [vp, vp, u32, u32]
+    L.prosper_pt_comm_adopt.argtypes = [vp, vp, u32, u32]
+    L.prosper_pt_comm_destroy.argtypes = [vp]
+    L.prosper_pt_gather_tiles.argtypes = [vp, u32, vp, C.c_size_t, u32, vp]
+    L.prosper_pt_gather_wait.argtypes = [vp, vp]
+    L.prosper_pt_get_gathered_device_ptr.argtypes = [vp, C.POINTER(vp), C.POINTER(u32), C.POINTER(u32)]
+    L.prosper_pt_read_gathered.argtypes = [vp, vp, C.c_size_t, vp]
+    L.prosper_pt_deinterleave_tiles.argtypes = [vp, vp, u32, u32, u32, u32, vp, C.c_size_t, vp]
     # host layer
     L.prosper_host_last_error.restype = C.c_char_p
     L.prosper_host_camera_create.restype = vp
@@ -104,6 +114,15 @@ def lib():
     L.prosper_host_rt_reference_release_preserved.restype = None
     L.prosper_host_rt_reference_record.argtypes = [
         vp, vp, u32, u32, C.POINTER(RecordOptions), u32, C.POINTER(S.TileDesc), u32, vp, C.POINTER(S.ReferencePC)]
+    L.prosper_host_tiled_rt_reference_create.argtypes = [i32, u32, u32, vp, u32, u32, C.POINTER(vp)]
+    L.prosper_host_tiled_rt_reference_destroy.argtypes = [vp]
+    L.prosper_host_tiled_rt_reference_destroy.restype = None
+    L.prosper_host_tiled_rt_reference_context.argtypes = [vp]
+    L.prosper_host_tiled_rt_reference_context.restype = vp
+    L.prosper_host_tiled_rt_reference_set_scene.argtypes = [vp, C.POINTER(S.SceneView)]
+    L.prosper_host_tiled_rt_reference_record.argtypes = [
+        vp, vp, u32, u32, C.POINTER(RecordOptions), u32, u32, vp, C.POINTER(C.POINTER(C.c_float))]
+    L.prosper_host_tiled_rt_reference_wait_for_gather.argtypes = [vp, vp]
     L.prosper_host_tone_map_create.argtypes = [vp, C.c_char_p, C.POINTER(vp)]
     L.prosper_host_tone_map_create_from_texels.argtypes = [vp, vp, u32, C.POINTER(vp)]
     L.prosper_host_tone_map_destroy.argtypes = [vp]
@@ -261,6 +280,41 @@ class Context:
         _check(lib().prosper_pt_get_last_render_ms(self._h, C.byref(total), per))
         names = [lib().prosper_pt_kernel_name(i).decode() for i in range(S.MAX_KERNELS)]
         return total.value, {n: per[i] for i, n in enumerate(names) if n}
+
+    # ---- multi-GPU (include/prosper_pt/prosper_pt.h, "multi-GPU") ----
+    @staticmethod
+    def comm_unique_id():
+        """ncclGetUniqueId: 128 bytes to hand to every rank's comm_init."""
+        buf = (C.c_uint8 * 128)()
+        _check(lib().prosper_pt_comm_get_unique_id(buf))
+        return bytes(buf)
+
+    def comm_init(self, unique_id, rank, ranks):
+        buf = (C.c_uint8 * 128).from_buffer_copy(bytes(unique_id))
+        _check(lib().prosper_pt_comm_init(self._h, buf, rank, ranks))
+
+    def comm_destroy(self):
+        _check(lib().prosper_pt_comm_destroy(self._h))
+
+    def gather_tiles(self, root=0, device_ptr=None, byte_size=0, flags=0, stream=None):
+        """RCCL gather of the ranks' tiles to `root` + de-interleave there (enqueue only)."""
+        _check(lib().prosper_pt_gather_tiles(self._h, root, C.c_void_p(device_ptr), byte_size, flags, C.c_void_p(stream)))
+
+    def gather_wait(self, stream=None):
+        _check(lib().prosper_pt_gather_wait(self._h, C.c_void_p(stream)))
+
+    def read_gathered(self, stream=None):
+        """Root only: the gathered [height, width, 4] float32 image (synchronises)."""
+        p, w, h = C.c_void_p(), C.c_uint32(), C.c_uint32()
+        _check(lib().prosper_pt_get_gathered_device_ptr(self._h, C.byref(p), C.byref(w), C.byref(h)))
+        out = np.empty((h.value, w.value, 4), np.float32)
+        _check(lib().prosper_pt_read_gathered(self._h, out.ctypes.data, out.nbytes, C.c_void_p(stream)))
+        return out
+
+    def deinterleave_tiles(self, tiles_ptr, ranks, stripe_width, width, height, full_ptr, stream=None):
+        """The root's kernel alone, on raw device pointers."""
+        _check(lib().prosper_pt_deinterleave_tiles(self._h, C.c_void_p(tiles_ptr), ranks, stripe_width, width, height,
+                                                   C.c_void_p(full_ptr), width * height * 16, C.c_void_p(stream)))
 
     def eval_device_fn(self, fn, inputs, in_stride, out_stride):
         a = np.ascontiguousarray(inputs, dtype=np.float32).reshape(-1, in_stride)

@@ -256,6 +256,7 @@ void prosper_host_camera_update_buffer(prosper_host_camera *c, prosper_CameraUni
 int prosper_host_camera_changed_this_frame(const prosper_host_camera *c) { return c->cam.changedThisFrame() ? 1 : 0; }
 void prosper_host_set_error(const char *message) { g_hostError = message ? message : ""; }
 void prosper_host_camera_end_frame(prosper_host_camera *c) { c->cam.endFrame(); }
+scene::Camera *prosper_host_camera_object(prosper_host_camera *c) { return &c->cam; }
 
 int prosper_host_rt_reference_create(int32_t deviceOrdinal, uint32_t createFlags, prosper_host_rt_reference **out)
 {

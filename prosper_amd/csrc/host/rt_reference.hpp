@@ -119,3 +119,7 @@ class RtReference
 };
 
 } // namespace render
+
+// the scene::Camera behind a prosper_host_camera handle (for the other shims of the host layer)
+struct prosper_host_camera;
+extern "C" scene::Camera *prosper_host_camera_object(prosper_host_camera *camera);

@@ -17,108 +17,23 @@
 #include <vector>
 
 #include "bvh_build.hpp"
+#include "pt_context.hpp"
 #include "pt_kernels.hpp"
 #include "pt_scene.hpp"
+#include "pt_tiling.hpp"
 
 using namespace ppt;
 
-namespace
+namespace ppt
 {
-
-thread_local std::string g_lastError;
-
+thread_local std::string g_lastErrorStorage;
 int fail(int code, const std::string &msg)
 {
-    g_lastError = msg;
+    g_lastErrorStorage = msg;
     return code;
 }
+} // namespace ppt
 
-#define PPT_HIP(call)                                                                                                  \
-    do                                                                                                                 \
-    {                                                                                                                  \
-        const hipError_t e_ = (call);                                                                                  \
-        if (e_ != hipSuccess)                                                                                          \
-            return fail(PROSPER_PT_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e_));                        \
-    } while (0)
-
-struct DeviceAllocation
-{
-    void *ptr = nullptr;
-    size_t bytes = 0;
-};
-
-} // namespace
-
-struct prosper_pt_ctx
-{
-    int device = 0;
-    uint32_t flags = 0;
-    std::vector<DeviceAllocation> sceneAllocations;
-    uint64_t sceneBytes = 0;
-    bool haveScene = false;
-    DeviceScene scene = {};
-    prosper_pt_scene_stats stats = {};
-    // light buffers are re-uploaded every frame in prosper; keep their device addresses mutable
-    prosper_DirectionalLightParameters *dDirectional = nullptr;
-    prosper_PointLightsBuffer *dPointLights = nullptr;
-    prosper_SpotLightsBuffer *dSpotLights = nullptr;
-
-    float4 *hdr = nullptr; // current HDR buffer (internal or caller-owned)
-    float4 *ownedHdr = nullptr;
-    size_t ownedHdrBytes = 0;
-    void *externalHdr = nullptr;
-    size_t externalHdrBytes = 0;
-    uint32_t localWidth = 0, height = 0;
-
-    unsigned long long *dCounters = nullptr; // kStageCount x 16 u64: one block of work counters per kernel stage
-    uint32_t *dWorkCounter = nullptr;        // work-distribution counter of the persistent kernel
-    // wavefront workspace (one allocation, carved into the WavefrontBuffers arrays)
-    // global overflow of the traversal stacks (only for trees whose stack bound exceeds the LDS stack)
-    uint64_t wfSlots = 0;
-
-    bool kernelTiming = false;
-    static constexpr uint32_t kMaxTimedLaunches = 96;
-    hipEvent_t events[kMaxTimedLaunches + 1] = {};
-    uint32_t eventStage[kMaxTimedLaunches] = {};
-    uint32_t timedLaunches = 0;
-    bool timingValid = false;
-
-    void *restirScratch = nullptr; // device copies of host G-buffer inputs (prosper_pt_restir_di_trace)
-    size_t restirScratchBytes = 0;
-    uint32_t *toneLut = nullptr; // dim^3 R9G9B9E5 texels
-    uint32_t toneLutDim = 0;
-    void *toneScratch = nullptr; // RGBA8 output when the caller only wants a host copy
-    size_t toneScratchBytes = 0;
-
-    // Everything a render has in flight between its first launch and its accumulate kernel: the wavefront
-    // workspace, the stack-overflow array and the two launch chains (pt_kernels.hpp WavefrontChains) with their
-    // timing events.  kRenderSlots slots = that many frames in flight (PROSPER_PT_RENDER_PIPELINED), the role `nextFrame` and
-    // the per-frame descriptor sets play in RtReference::record; everything else uses slot 0.
-    struct RenderSlot
-    {
-        int32_t *stackOverflow = nullptr;
-        size_t stackOverflowBytes = 0;
-        void *wfBlock = nullptr;
-        size_t wfBytes = 0;
-        hipEvent_t chainJoin[kMaxChains] = {};
-        hipEvent_t chainEvents[kMaxChains][kMaxTimedLaunches + 1] = {};
-        uint32_t chainStage[kMaxChains][kMaxTimedLaunches] = {};
-        uint32_t chainLaunches[kMaxChains] = {};
-        hipEvent_t free = nullptr; // recorded after the accumulate kernel of the slot's last render
-        bool freeRecorded = false;
-    };
-    // prosper keeps two frames in flight; a third one fills the machine better at the batch sizes of a multi-GPU
-    // rank share (1/4 share 0.71 -> 0.66 ms, C3 19.3 -> 18.9 ms; profiles/r01_pipelined.txt)
-    static constexpr uint32_t kRenderSlots = 3;
-    // The internal streams, three in all (+ the caller's = the four hardware queues of the device; more streams
-    // share queues and serialise): a pipelined render's chain runs on workStreams[slot], the two chains of an
-    // in-order render on workStreams[0] and [1].  All ordering between them goes through events.
-    hipStream_t workStreams[kRenderSlots] = {};
-    RenderSlot slots[kRenderSlots];
-    uint32_t lastSlot = 0;  // of the last render
-    uint32_t timedSlot = 0; // of the last render that ran with kernel timing on (timing readout)
-    hipEvent_t chainFork = nullptr;
-};
 using RenderSlot = prosper_pt_ctx::RenderSlot;
 constexpr uint32_t kStageChains = 4; // unnamed interval of the caller's stream: fork .. join of the chains
 
@@ -605,7 +520,7 @@ uint32_t compute_local_width(uint32_t width, const prosper_pt_tile_desc *tile)
 
 extern "C" {
 
-const char *prosper_pt_last_error(void) { return g_lastError.c_str(); }
+const char *prosper_pt_last_error(void) { return ppt::g_lastErrorStorage.c_str(); }
 uint32_t prosper_pt_abi_version(void) { return PROSPER_PT_ABI_VERSION; }
 
 int prosper_pt_create(const prosper_pt_device_desc *desc, prosper_pt_ctx **out_ctx)
@@ -656,6 +571,7 @@ void prosper_pt_destroy(prosper_pt_ctx *ctx)
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     (void)hipDeviceSynchronize();
+    destroy_tiling(ctx);
     free_scene(ctx);
     if (ctx->ownedHdr) (void)hipFree(ctx->ownedHdr);
     if (ctx->dCounters) (void)hipFree(ctx->dCounters);
@@ -787,6 +703,14 @@ int prosper_pt_render_frames(
     }
     ctx->localWidth = localWidth;
     ctx->height = height;
+    ctx->lastWidth = width;
+    ctx->stripeWidth = tiled ? tile->stripeWidth : 0;
+    ctx->stripeIndex = tiled ? tile->stripeIndex : 0;
+    ctx->stripeCount = tiled ? tile->stripeCount : 1;
+    // a gather of this tile may still be in flight on the communicator's stream (prosper_pt_gather_tiles): the
+    // accumulate kernel, which writes the tile, is enqueued on `s` and must come after it; detached path stages
+    // (PROSPER_PT_RENDER_PIPELINED) do not wait for `s` and overlap the gather
+    wait_for_gather_before_writing_tile(ctx, s);
 
     RenderParams p = {};
     p.pc = *pc;
@@ -1008,6 +932,11 @@ int prosper_pt_restir_di_trace(
     }
     ctx->localWidth = width;
     ctx->height = height;
+    ctx->lastWidth = width;
+    ctx->stripeWidth = 0;
+    ctx->stripeIndex = 0;
+    ctx->stripeCount = 1;
+    wait_for_gather_before_writing_tile(ctx, s);
 
     const void *ar = in->albedoRoughness, *nm = in->normalMetallic, *res = in->reservoirs;
     const float *depth = in->nonLinearDepth;

@@ -1,0 +1,112 @@
+// pt_context.hpp — the context behind the C-ABI handle (private to the library's translation units).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/prosper_pt/prosper_pt.h"
+#include "pt_kernels.hpp"
+#include "pt_scene.hpp"
+
+namespace ppt
+{
+
+struct DeviceAllocation
+{
+    void *ptr = nullptr;
+    size_t bytes = 0;
+};
+
+// records `msg` as the calling thread's last error (prosper_pt_last_error) and returns `code`
+int fail(int code, const std::string &msg);
+
+// multi-GPU state of a context (pt_tiling.cpp): the communicator, its stream and the root's staging buffer
+struct TilingState;
+
+} // namespace ppt
+
+#define PPT_HIP(call)                                                                                                  \
+    do                                                                                                                 \
+    {                                                                                                                  \
+        const hipError_t e_ = (call);                                                                                  \
+        if (e_ != hipSuccess)                                                                                          \
+            return ppt::fail(PROSPER_PT_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e_));                   \
+    } while (0)
+
+struct prosper_pt_ctx
+{
+    int device = 0;
+    uint32_t flags = 0;
+    std::vector<ppt::DeviceAllocation> sceneAllocations;
+    uint64_t sceneBytes = 0;
+    bool haveScene = false;
+    ppt::DeviceScene scene = {};
+    prosper_pt_scene_stats stats = {};
+    // light buffers are re-uploaded every frame in prosper; keep their device addresses mutable
+    prosper_DirectionalLightParameters *dDirectional = nullptr;
+    prosper_PointLightsBuffer *dPointLights = nullptr;
+    prosper_SpotLightsBuffer *dSpotLights = nullptr;
+
+    float4 *hdr = nullptr; // current HDR buffer (internal or caller-owned)
+    float4 *ownedHdr = nullptr;
+    size_t ownedHdrBytes = 0;
+    void *externalHdr = nullptr;
+    size_t externalHdrBytes = 0;
+    uint32_t localWidth = 0, height = 0;
+
+    unsigned long long *dCounters = nullptr; // kStageCount x 16 u64: one block of work counters per kernel stage
+    uint32_t *dWorkCounter = nullptr;        // work-distribution counter of the persistent kernel
+    // wavefront workspace (one allocation, carved into the WavefrontBuffers arrays)
+    // global overflow of the traversal stacks (only for trees whose stack bound exceeds the LDS stack)
+    uint64_t wfSlots = 0;
+
+    bool kernelTiming = false;
+    static constexpr uint32_t kMaxTimedLaunches = 96;
+    hipEvent_t events[kMaxTimedLaunches + 1] = {};
+    uint32_t eventStage[kMaxTimedLaunches] = {};
+    uint32_t timedLaunches = 0;
+    bool timingValid = false;
+
+    void *restirScratch = nullptr; // device copies of host G-buffer inputs (prosper_pt_restir_di_trace)
+    size_t restirScratchBytes = 0;
+    uint32_t *toneLut = nullptr; // dim^3 R9G9B9E5 texels
+    uint32_t toneLutDim = 0;
+    void *toneScratch = nullptr; // RGBA8 output when the caller only wants a host copy
+    size_t toneScratchBytes = 0;
+
+    // Everything a render has in flight between its first launch and its accumulate kernel: the wavefront
+    // workspace, the stack-overflow array and the two launch chains (pt_kernels.hpp WavefrontChains) with their
+    // timing events.  kRenderSlots slots = that many frames in flight (PROSPER_PT_RENDER_PIPELINED), the role `nextFrame` and
+    // the per-frame descriptor sets play in RtReference::record; everything else uses slot 0.
+    struct RenderSlot
+    {
+        int32_t *stackOverflow = nullptr;
+        size_t stackOverflowBytes = 0;
+        void *wfBlock = nullptr;
+        size_t wfBytes = 0;
+        hipEvent_t chainJoin[ppt::kMaxChains] = {};
+        hipEvent_t chainEvents[ppt::kMaxChains][kMaxTimedLaunches + 1] = {};
+        uint32_t chainStage[ppt::kMaxChains][kMaxTimedLaunches] = {};
+        uint32_t chainLaunches[ppt::kMaxChains] = {};
+        hipEvent_t free = nullptr; // recorded after the accumulate kernel of the slot's last render
+        bool freeRecorded = false;
+    };
+    // prosper keeps two frames in flight; a third one fills the machine better at the batch sizes of a multi-GPU
+    // rank share (1/4 share 0.71 -> 0.66 ms, C3 19.3 -> 18.9 ms; profiles/r01_pipelined.txt)
+    static constexpr uint32_t kRenderSlots = 3;
+    // The internal streams, three in all (+ the caller's = the four hardware queues of the device; more streams
+    // share queues and serialise): a pipelined render's chain runs on workStreams[slot], the two chains of an
+    // in-order render on workStreams[0] and [1].  All ordering between them goes through events.
+    hipStream_t workStreams[kRenderSlots] = {};
+    RenderSlot slots[kRenderSlots];
+    uint32_t lastSlot = 0;  // of the last render
+    uint32_t timedSlot = 0; // of the last render that ran with kernel timing on (timing readout)
+    hipEvent_t chainFork = nullptr;
+
+    // stripe partition of the last render (prosper_pt_tile_desc) and the multi-GPU gather state
+    uint32_t lastWidth = 0;
+    uint32_t stripeWidth = 0, stripeIndex = 0, stripeCount = 1;
+    ppt::TilingState *tiling = nullptr;
+};

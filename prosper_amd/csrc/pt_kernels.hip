@@ -488,6 +488,29 @@ void launch_render_persistent(
 // RGBA32F -> RGBA16F
 // ------------------------------------------------------------------------------------------
 
+// De-interleave of gathered rank tiles ("then a de-interleave copy kernel on rank 0"): rank r's tile
+// holds the image stripes s with s % ranks == r, rows of localWidth[r] texels; the full image row takes stripe s
+// from rank s % ranks at local stripe s / ranks.  One thread per texel (16 B): a stripe of 16 texels is a
+// 256-byte run on both sides, so loads and stores stay coalesced.  HBM-bound copy: 32 B per texel.
+__global__ __launch_bounds__(256) void deinterleave_tiles_kernel(
+    const float4 *__restrict__ tiles, TileLayout layout, float4 *__restrict__ full)
+{
+    const uint32_t x = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t y = blockIdx.y;
+    if (x >= layout.width) return;
+    const uint32_t stripe = x / layout.stripeWidth;
+    const uint32_t rank = stripe % layout.ranks;
+    const uint32_t lx = (stripe / layout.ranks) * layout.stripeWidth + (x - stripe * layout.stripeWidth);
+    full[(size_t)y * layout.width + x] = tiles[layout.tileOffset[rank] + (size_t)y * layout.localWidth[rank] + lx];
+}
+
+void launch_deinterleave_tiles(const float4 *tiles, const TileLayout &layout, float4 *full, hipStream_t stream)
+{
+    if (layout.width == 0 || layout.height == 0) return;
+    hipLaunchKernelGGL(
+        deinterleave_tiles_kernel, dim3((layout.width + 255u) / 256u, layout.height), dim3(256), 0, stream, tiles, layout, full);
+}
+
 __global__ void blit_rgba16f_kernel(const float4 *__restrict__ in, uint2 *__restrict__ out, uint32_t count)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;

@@ -93,6 +93,15 @@ uint32_t wavefront_lds_stack_entries(uint32_t stackBound);
 bool wavefront_shade_tables_in_lds(const DeviceScene &s);
 bool wavefront_scene_in_lds(uint32_t ldsStackEntries, uint32_t nodeCount, uint32_t triCount);
 void launch_blit_rgba16f(const float4 *in, void *out, uint32_t count, hipStream_t stream);
+// Where each rank's tile sits in the gathered buffer (texel offsets) and how wide its rows are
+constexpr uint32_t kMaxRanks = 64;
+struct TileLayout
+{
+    uint32_t width, height, stripeWidth, ranks;
+    uint32_t localWidth[kMaxRanks];
+    uint64_t tileOffset[kMaxRanks];
+};
+void launch_deinterleave_tiles(const float4 *tiles, const TileLayout &layout, float4 *full, hipStream_t stream);
 // BC7 blocks of one level (row-major, 16 B each; width and height multiples of 4) -> RGBA8 texels in the tiled
 // layout of DeviceTexture
 void launch_decode_bc7(

@@ -136,6 +136,66 @@ class RtReference:
         lib().prosper_host_rt_reference_release_preserved(self._h)
 
 
+class TiledRtReference:
+    """render::TiledRtReference (csrc/host/tiled_rt_reference.hpp): one rank of a multi-GPU job.  record() renders the
+    rank's stripes and enqueues the RCCL gather + de-interleave to the root; read_gathered() there returns the image."""
+
+    @staticmethod
+    def create_comm_id():
+        return Context.comm_unique_id()
+
+    def __init__(self, device, rank, ranks, comm_id=None, root=0, flags=0):
+        h = C.c_void_p()
+        buf = (C.c_uint8 * 128).from_buffer_copy(bytes(comm_id) if comm_id is not None else bytes(128))
+        rc = lib().prosper_host_tiled_rt_reference_create(device, rank, ranks, buf, root, flags, C.byref(h))
+        if rc != 0:
+            raise ProsperPtError(rc, lib().prosper_host_last_error().decode())
+        self._h = h
+        self._ctx = Context(_borrowed=lib().prosper_host_tiled_rt_reference_context(h))
+        self.rank, self.ranks, self.root = rank, ranks, root
+        self._world = None
+
+    @property
+    def context(self):
+        return self._ctx
+
+    def set_world(self, world):
+        view = world.view()
+        rc = lib().prosper_host_tiled_rt_reference_set_scene(self._h, C.byref(view))
+        if rc != 0:
+            raise ProsperPtError(rc, lib().prosper_host_last_error().decode())
+        self._world = world
+
+    def record(self, camera, width, height, options=None, frame_count=1, render_flags=0, stream=None):
+        """-> device pointer of the gathered image on the root (None elsewhere)."""
+        options = options or RtReference.Options()
+        o = RecordOptions(int(options.depthOfField), int(options.ibl), int(options.colorDirty),
+                          S.DrawType[options.drawType] if isinstance(options.drawType, str) else int(options.drawType))
+        out = C.POINTER(C.c_float)()
+        rc = lib().prosper_host_tiled_rt_reference_record(
+            self._h, camera._h, width, height, C.byref(o), frame_count, render_flags, C.c_void_p(stream), C.byref(out))
+        if rc != 0:
+            raise ProsperPtError(rc, lib().prosper_host_last_error().decode())
+        return C.cast(out, C.c_void_p).value
+
+    def wait_for_gather(self, stream=None):
+        rc = lib().prosper_host_tiled_rt_reference_wait_for_gather(self._h, C.c_void_p(stream))
+        if rc != 0:
+            raise ProsperPtError(rc, lib().prosper_host_last_error().decode())
+
+    def close(self):
+        if self._h:
+            lib().prosper_host_tiled_rt_reference_destroy(self._h)
+            self._h = None
+            self._ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class ToneMap:
     """Handle on the C++ render::ToneMap (csrc/host/tone_map.hpp; reference src/render/ToneMap.hpp)."""
 

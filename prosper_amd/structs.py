@@ -268,6 +268,7 @@ class SceneStats(C.Structure):
     ]
 
 
+GATHER_IN_STREAM = 1
 VARIANT_LDS_SCENE = 1
 VARIANT_LDS_TABLES = 2
 VARIANT_BATCHED_TEXTURES = 4

@@ -6,7 +6,8 @@
 // nothing for the compiler to fold), at 1 / 2 / 5 waves per SIMD, timed with hipEvents; in-kernel
 // s_memtime / s_memrealtime gives the shader clock the loop really ran at.  The "a+b" rows interleave two
 // kinds 1:1 to see whether their costs add or overlap.  Rows whose asm writes VCC or an SGPR declare that clobber,
-// and the compiler then separates the statements by an s_nop (hazard recogniser): their figures include it.
+// and the compiler then separates the statements by an s_nop (hazard recogniser): their figures include it.  SALU rows
+// declare SCC (the loop's own compare lives there).
 //
 //   hipcc -O2 --offload-arch=gfx950 scripts/valu_calibration.hip -o scripts/valu_calibration
 //   scripts/valu_calibration > profiles/r02_valu_calibration.json
@@ -66,6 +67,9 @@ typedef float v2f __attribute__((ext_vector_type(2)));
     X(cmp_lt_f32_vcc, 1, "v_cmp_lt_f32 vcc, %0, %1", "+v"(a[i]), "v"(x), "v"(y), "vcc")                                          \
     X(cmp_lt_f32_sgpr, 1, "v_cmp_lt_f32_e64 s[20:21], %0, %1", "+v"(a[i]), "v"(x), "v"(y), "s20", "s21")                                \
     X(cmp_then_cndmask, 2, "v_cmp_lt_f32 vcc, %0, %1\n v_cndmask_b32 %0, %0, %2, vcc", "+v"(a[i]), "v"(x), "v"(y), "vcc")        \
+    X(cmp_then_4cndmask, 5, "v_cmp_lt_f32 vcc, %0, %1\n v_cndmask_b32 %0, %0, %2, vcc\n v_cndmask_b32 %0, %0, %1, vcc\n v_cndmask_b32 %0, %0, %2, vcc\n v_cndmask_b32 %0, %0, %1, vcc", "+v"(a[i]), "v"(x), "v"(y), "vcc") \
+    X(cmp_sgpr_then_4cndmask, 5, "v_cmp_lt_f32_e64 s[20:21], %0, %1\n v_cndmask_b32_e64 %0, %0, %2, s[20:21]\n v_cndmask_b32_e64 %0, %0, %1, s[20:21]\n v_cndmask_b32_e64 %0, %0, %2, s[20:21]\n v_cndmask_b32_e64 %0, %0, %1, s[20:21]", "+v"(a[i]), "v"(x), "v"(y), "s20", "s21") \
+    X(cndmask_vcc_set_once, 1, "v_cndmask_b32 %0, %0, %1, vcc", "+v"(u[i]), "v"(ux), "v"(ux))                                 \
     X(rcp_f32, 1, "v_rcp_f32 %0, %0", "+v"(a[i]), "v"(x), "v"(y))                                                         \
     X(sqrt_f32, 1, "v_sqrt_f32 %0, %0", "+v"(a[i]), "v"(x), "v"(y))                                                       \
     X(div_scale_f32, 1, "v_div_scale_f32 %0, vcc, %0, %1, %2", "+v"(a[i]), "v"(x), "v"(y), "vcc")                                \
@@ -78,9 +82,9 @@ typedef float v2f __attribute__((ext_vector_type(2)));
     X(fma_plus_max3, 2, "v_fma_f32 %0, %0, %1, %2\n v_max3_f32 %0, %0, %1, %2", "+v"(a[i]), "v"(x), "v"(y))               \
     X(fma_plus_fma_mix, 2, "v_fma_f32 %0, %0, %1, %2\n v_fma_mix_f32 %0, %0, 1.0, -%1 op_sel_hi:[1,0,0]", "+v"(a[i]), "v"(x), "v"(y)) \
     X(fma_plus_mov, 2, "v_fma_f32 %0, %0, %1, %2\n v_mov_b32 %0, %0", "+v"(a[i]), "v"(x), "v"(y))                         \
-    X(salu_s_or_b64, 1, "s_or_b64 s[20:21], s[20:21], s[22:23]", "+v"(a[i]), "v"(x), "v"(y), "s20", "s21")                              \
-    X(fma_plus_salu, 2, "v_fma_f32 %0, %0, %1, %2\n s_or_b64 s[20:21], s[20:21], s[22:23]", "+v"(a[i]), "v"(x), "v"(y), "s20", "s21")   \
-    X(saveexec_pair, 2, "s_and_saveexec_b64 s[20:21], -1\n s_or_b64 exec, exec, s[20:21]", "+v"(a[i]), "v"(x), "v"(y), "s20", "s21")
+    X(salu_s_or_b64, 1, "s_or_b64 s[20:21], s[20:21], s[22:23]", "+v"(a[i]), "v"(x), "v"(y), "s20", "s21", "scc")                              \
+    X(fma_plus_salu, 2, "v_fma_f32 %0, %0, %1, %2\n s_or_b64 s[20:21], s[20:21], s[22:23]", "+v"(a[i]), "v"(x), "v"(y), "s20", "s21", "scc")   \
+    X(saveexec_pair, 2, "s_and_saveexec_b64 s[20:21], -1\n s_or_b64 exec, exec, s[20:21]", "+v"(a[i]), "v"(x), "v"(y), "s20", "s21", "scc")
 
 enum Kind
 {
@@ -118,6 +122,7 @@ __global__ __launch_bounds__(256) void valu_loop(float *out, unsigned long long 
     const unsigned int ux = __builtin_bit_cast(unsigned int, x);
     const unsigned long long m = __ballot(threadIdx.x & 1);
     asm volatile("s_mov_b64 s[20:21], 0\n s_mov_b64 s[22:23], 0" ::: "s20", "s21", "s22", "s23");
+    if constexpr (KIND == k_cndmask_vcc_set_once) asm volatile("v_cmp_lt_f32 vcc, %0, %1" ::"v"(x), "v"(y) : "vcc");
 
     const unsigned long long t0 = __builtin_amdgcn_s_memtime();
     const unsigned long long r0 = __builtin_amdgcn_s_memrealtime();
@@ -212,6 +217,7 @@ int main(int argc, char **argv)
                    "\"cycles_per_inst_per_simd\": %.3f, \"wave_insts_per_s_chip\": %.4e}",
                    first ? "" : ",\n", kNames[kind], k, ms, ghz, ns, ns * ghz, insts * k * cus * 4 / (ms * 1e-3));
             first = false;
+            fflush(stdout);
         }
     }
     printf("\n ]}\n");
