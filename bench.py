@@ -273,7 +273,7 @@ def roofline_object(kernels, pmc, pmc_source, peak, peak_source, ms_per_step, ti
     return r
 
 
-def time_config(ctx, torch, name, world, width, height, spp, max_bounces, ibl, steps, warmup, stream, render_flags):
+def time_config(ctx, torch, name, world, width, height, spp, max_bounces, ibl, steps, warmup, stream, render_flags, pmc):
     """A sub-configuration on one GPU (C3, C4): upload, one counted render, preheat, `steps` timed pipelined steps with
     per-launch events on one of them."""
     t0 = time.perf_counter()
@@ -302,7 +302,6 @@ def time_config(ctx, torch, name, world, width, height, spp, max_bounces, ibl, s
     ms_per_step = (time.perf_counter() - t0) * 1e3 / steps
     _, per_kernel = ctx.last_render_timing()
     ctx.set_kernel_timing(False)
-    pmc = pmc_tools.load_committed(name)
     kernels, _ = kernel_table(per_kernel, stage_bytes, ms_per_step, pmc)
     dominant = max(kernels, key=lambda k: kernels[k]["ms_per_launch"] * kernels[k]["launches_per_step"])
     out = {
@@ -354,18 +353,25 @@ def main():
     wavefront = not (args.megakernel or args.persistent)
 
     # ---- PMC passes of the headline configuration, as child processes, BEFORE this process touches the GPU ----
-    pmc, pmc_source = None, None
-    if world_size == 1 and wavefront and args.config in ("c2", "c3", "c4", "c5", "helmet"):
-        if not args.no_pmc:
-            try:
-                t0 = time.perf_counter()
-                pmc = pmc_tools.collect(args.config, timeout=420)
-                pmc_source = "rocprofv3 --pmc child passes of this run (%.0f s; scripts/pmc_tools.py)" % (time.perf_counter() - t0)
-            except Exception as e:  # no profiler, a refused counter, a timeout: the line says so instead of failing
-                print("bench: live PMC passes unavailable (%s)" % str(e)[:300], file=sys.stderr)
-        if pmc is None:
-            pmc = pmc_tools.load_committed(args.config)
-            pmc_source = pmc["source"] if pmc else "none (no live pass, no committed profile for these kernel sources)"
+    sub_names = [c for c in args.subconfigs.split(",") if c] if (args.config == "c2" and not args.no_subconfigs) else []
+    pmc_by_config = {}
+    if world_size == 1 and wavefront:
+        for name in [args.config] + sub_names:
+            if name not in ("c2", "c3", "c4", "c5", "helmet"):
+                continue
+            got = None
+            if not args.no_pmc:
+                try:
+                    t0 = time.perf_counter()
+                    got = pmc_tools.collect(name, timeout=420)
+                    got["source"] = "rocprofv3 --pmc child passes of this run (%.0f s; scripts/pmc_tools.py)" % (time.perf_counter() - t0)
+                except Exception as e:  # no profiler, a refused counter, a timeout: the line says so instead of failing
+                    print("bench: live PMC passes unavailable for %s (%s)" % (name, str(e)[:300]), file=sys.stderr)
+            if got is None:
+                got = pmc_tools.load_committed(name)
+            pmc_by_config[name] = got
+    pmc = pmc_by_config.get(args.config)
+    pmc_source = pmc["source"] if pmc else "none (no live pass, no committed profile for these kernel sources)"
 
     import torch
     import torch.distributed as dist
@@ -544,12 +550,13 @@ def main():
             if not args.no_extras:
                 result["tone_map"] = bench_tone_map(ctx, torch, width, height, stream)
                 result["restir_di_trace"] = bench_restir_di(ctx, torch, world, cam, focal, width, height, stream)
-            if not args.no_subconfigs and args.config == "c2":
+            if sub_names:
                 result["configs"] = {}
-                for name in [c for c in args.subconfigs.split(",") if c]:
+                for name in sub_names:
                     w2, b2, ww, hh, s2, mb2, ibl2 = CONFIGS[name]
                     try:
-                        sub = time_config(ctx, torch, name, b2(), ww, hh, s2, mb2, ibl2, max(6, args.steps // 2), 2, stream, render_flags)
+                        sub = time_config(ctx, torch, name, b2(), ww, hh, s2, mb2, ibl2, max(6, args.steps // 2), 2, stream, render_flags,
+                                          pmc_by_config.get(name))
                         sub["workload"] = w2
                         result["configs"][name] = sub
                     except Exception as e:  # a sub-configuration must never cost the headline line

@@ -233,6 +233,40 @@ int upload_scene_impl(prosper_pt_ctx *ctx, const prosper_pt_scene_view *v)
     // (PROSPER_PT_DEBUG_BATCHED_TEXTURES = 0 / 1 forces either path: same pixels, tested)
     s.batchedTextures = texelBytes > (32ull << 20) ? 1u : 0u;
     if (const char *forced = std::getenv("PROSPER_PT_DEBUG_BATCHED_TEXTURES")) s.batchedTextures = std::atoi(forced) ? 1u : 0u;
+    // material texture packs (pt_scene.hpp MaterialPack): base / MR / normal interleaved per texel where a material's
+    // three textures share extent and sampler.  PROSPER_PT_DEBUG_NO_TEXTURE_PACKS=1 keeps every material unpacked.
+    std::vector<MaterialPack> packs(v->materialCount);
+    uint32_t packedMaterials = 0;
+    const bool noPacks = std::getenv("PROSPER_PT_DEBUG_NO_TEXTURE_PACKS") != nullptr;
+    for (uint32_t i = 0; i < v->materialCount; ++i)
+    {
+        packs[i] = MaterialPack{nullptr, 0u, 0u, 0u, 0u};
+        const prosper_MaterialData &m = v->materials[i];
+        const uint32_t tb = m.baseColorTextureSampler & 0xFFFFFFu, tm = m.metallicRoughnessTextureSampler & 0xFFFFFFu,
+                       tn = m.normalTextureSampler & 0xFFFFFFu;
+        const uint32_t sb = m.baseColorTextureSampler >> 24, sm = m.metallicRoughnessTextureSampler >> 24,
+                       sn = m.normalTextureSampler >> 24;
+        if (noPacks || tb == 0 || tm == 0 || tn == 0 || sb != sm || sb != sn) continue;
+        const DeviceTexture &b = textures[tb], &r = textures[tm], &n = textures[tn];
+        if (b.width != r.width || b.width != n.width || b.height != r.height || b.height != n.height) continue;
+        if (b.width < 8u || b.height < 8u) continue; // tiny placeholder textures: nothing to gain
+        MaterialPack pk;
+        pk.width = b.width;
+        pk.height = b.height;
+        pk.tilesPerRow = (b.width + kPackTileW - 1u) / kPackTileW;
+        pk.sampler = sb;
+        const size_t texelCount = (size_t)pk.tilesPerRow * kPackTileW * (((size_t)b.height + kPackTileH - 1u) / kPackTileH) * kPackTileH;
+        if ((rc = device_alloc(ctx, texelCount * sizeof(uint4), &d))) return rc;
+        pk.texels = static_cast<const uint4 *>(d);
+        launch_pack_material_textures(b, r, n, pk, nullptr);
+        packs[i] = pk;
+        ++packedMaterials;
+    }
+    PPT_HIP(hipGetLastError());
+    PPT_HIP(hipDeviceSynchronize());
+    if ((rc = upload(ctx, packs.data(), packs.size() * sizeof(MaterialPack), &d))) return rc;
+    s.materialPacks = static_cast<const MaterialPack *>(d);
+    ctx->packedMaterials = packedMaterials;
     const double textureSeconds = seconds_since(tTextures);
 
     // lights
@@ -652,7 +686,8 @@ int prosper_pt_get_scene_stats(prosper_pt_ctx *ctx, prosper_pt_scene_stats *out)
              ? PROSPER_PT_VARIANT_LDS_SCENE
              : 0u) |
         (wavefront_shade_tables_in_lds(ctx->scene) ? PROSPER_PT_VARIANT_LDS_TABLES : 0u) |
-        (ctx->scene.batchedTextures ? PROSPER_PT_VARIANT_BATCHED_TEXTURES : 0u) | (ldsEntries << PROSPER_PT_VARIANT_STACK_SHIFT);
+        (ctx->scene.batchedTextures ? PROSPER_PT_VARIANT_BATCHED_TEXTURES : 0u) |
+        (ctx->packedMaterials ? PROSPER_PT_VARIANT_TEXTURE_PACKS : 0u) | (ldsEntries << PROSPER_PT_VARIANT_STACK_SHIFT);
     return PROSPER_PT_OK;
 }
 

@@ -44,6 +44,7 @@ struct prosper_pt_ctx
     bool haveScene = false;
     ppt::DeviceScene scene = {};
     prosper_pt_scene_stats stats = {};
+    uint32_t packedMaterials = 0; // materials whose three textures are interleaved (MaterialPack)
     // light buffers are re-uploaded every frame in prosper; keep their device addresses mutable
     prosper_DirectionalLightParameters *dDirectional = nullptr;
     prosper_PointLightsBuffer *dPointLights = nullptr;

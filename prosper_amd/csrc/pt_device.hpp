@@ -325,6 +325,47 @@ PPT_D TexelTaps texel_taps(const DeviceTexture &t, const prosper_pt_sampler_desc
     k.o11 = texel_offset(t, i1, j1);
     return k;
 }
+// The same footprint in a MaterialPack (4 x 2-texel tiles of uint4 texels): offsets in uint4 units.
+struct PackTaps
+{
+    uint32_t o00, o10, o01, o11;
+    float a, b;
+};
+PPT_D uint32_t pack_texel_offset(const MaterialPack &t, int32_t i, int32_t j)
+{
+    const uint32_t tile = ((uint32_t)j >> 1) * t.tilesPerRow + ((uint32_t)i >> 2);
+    return tile * 8u + ((((uint32_t)j & 1u) << 2) | ((uint32_t)i & 3u));
+}
+PPT_D PackTaps pack_taps(const MaterialPack &t, const prosper_pt_sampler_desc &sd, f2 uv)
+{
+    const int32_t w = (int32_t)t.width;
+    const int32_t h = (int32_t)t.height;
+    PackTaps k;
+    if (sd.magFilter == PROSPER_PT_FILTER_NEAREST)
+    {
+        const int32_t i = wrap_coord(f2i(__builtin_floorf(uv.x * (float)w)), w, sd.wrapS);
+        const int32_t j = wrap_coord(f2i(__builtin_floorf(uv.y * (float)h)), h, sd.wrapT);
+        k.o00 = k.o10 = k.o01 = k.o11 = pack_texel_offset(t, i, j);
+        k.a = 0.0f;
+        k.b = 0.0f;
+        return k;
+    }
+    const float u = __builtin_fmaf(uv.x, (float)w, -0.5f);
+    const float v = __builtin_fmaf(uv.y, (float)h, -0.5f);
+    const float fu = __builtin_floorf(u);
+    const float fv = __builtin_floorf(v);
+    k.a = u - fu;
+    k.b = v - fv;
+    int32_t i0, i1, j0, j1;
+    wrap_pair(f2i(fu), w, sd.wrapS, i0, i1);
+    wrap_pair(f2i(fv), h, sd.wrapT, j0, j1);
+    k.o00 = pack_texel_offset(t, i0, j0);
+    k.o10 = pack_texel_offset(t, i1, j0);
+    k.o01 = pack_texel_offset(t, i0, j1);
+    k.o11 = pack_texel_offset(t, i1, j1);
+    return k;
+}
+
 struct RawTaps
 {
     uint32_t p00, p10, p01, p11;
@@ -502,7 +543,26 @@ PPT_D Material sample_material(const DeviceScene &s, uint32_t index, f2 uv)
     const uint32_t mrTex = data.metallicRoughnessTextureSampler & 0xFFFFFFu;
     const uint32_t nTex = data.normalTextureSampler & 0xFFFFFFu;
     f4 sBaseT = f4{1.0f, 1.0f, 1.0f, 1.0f}, sMrT = f4{0.0f, 0.0f, 0.0f, 0.0f}, sNT = f4{0.0f, 0.0f, 0.0f, 0.0f};
-    if constexpr (!BATCHED)
+    const MaterialPack pack = s.materialPacks[index];
+    if (pack.texels != nullptr)
+    {
+        // the three textures interleaved per texel (pt_scene.hpp MaterialPack): one footprint, four 12-byte loads
+        typedef uint32_t u32x3 __attribute__((ext_vector_type(3)));
+        typedef const __attribute__((address_space(1))) u32x3 *global_u32x3_ptr;
+        const PackTaps k = pack_taps(pack, s.samplers[pack.sampler], uv);
+        const global_u32_ptr base = (global_u32_ptr)pack.texels;
+        const u32x3 p00 = *(global_u32x3_ptr)(base + k.o00 * 4u);
+        const u32x3 p10 = *(global_u32x3_ptr)(base + k.o10 * 4u);
+        const u32x3 p01 = *(global_u32x3_ptr)(base + k.o01 * 4u);
+        const u32x3 p11 = *(global_u32x3_ptr)(base + k.o11 * 4u);
+        TexelTaps w;
+        w.a = k.a;
+        w.b = k.b;
+        sBaseT = filter_taps(w, RawTaps{p00.x, p10.x, p01.x, p11.x});
+        sMrT = filter_taps(w, RawTaps{p00.y, p10.y, p01.y, p11.y});
+        sNT = filter_taps(w, RawTaps{p00.z, p10.z, p01.z, p11.z});
+    }
+    else if constexpr (!BATCHED)
     {
         // one texture after the other: fewer live registers
         if (baseTex > 0) sBaseT = sample_texture(s, baseTex, data.baseColorTextureSampler >> 24, uv);

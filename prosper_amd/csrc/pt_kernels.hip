@@ -949,6 +949,35 @@ void launch_decode_bc7(
         tilesPerRow, static_cast<uint32_t *>(tiled));
 }
 
+// Interleaves the three tiled RGBA8 textures of a material into a MaterialPack (pt_scene.hpp): one thread per texel of
+// the padded pack extent (texels outside the image are zero and never addressed).
+__global__ __launch_bounds__(256) void pack_material_textures_kernel(
+    DeviceTexture base, DeviceTexture mr, DeviceTexture normal, MaterialPack pack, uint4 *__restrict__ out, uint32_t paddedW,
+    uint32_t paddedH)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t j = blockIdx.y;
+    if (i >= paddedW || j >= paddedH) return;
+    uint4 t = make_uint4(0u, 0u, 0u, 0u);
+    if (i < pack.width && j < pack.height)
+    {
+        t.x = reinterpret_cast<const uint32_t *>(base.texels)[texel_offset(base, (int32_t)i, (int32_t)j)];
+        t.y = reinterpret_cast<const uint32_t *>(mr.texels)[texel_offset(mr, (int32_t)i, (int32_t)j)];
+        t.z = reinterpret_cast<const uint32_t *>(normal.texels)[texel_offset(normal, (int32_t)i, (int32_t)j)];
+    }
+    out[pack_texel_offset(pack, (int32_t)i, (int32_t)j)] = t;
+}
+
+void launch_pack_material_textures(
+    const DeviceTexture &base, const DeviceTexture &mr, const DeviceTexture &normal, const MaterialPack &pack, hipStream_t stream)
+{
+    const uint32_t paddedW = pack.tilesPerRow * kPackTileW;
+    const uint32_t paddedH = ((pack.height + kPackTileH - 1u) / kPackTileH) * kPackTileH;
+    hipLaunchKernelGGL(
+        pack_material_textures_kernel, dim3((paddedW + 255u) / 256u, paddedH), dim3(256), 0, stream, base, mr, normal, pack,
+        const_cast<uint4 *>(pack.texels), paddedW, paddedH);
+}
+
 void launch_eval_fn(
     uint32_t fn, const float *in, uint32_t inStride, float *out, uint32_t outStride, uint32_t n, hipStream_t stream)
 {

@@ -106,6 +106,9 @@ void launch_deinterleave_tiles(const float4 *tiles, const TileLayout &layout, fl
 // layout of DeviceTexture
 void launch_decode_bc7(
     const void *blocks, uint32_t width, uint32_t height, uint32_t tilesPerRow, void *tiled, hipStream_t stream);
+// fills `pack.texels` (device memory, tilesPerRow * 4 x ceil(height / 2) * 2 uint4s) from the three tiled textures
+void launch_pack_material_textures(
+    const DeviceTexture &base, const DeviceTexture &mr, const DeviceTexture &normal, const MaterialPack &pack, hipStream_t stream);
 void launch_eval_fn(
     uint32_t fn, const float *in, uint32_t inStride, float *out, uint32_t outStride, uint32_t n, hipStream_t stream);
 

@@ -86,6 +86,23 @@ struct DeviceTexture
 };
 constexpr uint32_t kTexTileW = 8, kTexTileH = 4;
 
+// The three textures of a material - base colour, metallic-roughness, normal - are sampled at the SAME uv of every hit
+// (materials.glsl:47-119).  When they have the same extent and sampler (the usual glTF export) their texels are also
+// kept interleaved: one uint4 per texel = {base RGBA8, MR RGBA8, normal RGBA8, 0}, in 4 x 2-texel tiles of one 128-byte
+// line.  A hit's bilinear footprint is then four 12-byte loads out of ~1.9 lines instead of twelve 4-byte loads out of
+// ~4.2 lines, and one footprint computation instead of three.  Same texel values, same filter arithmetic: same bits.
+// texels == nullptr: the material is not packable (a texture missing, extents or samplers differ) and samples its
+// textures one by one.
+struct MaterialPack
+{
+    const uint4 *texels;
+    uint32_t width;
+    uint32_t height;
+    uint32_t tilesPerRow; // (width + 3) / 4
+    uint32_t sampler;
+};
+constexpr uint32_t kPackTileW = 4, kPackTileH = 2;
+
 // Everything a kernel needs about the scene; passed by value as a kernel argument so every
 // pointer arrives in SGPRs.
 struct DeviceScene
@@ -100,6 +117,7 @@ struct DeviceScene
     const prosper_ModelInstanceTransforms *modelInstanceTransforms;
     const prosper_MaterialData *materials;
     const DeviceTexture *textures;
+    const MaterialPack *materialPacks; // [materialCount]
     const prosper_pt_sampler_desc *samplers;
     const prosper_DirectionalLightParameters *directionalLight;
     const prosper_PointLightsBuffer *pointLights;

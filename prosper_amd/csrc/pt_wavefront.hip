@@ -329,7 +329,8 @@ __host__ __device__ inline uint32_t shade_table_bytes(const DeviceScene &s)
 {
     return s.drawInstanceCount * (uint32_t)sizeof(prosper_DrawInstance) +
            s.modelInstanceCount * (uint32_t)sizeof(prosper_ModelInstanceTransforms) +
-           s.materialCount * (uint32_t)sizeof(prosper_MaterialData) + s.pointLightCount * (uint32_t)sizeof(prosper_PointLight) +
+           s.materialCount * (uint32_t)(sizeof(prosper_MaterialData) + sizeof(MaterialPack)) +
+           s.pointLightCount * (uint32_t)sizeof(prosper_PointLight) +
            s.spotLightCount * (uint32_t)sizeof(prosper_SpotLight) + (uint32_t)sizeof(prosper_DirectionalLightParameters) + 64u;
 }
 // copies `bytes` (a multiple of 4) from global memory to the next 16-byte aligned LDS offset
@@ -359,6 +360,8 @@ __global__ __launch_bounds__(256, PPT_SHADE_WPE) void wf_shade(
             ldsTables, off, s.modelInstanceTransforms, s.modelInstanceCount * (uint32_t)sizeof(prosper_ModelInstanceTransforms)));
         s.materials = static_cast<const prosper_MaterialData *>(
             stage_table(ldsTables, off, s.materials, s.materialCount * (uint32_t)sizeof(prosper_MaterialData)));
+        s.materialPacks = static_cast<const MaterialPack *>(
+            stage_table(ldsTables, off, s.materialPacks, s.materialCount * (uint32_t)sizeof(MaterialPack)));
         s.directionalLight = static_cast<const prosper_DirectionalLightParameters *>(
             stage_table(ldsTables, off, s.directionalLight, (uint32_t)sizeof(prosper_DirectionalLightParameters)));
         // only the first `count` lights of each list are ever indexed (sample_light)

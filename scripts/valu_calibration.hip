@@ -16,6 +16,7 @@
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <vector>
 
 #define CHECK(x)                                                                                     \
@@ -70,6 +71,18 @@ typedef float v2f __attribute__((ext_vector_type(2)));
     X(cmp_then_4cndmask, 5, "v_cmp_lt_f32 vcc, %0, %1\n v_cndmask_b32 %0, %0, %2, vcc\n v_cndmask_b32 %0, %0, %1, vcc\n v_cndmask_b32 %0, %0, %2, vcc\n v_cndmask_b32 %0, %0, %1, vcc", "+v"(a[i]), "v"(x), "v"(y), "vcc") \
     X(cmp_sgpr_then_4cndmask, 5, "v_cmp_lt_f32_e64 s[20:21], %0, %1\n v_cndmask_b32_e64 %0, %0, %2, s[20:21]\n v_cndmask_b32_e64 %0, %0, %1, s[20:21]\n v_cndmask_b32_e64 %0, %0, %2, s[20:21]\n v_cndmask_b32_e64 %0, %0, %1, s[20:21]", "+v"(a[i]), "v"(x), "v"(y), "s20", "s21") \
     X(cndmask_vcc_set_once, 1, "v_cndmask_b32 %0, %0, %1, vcc", "+v"(u[i]), "v"(ux), "v"(ux))                                 \
+    X(cndmask_e64_vcc, 1, "v_cndmask_b32_e64 %0, %0, %1, vcc", "+v"(u[i]), "v"(ux), "v"(ux))                                  \
+    X(cndmask_vcc_nop_between, 1, "v_cndmask_b32 %0, %0, %1, vcc\n s_nop 0", "+v"(u[i]), "v"(ux), "v"(ux))                  \
+    X(cndmask_vcc_nop4_between, 1, "v_cndmask_b32 %0, %0, %1, vcc\n s_nop 3", "+v"(u[i]), "v"(ux), "v"(ux))                 \
+    X(cndmask_vcc_2_then_fma, 3, "v_cndmask_b32 %0, %0, %1, vcc\n v_cndmask_b32 %0, %0, %2, vcc\n v_fma_f32 %0, %0, %1, %2", "+v"(a[i]), "v"(x), "v"(y)) \
+    X(cndmask_alternating_sgprs, 2, "v_cndmask_b32_e64 %0, %0, %1, s[20:21]\n v_cndmask_b32_e64 %0, %0, %2, s[22:23]", "+v"(a[i]), "v"(x), "v"(y)) \
+    X(cmp_e64_vcc_then_4cndmask_e64, 5, "v_cmp_lt_f32_e64 vcc, %0, %1\n v_cndmask_b32_e64 %0, %0, %2, vcc\n v_cndmask_b32_e64 %0, %0, %1, vcc\n v_cndmask_b32_e64 %0, %0, %2, vcc\n v_cndmask_b32_e64 %0, %0, %1, vcc", "+v"(a[i]), "v"(x), "v"(y), "vcc") \
+    X(addc_vcc_chain, 1, "v_addc_co_u32 %0, vcc, %0, %1, vcc", "+v"(u[i]), "v"(ux), "v"(ux), "vcc")                          \
+    X(min_u32, 1, "v_min_u32 %0, %0, %1", "+v"(u[i]), "v"(ux), "v"(ux))                                                     \
+    X(max_f32, 1, "v_max_f32 %0, %0, %1", "+v"(a[i]), "v"(x), "v"(y))                                                       \
+    X(min3_f32, 1, "v_min3_f32 %0, %0, %1, %2", "+v"(a[i]), "v"(x), "v"(y))                                                 \
+    X(mov_dpp_quad, 1, "v_mov_b32_dpp %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf", "+v"(a[i]), "v"(x), "v"(y))   \
+    X(ds_swizzle, 1, "ds_swizzle_b32 %0, %0 offset:swizzle(SWAP,1)\n s_waitcnt lgkmcnt(0)", "+v"(a[i]), "v"(x), "v"(y))    \
     X(rcp_f32, 1, "v_rcp_f32 %0, %0", "+v"(a[i]), "v"(x), "v"(y))                                                         \
     X(sqrt_f32, 1, "v_sqrt_f32 %0, %0", "+v"(a[i]), "v"(x), "v"(y))                                                       \
     X(div_scale_f32, 1, "v_div_scale_f32 %0, vcc, %0, %1, %2", "+v"(a[i]), "v"(x), "v"(y), "vcc")                                \
@@ -121,8 +134,8 @@ __global__ __launch_bounds__(256) void valu_loop(float *out, unsigned long long 
     const v2f xx = v2f{x, x}, yy = v2f{y, y};
     const unsigned int ux = __builtin_bit_cast(unsigned int, x);
     const unsigned long long m = __ballot(threadIdx.x & 1);
-    asm volatile("s_mov_b64 s[20:21], 0\n s_mov_b64 s[22:23], 0" ::: "s20", "s21", "s22", "s23");
-    if constexpr (KIND == k_cndmask_vcc_set_once) asm volatile("v_cmp_lt_f32 vcc, %0, %1" ::"v"(x), "v"(y) : "vcc");
+    asm volatile("s_mov_b64 s[20:21], 0x5555\n s_mov_b64 s[22:23], 0" ::: "s20", "s21", "s22", "s23");
+    if constexpr (KIND == k_cndmask_vcc_set_once || KIND == k_cndmask_e64_vcc || KIND == k_cndmask_vcc_nop_between || KIND == k_cndmask_vcc_nop4_between || KIND == k_cndmask_vcc_2_then_fma) asm volatile("v_cmp_lt_f32 vcc, %0, %1" ::"v"(x), "v"(y) : "vcc");
 
     const unsigned long long t0 = __builtin_amdgcn_s_memtime();
     const unsigned long long r0 = __builtin_amdgcn_s_memrealtime();
@@ -169,6 +182,7 @@ static KernelFn kKernels[kKinds] = {
 int main(int argc, char **argv)
 {
     const int iters = argc > 1 ? atoi(argv[1]) : 10000;
+    const char *only = argc > 2 ? argv[2] : nullptr; // run only the kinds whose name contains this
     hipDeviceProp_t prop;
     CHECK(hipGetDeviceProperties(&prop, 0));
     const int cus = prop.multiProcessorCount;
@@ -194,6 +208,7 @@ int main(int argc, char **argv)
     CHECK(hipDeviceSynchronize());
     for (int kind = 0; kind < kKinds; ++kind)
     {
+        if (only && !strstr(kNames[kind], only)) continue;
         const int wavesList[] = {1, 2, 5};
         for (int wi = 0; wi < 3; ++wi)
         {

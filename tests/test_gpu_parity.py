@@ -813,6 +813,55 @@ def test_lds_staged_tables_equal_global_memory_tables(gpu_ctx, oracle, monkeypat
     assert not (gpu_ctx.scene_stats().variantFlags & S.VARIANT_LDS_TABLES)
 
 
+def test_texture_packs_equal_separate_textures(gpu_ctx, oracle, sponza_small, monkeypatch):
+    """Materials whose base / MR / normal textures share extent and sampler are sampled from an interleaved copy
+    (pt_scene.hpp MaterialPack: one footprint, four 12-byte loads).  Same texels, same filter arithmetic: the images with
+    and without the packs (PROSPER_PT_DEBUG_NO_TEXTURE_PACKS=1, read at upload) are bit-equal - on S-sponza-class and on
+    a wall of odd-sized textures under every wrap mode and both filters, which also equals the oracle."""
+    from prosper_amd.world import World
+    w, h = 240, 136
+    cam, fl = _camera(oracle, sponza_small, w, h)
+    pc = default_pc(S, fl, max_bounces=3, ibl=True)
+    images = []
+    for no_packs in (False, True):
+        if no_packs:
+            monkeypatch.setenv("PROSPER_PT_DEBUG_NO_TEXTURE_PACKS", "1")
+        gpu_ctx.upload_scene(sponza_small)
+        assert bool(gpu_ctx.scene_stats().variantFlags & S.VARIANT_TEXTURE_PACKS) == (not no_packs)
+        gpu_ctx.render(pc, cam, w, h, frames=2)
+        images.append(gpu_ctx.read_hdr())
+    monkeypatch.delenv("PROSPER_PT_DEBUG_NO_TEXTURE_PACKS")
+    assert same_bits(images[0], images[1]).all()
+
+    rng = np.random.default_rng(7)
+    world = World()
+    k = 0
+    for size in ((10, 7), (9, 16), (33, 8)):                      # (width, height): not multiples of the 4 x 2 tiles
+        for mag in (S.FILTER_LINEAR, S.FILTER_NEAREST):
+            for wrap in (S.WRAP_REPEAT, S.WRAP_MIRRORED_REPEAT, S.WRAP_CLAMP_TO_EDGE):
+                smp = world.add_sampler(mag, mag, wrap, wrap)
+                tex = [world.add_texture(rng.integers(0, 256, size=(size[1], size[0], 4), dtype=np.uint8)) for _ in range(3)]
+                mat = world.add_material(base_color=(1, 1, 1, 1), metallic=1.0, roughness=1.0, base_tex=(tex[0], smp),
+                                         mr_tex=(tex[1], smp), normal_tex=(tex[2], smp))
+                x, y = (k % 6) * 1.1 - 3.3, (k // 6) * 1.1 - 1.65
+                mesh = scenes._add(world, scenes.quad((x, y, 0), (x + 1, y, 0), (x + 1, y + 1, 0), (x, y + 1, 0), uv_scale=2.5), mat)
+                world.add_instance(world.add_model([(mesh, mat)]))
+                k += 1
+    world.set_directional_light((1.0, 1.0, 1.0), 3.0, (-0.3, -0.4, -1.0))
+    world.camera = dict(eye=(0.0, 0.0, 6.0), target=(0.0, 0.0, 0.0), up=(0.0, 1.0, 0.0), fov=0.9, zN=0.1, zF=100.0)
+    w, h = 384, 192
+    cam, fl = _camera(oracle, world, w, h)
+    gpu_ctx.upload_scene(world)
+    assert gpu_ctx.scene_stats().variantFlags & S.VARIANT_TEXTURE_PACKS
+    osc = oracle.OracleScene(world, brute_force=True)
+    for draw_type in ("Albedo", "Roughness", "Metallic", "ShadingNormal", "Default"):
+        pc = default_pc(S, fl, draw_type=S.DrawType[draw_type], max_bounces=2)
+        gpu_ctx.render(pc, cam, w, h)
+        want, _ = osc.render(pc, cam, w, h)
+        ok = same_bits(gpu_ctx.read_hdr(), want).all(axis=2)
+        assert ok.all(), "%s: %d of %d pixels differ" % (draw_type, (~ok).sum(), ok.size)
+
+
 def test_pipelined_renders_survive_changing_extents(gpu_ctx, oracle, cornell_world):
     """Frames in flight while the image extent (and with it every slot's workspace size) changes from call to call,
     growing and shrinking: each image equals the in-order render of the same call."""
