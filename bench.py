@@ -387,7 +387,17 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         # control plane only (communicator id, barriers, max-over-ranks): CPU tensors over gloo.  The data plane - the
         # gather of the HDR tiles - is the library's own RCCL communicator (prosper_pt_comm_init).
-        dist.init_process_group("gloo", rank=rank, world_size=world_size)
+        # (gloo announces its connections on STDOUT; this program's stdout carries exactly one JSON line)
+        sys.stdout.flush()
+        saved_stdout = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            dist.init_process_group("gloo", rank=rank, world_size=world_size)
+            dist.barrier()
+        finally:
+            sys.stdout.flush()
+            os.dup2(saved_stdout, 1)
+            os.close(saved_stdout)
 
     workload, builder, width, height, spp, max_bounces, ibl = CONFIGS[args.config]
     world = builder()

@@ -12,6 +12,7 @@
  *                                                                                  src/scene/World.cpp:468-536,585-802
  *                                     and the descriptor sets the pass binds       RtReference.cpp:238-274
  *   prosper_pt_update_lights          lights ring write                            World.cpp:531-535
+ *   prosper_pt_update_transforms      instance transforms + TLAS rebuild           World.cpp:359-466,749-802,878-928
  *   prosper_pt_render                 pushConstants + traceRaysKHR                 RtReference.cpp:278-330
  *                                     + the previous/illumination ping-pong        RtReference.cpp:178-219,332-334
  *   prosper_pt_read_hdr               the RGBA32F "rtIllumination" image           RtReference.cpp:178-187
@@ -265,6 +266,14 @@ int prosper_pt_upload_scene(prosper_pt_ctx *ctx, const prosper_pt_scene_view *sc
 int prosper_pt_update_lights(
     prosper_pt_ctx *ctx, const prosper_DirectionalLightParameters *directionalLight,
     const prosper_PointLightsBuffer *pointLights, const prosper_SpotLightsBuffer *spotLights);
+/* New instance transforms for the uploaded scene (the whole ModelInstanceTransforms table, `count` = the scene's
+ * modelInstanceCount; World::updateScene rewrites it every frame, World.cpp:359-466).  prosper then rebuilds its TLAS
+ * (World.cpp:749-802, 878-928); here the acceleration structure is one tree made of a subtree per model instance under a
+ * top level over the instances, so only the instances whose transform changed are re-flattened to world space and
+ * re-split, the top level is rebuilt and the nodes re-emitted - the cost of the moved instances' triangles, not the
+ * scene's (prosper_pt_scene_stats.bvhBuildSeconds reports it).  Synchronises the device.  Same pixels as a fresh
+ * prosper_pt_upload_scene of the moved scene (hits do not depend on the hierarchy). */
+int prosper_pt_update_transforms(prosper_pt_ctx *ctx, const prosper_ModelInstanceTransforms *transforms, uint32_t count);
 int prosper_pt_get_scene_stats(prosper_pt_ctx *ctx, prosper_pt_scene_stats *out);
 
 /* Optional: render into caller-owned device memory (localWidth*height RGBA32F texels, 16-byte

@@ -51,6 +51,7 @@ def lib():
     L.prosper_pt_update_lights.argtypes = [
         vp, C.POINTER(S.DirectionalLightParameters), C.POINTER(S.PointLightsBuffer), C.POINTER(S.SpotLightsBuffer)]
     L.prosper_pt_get_scene_stats.argtypes = [vp, C.POINTER(S.SceneStats)]
+    L.prosper_pt_update_transforms.argtypes = [vp, vp, u32]
     L.prosper_pt_set_output_buffer.argtypes = [vp, vp, C.c_size_t]
     L.prosper_pt_render.argtypes = [
         vp, C.POINTER(S.ReferencePC), C.POINTER(S.CameraUniforms), u32, u32, C.POINTER(S.TileDesc), u32, vp]
@@ -183,6 +184,14 @@ class Context:
     def update_lights(self, world):
         _check(lib().prosper_pt_update_lights(self._h, C.byref(world.directional), C.byref(world.point_lights),
                                               C.byref(world.spot_lights)))
+
+    def update_transforms(self, world):
+        """New ModelInstanceTransforms of the uploaded scene from `world` (same scene, moved instances)."""
+        world._frozen = None
+        f = world.freeze()
+        t = f["transforms"]
+        _check(lib().prosper_pt_update_transforms(self._h, C.cast(t, C.c_void_p), len(world.model_instances)))
+        self._world = world
 
     def scene_stats(self):
         st = S.SceneStats()

@@ -25,4 +25,35 @@ struct BvhBuildResult
 // Throws std::runtime_error if the depth bound of the LDS traversal stack cannot be met.
 BvhBuildResult build_bvh(const WorldTriangle *triangles, uint64_t count);
 
+// The same hierarchy built the way prosper builds its acceleration structures (src/scene/World.cpp:585-802: one BLAS
+// per mesh, a TLAS over the instances rebuilt every frame): one SAH subtree per model INSTANCE over that instance's
+// world-space triangles, and a top level over the instances' boxes whose leaves are those subtrees - spliced into
+// ONE 4-wide tree, so the traversal kernels do not know the difference and every box test stays world-space
+// arithmetic (hit contract).  The subtrees are kept: after an instance moved, rebuild() re-splits only that
+// instance's triangles and the (tiny) top level, then re-emits the nodes - a moved instance costs its own triangles,
+// not the scene's.  Subtrees build in parallel on the host's threads.
+class InstancedBvh
+{
+  public:
+    struct Range
+    {
+        uint32_t first; // first world triangle of the instance (in (drawInstance, primitive) order)
+        uint32_t count;
+    };
+    InstancedBvh();
+    ~InstancedBvh();
+    InstancedBvh(const InstancedBvh &) = delete;
+    InstancedBvh &operator=(const InstancedBvh &) = delete;
+    // Full build: every instance's subtree, the top level, the emitted nodes.
+    BvhBuildResult build(const WorldTriangle *triangles, uint64_t count, const std::vector<Range> &instances);
+    // `triangles` again holds ALL world triangles; only the subtrees of the instances flagged in `changed`
+    // (one flag per entry of the `instances` given to build) are rebuilt.
+    BvhBuildResult rebuild(const WorldTriangle *triangles, const std::vector<uint8_t> &changed);
+    [[nodiscard]] size_t instanceCount() const;
+
+  private:
+    struct Impl;
+    Impl *m;
+};
+
 } // namespace ppt

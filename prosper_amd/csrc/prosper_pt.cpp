@@ -63,6 +63,9 @@ void free_scene(prosper_pt_ctx *ctx)
 {
     for (auto &a : ctx->sceneAllocations) (void)hipFree(a.ptr);
     ctx->sceneAllocations.clear();
+    delete ctx->accel; // its device arrays are in the list above
+    ctx->accel = nullptr;
+    ctx->dTransforms = nullptr;
     ctx->sceneBytes = 0;
     ctx->haveScene = false;
     ctx->scene = DeviceScene{};
@@ -147,6 +150,32 @@ int validate_scene(const prosper_pt_scene_view *v)
         const prosper_DrawInstance &d = v->drawInstances[i];
         if (d.meshIndex >= v->meshCount || d.materialIndex >= v->materialCount || d.modelInstanceIndex >= v->modelInstanceCount)
             return fail(PROSPER_PT_ERR_SCENE, "draw instance " + std::to_string(i) + " references a missing mesh/material/transform");
+    }
+    return PROSPER_PT_OK;
+}
+
+// Nodes + leaf-order triangles of a freshly built hierarchy to the device (the node array grows when it has to).
+int upload_hierarchy(prosper_pt_ctx *ctx, const BvhBuildResult &bvh)
+{
+    AccelState *acc = ctx->accel;
+    const size_t nodeBytes = bvh.nodes.size() * sizeof(BvhNode);
+    if (nodeBytes > acc->nodeCapacityBytes)
+    {
+        void *d = nullptr;
+        const size_t capacity = nodeBytes + nodeBytes / 4 + 4096; // headroom: a moved instance changes the node count a little
+        const int rc = device_alloc(ctx, capacity, &d);          // (the previous array stays in the scene's list until the next upload)
+        if (rc != PROSPER_PT_OK) return rc;
+        acc->dNodes = static_cast<BvhNode *>(d);
+        acc->nodeCapacityBytes = capacity;
+    }
+    PPT_HIP(hipMemcpy(acc->dNodes, bvh.nodes.data(), nodeBytes, hipMemcpyHostToDevice));
+    ctx->scene.nodes = acc->dNodes;
+    if (acc->total)
+    {
+        PPT_HIP(hipMemcpy(acc->dPerm, bvh.permutation.data(), bvh.permutation.size() * 4, hipMemcpyHostToDevice));
+        launch_permute_triangles(acc->dFlat, acc->dPerm, acc->dTris, (uint32_t)acc->total, nullptr);
+        PPT_HIP(hipGetLastError());
+        PPT_HIP(hipDeviceSynchronize());
     }
     return PROSPER_PT_OK;
 }
@@ -298,101 +327,83 @@ int upload_scene_impl(prosper_pt_ctx *ctx, const prosper_pt_scene_view *v)
 
     // ---- acceleration structure (replaces buildNextBlas/buildCurrentTlas, World.cpp:585-802) ----
     const auto t0 = std::chrono::steady_clock::now();
-    std::vector<uint32_t> triOffsets(v->drawInstanceCount + 1, 0);
+    AccelState *acc = new (std::nothrow) AccelState();
+    if (!acc) return fail(PROSPER_PT_ERR_INVALID_ARGUMENT, "out of host memory");
+    ctx->accel = acc;
+    acc->triOffsets.assign(v->drawInstanceCount + 1, 0);
     std::vector<uint32_t> diFlags(v->drawInstanceCount ? v->drawInstanceCount : 1, 0);
     uint64_t total = 0;
     for (uint32_t i = 0; i < v->drawInstanceCount; ++i)
     {
         const prosper_pt_mesh_info &info = v->meshInfos[v->drawInstances[i].meshIndex];
-        triOffsets[i] = (uint32_t)total;
+        acc->triOffsets[i] = (uint32_t)total;
         total += info.indexCount / 3;
         // World.cpp:646-651: eOpaque iff the mesh's material is AlphaMode_Opaque
         diFlags[i] = v->materials[info.materialIndex].alphaMode == PROSPER_ALPHA_MODE_OPAQUE ? kTriFlagOpaque : 0u;
         if (v->geometryMetadatas[v->drawInstances[i].meshIndex].usesShortIndices == 1) diFlags[i] |= kTriFlagShortIndices;
+        // one subtree per run of draw instances of the same model instance (World.cpp:480-513 emits them together):
+        // prosper's TLAS instance (World.cpp:878-928)
+        const uint32_t mi = v->drawInstances[i].modelInstanceIndex;
+        if (acc->ranges.empty() || acc->rangeModelInstance.back() != mi)
+        {
+            acc->ranges.push_back(InstancedBvh::Range{acc->triOffsets[i], 0u});
+            acc->rangeModelInstance.push_back(mi);
+        }
+        acc->ranges.back().count += info.indexCount / 3;
     }
-    triOffsets[v->drawInstanceCount] = (uint32_t)total;
+    acc->triOffsets[v->drawInstanceCount] = (uint32_t)total;
     if (total >= (1ull << 28)) return fail(PROSPER_PT_ERR_UNSUPPORTED, "more than 2^28 triangles after instancing");
+    acc->total = total;
+    acc->drawInstanceCount = v->drawInstanceCount;
+    acc->transforms.assign(v->modelInstanceTransforms, v->modelInstanceTransforms + v->modelInstanceCount);
+    ctx->dTransforms = const_cast<prosper_ModelInstanceTransforms *>(s.modelInstanceTransforms);
 
-    WorldTriangle *dFlat = nullptr;
-    uint32_t *dOffsets = nullptr, *dFlags = nullptr, *dPerm = nullptr;
     const size_t triBytes = sizeof(WorldTriangle) * (size_t)(total ? total : 1);
-    PPT_HIP(hipMalloc((void **)&dFlat, triBytes));
-    auto cleanupTemp = [&]() {
-        (void)hipFree(dFlat);
-        (void)hipFree(dOffsets);
-        (void)hipFree(dFlags);
-        (void)hipFree(dPerm);
-    };
-    hipError_t e;
-    if ((e = hipMalloc((void **)&dOffsets, triOffsets.size() * 4)) != hipSuccess ||
-        (e = hipMalloc((void **)&dFlags, diFlags.size() * 4)) != hipSuccess ||
-        (e = hipMemcpy(dOffsets, triOffsets.data(), triOffsets.size() * 4, hipMemcpyHostToDevice)) != hipSuccess ||
-        (e = hipMemcpy(dFlags, diFlags.data(), diFlags.size() * 4, hipMemcpyHostToDevice)) != hipSuccess)
-    {
-        cleanupTemp();
-        return fail(PROSPER_PT_ERR_HIP, std::string("scene upload: ") + hipGetErrorString(e));
-    }
+    if ((rc = device_alloc(ctx, triBytes, &d))) return rc;
+    acc->dFlat = static_cast<WorldTriangle *>(d);
+    if ((rc = upload(ctx, acc->triOffsets.data(), acc->triOffsets.size() * 4, &d))) return rc;
+    acc->dOffsets = static_cast<uint32_t *>(d);
+    if ((rc = upload(ctx, diFlags.data(), diFlags.size() * 4, &d))) return rc;
+    acc->dFlags = static_cast<uint32_t *>(d);
+    if ((rc = device_alloc(ctx, (size_t)(total ? total : 1) * 4, &d))) return rc;
+    acc->dPerm = static_cast<uint32_t *>(d);
     // persistent (scene-lifetime) arrays the flatten kernel fills: shading records + their per-instance bases
-    void *dShade = nullptr, *dTriOffsets = nullptr;
-    if ((rc = device_alloc(ctx, sizeof(ShadeTriangle) * (size_t)(total ? total : 1), &dShade)) ||
-        (rc = upload(ctx, triOffsets.data(), triOffsets.size() * 4, &dTriOffsets)))
-    {
-        cleanupTemp();
-        return rc;
-    }
+    void *dShade = nullptr;
+    if ((rc = device_alloc(ctx, sizeof(ShadeTriangle) * (size_t)(total ? total : 1), &dShade))) return rc;
     s.shadeTriangles = static_cast<const ShadeTriangle *>(dShade);
-    s.triangleOffsets = static_cast<const uint32_t *>(dTriOffsets);
+    s.triangleOffsets = acc->dOffsets;
+    void *dTris = nullptr;
+    if ((rc = device_alloc(ctx, triBytes, &dTris))) return rc;
+    PPT_HIP(hipMemset(dTris, 0, triBytes));
+    acc->dTris = static_cast<WorldTriangle *>(dTris);
+    s.triangles = acc->dTris;
+
     launch_flatten_triangles(
-        s, dOffsets, v->drawInstanceCount, dFlags, dFlat, static_cast<ShadeTriangle *>(dShade), (uint32_t)total, nullptr);
-    std::vector<WorldTriangle> flat((size_t)total);
-    if ((e = hipGetLastError()) != hipSuccess ||
-        (total && (e = hipMemcpy(flat.data(), dFlat, sizeof(WorldTriangle) * (size_t)total, hipMemcpyDeviceToHost)) != hipSuccess) ||
-        (e = hipDeviceSynchronize()) != hipSuccess)
-    {
-        cleanupTemp();
-        return fail(PROSPER_PT_ERR_HIP, std::string("flatten_triangles: ") + hipGetErrorString(e));
-    }
+        s, acc->dOffsets, v->drawInstanceCount, acc->dFlags, acc->dFlat, static_cast<ShadeTriangle *>(dShade), (uint32_t)total, nullptr);
+    PPT_HIP(hipGetLastError());
+    acc->flat.resize((size_t)total);
+    if (total) PPT_HIP(hipMemcpy(acc->flat.data(), acc->dFlat, sizeof(WorldTriangle) * (size_t)total, hipMemcpyDeviceToHost));
+    PPT_HIP(hipDeviceSynchronize());
 
     BvhBuildResult bvh;
     const auto tBuild = std::chrono::steady_clock::now();
     try
     {
-        bvh = build_bvh(flat.data(), total);
+        // PROSPER_PT_DEBUG_FLAT_BVH=1: one SAH tree over all triangles, as round 1 built it (A/B, hierarchy tests)
+        if (std::getenv("PROSPER_PT_DEBUG_FLAT_BVH"))
+            bvh = build_bvh(acc->flat.data(), total);
+        else
+        {
+            bvh = acc->bvh.build(acc->flat.data(), total, acc->ranges);
+            acc->instanced = true;
+        }
     }
     catch (const std::exception &ex)
     {
-        cleanupTemp();
         return fail(PROSPER_PT_ERR_UNSUPPORTED, std::string("BVH build failed: ") + ex.what());
     }
-
     const double bvhBuildSeconds = seconds_since(tBuild);
-    if ((rc = upload(ctx, bvh.nodes.data(), bvh.nodes.size() * sizeof(BvhNode), &d)))
-    {
-        cleanupTemp();
-        return rc;
-    }
-    s.nodes = static_cast<const BvhNode *>(d);
-    void *dTris = nullptr;
-    if ((rc = device_alloc(ctx, triBytes, &dTris)))
-    {
-        cleanupTemp();
-        return rc;
-    }
-    if ((e = hipMemset(dTris, 0, triBytes)) != hipSuccess ||
-        (e = hipMalloc((void **)&dPerm, (bvh.permutation.size() ? bvh.permutation.size() : 1) * 4)) != hipSuccess ||
-        (total && (e = hipMemcpy(dPerm, bvh.permutation.data(), bvh.permutation.size() * 4, hipMemcpyHostToDevice)) != hipSuccess))
-    {
-        cleanupTemp();
-        return fail(PROSPER_PT_ERR_HIP, std::string("BVH upload: ") + hipGetErrorString(e));
-    }
-    launch_permute_triangles(dFlat, dPerm, static_cast<WorldTriangle *>(dTris), (uint32_t)total, nullptr);
-    if ((e = hipGetLastError()) != hipSuccess || (e = hipDeviceSynchronize()) != hipSuccess)
-    {
-        cleanupTemp();
-        return fail(PROSPER_PT_ERR_HIP, std::string("permute_triangles: ") + hipGetErrorString(e));
-    }
-    cleanupTemp();
-    s.triangles = static_cast<const WorldTriangle *>(dTris);
+    if ((rc = upload_hierarchy(ctx, bvh))) return rc;
 
     ctx->stats = prosper_pt_scene_stats{};
     ctx->stats.triangleCount = total;
@@ -670,6 +681,61 @@ int prosper_pt_update_lights(
     PPT_HIP(hipMemcpy(ctx->dSpotLights, spotLights, sizeof(*spotLights), hipMemcpyHostToDevice));
     ctx->scene.pointLightCount = pointLights->count;
     ctx->scene.spotLightCount = spotLights->count;
+    return PROSPER_PT_OK;
+}
+
+int prosper_pt_update_transforms(prosper_pt_ctx *ctx, const prosper_ModelInstanceTransforms *transforms, uint32_t count)
+{
+    if (!ctx || !transforms) return fail(PROSPER_PT_ERR_INVALID_ARGUMENT, "prosper_pt_update_transforms: null argument");
+    if (!ctx->haveScene || !ctx->accel) return fail(PROSPER_PT_ERR_NO_SCENE, "no scene uploaded");
+    AccelState *acc = ctx->accel;
+    if (count != acc->transforms.size())
+        return fail(PROSPER_PT_ERR_INVALID_ARGUMENT, "prosper_pt_update_transforms: count differs from the scene's modelInstanceCount");
+    const auto t0 = std::chrono::steady_clock::now();
+    // which instances moved (World::updateScene rewrites every transform each frame, World.cpp:359-466; most are unchanged)
+    std::vector<uint8_t> changed(acc->ranges.size(), 0);
+    bool any = false;
+    for (size_t r = 0; r < acc->ranges.size(); ++r)
+    {
+        const uint32_t mi = acc->rangeModelInstance[r];
+        if (std::memcmp(&transforms[mi], &acc->transforms[mi], sizeof(prosper_ModelInstanceTransforms)) != 0)
+        {
+            changed[r] = 1;
+            any = true;
+        }
+    }
+    PPT_HIP(hipSetDevice(ctx->device));
+    PPT_HIP(hipDeviceSynchronize()); // renders in flight read the old transforms and the old hierarchy
+    PPT_HIP(hipMemcpy(ctx->dTransforms, transforms, sizeof(prosper_ModelInstanceTransforms) * count, hipMemcpyHostToDevice));
+    acc->transforms.assign(transforms, transforms + count);
+    if (!any) return PROSPER_PT_OK;
+    // world-space triangles again (the shading records hold object-space attributes and stay as they are)
+    launch_flatten_triangles(
+        ctx->scene, acc->dOffsets, acc->drawInstanceCount, acc->dFlags, acc->dFlat, nullptr, (uint32_t)acc->total, nullptr);
+    PPT_HIP(hipGetLastError());
+    for (size_t r = 0; r < acc->ranges.size(); ++r)
+        if ((changed[r] || !acc->instanced) && acc->ranges[r].count)
+            PPT_HIP(hipMemcpy(
+                acc->flat.data() + acc->ranges[r].first, acc->dFlat + acc->ranges[r].first,
+                sizeof(WorldTriangle) * (size_t)acc->ranges[r].count, hipMemcpyDeviceToHost));
+    BvhBuildResult bvh;
+    const auto tBuild = std::chrono::steady_clock::now();
+    try
+    {
+        bvh = acc->instanced ? acc->bvh.rebuild(acc->flat.data(), changed) : build_bvh(acc->flat.data(), acc->total);
+    }
+    catch (const std::exception &ex)
+    {
+        return fail(PROSPER_PT_ERR_UNSUPPORTED, std::string("BVH rebuild failed: ") + ex.what());
+    }
+    const double buildSeconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - tBuild).count();
+    const int rc = upload_hierarchy(ctx, bvh);
+    if (rc != PROSPER_PT_OK) return rc;
+    ctx->stats.nodeCount = bvh.nodes.size();
+    ctx->stats.maxDepth = bvh.maxDepth;
+    ctx->stats.deviceBytes = ctx->sceneBytes;
+    ctx->stats.bvhBuildSeconds = buildSeconds;
+    ctx->stats.buildSeconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     return PROSPER_PT_OK;
 }
 

@@ -7,6 +7,7 @@
 #include <vector>
 
 #include "../../include/prosper_pt/prosper_pt.h"
+#include "bvh_build.hpp"
 #include "pt_kernels.hpp"
 #include "pt_scene.hpp"
 
@@ -21,6 +22,27 @@ struct DeviceAllocation
 
 // records `msg` as the calling thread's last error (prosper_pt_last_error) and returns `code`
 int fail(int code, const std::string &msg);
+
+// Host + device state of the acceleration structure that outlives prosper_pt_upload_scene, so that moved instances can
+// be re-fitted without rebuilding the scene (prosper_pt_update_transforms): the world triangles in (drawInstance,
+// primitive) order on both sides, the per-instance subtrees (bvh_build.hpp InstancedBvh), the instance table.
+struct AccelState
+{
+    WorldTriangle *dFlat = nullptr; // (drawInstance, primitive) order: what flatten_triangles writes
+    WorldTriangle *dTris = nullptr; // leaf order: what the traversal reads
+    uint32_t *dOffsets = nullptr, *dFlags = nullptr, *dPerm = nullptr;
+    BvhNode *dNodes = nullptr;
+    size_t nodeCapacityBytes = 0;
+    std::vector<uint32_t> triOffsets;
+    std::vector<WorldTriangle> flat;
+    std::vector<InstancedBvh::Range> ranges;      // one per run of draw instances of a model instance
+    std::vector<uint32_t> rangeModelInstance;
+    std::vector<prosper_ModelInstanceTransforms> transforms;
+    InstancedBvh bvh;
+    bool instanced = false;
+    uint64_t total = 0;
+    uint32_t drawInstanceCount = 0;
+};
 
 // multi-GPU state of a context (pt_tiling.cpp): the communicator, its stream and the root's staging buffer
 struct TilingState;
@@ -110,4 +132,6 @@ struct prosper_pt_ctx
     uint32_t lastWidth = 0;
     uint32_t stripeWidth = 0, stripeIndex = 0, stripeCount = 1;
     ppt::TilingState *tiling = nullptr;
+    ppt::AccelState *accel = nullptr;
+    prosper_ModelInstanceTransforms *dTransforms = nullptr; // the scene's transform table (mutable alias)
 };

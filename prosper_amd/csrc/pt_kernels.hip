@@ -54,6 +54,7 @@ __global__ void flatten_triangles_kernel(
     t.primitive = prim;
     t.flags = drawInstanceFlags[di];
     out[g] = t;
+    if (shadeOut == nullptr) return; // re-flatten after moved instances: the shading records are object-space
 
     // the shading record of this triangle (pt_scene.hpp ShadeTriangle): geometry.glsl:220-244 per corner
     ShadeTriangle sh;

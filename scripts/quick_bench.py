@@ -37,6 +37,7 @@ def main():
         "c2": (lambda: scenes.cornell(), 1920, 1080, 8, 4, False),
         "c3": (lambda: scenes.sponza_class(texture_size=tex), 1920, 1080, 8, 4, True),
         "c4": (lambda: scenes.sponza_class(lights=True, foliage=True, texture_size=tex), 1920, 1080, 8, 4, True),
+        "helmet": (lambda: __import__("prosper_amd.flight_helmet", fromlist=["x"]).load_fixture(), 1920, 1080, 8, 4, True),
     }[args.config]
     builder, w, h, spp, mb, ibl = cfg
     spp = args.spp or spp

@@ -862,6 +862,64 @@ def test_texture_packs_equal_separate_textures(gpu_ctx, oracle, sponza_small, mo
         assert ok.all(), "%s: %d of %d pixels differ" % (draw_type, (~ok).sum(), ok.size)
 
 
+def test_moved_instances_refit_equals_fresh_upload(gpu_ctx, oracle, monkeypatch):
+    """prosper_pt_update_transforms (prosper: World::updateScene + the per-frame TLAS rebuild, World.cpp:359-466,749-802):
+    the acceleration structure is one subtree per model instance under a top level, so a moved instance re-splits only
+    its own triangles.  After moving two instances the image equals a fresh upload of the moved scene, the flat
+    (round-1) hierarchy's image and the oracle's, bit for bit; and the refit is cheaper than the full build."""
+    from prosper_amd import capi
+    from prosper_amd.world import rotate_y, translate
+
+    def build(moved):
+        world = scenes.sponza_class(lights=(8, 8), foliage=True, texture_size=64, sky_size=32, detail=0.5)
+        if moved:
+            for i, delta in ((3, translate((0.4, 0.25, -0.3)) @ rotate_y(0.6)), (17, translate((-0.2, 0.0, 0.5)))):
+                model, m = world.model_instances[i]
+                world.model_instances[i] = (model, delta @ m)
+        return world
+    still, moved = build(False), build(True)
+    w, h = 320, 180
+    cam, fl = _camera(oracle, still, w, h)
+    pc = default_pc(S, fl, max_bounces=3, ibl=True)
+    gpu_ctx.upload_scene(still)
+    full_build = gpu_ctx.scene_stats().bvhBuildSeconds
+    gpu_ctx.render(pc, cam, w, h, frames=2)
+    before = gpu_ctx.read_hdr()
+    gpu_ctx.update_transforms(moved)
+    st = gpu_ctx.scene_stats()
+    assert st.triangleCount == moved.triangle_count() and st.bvhBuildSeconds < full_build
+    gpu_ctx.render(pc, cam, w, h, frames=2)
+    refit = gpu_ctx.read_hdr()
+    assert not same_bits(refit, before).all()  # the instances are in view: something moved
+    fresh = capi.Context(device=0)
+    try:
+        images = []
+        for flat in (False, True):
+            if flat:
+                monkeypatch.setenv("PROSPER_PT_DEBUG_FLAT_BVH", "1")
+            fresh.upload_scene(moved)
+            fresh.render(pc, cam, w, h, frames=2)
+            images.append(fresh.read_hdr())
+        monkeypatch.delenv("PROSPER_PT_DEBUG_FLAT_BVH")
+    finally:
+        fresh.close()
+    assert same_bits(refit, images[0]).all() and same_bits(refit, images[1]).all()
+    osc = oracle.OracleScene(moved)
+    want = None
+    for frame in (1, 2):
+        want, _ = osc.render(default_pc(S, fl, frame_index=frame, max_bounces=3, ibl=True, skip_history=(frame == 1)),
+                             cam, w, h, history=want)
+    assert same_bits(refit, want).all()
+    # moving them back restores the first image
+    gpu_ctx.update_transforms(still)
+    gpu_ctx.render(pc, cam, w, h, frames=2)
+    assert same_bits(gpu_ctx.read_hdr(), before).all()
+    # an unchanged table is a no-op; a table of the wrong length is refused
+    gpu_ctx.update_transforms(still)
+    with pytest.raises(capi.ProsperPtError):
+        capi._check(capi.lib().prosper_pt_update_transforms(gpu_ctx._h, None, 3))
+
+
 def test_pipelined_renders_survive_changing_extents(gpu_ctx, oracle, cornell_world):
     """Frames in flight while the image extent (and with it every slot's workspace size) changes from call to call,
     growing and shrinking: each image equals the in-order render of the same call."""
