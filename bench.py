@@ -203,18 +203,25 @@ def bench_restir_di(ctx, torch, world, cam, focal, width, height, stream, repeat
             "gbuffer_bytes_per_pixel": 60, "lights": int(lights)}
 
 
-def kernel_table(per_kernel, stage_bytes, ms_per_step, pmc):
-    """Per kernel: launches, raw per-launch duration (hipEvents; launches of frames in flight overlap), its EXCLUSIVE
-    share of the step (raw x ms_per_step / sum of raw: the shares add up to the step time), algorithmic bytes, and -
-    when PMC figures for this launch shape exist - VALU wave-instructions, lane utilisation and HBM bytes."""
-    raw_sum = sum(ms for ms, n in per_kernel.values() if n)
-    scale = min(1.0, ms_per_step / raw_sum) if raw_sum > 0 else 1.0
+def kernel_table(per_kernel, stage_bytes, ms_per_step, pmc, alone=None):
+    """Per kernel: launches, the raw per-launch duration inside the pipelined step (hipEvents; launches of the frames in
+    flight overlap and queue behind one another, so these sum to 2-3x the step), the duration of the same launch ALONE on
+    the GPU (one chain, in order: `alone`), and its EXCLUSIVE share of the step = alone x (ms_per_step / sum of the alone
+    durations of the step's launches): the shares add up to the step time.  (Without `alone`: raw x ms_per_step / sum
+    raw.)  Then algorithmic bytes and - when PMC figures for this launch shape exist - VALU wave-instructions, lane
+    utilisation and HBM bytes, priced against the exclusive time."""
+    basis = {}
+    for name, (sum_ms, launches) in per_kernel.items():
+        if launches:
+            basis[name] = (alone[name] if alone and name in alone else sum_ms / launches)
+    total = sum(basis[name] * per_kernel[name][1] for name in basis)
+    scale = min(1.0, ms_per_step / total) if total > 0 else 1.0
     kernels = {}
     for i, (name, (sum_ms, launches)) in enumerate(per_kernel.items()):
         if not launches:
             continue
-        raw = sum_ms / launches
-        k = {"launches_per_step": launches, "ms_per_launch_raw": raw, "ms_per_launch": raw * scale,
+        k = {"launches_per_step": launches, "ms_per_launch_raw": sum_ms / launches,
+             "ms_per_launch_alone": alone.get(name) if alone else None, "ms_per_launch": basis[name] * scale,
              "algorithmic_bytes_per_launch": stage_bytes[i] / launches}
         p = (pmc or {}).get("kernels", {}).get(name)
         if p:
@@ -230,6 +237,29 @@ def kernel_table(per_kernel, stage_bytes, ms_per_step, pmc):
             })
         kernels[name] = k
     return kernels, scale
+
+
+def time_alone(alone_ctx, world, cam, pc, width, height, spp, stream, torch):
+    """Per-launch durations with every launch alone on the GPU: the same workload on a one-chain, in-order context."""
+    alone_ctx.upload_scene(world)
+    buf = torch.zeros((height, width, 4), dtype=torch.float32, device="cuda")
+    alone_ctx.set_output_buffer(buf.data_ptr(), buf.numel() * 4)
+    alone_ctx.set_kernel_timing(False)
+    for _ in range(3):
+        alone_ctx.render(pc, cam, width, height, frames=spp, stream=stream)
+    acc = {}
+    repeats = 3
+    alone_ctx.set_kernel_timing(True)
+    for _ in range(repeats):
+        alone_ctx.render(pc, cam, width, height, frames=spp, stream=stream)
+        _, per = alone_ctx.last_render_timing()
+        for name, (sum_ms, launches) in per.items():
+            if launches:
+                acc[name] = acc.get(name, 0.0) + sum_ms / launches / repeats
+    alone_ctx.set_kernel_timing(False)
+    torch.cuda.synchronize()
+    alone_ctx.set_output_buffer(0, 0)
+    return acc
 
 
 def roofline_object(kernels, pmc, pmc_source, peak, peak_source, ms_per_step, timed_note):
@@ -273,7 +303,7 @@ def roofline_object(kernels, pmc, pmc_source, peak, peak_source, ms_per_step, ti
     return r
 
 
-def time_config(ctx, torch, name, world, width, height, spp, max_bounces, ibl, steps, warmup, stream, render_flags, pmc):
+def time_config(ctx, alone_ctx, torch, name, world, width, height, spp, max_bounces, ibl, steps, warmup, stream, render_flags, pmc):
     """A sub-configuration on one GPU (C3, C4): upload, one counted render, preheat, `steps` timed pipelined steps with
     per-launch events on one of them."""
     t0 = time.perf_counter()
@@ -302,7 +332,8 @@ def time_config(ctx, torch, name, world, width, height, spp, max_bounces, ibl, s
     ms_per_step = (time.perf_counter() - t0) * 1e3 / steps
     _, per_kernel = ctx.last_render_timing()
     ctx.set_kernel_timing(False)
-    kernels, _ = kernel_table(per_kernel, stage_bytes, ms_per_step, pmc)
+    alone = time_alone(alone_ctx, world, cam, pc, width, height, spp, stream, torch) if alone_ctx is not None else None
+    kernels, _ = kernel_table(per_kernel, stage_bytes, ms_per_step, pmc, alone)
     dominant = max(kernels, key=lambda k: kernels[k]["ms_per_launch"] * kernels[k]["launches_per_step"])
     out = {
         "ms_per_step": ms_per_step, "Mpaths_per_s": width * height * spp / ms_per_step / 1e3, "steps": steps,
@@ -418,11 +449,35 @@ def main():
     full = torch.zeros((height, width, 4), dtype=torch.float32, device="cuda") if (rank == 0 and world_size > 1) else None
 
     gather_mode = "none"
+    fallback_group, fallback_recv = None, None
     if world_size > 1 and not rehearse:
-        ids = [capi.Context.comm_unique_id() if rank == 0 else None]
+        ids = [None]
+        ok = 1
+        try:
+            if rank == 0:
+                ids[0] = capi.Context.comm_unique_id()
+        except capi.ProsperPtError as e:
+            print("bench: prosper_pt_comm_get_unique_id failed (%s)" % e, file=sys.stderr)
         dist.broadcast_object_list(ids, src=0)
-        ctx.comm_init(ids[0], rank, world_size)  # ncclCommInitRank: collective over the ranks
-        gather_mode = "prosper_pt_gather_tiles: ncclGather over RCCL + HIP de-interleave on rank 0, on the context's comm stream"
+        try:
+            if ids[0] is None:
+                raise capi.ProsperPtError(-6, "rank 0 could not create a communicator id")
+            ctx.comm_init(ids[0], rank, world_size)  # ncclCommInitRank: collective over the ranks
+        except capi.ProsperPtError as e:
+            print("bench: rank %d: prosper_pt_comm_init failed (%s)" % (rank, e), file=sys.stderr)
+            ok = 0
+        agreed = torch.tensor([ok], dtype=torch.int32)
+        dist.all_reduce(agreed, op=dist.ReduceOp.MIN)
+        if int(agreed.item()) == 1:
+            gather_mode = "prosper_pt_gather_tiles: ncclGather over RCCL + HIP de-interleave on rank 0, on the context's comm stream"
+        else:
+            # the library's own communicator is not available on this box: torch's RCCL process group carries the tiles,
+            # the product's kernel still de-interleaves them (said in config.parallelism)
+            ctx.comm_destroy()
+            fallback_group = dist.new_group(backend="nccl")
+            if rank == 0:
+                fallback_recv = [torch.empty_like(hdr) for _ in range(world_size)]
+            gather_mode = "FALLBACK: torch.distributed RCCL gather + prosper_pt_deinterleave_tiles (prosper_pt_comm_init failed, see stderr)"
     elif world_size > 1:
         gather_mode = "REHEARSAL: gloo through host memory + prosper_pt_deinterleave_tiles"
 
@@ -431,6 +486,12 @@ def main():
     def gather(step_tile):
         """The one data-path collective of step i, enqueued behind its render."""
         if world_size == 1:
+            return
+        if fallback_group is not None:
+            dist.gather(step_tile, fallback_recv, dst=0, group=fallback_group)
+            if rank == 0:
+                staging = torch.cat([p.reshape(-1) for p in fallback_recv])
+                ctx.deinterleave_tiles(staging.data_ptr(), world_size, STRIPE_WIDTH, width, height, full.data_ptr(), stream=stream)
             return
         if not rehearse:
             ctx.gather_tiles(root=0, device_ptr=full.data_ptr() if rank == 0 else None,
@@ -457,7 +518,7 @@ def main():
         gather(hdr)
 
     def drain():
-        if world_size > 1 and not rehearse:
+        if world_size > 1 and not rehearse and fallback_group is None:
             ctx.gather_wait(stream)
 
     # deterministic work counters of one launch (outside the timed region)
@@ -507,6 +568,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
 
+    alone_ctx = None
     if rank == 0:
         if world_size > 1:
             torch.cuda.synchronize()
@@ -514,10 +576,18 @@ def main():
         paths_per_step = width * height * spp
         ms_per_step = elapsed * 1e3 / args.steps
         peak, peak_source = valu_peak()
-        kernels, scale = kernel_table(per_kernel, stage_bytes, ms_per_step, pmc if world_size == 1 else None)
-        timed_note = ("hipEvents around every launch of timed step %d of %d, scaled by %.3f = ms_per_step / sum of the raw "
-                      "durations (launches of the frames in flight overlap): the exclusive shares add up to the step" % (
-                          timed_step + 1, args.steps, scale))
+        alone = None
+        if world_size == 1 and wavefront and render_flags:
+            alone_ctx = capi.Context(device=local_rank, flags=S.CREATE_SINGLE_CHAIN)
+            alone = time_alone(alone_ctx, world, cam, make_pc(focal, 1, max_bounces, ibl, True), width, height, spp, stream, torch)
+        kernels, scale = kernel_table(per_kernel, stage_bytes, ms_per_step, pmc if world_size == 1 else None, alone)
+        if alone:
+            timed_note = ("each launch ALONE on the GPU (one chain, in order, hipEvents, mean of 3 renders) x %.3f = ms_per_step / "
+                          "sum of the alone durations of a step's launches: with three frames in flight the launches overlap, the "
+                          "exclusive shares add up to the step" % scale)
+        else:
+            timed_note = ("hipEvents around every launch of timed step %d of %d, scaled by %.3f = ms_per_step / sum of the raw "
+                          "durations: the exclusive shares add up to the step" % (timed_step + 1, args.steps, scale))
         result = {
             "metric": "Mpaths/s",
             "value": paths_per_step * args.steps / elapsed / 1e6,
@@ -565,7 +635,7 @@ def main():
                 for name in sub_names:
                     w2, b2, ww, hh, s2, mb2, ibl2 = CONFIGS[name]
                     try:
-                        sub = time_config(ctx, torch, name, b2(), ww, hh, s2, mb2, ibl2, max(6, args.steps // 2), 2, stream, render_flags,
+                        sub = time_config(ctx, alone_ctx, torch, name, b2(), ww, hh, s2, mb2, ibl2, max(6, args.steps // 2), 2, stream, render_flags,
                                           pmc_by_config.get(name))
                         sub["workload"] = w2
                         result["configs"][name] = sub
@@ -578,6 +648,8 @@ def main():
 
     ctx.set_output_buffer(0, 0)
     ctx.close()
+    if alone_ctx is not None:
+        alone_ctx.close()
     if world_size > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -31,6 +31,11 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SQ_COUNTERS = ["SQ_WAVES", "SQ_INSTS_VALU", "SQ_THREAD_CYCLES_VALU", "SQ_ACTIVE_INST_VALU", "SQ_INSTS_SALU", "SQ_INSTS_VMEM",
                "SQ_INSTS_LDS", "SQ_BUSY_CU_CYCLES", "GRBM_GUI_ACTIVE"]
 PASSES = {"sq": SQ_COUNTERS, "fetch": ["FETCH_SIZE"], "write": ["WRITE_SIZE"]}
+# optional fourth pass (profiles only): what kinds of vector instructions a kernel issues.  ADD / MUL / FMA F32 are the
+# full-rate class of profiles/r02_valu_calibration.json; conversions and transcendentals are slower; the rest of
+# SQ_INSTS_VALU is compares, selects, min / max, moves, shifts and integer arithmetic
+MIX_COUNTERS = ["SQ_INSTS_VALU", "SQ_INSTS_VALU_ADD_F32", "SQ_INSTS_VALU_MUL_F32", "SQ_INSTS_VALU_FMA_F32",
+                "SQ_INSTS_VALU_TRANS_F32", "SQ_INSTS_VALU_INT32", "SQ_INSTS_VALU_CVT"]
 
 
 def kernel_source_hash():
@@ -102,7 +107,7 @@ def run_pass(config, counters, out_dir, extra_args=(), timeout=600):
         raise RuntimeError("rocprofv3 pass failed (%d): %s" % (p.returncode, p.stdout[-800:]))
 
 
-def collect(config, work_dir=None, extra_args=(), keep=False, timeout=600):
+def collect(config, work_dir=None, extra_args=(), keep=False, timeout=600, with_mix=False):
     """Runs the three passes and returns the per-kernel summary dict (see module docstring)."""
     if shutil.which("rocprofv3") is None:
         raise RuntimeError("rocprofv3 is not on PATH")
@@ -115,6 +120,11 @@ def collect(config, work_dir=None, extra_args=(), keep=False, timeout=600):
             d = os.path.join(work_dir, "%s_%s" % (config, name))
             run_pass(config, counters, d, extra_args, timeout)
             parts[name] = summarise(d)
+        mix = {}
+        if with_mix:
+            d = os.path.join(work_dir, "%s_mix" % config)
+            run_pass(config, MIX_COUNTERS, d, extra_args, timeout)
+            mix = summarise(d)
         kernels = {}
         for k, sq in parts["sq"].items():
             valu = sq.get("SQ_INSTS_VALU", 0.0)
@@ -137,6 +147,11 @@ def collect(config, work_dir=None, extra_args=(), keep=False, timeout=600):
                 "WRITE_SIZE_KB_per_launch": write_kb,
                 "hbm_bytes_per_launch": (2.0 * fetch_kb + write_kb) * 1024.0,
             }
+            if k in mix and mix[k].get("SQ_INSTS_VALU"):
+                total = mix[k]["SQ_INSTS_VALU"]
+                named = {n[len("SQ_INSTS_VALU_"):].lower(): mix[k].get(n, 0.0) / total for n in MIX_COUNTERS[1:]}
+                named["other"] = 1.0 - sum(named.values())
+                kernels[k]["valu_mix"] = named
         return {"config": config, "kernel_source_sha16": kernel_source_hash(),
                 "note": "rocprofv3 --pmc, three passes (SQ + GRBM; FETCH_SIZE; WRITE_SIZE) over scripts/quick_bench.py "
                         "--single-chain --steps 1: whole-batch launches, each alone on the GPU; means per launch; "
@@ -164,7 +179,7 @@ def load_committed(config):
 def main():
     for config in sys.argv[1:]:
         extra = []
-        out = collect(config, extra_args=extra)
+        out = collect(config, extra_args=extra, with_mix=True)
         path = os.path.join(ROOT, "profiles", "r02_%s_pmc.json" % config)
         with open(path, "w") as f:
             json.dump(out, f, indent=1)
@@ -174,6 +189,8 @@ def main():
                 config, k, v["launches_profiled"], v["valu_insts_per_launch"], v["lane_util"],
                 v["cycles_per_valu_inst_per_simd_profiled"], v["cu_busy"], v["hbm_bytes_per_launch"] / 1e9,
                 v["us_per_launch_profiled"]))
+            if "valu_mix" in v:
+                print("      mix: " + "  ".join("%s %.2f" % kv for kv in v["valu_mix"].items()))
 
 
 if __name__ == "__main__":
