@@ -167,3 +167,66 @@ def cache_path(source):
     import os
     folder = os.path.join(os.path.dirname(source), "prosper_cache")
     return os.path.join(folder, os.path.splitext(os.path.basename(source))[0] + ".dds")
+
+
+# ---- the texture cache's validity tag (src/scene/Texture.cpp:27-29,49-160) ----
+TEXTURE_CACHE_MAGIC = 0x5845545250535250  # "PRSPRTEX"
+TEXTURE_CACHE_VERSION = 5
+# std::filesystem::file_time_type as libstdc++ stores it (the tag is not meant to be portable, Texture.cpp:72-74):
+# int64 nanoseconds on chrono::file_clock, whose epoch is 2174-01-01T00:00:00Z = 6 437 664 000 s after the Unix epoch
+_FILE_CLOCK_EPOCH_DIFF_NS = 6437664000 * 10**9
+
+
+def cache_tag_path(cache_file):
+    """cacheTagPath: the cache file with the extension replaced (Texture.cpp:49-54)."""
+    import os
+    return os.path.splitext(cache_file)[0] + ".prosper_cache_tag"
+
+
+def source_write_time(source):
+    """std::filesystem::last_write_time(source) in the tag's representation."""
+    import os
+    return os.stat(source).st_mtime_ns - _FILE_CLOCK_EPOCH_DIFF_NS
+
+
+def read_cache_tag(cache_file):
+    """readCacheTag (Texture.cpp:63-95) -> (version, sourceWriteTime); a missing tag or another version gives
+    (0xFFFFFFFF or that version, None); a wrong magic raises DdsError like the original's runtime_error."""
+    import os
+    path = cache_tag_path(cache_file)
+    if not os.path.exists(path):
+        return 0xFFFFFFFF, None
+    with open(path, "rb") as f:
+        blob = f.read()
+    if len(blob) < 4:
+        return 0xFFFFFFFF, None
+    version = struct.unpack_from("<I", blob, 0)[0]
+    if version != TEXTURE_CACHE_VERSION:
+        return version, None
+    if len(blob) < 20 or struct.unpack_from("<Q", blob, 4)[0] != TEXTURE_CACHE_MAGIC:
+        raise DdsError("expected a valid texture cache tag in file '%s'" % path)
+    return version, struct.unpack_from("<q", blob, 12)[0]
+
+
+def write_cache_tag(cache_file, source):
+    """writeCacheTag (Texture.cpp:97-122): version, magic, the source's write time; through a temporary file."""
+    import os
+    path = cache_tag_path(cache_file)
+    tmp = os.path.splitext(path)[0] + ".prosper_cache_tag_TMP"
+    with open(tmp, "wb") as f:
+        f.write(struct.pack("<IQq", TEXTURE_CACHE_VERSION, TEXTURE_CACHE_MAGIC, source_write_time(source)))
+    os.replace(tmp, path)
+
+
+def cache_valid(cache_file, source):
+    """cacheValid (Texture.cpp:124-160): the cache file exists, its tag has the current version and the write time of
+    the source file it was made from; any error reading the tag means invalid."""
+    import os
+    try:
+        if not os.path.exists(cache_file):
+            return False
+        version, write_time = read_cache_tag(cache_file)
+        return version == TEXTURE_CACHE_VERSION and write_time == source_write_time(source)
+    except (OSError, DdsError, struct.error):
+        return False
+

@@ -318,8 +318,10 @@ def load_gltf(path, load_images=True, scene=None, use_texture_cache=True, bc7_on
     """Reads `path` (.gltf or .glb) into a World laid out the way prosper lays the same file out.
 
     With `use_texture_cache`, an image file whose `prosper_cache/<name>.dds` exists (prosper's BC7 / RGBA8 cache,
-    src/scene/Texture.cpp:377-415) is read from there: level 0 of that file is what prosper's sampler returns, the
-    PNG next to it is only the encoder's input.  (No staleness check: prosper's cache tag holds a file time.)
+    src/scene/Texture.cpp:38-47,213-296) AND is valid - its `.prosper_cache_tag` carries the current cache version and
+    the source file's write time (Texture.cpp:124-160; `use_texture_cache="always"` skips that check, for caches that
+    were copied between machines) - is read from there: that is what prosper samples, the PNG next to it is only the
+    encoder's input.  A stale or untagged cache is ignored (prosper would re-encode it from the source).
     With `bc7_on_gpu` a BC7 cache file is handed to the library undecoded (`World.add_texture_bc7`: decoded by the
     HIP kernel at upload); otherwise `prosper_amd.bc7` decodes it here - same texels either way (tested).
 
@@ -330,6 +332,7 @@ def load_gltf(path, load_images=True, scene=None, use_texture_cache=True, bc7_on
     w = World()
     w.missing_images = []
     w.cached_images = []
+    w.stale_cached_images = []
 
     # samplers: index + 1 (WorldData.cpp:699-719)
     for smp in doc.get("samplers", []):
@@ -343,7 +346,14 @@ def load_gltf(path, load_images=True, scene=None, use_texture_cache=True, bc7_on
             try:
                 cached = None
                 if use_texture_cache and "uri" in img and not img["uri"].startswith("data:"):
-                    cached = dds.cache_path(os.path.join(d.base, img["uri"].replace("%20", " ")))
+                    source = os.path.join(d.base, img["uri"].replace("%20", " "))
+                    cached = dds.cache_path(source)
+                    # Texture2D::init (Texture.cpp:377-415) reads the cache only when its tag names this source file's
+                    # write time and the current cache version; otherwise it re-encodes from the source
+                    if use_texture_cache != "always" and not dds.cache_valid(cached, source):
+                        if os.path.exists(cached):
+                            w.stale_cached_images.append(cached)
+                        cached = None
                 if cached is not None and os.path.exists(cached):
                     w.cached_images.append(cached)
                     fmt, tw, th, payload = dds.read_texture_raw(cached)

@@ -190,9 +190,36 @@ def test_gltf_prefers_prosper_cache(tmp_path):
     blocks = np.concatenate([random_blocks(m, 1, 500 + m) for m in (6, 1, 3, 5)])
     dds.write_texture(dds.cache_path(str(tmp_path / "albedo.png")), dds.DXGI_FORMAT_BC7_UNORM, 8, 8,
                       [blocks.tobytes(), random_blocks(6, 1, 1).tobytes()])
+    cache = dds.cache_path(str(tmp_path / "albedo.png"))
+    # an untagged cache is not valid (Texture.cpp:124-160): the PNG's texels are used, as prosper would re-encode
+    w_untagged = gltf.load_gltf(path)
+    assert not w_untagged.cached_images and w_untagged.stale_cached_images == [cache]
+    assert np.array_equal(w_untagged.textures[1], png)
+    assert np.array_equal(gltf.load_gltf(path, use_texture_cache="always").textures[1], bc7.decode_image(blocks.tobytes(), 8, 8))
+    dds.write_cache_tag(cache, str(tmp_path / "albedo.png"))
+    assert dds.cache_valid(cache, str(tmp_path / "albedo.png"))
+    assert dds.read_cache_tag(cache) == (5, dds.source_write_time(str(tmp_path / "albedo.png")))
     w1 = gltf.load_gltf(path)
     assert w1.cached_images == [str(tmp_path / "prosper_cache" / "albedo.dds")]
     assert np.array_equal(w1.textures[1], bc7.decode_image(blocks.tobytes(), 8, 8))
+    # touching the source makes the cache stale; an old-version tag and a wrong magic too
+    st = os.stat(tmp_path / "albedo.png")
+    os.utime(tmp_path / "albedo.png", ns=(st.st_atime_ns, st.st_mtime_ns + 10**9))
+    assert not dds.cache_valid(cache, str(tmp_path / "albedo.png"))
+    assert np.array_equal(gltf.load_gltf(path).textures[1], png)
+    dds.write_cache_tag(cache, str(tmp_path / "albedo.png"))
+    assert dds.cache_valid(cache, str(tmp_path / "albedo.png"))
+    tag = dds.cache_tag_path(cache)
+    assert tag.endswith("albedo.prosper_cache_tag")
+    blob = open(tag, "rb").read()
+    assert len(blob) == 20 and blob[4:12] == b"PRSPRTEX"
+    open(tag, "wb").write(b"\x04\0\0\0" + blob[4:])
+    assert dds.read_cache_tag(cache) == (4, None) and not dds.cache_valid(cache, str(tmp_path / "albedo.png"))
+    open(tag, "wb").write(blob[:4] + b"NOTMAGIC" + blob[12:])
+    with pytest.raises(dds.DdsError):
+        dds.read_cache_tag(cache)
+    assert not dds.cache_valid(cache, str(tmp_path / "albedo.png"))
+    open(tag, "wb").write(blob)
     w2 = gltf.load_gltf(path, use_texture_cache=False)
     assert np.array_equal(w2.textures[1], png)
 
