@@ -528,13 +528,22 @@ int ensure_wavefront_workspace(
 
 // Makes sure the global stack-overflow array covers `gridBlocks` workgroups of 256 lanes for a kernel
 // whose LDS stack holds `ldsEntries` entries; returns nullptr when the tree never needs more.
+static int ensure_scratch_dwords(
+    prosper_pt_ctx *ctx, RenderSlot &slot, size_t dwordsPerBlock, uint32_t gridBlocks, hipStream_t stream, int32_t **out);
 int ensure_stack_overflow(
     prosper_pt_ctx *ctx, RenderSlot &slot, uint32_t ldsEntries, uint32_t gridBlocks, hipStream_t stream, int32_t **out)
 {
-    *out = nullptr;
     const uint32_t bound = ctx->stats.maxDepth;
-    if (bound <= ldsEntries) return PROSPER_PT_OK;
-    const size_t bytes = (size_t)(bound - ldsEntries) * gridBlocks * 256u * sizeof(int32_t);
+    return ensure_scratch_dwords(ctx, slot, bound <= ldsEntries ? 0u : (size_t)(bound - ldsEntries) * 256u, gridBlocks, stream, out);
+}
+// `dwordsPerBlock` ints of kernel scratch per workgroup (stack overflow columns, ray-pool records)
+static int ensure_scratch_dwords(
+    prosper_pt_ctx *ctx, RenderSlot &slot, size_t dwordsPerBlock, uint32_t gridBlocks, hipStream_t stream, int32_t **out)
+{
+    (void)ctx;
+    *out = nullptr;
+    if (dwordsPerBlock == 0u) return PROSPER_PT_OK;
+    const size_t bytes = dwordsPerBlock * gridBlocks * sizeof(int32_t);
     if (bytes > slot.stackOverflowBytes)
     {
         (void)stream;
@@ -916,18 +925,18 @@ int prosper_pt_render_frames(
             pp.frameCount = frames;
             pp.pc.frameIndex = (p.pc.frameIndex + f0) % PROSPER_RT_FRAME_PERIOD;
             if (f0 > 0) pp.pc.flags &= ~(uint32_t)PROSPER_PC_FLAG_SKIP_HISTORY;
-            const uint32_t ldsEntries = wavefront_lds_stack_entries(ctx->stats.maxDepth);
+            const WavefrontPlan plan = wavefront_plan(
+                ctx->stats.maxDepth, (uint32_t)ctx->stats.nodeCount, (uint32_t)ctx->stats.triangleCount);
             int32_t *ovf = nullptr;
-            const int orc = ensure_stack_overflow(ctx, slot, ldsEntries, wavefront_grid_blocks(w), s, &ovf);
+            const int orc = ensure_scratch_dwords(ctx, slot, plan.scratchDwordsPerBlock, wavefront_grid_blocks(w), s, &ovf);
             if (orc != PROSPER_PT_OK) return orc;
-            const uint32_t overflowEntries = ctx->stats.maxDepth > ldsEntries ? ctx->stats.maxDepth - ldsEntries : 0u;
             // the slot's previous user (a render of two calls ago, or the previous chunk of this one) must be done
             // with the workspace: detached chains wait for that on their own stream, the others on the caller's
             chains.after = slot.freeRecorded ? slot.free : nullptr;
             if (!pipelined) wait_for_slot(slot, s);
             if (tp) tp->mark(kStageChains, s);
             launch_render_wavefront(
-                ctx->scene, pp, ctx->hdr, ctx->dCounters, w, ldsEntries, ovf, overflowEntries, (uint32_t)ctx->stats.nodeCount,
+                ctx->scene, pp, ctx->hdr, ctx->dCounters, w, plan, ovf, (uint32_t)ctx->stats.nodeCount,
                 (uint32_t)ctx->stats.triangleCount, countWork, tp, chains, s);
             release_slot(slot, s);
         }

@@ -1149,7 +1149,27 @@ struct GlobalGeom
     PPT_D NodeData node(int32_t i) const
     {
         const uint4 *np = reinterpret_cast<const uint4 *>(nodes + i);
+#ifdef PPT_EXPERIMENT_SPLIT_NODE_LOADS
+        // measurement only (scripts/build_variant.sh split -DPPT_EXPERIMENT_SPLIT_NODE_LOADS): the same 80 bytes as ten
+        // 8-byte loads - twice the cache accesses, same lines (profiles/r02_gather_microbench.txt)
+        typedef uint32_t u32x2v __attribute__((ext_vector_type(2)));
+        u32x2v h[10];
+        asm volatile("global_load_dwordx2 %0, %10, off\n\tglobal_load_dwordx2 %1, %10, off offset:8\n\t"
+                     "global_load_dwordx2 %2, %10, off offset:16\n\tglobal_load_dwordx2 %3, %10, off offset:24\n\t"
+                     "global_load_dwordx2 %4, %10, off offset:32\n\tglobal_load_dwordx2 %5, %10, off offset:40\n\t"
+                     "global_load_dwordx2 %6, %10, off offset:48\n\tglobal_load_dwordx2 %7, %10, off offset:56\n\t"
+                     "global_load_dwordx2 %8, %10, off offset:64\n\tglobal_load_dwordx2 %9, %10, off offset:72\n\t"
+                     "s_waitcnt vmcnt(0)"
+                     : "=&v"(h[0]), "=&v"(h[1]), "=&v"(h[2]), "=&v"(h[3]), "=&v"(h[4]), "=&v"(h[5]), "=&v"(h[6]),
+                       "=&v"(h[7]), "=&v"(h[8]), "=&v"(h[9])
+                     : "v"(np)
+                     : "memory");
+        return NodeData{uint4{h[0].x, h[0].y, h[1].x, h[1].y}, uint4{h[2].x, h[2].y, h[3].x, h[3].y},
+                        uint4{h[4].x, h[4].y, h[5].x, h[5].y}, uint4{h[6].x, h[6].y, h[7].x, h[7].y},
+                        uint4{h[8].x, h[8].y, h[9].x, h[9].y}};
+#else
         return NodeData{np[0], np[1], np[2], np[3], np[4]};
+#endif
     }
     PPT_D TriangleData tri(uint32_t i) const
     {
@@ -1186,10 +1206,11 @@ struct TraversalStack
     int32_t *ovf;
     uint32_t cap;
     uint32_t ovfStride;
+    uint32_t ldsStride; // 64: one column per lane of the wave
     PPT_D void push(int32_t &sp, int32_t v) const
     {
         if ((uint32_t)sp < cap)
-            lds[sp * 64] = v;
+            lds[(uint32_t)sp * ldsStride] = v;
         else
             ovf[(size_t)((uint32_t)sp - cap) * ovfStride] = v;
         ++sp;
@@ -1197,7 +1218,7 @@ struct TraversalStack
     PPT_D int32_t pop(int32_t &sp) const
     {
         --sp;
-        if ((uint32_t)sp < cap) return lds[sp * 64];
+        if ((uint32_t)sp < cap) return lds[(uint32_t)sp * ldsStride];
         return ovf[(size_t)((uint32_t)sp - cap) * ovfStride];
     }
 };

@@ -225,7 +225,7 @@ __global__ __launch_bounds__(256) void render_megakernel(
     const uint32_t lx = (tile % tilesX) * 16u + (wave & 1u) * 8u + (lane & 7u);
     const uint32_t py = (tile / tilesX) * 16u + (wave >> 1) * 8u + (lane >> 3);
     const TraversalStack stack{(lds_int32 *)ldsStack + wave * (kTraversalStackDepth * 64u) + lane,
-                               stackOverflow + blockIdx.x * 256u + threadIdx.x, kTraversalStackDepth, gridDim.x * 256u};
+                               stackOverflow + blockIdx.x * 256u + threadIdx.x, kTraversalStackDepth, gridDim.x * 256u, 64u};
 
     LaneCounters cnt = {};
     if (lx < p.localWidth && py < p.height)
@@ -361,7 +361,7 @@ __global__ __launch_bounds__(256) void render_persistent(
     const uint32_t wave = threadIdx.x >> 6;
     const uint32_t lane = threadIdx.x & 63u;
     const TraversalStack stack{(lds_int32 *)ldsStack + wave * (kTraversalStackDepth * 64u) + lane,
-                               stackOverflow + blockIdx.x * 256u + threadIdx.x, kTraversalStackDepth, gridDim.x * 256u};
+                               stackOverflow + blockIdx.x * 256u + threadIdx.x, kTraversalStackDepth, gridDim.x * 256u, 64u};
 
     const uint32_t tilesX = (p.localWidth + 7u) / 8u;
     const uint32_t tilesY = (p.height + 7u) / 8u;
@@ -566,7 +566,7 @@ __global__ __launch_bounds__(256) void restir_di_trace_kernel(
     const uint32_t px = (tile % tilesX) * 16u + (wave & 1u) * 8u + (lane & 7u);
     const uint32_t py = (tile / tilesX) * 16u + (wave >> 1) * 8u + (lane >> 3);
     const TraversalStack stack{(lds_int32 *)ldsStack + wave * (kTraversalStackDepth * 64u) + lane,
-                               stackOverflow + blockIdx.x * 256u + threadIdx.x, kTraversalStackDepth, gridDim.x * 256u};
+                               stackOverflow + blockIdx.x * 256u + threadIdx.x, kTraversalStackDepth, gridDim.x * 256u, 64u};
     if (px >= p.width || py >= p.height) return;
     const size_t i = (size_t)py * p.width + px;
 

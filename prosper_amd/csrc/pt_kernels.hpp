@@ -82,11 +82,21 @@ struct WavefrontChains
     hipEvent_t join[kMaxChains] = {};
     LaunchTimer *timers[kMaxChains] = {};
 };
-// `overflowEntries`: ints per lane in `stackOverflow` (stack bound - LDS entries), 0 when unused
+// Which traversal-kernel variants a render of a tree with this stack bound takes, and the global scratch they need
+struct WavefrontPlan
+{
+    uint32_t ldsStackEntries;       // 16 / 24 / 32: LDS stack entries per lane of the lane-owned traversal kernels
+    uint32_t overflowEntries;       // their stack entries per lane in global memory (stack bound - LDS entries)
+    uint32_t poolVariant;           // 0: wf_trace walks its rays lane-owned (trace_stream); else index + 1 of the ray-pool variant
+    uint32_t poolOverflowEntries;   // stack entries per pool slot in global memory
+    uint32_t scratchDwordsPerBlock; // ints of `scratch` per workgroup: the larger of the two kernels' needs
+};
+WavefrontPlan wavefront_plan(uint32_t stackBound, uint32_t nodeCount, uint32_t triCount);
+// `scratch`: plan.scratchDwordsPerBlock ints per workgroup of the launch grid (nullptr when that is 0)
 void launch_render_wavefront(
     const DeviceScene &s, const RenderParams &p, float4 *hdr, unsigned long long *counters, const WavefrontBuffers &w,
-    uint32_t ldsStackEntries, int32_t *stackOverflow, uint32_t overflowEntries, uint32_t nodeCount, uint32_t triCount,
-    bool countWork, LaunchTimer *timer, const WavefrontChains &chains, hipStream_t stream);
+    const WavefrontPlan &plan, int32_t *scratch, uint32_t nodeCount, uint32_t triCount, bool countWork, LaunchTimer *timer,
+    const WavefrontChains &chains, hipStream_t stream);
 // LDS stack entries (16/24/32) the wavefront traversal kernels use for a tree with this stack bound
 uint32_t wavefront_lds_stack_entries(uint32_t stackBound);
 // kernel variants a render takes: wf_shade with the scene tables staged in LDS; traversal out of an LDS copy of the scene

@@ -254,6 +254,9 @@ PPT_D void trace_stream(
         }
         else if (pick == kLaneAny)
         {
+#ifdef PPT_EXPERIMENT_COUNT_ANY_STEPS
+            if constexpr (COUNT) cnt.historyReads += lane == 0 ? 1u : 0u; // measurement only: any-hit phase steps
+#endif
             if (state == kLaneAny)
             {
                 state = kLaneTri;
@@ -263,6 +266,9 @@ PPT_D void trace_stream(
         }
         else
         {
+#ifdef PPT_EXPERIMENT_COUNT_ANY_STEPS
+            if constexpr (COUNT) cnt.pixelsWritten += lane == 0 ? 1u : 0u; // measurement only: refill steps
+#endif
             // hand finished rays over (converged call), then refill finished + idle lanes
             commit(state == kLaneFinished, ray, hit.drawInstance != kMissIndex, hit, d);
             if (state == kLaneFinished) state = kLaneIdle;

@@ -25,6 +25,7 @@
 
 #include "pt_device.hpp"
 #include "pt_render_common.hpp"
+#include "pt_trace_pool.hpp"
 #include "pt_trace_stream.hpp"
 
 // Register budgets (measured on C2/C3, profiles/r01_occupancy_ab.txt): the traversal kernels (generate,
@@ -110,6 +111,29 @@ __device__ __forceinline__ void add_to_slot(float4 *color, uint32_t slot, uint32
     color[slot] = make_float4(acc.x, acc.y, acc.z, 0.0f);
 }
 
+// How a wave walks a stream of rays: lane-owned (trace_stream) or out of its LDS ray pool (trace_pool)
+struct StreamTracer
+{
+    TraversalStack stack;
+    template <bool ANY, bool COUNT, class Geom, class Fetch, class Commit>
+    __device__ __forceinline__ void run(
+        const Geom &g, const DeviceScene &s, uint32_t n, float, LaneCounters &cnt, Fetch &&fetch, Commit &&commit) const
+    {
+        trace_stream<ANY, COUNT>(g, s, n, stack, cnt, fetch, commit);
+    }
+};
+template <uint32_t P, uint32_t S, uint32_t B>
+struct PoolTracer
+{
+    RayPool<P, S> pool;
+    template <bool ANY, bool COUNT, class Geom, class Fetch, class Commit>
+    __device__ __forceinline__ void run(
+        const Geom &g, const DeviceScene &s, uint32_t n, float tMin, LaneCounters &cnt, Fetch &&fetch, Commit &&commit) const
+    {
+        trace_pool<ANY, COUNT, B>(g, s, n, tMin, pool, cnt, fetch, commit);
+    }
+};
+
 // Copies the BVH nodes and world triangles into this workgroup's LDS.
 __device__ __forceinline__ LdsGeom stage_scene_in_lds(const DeviceScene &s, float4 *lds, uint32_t nodeCount, uint32_t triCount)
 {
@@ -142,7 +166,7 @@ __global__ __launch_bounds__(256, PPT_GEN_WPE) void wf_generate_extend(
     if (!id.valid) return;
     const uint32_t lane = lane_id();
     const TraversalStack stack{(lds_int32 *)ldsStack + (threadIdx.x >> 6) * (STACK * 64u) + lane,
-                               stackOverflow + blockIdx.x * 256u + threadIdx.x, (uint32_t)STACK, gridDim.x * 256u};
+                               stackOverflow + blockIdx.x * 256u + threadIdx.x, (uint32_t)STACK, gridDim.x * 256u, 64u};
     const bool traceRays = p.pc.maxBounces > 0;
 
     LaneCounters cnt = {};
@@ -235,8 +259,10 @@ __global__ __launch_bounds__(256, PPT_GEN_WPE) void wf_generate_extend(
             }
             nHit += total;
         };
-        // Camera rays of an 8x8 tile are coherent: 64 of them in lockstep keep ~96 % of the lanes
-        // busy (measured), so they skip the stream scheduler and its bookkeeping.
+        // Camera rays of an 8x8 tile are coherent: 64 of them in lockstep keep ~96 % of the lanes busy on C2 (0.73 on
+        // C3, 0.56 on C4: measured), so they skip the stream scheduler and its bookkeeping.  Running them through
+        // trace_stream() instead was measured slower on every configuration (profiles/r02_scheduler_experiments.txt:
+        // C2 365 -> 572 us, C3 1551 -> 1922, C4 7119 -> 9805, FlightHelmet 1438 -> 1562).
         for (uint32_t k0 = 0; k0 < w.segLen; k0 += 64u)
         {
             const uint32_t k = k0 + lane;
@@ -274,10 +300,10 @@ __global__ __launch_bounds__(256, PPT_GEN_WPE) void wf_generate_extend(
 // ------------------------------------------------------------------------------------------
 
 // One wave's extend work: traces the live rays of its segment (buffer set `cur`), compacts the hits.
-template <bool COUNT, class Geom>
+template <bool COUNT, class Geom, class Tracer>
 __device__ __forceinline__ void extend_segment(
     const Geom &g, const DeviceScene &s, const RenderParams &p, const WavefrontBuffers &w, const SegmentId &id, uint32_t bounce,
-    uint32_t cur, const TraversalStack &stack, LaneCounters &cnt)
+    uint32_t cur, const Tracer &tracer, LaneCounters &cnt)
 {
     const float4 *__restrict__ rayA = w.rayA[cur];
     const float4 *__restrict__ rayB = w.rayB[cur];
@@ -312,7 +338,7 @@ __device__ __forceinline__ void extend_segment(
         }
         nHit += total;
     };
-    trace_stream<false, COUNT>(g, s, n, stack, cnt, fetch, commit);
+    tracer.template run<false, COUNT>(g, s, n, 0.0f, cnt, fetch, commit);
     if (lane_id() == 0) w.segHits[id.seg] = nHit;
 }
 
@@ -486,10 +512,10 @@ __global__ __launch_bounds__(256, PPT_SHADE_WPE) void wf_shade(
 
 // One wave's shadow work: shadow() for the shadow rays shade queued in its segment; adds the direct
 // term of bounce `bounce` where the light is visible.
-template <bool COUNT, class Geom>
+template <bool COUNT, class Geom, class Tracer>
 __device__ __forceinline__ void shadow_segment(
     const Geom &g, const DeviceScene &s, const RenderParams &p, const WavefrontBuffers &w, const SegmentId &id, uint32_t bounce,
-    const TraversalStack &stack, LaneCounters &cnt)
+    const Tracer &tracer, LaneCounters &cnt)
 {
     const uint32_t n = w.segShadow[id.seg];
     auto fetch = [&](uint32_t k) {
@@ -521,7 +547,7 @@ __device__ __forceinline__ void shadow_segment(
             }
         }
     };
-    trace_stream<true, COUNT>(g, s, n, stack, cnt, fetch, commit);
+    tracer.template run<true, COUNT>(g, s, n, 0.1f, cnt, fetch, commit);
 }
 
 // Shadow rays of bounce `bounce` and (unless it was the last bounce) the closest-hit rays of bounce
@@ -542,8 +568,9 @@ __global__ __launch_bounds__(256, PPT_TRACE_WPE(STACK)) void wf_trace(
     const GlobalGeom gg{s.nodes, s.triangles};
     const SegmentId id = my_segment(w);
     if (!id.valid) return;
-    const TraversalStack stack{(lds_int32 *)ldsStack + (threadIdx.x >> 6) * (STACK * 64u) + lane_id(),
-                               stackOverflow + blockIdx.x * 256u + threadIdx.x, (uint32_t)STACK, gridDim.x * 256u};
+    const StreamTracer stack{TraversalStack{(lds_int32 *)ldsStack + (threadIdx.x >> 6) * (STACK * 64u) + lane_id(),
+                                            stackOverflow + blockIdx.x * 256u + threadIdx.x, (uint32_t)STACK,
+                                            gridDim.x * 256u, 64u}};
     LaneCounters cnt = {};
     if constexpr (LDS_SCENE)
         shadow_segment<COUNT>(lg, s, p, w, id, bounce, stack, cnt);
@@ -558,6 +585,39 @@ __global__ __launch_bounds__(256, PPT_TRACE_WPE(STACK)) void wf_trace(
             extend_segment<COUNT>(lg, s, p, w, id, bounce + 1u, nextCur, stack, cnt);
         else
             extend_segment<COUNT>(gg, s, p, w, id, bounce + 1u, nextCur, stack, cnt);
+    }
+    flush_counters<COUNT>(cnt, counters);
+}
+
+// wf_trace with the wave's rays in an LDS pool of P slots (pt_trace_pool.hpp) instead of one per lane.
+template <bool COUNT, uint32_t P, uint32_t S, uint32_t B, bool LDS_SCENE>
+__global__ __launch_bounds__(256, 4) void wf_trace_pool(
+    DeviceScene s, RenderParams p, WavefrontBuffers w, uint32_t bounce, uint32_t nextCur, uint32_t doExtend,
+    uint32_t nodeCount, uint32_t triCount, int32_t *__restrict__ scratch, uint32_t overflowEntries,
+    unsigned long long *__restrict__ counters)
+{
+    __shared__ uint32_t ldsPool[RayPool<P, S>::kLdsDwords * 4u];
+    __shared__ float4 ldsScene[LDS_SCENE ? kLdsSceneFloat4s : 1];
+    LdsGeom lg = {};
+    if constexpr (LDS_SCENE) lg = stage_scene_in_lds(s, ldsScene, nodeCount, triCount);
+    const GlobalGeom gg{s.nodes, s.triangles};
+    const SegmentId id = my_segment(w);
+    if (!id.valid) return;
+    const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const PoolTracer<P, S, B> tracer{
+        RayPool<P, S>::carve(ldsPool, wave, reinterpret_cast<uint32_t *>(scratch), blockIdx.x * 4u + wave, overflowEntries)};
+    LaneCounters cnt = {};
+    if constexpr (LDS_SCENE)
+        shadow_segment<COUNT>(lg, s, p, w, id, bounce, tracer, cnt);
+    else
+        shadow_segment<COUNT>(gg, s, p, w, id, bounce, tracer, cnt);
+    if (doExtend)
+    {
+        __threadfence_block();
+        if constexpr (LDS_SCENE)
+            extend_segment<COUNT>(lg, s, p, w, id, bounce + 1u, nextCur, tracer, cnt);
+        else
+            extend_segment<COUNT>(gg, s, p, w, id, bounce + 1u, nextCur, tracer, cnt);
     }
     flush_counters<COUNT>(cnt, counters);
 }
@@ -608,10 +668,36 @@ __global__ __launch_bounds__(256) void wf_accumulate(
 // host-side sequencing
 // ------------------------------------------------------------------------------------------
 
+// ray-pool variants of wf_trace (PROSPER_PT_DEBUG_POOL = index): slots per wave, LDS stack entries per slot, batches per
+// step.  An experiment kept for its measurements (profiles/r02_pool_experiment.txt): fewer, fuller instructions, but slower.
+#define PPT_POOL_VARIANTS(X) X(1, 128, 8, 1) X(2, 96, 10, 1) X(3, 128, 8, 2)
+
+template <bool COUNT, bool LDS_SCENE>
+static void launch_trace_pool(
+    uint32_t variant, dim3 grid, dim3 block, hipStream_t stream, const DeviceScene &s, const RenderParams &p,
+    const WavefrontBuffers &w, uint32_t b, uint32_t nextCur, uint32_t doExtend, uint32_t nodeCount, uint32_t triCount,
+    int32_t *scratch, uint32_t overflowEntries, unsigned long long *counters)
+{
+    switch (variant)
+    {
+#define PPT_POOL_CASE(index, P, S, B)                                                                                  \
+    case index:                                                                                                        \
+        hipLaunchKernelGGL(                                                                                            \
+            (wf_trace_pool<COUNT, P, S, B, LDS_SCENE>), grid, block, 0, stream, s, p, w, b, nextCur, doExtend, nodeCount,  \
+            triCount, scratch, overflowEntries, counters);                                                             \
+        break;
+        PPT_POOL_VARIANTS(PPT_POOL_CASE)
+#undef PPT_POOL_CASE
+    default:
+        break;
+    }
+}
+
 template <bool COUNT, int STACK, bool LDS_SCENE>
 static void enqueue_wavefront(
     const DeviceScene &s, const RenderParams &p, unsigned long long *counters, const WavefrontBuffers &w,
-    uint32_t nodeCount, uint32_t triCount, int32_t *stackOverflow, LaunchTimer *timer, hipStream_t stream)
+    const WavefrontPlan &plan, uint32_t nodeCount, uint32_t triCount, int32_t *stackOverflow, LaunchTimer *timer,
+    hipStream_t stream)
 {
     unsigned long long *cGen = counters + kStageGenerate * 16u, *cShade = counters + kStageShade * 16u,
                        *cTrace = counters + kStageTrace * 16u;
@@ -642,9 +728,14 @@ static void enqueue_wavefront(
         if (!debugDraw)
         {
             mark(kStageTrace);
-            hipLaunchKernelGGL(
-                (wf_trace<COUNT, STACK, LDS_SCENE>), grid, block, 0, stream, s, p, w, b, cur ^ 1u, last ? 0u : 1u, nodeCount,
-                triCount, stackOverflow, cTrace);
+            if (plan.poolVariant)
+                launch_trace_pool<COUNT, LDS_SCENE>(
+                    plan.poolVariant, grid, block, stream, s, p, w, b, cur ^ 1u, last ? 0u : 1u, nodeCount, triCount,
+                    stackOverflow, plan.poolOverflowEntries, cTrace);
+            else
+                hipLaunchKernelGGL(
+                    (wf_trace<COUNT, STACK, LDS_SCENE>), grid, block, 0, stream, s, p, w, b, cur ^ 1u, last ? 0u : 1u,
+                    nodeCount, triCount, stackOverflow, cTrace);
         }
     }
 }
@@ -682,28 +773,58 @@ bool wavefront_scene_in_lds(uint32_t ldsStackEntries, uint32_t nodeCount, uint32
            !std::getenv("PROSPER_PT_DEBUG_NO_LDS_SCENE");
 }
 
+// The traversal kernels of a render and the global scratch they index: the lane-owned kernels keep `overflowEntries`
+// stack entries per lane there, a ray-pool wf_trace its slots' hit / candidate records and deeper stack entries.
+WavefrontPlan wavefront_plan(uint32_t stackBound, uint32_t nodeCount, uint32_t triCount)
+{
+    (void)nodeCount;
+    (void)triCount;
+    WavefrontPlan plan = {};
+    plan.ldsStackEntries = wavefront_lds_stack_entries(stackBound);
+    plan.overflowEntries = stackBound > plan.ldsStackEntries ? stackBound - plan.ldsStackEntries : 0u;
+    uint32_t variant = 0;
+    if (const char *forced = std::getenv("PROSPER_PT_DEBUG_POOL")) variant = (uint32_t)std::atoi(forced);
+    uint32_t poolDwords = 0;
+    switch (variant)
+    {
+#define PPT_POOL_CASE(index, P, S, B)                                                                                  \
+    case index:                                                                                                        \
+        plan.poolVariant = index;                                                                                      \
+        plan.poolOverflowEntries = stackBound > S ? stackBound - S : 0u;                                               \
+        poolDwords = 4u * RayPool<P, S>::scratch_dwords(plan.poolOverflowEntries);                                     \
+        break;
+        PPT_POOL_VARIANTS(PPT_POOL_CASE)
+#undef PPT_POOL_CASE
+    default:
+        break;
+    }
+    const uint32_t laneDwords = plan.overflowEntries * 256u;
+    plan.scratchDwordsPerBlock = laneDwords > poolDwords ? laneDwords : poolDwords;
+    return plan;
+}
+
 template <bool COUNT>
 static void enqueue_for_stack(
     const DeviceScene &s, const RenderParams &p, unsigned long long *counters, const WavefrontBuffers &w,
-    uint32_t ldsStackEntries, int32_t *stackOverflow, uint32_t nodeCount, uint32_t triCount, LaunchTimer *timer,
+    const WavefrontPlan &plan, int32_t *stackOverflow, uint32_t nodeCount, uint32_t triCount, LaunchTimer *timer,
     hipStream_t stream)
 {
     // a scene of a few KB is traversed out of LDS
-    const bool ldsScene = wavefront_scene_in_lds(ldsStackEntries, nodeCount, triCount);
+    const bool ldsScene = wavefront_scene_in_lds(plan.ldsStackEntries, nodeCount, triCount);
     if (ldsScene)
-        enqueue_wavefront<COUNT, 16, true>(s, p, counters, w, nodeCount, triCount, stackOverflow, timer, stream);
-    else if (ldsStackEntries == 16u)
-        enqueue_wavefront<COUNT, 16, false>(s, p, counters, w, nodeCount, triCount, stackOverflow, timer, stream);
-    else if (ldsStackEntries == 24u)
-        enqueue_wavefront<COUNT, 24, false>(s, p, counters, w, nodeCount, triCount, stackOverflow, timer, stream);
+        enqueue_wavefront<COUNT, 16, true>(s, p, counters, w, plan, nodeCount, triCount, stackOverflow, timer, stream);
+    else if (plan.ldsStackEntries == 16u)
+        enqueue_wavefront<COUNT, 16, false>(s, p, counters, w, plan, nodeCount, triCount, stackOverflow, timer, stream);
+    else if (plan.ldsStackEntries == 24u)
+        enqueue_wavefront<COUNT, 24, false>(s, p, counters, w, plan, nodeCount, triCount, stackOverflow, timer, stream);
     else
-        enqueue_wavefront<COUNT, 32, false>(s, p, counters, w, nodeCount, triCount, stackOverflow, timer, stream);
+        enqueue_wavefront<COUNT, 32, false>(s, p, counters, w, plan, nodeCount, triCount, stackOverflow, timer, stream);
 }
 
 void launch_render_wavefront(
     const DeviceScene &s, const RenderParams &p, float4 *hdr, unsigned long long *counters, const WavefrontBuffers &w,
-    uint32_t ldsStackEntries, int32_t *stackOverflow, uint32_t overflowEntries, uint32_t nodeCount, uint32_t triCount,
-    bool countWork, LaunchTimer *timer, const WavefrontChains &chains, hipStream_t stream)
+    const WavefrontPlan &plan, int32_t *stackOverflow, uint32_t nodeCount, uint32_t triCount, bool countWork,
+    LaunchTimer *timer, const WavefrontChains &chains, hipStream_t stream)
 {
     if (w.nSeg == 0) return;
     static_assert(kTraversalStackDepth == 32, "largest LDS stack variant");
@@ -726,11 +847,11 @@ void launch_render_wavefront(
         if (chains.detached && chains.after) (void)hipStreamWaitEvent(cs, chains.after, 0);
         // every chain gets its own region of the stack-overflow array: its kernels index it by their own
         // blockIdx / gridDim (TraversalStack), and the chains run concurrently
-        int32_t *ovf = stackOverflow ? stackOverflow + (size_t)blocksBefore * 256u * overflowEntries : nullptr;
+        int32_t *ovf = stackOverflow ? stackOverflow + (size_t)blocksBefore * plan.scratchDwordsPerBlock : nullptr;
         if (countWork)
-            enqueue_for_stack<true>(s, p, counters, part, ldsStackEntries, ovf, nodeCount, triCount, ct, cs);
+            enqueue_for_stack<true>(s, p, counters, part, plan, ovf, nodeCount, triCount, ct, cs);
         else
-            enqueue_for_stack<false>(s, p, counters, part, ldsStackEntries, ovf, nodeCount, triCount, ct, cs);
+            enqueue_for_stack<false>(s, p, counters, part, plan, ovf, nodeCount, triCount, ct, cs);
         blocksBefore += ((part.groupCount + 7u) / 8u) * 8u;
         if (ownStreams)
         {

@@ -1,0 +1,12 @@
+#!/usr/bin/env python3
+"""Ad-hoc PMC comparison of trace-kernel variants (tooling): python scripts/pmc_ab.py <counters,comma> <config>..."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import pmc_tools, tempfile
+counters = sys.argv[1].split(",")
+for cfg in sys.argv[2:]:
+    d = tempfile.mkdtemp(prefix="pmcab_", dir="/tmp")
+    pmc_tools.run_pass(cfg, counters, d)
+    for k, v in sorted(pmc_tools.summarise(d).items()):
+        if "trace" in k:
+            print(cfg, "pool=%s" % os.environ.get("PROSPER_PT_DEBUG_POOL"), k, " ".join("%s=%.3e" % (c, v.get(c, 0.0)) for c in counters), "us=%.0f" % v["us_per_launch"], flush=True)

@@ -1029,6 +1029,25 @@ def test_lds_resident_scene_equals_global_memory_traversal(gpu_ctx, oracle, corn
     monkeypatch.delenv("PROSPER_PT_DEBUG_NO_LDS_SCENE")
 
 
+@pytest.mark.parametrize("variant", ["1", "2", "3"])
+def test_ray_pool_trace_variants_equal_the_lane_owned_traversal(gpu_ctx, oracle, monkeypatch, variant):
+    """wf_trace_pool (pt_trace_pool.hpp: the wave's rays in an LDS pool, PROSPER_PT_DEBUG_POOL) is an experiment kept
+    for its measurements; it must still produce the oracle's pixels - opaque and alpha-tested geometry, lights, sky."""
+    from prosper_amd import scenes
+    world = scenes.sponza_class(detail=0.25, lights=(24, 24), foliage=True, texture_size=64, sky_size=64)
+    w, h = 200, 120
+    cam, fl = _camera(oracle, world, w, h)
+    pc = default_pc(S, fl, max_bounces=4, ibl=True)
+    gpu_ctx.upload_scene(world)
+    want, _ = oracle.OracleScene(world).render(pc, cam, w, h)
+    monkeypatch.setenv("PROSPER_PT_DEBUG_POOL", variant)
+    gpu_ctx.render(pc, cam, w, h)
+    got = gpu_ctx.read_hdr()
+    monkeypatch.delenv("PROSPER_PT_DEBUG_POOL")
+    ok = same_bits(got, want).all(axis=2)
+    assert ok.all(), "%d of %d pixels differ" % ((~ok).sum(), ok.size)
+
+
 def test_full_sponza_class_scene_parity(gpu_ctx, oracle):
     """The full 262 k-triangle S-sponza-class scene (64^2 textures) at reduced resolution: grazing rays
     over tessellated flats are where a traversal could disagree with the oracle about hit selection
