@@ -591,7 +591,7 @@ __global__ __launch_bounds__(256, PPT_TRACE_WPE(STACK)) void wf_trace(
 
 // wf_trace with the wave's rays in an LDS pool of P slots (pt_trace_pool.hpp) instead of one per lane.
 template <bool COUNT, uint32_t P, uint32_t S, uint32_t B, bool LDS_SCENE>
-__global__ __launch_bounds__(256, 4) void wf_trace_pool(
+__global__ __launch_bounds__(256, 3) void wf_trace_pool(
     DeviceScene s, RenderParams p, WavefrontBuffers w, uint32_t bounce, uint32_t nextCur, uint32_t doExtend,
     uint32_t nodeCount, uint32_t triCount, int32_t *__restrict__ scratch, uint32_t overflowEntries,
     unsigned long long *__restrict__ counters)
