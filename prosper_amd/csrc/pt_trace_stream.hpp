@@ -143,6 +143,13 @@ PPT_D void trace_stream(
             do
             {
                 if constexpr (COUNT) cnt.nodePhaseSteps += lane == 0 ? 1u : 0u;
+#ifdef PPT_EXPERIMENT_COUNT_NARROW_STEPS
+                if constexpr (COUNT) // measurement only (profiles/r02_exec_mask_microbench.txt): node steps with <= 8 lanes
+                {
+                    const int active = __builtin_popcountll(__ballot(state == kLaneNode));
+                    cnt.historyReads += (lane == 0 && active <= 8) ? 1u : 0u;
+                }
+#endif
                 if (state == kLaneNode)
                 {
                     const NodeData nd = g.node(node);
@@ -188,6 +195,13 @@ PPT_D void trace_stream(
             do
             {
                 if constexpr (COUNT) cnt.trianglePhaseSteps += lane == 0 ? 1u : 0u;
+#ifdef PPT_EXPERIMENT_COUNT_NARROW_STEPS
+                if constexpr (COUNT) // triangle steps with <= 8 lanes
+                {
+                    const int active = __builtin_popcountll(__ballot(state == kLaneTri));
+                    cnt.pixelsWritten += (lane == 0 && active <= 8) ? 1u : 0u;
+                }
+#endif
                 // One step tests the next TWO triangles of the leaf when some lane has two left (SAH leaves are
                 // mostly pairs: a quad, a box face): both edge-function sets (the cheap rejection), then ONE pass
                 // through distance / guard / acceptance for whichever of them the ray goes through.  A ray through
@@ -266,9 +280,6 @@ PPT_D void trace_stream(
         }
         else
         {
-#ifdef PPT_EXPERIMENT_COUNT_ANY_STEPS
-            if constexpr (COUNT) cnt.pixelsWritten += lane == 0 ? 1u : 0u; // measurement only: refill steps
-#endif
             // hand finished rays over (converged call), then refill finished + idle lanes
             commit(state == kLaneFinished, ray, hit.drawInstance != kMissIndex, hit, d);
             if (state == kLaneFinished) state = kLaneIdle;
