@@ -350,6 +350,17 @@ def time_config(ctx, alone_ctx, torch, name, world, width, height, spp, max_boun
         out["measured_traffic_ratio"] = {k: v.get("traffic_over_algorithmic") for k, v in kernels.items()}
         out["hbm_bytes_per_step"] = sum(v["hbm_bytes_per_launch"] * v["launches_per_step"] for v in kernels.values() if "hbm_bytes_per_launch" in v)
         out["lane_util"] = {k: v.get("lane_util") for k, v in kernels.items()}
+    # the same roofline object as the headline's, for this configuration's dominant kernel, and the kernel nearest
+    # the HBM roof beside it (C3's wf_shade is the one kernel of the pass that waits for memory)
+    peak, peak_source = valu_peak()
+    out["roofline"] = roofline_object(
+        kernels, pmc, out["pmc_source"], peak, peak_source, ms_per_step,
+        "each launch alone on the GPU x ms_per_step / sum of the alone durations (as in the headline)")
+    hbm = {k: v["hbm_GBps"] for k, v in kernels.items() if "hbm_GBps" in v and k != "wf_accumulate"}
+    if hbm:
+        k = max(hbm, key=hbm.get)
+        out["nearest_hbm_roof"] = {"kernel": k, "GBps": hbm[k], "frac_of_peak": hbm[k] / HBM_PEAK_GBS,
+                                   "traffic_over_algorithmic": kernels[k].get("traffic_over_algorithmic")}
     ctx.set_output_buffer(0, 0)
     return out
 
