@@ -4,6 +4,8 @@
 
 #include <algorithm>
 #include <atomic>
+#include <cstdio>
+#include <chrono>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -88,20 +90,108 @@ uint32_t ceil_log2(uint64_t n)
     return l;
 }
 
+unsigned host_threads()
+{
+    unsigned threads = std::thread::hardware_concurrency();
+    threads = std::max(1u, std::min(threads ? threads : 1u, 32u));
+    if (const char *forced = std::getenv("PROSPER_PT_DEBUG_BUILD_THREADS")) threads = (unsigned)std::max(1, std::atoi(forced));
+    return threads;
+}
+
+// Runs job(0) .. job(n - 1) on the host's threads (the caller's included); rethrows the first exception.
+template <class Job>
+void run_parallel(size_t n, Job &&job)
+{
+    const unsigned threads = (unsigned)std::min<size_t>(host_threads(), n ? n : 1);
+    std::atomic<size_t> next{0};
+    std::exception_ptr failure;
+    std::mutex failureLock;
+    auto worker = [&]() {
+        for (size_t j = next.fetch_add(1); j < n; j = next.fetch_add(1))
+        {
+            try
+            {
+                job(j);
+            }
+            catch (...)
+            {
+                std::lock_guard<std::mutex> g(failureLock);
+                failure = std::current_exception();
+            }
+        }
+    };
+    std::vector<std::thread> pool;
+    for (unsigned t = 1; t < threads; ++t) pool.emplace_back(worker);
+    worker();
+    for (std::thread &t : pool) t.join();
+    if (failure) std::rethrow_exception(failure);
+}
+
 struct Builder
 {
     std::vector<Prim> &prims;
     std::vector<TmpNode> nodes;
     const float kTraversalCost = traversal_cost();
     uint32_t kMaxLeaf = max_leaf();
+    // build_parallel(): subranges of at most this many primitives are not split here but queued as jobs
+    uint32_t deferBelow = 0;
+    struct Deferred
+    {
+        int32_t self;
+        uint32_t first, count, depth;
+    };
+    std::vector<Deferred> deferred;
 
     explicit Builder(std::vector<Prim> &p) : prims(p) {}
+
+    // The same tree as build(), with the subranges below the first few splits built on the host's threads: every
+    // split only permutes its own slice of `prims`, so the slices of different jobs are disjoint.
+    int32_t build_parallel(uint32_t first, uint32_t count, uint32_t depth)
+    {
+        const unsigned threads = host_threads();
+        if (threads < 2 || count < 8192u) return build(first, count, depth);
+        deferBelow = std::max(1024u, count / (4u * threads));
+        const int32_t root = build(first, count, depth);
+        deferBelow = 0;
+        std::vector<Deferred> jobs;
+        jobs.swap(deferred);
+        std::sort(jobs.begin(), jobs.end(), [](const Deferred &a, const Deferred &b) { return a.count > b.count; });
+        std::vector<std::vector<TmpNode>> built(jobs.size());
+        std::vector<int32_t> roots(jobs.size());
+        run_parallel(jobs.size(), [&](size_t j) {
+            Builder local(prims);
+            local.kMaxLeaf = kMaxLeaf;
+            local.nodes.reserve((size_t)jobs[j].count * 2);
+            roots[j] = local.build(jobs[j].first, jobs[j].count, jobs[j].depth);
+            built[j].swap(local.nodes);
+        });
+        for (size_t j = 0; j < jobs.size(); ++j)
+        {
+            const int32_t shift = (int32_t)nodes.size();
+            for (TmpNode n : built[j])
+            {
+                if (n.left >= 0)
+                {
+                    n.left += shift;
+                    n.right += shift;
+                }
+                nodes.push_back(n);
+            }
+            nodes[(size_t)jobs[j].self] = nodes[(size_t)(shift + roots[j])]; // the placeholder becomes the job's root
+        }
+        return root;
+    }
 
     // Builds the subtree over prims[first, first+count) and returns its node index in `nodes`.
     int32_t build(uint32_t first, uint32_t count, uint32_t depth)
     {
         const int32_t self = (int32_t)nodes.size();
         nodes.emplace_back();
+        if (deferBelow && depth > 0 && count <= deferBelow)
+        {
+            deferred.push_back(Deferred{self, first, count, depth});
+            return self;
+        }
         Aabb box, cbox;
         for (uint32_t i = 0; i < count; ++i)
         {
@@ -302,113 +392,6 @@ uint16_t half_ceil(float f)
     return h;
 }
 
-// Collapses the binary SAH tree into 4-wide nodes (a node adopts its grandchildren, largest box
-// first, until it has four children or only leaves) and emits them depth-first.
-struct Emitter
-{
-    const std::vector<TmpNode> &tmp;
-    const std::vector<Prim> &prims;
-    BvhBuildResult &out;
-    float slack;
-    float padCoeff;
-
-    int32_t emit_leaf(int32_t t)
-    {
-        const TmpNode &n = tmp[t];
-        // leaves longer than kMaxLeafTriangles cannot occur (the builder splits them)
-        const uint32_t first = (uint32_t)out.permutation.size();
-        for (uint32_t i = 0; i < n.count; ++i) out.permutation.push_back(prims[n.first + i].index);
-        return ~(int32_t)((first << 3) | (n.count - 1));
-    }
-
-    // Emits the 4-wide node rooted at binary node t (an inner node, or a lone leaf wrapped as the
-    // root) and returns its index; `stackNeed` receives the traversal-stack bound of its subtree.
-    int32_t emit_node(int32_t t, uint32_t &stackNeed)
-    {
-        const int32_t self = (int32_t)out.nodes.size();
-        out.nodes.emplace_back();
-        int32_t kids[4];
-        uint32_t k = 0;
-        if (tmp[t].left < 0)
-            kids[k++] = t;
-        else
-        {
-            kids[k++] = tmp[t].left;
-            kids[k++] = tmp[t].right;
-            while (k < 4)
-            {
-                int best = -1;
-                float bestArea = -1.0f;
-                for (uint32_t i = 0; i < k; ++i)
-                    if (tmp[kids[i]].left >= 0 && tmp[kids[i]].box.half_area() > bestArea)
-                    {
-                        bestArea = tmp[kids[i]].box.half_area();
-                        best = (int)i;
-                    }
-                if (best < 0) break;
-                const int32_t open = kids[best];
-                kids[best] = tmp[open].left;
-                kids[k++] = tmp[open].right;
-            }
-        }
-        // Storage order = the order an any-hit (shadow) ray tries the children it enters (descend_any): smallest box
-        // first.  A small subtree is cheap to rule out and ends the ray if it occludes; measured on S-sponza-class
-        // (shadow + bounce rays, node visits per step): distance-sorted 1235 M, build order 1211 M, largest first
-        // 1192 M, most triangles first 1219 M, smallest first 1138 M.  Closest-hit rays sort by distance anyway.
-        // PROSPER_PT_DEBUG_CHILD_ORDER=0 keeps the build order (hierarchy-independence tests).
-        {
-            const char *order = std::getenv("PROSPER_PT_DEBUG_CHILD_ORDER");
-            if (!order || std::atoi(order) != 0)
-                std::stable_sort(kids, kids + k, [&](int32_t a, int32_t b) {
-                    return tmp[a].box.half_area() < tmp[b].box.half_area();
-                });
-        }
-        BvhNode node;
-        node.reserved = 0;
-        // unused slots: lo = hi = +inf (half 0x7C00) can never be entered (see build_bvh)
-        for (int a = 0; a < 3; ++a)
-            for (int c = 0; c < 4; ++c)
-            {
-                node.lo[a][c] = 0x7C00u;
-                node.hi[a][c] = 0x7C00u;
-            }
-        float lo[4][3], hi[4][3];
-        for (int a = 0; a < 3; ++a) node.origin[a] = std::numeric_limits<float>::infinity();
-        for (uint32_t c = 0; c < k; ++c)
-        {
-            padded(tmp[kids[c]].box, padCoeff, slack, lo[c], hi[c]);
-            for (int a = 0; a < 3; ++a) node.origin[a] = std::min(node.origin[a], lo[c][a]);
-        }
-        uint32_t deepest = 0;
-        for (uint32_t c = 0; c < 4; ++c)
-        {
-            node.child[c] = ~0;
-            if (c >= k) continue;
-            for (int a = 0; a < 3; ++a)
-            {
-                // offsets from the node origin; the fp32 subtraction is pushed one ulp outward before
-                // the outward half rounding, so origin + offset never lies inside the padded box
-                const float offLo = std::nextafter(lo[c][a] - node.origin[a], -std::numeric_limits<float>::infinity());
-                const float offHi = std::nextafter(hi[c][a] - node.origin[a], std::numeric_limits<float>::infinity());
-                node.lo[a][c] = half_floor(std::max(offLo, 0.0f));
-                node.hi[a][c] = half_ceil(offHi);
-            }
-            if (tmp[kids[c]].left < 0)
-                node.child[c] = emit_leaf(kids[c]);
-            else
-            {
-                uint32_t need = 0;
-                node.child[c] = emit_node(kids[c], need);
-                deepest = std::max(deepest, need);
-            }
-        }
-        // visiting this node leaves at most k-1 siblings on the stack while a child subtree is walked
-        stackNeed = (k > 0 ? k - 1 : 0) + deepest;
-        out.nodes[self] = node;
-        return self;
-    }
-};
-
 // Renumbers the nodes (speed only; the root stays node 0, leaf references do not change).  The emitter numbers them
 // depth-first, which interleaves the few hundred nodes every ray walks through (the top of the tree) with deep ones
 // only their own subtree's rays touch: every cache line of the hot set is then half cold.
@@ -465,22 +448,180 @@ void relayout_nodes(std::vector<BvhNode> &nodes)
     nodes.swap(moved);
 }
 
+// Collapses the binary SAH tree into 4-wide nodes (a node adopts its grandchildren, largest box
+// first, until it has four children or only leaves) and emits them depth-first.  Two passes: plan() walks the
+// tree once and records, for every binary node that becomes a 4-wide node, its children and the size of its
+// subtree - which fixes every node's index and every leaf's place in the triangle order - so that emit() can
+// fill disjoint parts of the output on the host's threads.
+struct Emitter
+{
+    const std::vector<TmpNode> &tmp;
+    const std::vector<Prim> &prims;
+    BvhBuildResult &out;
+    float slack;
+    float padCoeff;
+    bool sortChildren;
+
+    struct Plan
+    {
+        int32_t kids[4];
+        uint32_t k = 0;
+        uint32_t nodes = 0;     // 4-wide nodes in the subtree, this one included
+        uint32_t triangles = 0; // triangles in the subtree
+        uint32_t stackNeed = 0;
+    };
+    std::vector<Plan> plans; // by binary node index; filled for the nodes that become 4-wide nodes
+
+    uint32_t triangles_of(int32_t t) const { return tmp[(size_t)t].left < 0 ? tmp[(size_t)t].count : plans[(size_t)t].triangles; }
+
+    void plan(int32_t t)
+    {
+        Plan p;
+        int32_t *kids = p.kids;
+        uint32_t k = 0;
+        if (tmp[t].left < 0)
+            kids[k++] = t;
+        else
+        {
+            kids[k++] = tmp[t].left;
+            kids[k++] = tmp[t].right;
+            while (k < 4)
+            {
+                int best = -1;
+                float bestArea = -1.0f;
+                for (uint32_t i = 0; i < k; ++i)
+                    if (tmp[kids[i]].left >= 0 && tmp[kids[i]].box.half_area() > bestArea)
+                    {
+                        bestArea = tmp[kids[i]].box.half_area();
+                        best = (int)i;
+                    }
+                if (best < 0) break;
+                const int32_t open = kids[best];
+                kids[best] = tmp[open].left;
+                kids[k++] = tmp[open].right;
+            }
+        }
+        // Storage order = the order an any-hit (shadow) ray tries the children it enters (descend_any): smallest box
+        // first.  A small subtree is cheap to rule out and ends the ray if it occludes; measured on S-sponza-class
+        // (shadow + bounce rays, node visits per step): distance-sorted 1235 M, build order 1211 M, largest first
+        // 1192 M, most triangles first 1219 M, smallest first 1138 M.  Closest-hit rays sort by distance anyway.
+        // PROSPER_PT_DEBUG_CHILD_ORDER=0 keeps the build order (hierarchy-independence tests).
+        if (sortChildren)
+            std::stable_sort(kids, kids + k, [&](int32_t a, int32_t b) {
+                return tmp[a].box.half_area() < tmp[b].box.half_area();
+            });
+        p.k = k;
+        p.nodes = 1;
+        uint32_t deepest = 0;
+        for (uint32_t c = 0; c < k; ++c)
+        {
+            if (tmp[kids[c]].left < 0 && !(kids[c] == t))
+                p.triangles += tmp[kids[c]].count;
+            else if (kids[c] == t) // a lone leaf wrapped as the root
+                p.triangles += tmp[t].count;
+            else
+            {
+                plan(kids[c]);
+                p.nodes += plans[(size_t)kids[c]].nodes;
+                p.triangles += plans[(size_t)kids[c]].triangles;
+                deepest = std::max(deepest, plans[(size_t)kids[c]].stackNeed);
+            }
+        }
+        // visiting this node leaves at most k-1 siblings on the stack while a child subtree is walked
+        p.stackNeed = (k > 0 ? k - 1 : 0) + deepest;
+        plans[(size_t)t] = p;
+    }
+
+    struct Job
+    {
+        int32_t t;
+        uint32_t self, triBase;
+    };
+
+    // Emits the 4-wide node of binary node t at index `self`; its subtree's triangles start at `triBase` of the
+    // leaf order.  Subtrees of at most `chunk` nodes are queued in `jobs` instead of being walked (jobs == nullptr:
+    // walk everything).
+    void emit(int32_t t, uint32_t self, uint32_t triBase, uint32_t chunk, std::vector<Job> *jobs)
+    {
+        const Plan &p = plans[(size_t)t];
+        const int32_t *kids = p.kids;
+        const uint32_t k = p.k;
+        BvhNode node;
+        node.reserved = 0;
+        // unused slots: lo = hi = +inf (half 0x7C00) can never be entered (see build_bvh)
+        for (int a = 0; a < 3; ++a)
+            for (int c = 0; c < 4; ++c)
+            {
+                node.lo[a][c] = 0x7C00u;
+                node.hi[a][c] = 0x7C00u;
+            }
+        float lo[4][3], hi[4][3];
+        for (int a = 0; a < 3; ++a) node.origin[a] = std::numeric_limits<float>::infinity();
+        for (uint32_t c = 0; c < k; ++c)
+        {
+            padded(tmp[kids[c]].box, padCoeff, slack, lo[c], hi[c]);
+            for (int a = 0; a < 3; ++a) node.origin[a] = std::min(node.origin[a], lo[c][a]);
+        }
+        uint32_t nextNode = self + 1u, nextTri = triBase;
+        for (uint32_t c = 0; c < 4; ++c)
+        {
+            node.child[c] = ~0;
+            if (c >= k) continue;
+            for (int a = 0; a < 3; ++a)
+            {
+                // offsets from the node origin; the fp32 subtraction is pushed one ulp outward before
+                // the outward half rounding, so origin + offset never lies inside the padded box
+                const float offLo = std::nextafter(lo[c][a] - node.origin[a], -std::numeric_limits<float>::infinity());
+                const float offHi = std::nextafter(hi[c][a] - node.origin[a], std::numeric_limits<float>::infinity());
+                node.lo[a][c] = half_floor(std::max(offLo, 0.0f));
+                node.hi[a][c] = half_ceil(offHi);
+            }
+            const TmpNode &kid = tmp[kids[c]];
+            if (kid.left < 0)
+            {
+                // leaves longer than kMaxLeafTriangles cannot occur (the builder splits them)
+                for (uint32_t i = 0; i < kid.count; ++i) out.permutation[nextTri + i] = prims[kid.first + i].index;
+                node.child[c] = ~(int32_t)((nextTri << 3) | (kid.count - 1));
+                nextTri += kid.count;
+            }
+            else
+            {
+                node.child[c] = (int32_t)nextNode;
+                const Plan &cp = plans[(size_t)kids[c]];
+                if (jobs && cp.nodes <= chunk)
+                    jobs->push_back(Job{kids[c], nextNode, nextTri});
+                else
+                    emit(kids[c], nextNode, nextTri, chunk, jobs);
+                nextNode += cp.nodes;
+                nextTri += cp.triangles;
+            }
+        }
+        out.nodes[self] = node;
+    }
+};
+
 // Emits the binary tree `tmp` rooted at `root` as 4-wide nodes + leaf-order permutation into `out`.
+void relayout_nodes(std::vector<BvhNode> &nodes);
 void emit_tree(const std::vector<TmpNode> &tmp, int32_t root, const std::vector<Prim> &prims, uint64_t count, BvhBuildResult &out)
 {
-    out.nodes.clear();
-    out.permutation.clear();
-    out.nodes.reserve(tmp.size() / 2 + 1);
-    out.permutation.reserve((size_t)count);
     const Aabb &scene = tmp[(size_t)root].box;
     const float dx = scene.hi[0] - scene.lo[0], dy = scene.hi[1] - scene.lo[1], dz = scene.hi[2] - scene.lo[2];
     const float slack = 2e-6f * std::sqrt(dx * dx + dy * dy + dz * dz) + 1e-30f;
-    Emitter emitter{tmp, prims, out, slack, pad_coefficient()};
-    uint32_t need = 0;
-    emitter.emit_node(root, need);
-    out.maxDepth = need + 1; // entries the traversal stack must hold in the worst case
+    const char *order = std::getenv("PROSPER_PT_DEBUG_CHILD_ORDER");
+    Emitter emitter{tmp, prims, out, slack, pad_coefficient(), !order || std::atoi(order) != 0, {}};
+    emitter.plans.resize(tmp.size());
+    emitter.plan(root);
+    const Emitter::Plan &top = emitter.plans[(size_t)root];
+    out.maxDepth = top.stackNeed + 1; // entries the traversal stack must hold in the worst case
     if (out.maxDepth > kMaxStackBound)
         throw std::runtime_error("BVH stack bound exceeds the traversal's overflow capacity");
+    if (top.triangles != count) throw std::runtime_error("emit_tree: the tree does not hold every triangle");
+    out.nodes.assign(top.nodes, BvhNode());
+    out.permutation.assign((size_t)count, 0u);
+    std::vector<Emitter::Job> jobs;
+    const uint32_t chunk = std::max(256u, top.nodes / (8u * host_threads()));
+    emitter.emit(root, 0u, 0u, chunk, host_threads() > 1 ? &jobs : nullptr);
+    run_parallel(jobs.size(), [&](size_t j) { emitter.emit(jobs[j].t, jobs[j].self, jobs[j].triBase, 0u, nullptr); });
     relayout_nodes(out.nodes);
 }
 
@@ -525,7 +666,7 @@ BvhBuildResult build_bvh(const WorldTriangle *triangles, uint64_t count)
 
     Builder builder(prims);
     builder.nodes.reserve((size_t)count * 2);
-    const int32_t rootTmp = builder.build(0, (uint32_t)count, 0);
+    const int32_t rootTmp = builder.build_parallel(0, (uint32_t)count, 0);
     emit_tree(builder.nodes, rootTmp, prims, count, out);
     return out;
 }
@@ -582,32 +723,7 @@ struct InstancedBvh::Impl
             if (which.empty() || which[i]) todo.push_back(i);
         // largest first, so that the last thread to finish holds a small one
         std::sort(todo.begin(), todo.end(), [&](size_t a, size_t b) { return instances[a].count > instances[b].count; });
-        unsigned threads = std::thread::hardware_concurrency();
-        threads = std::max(1u, std::min(threads ? threads : 1u, 32u));
-        if (const char *forced = std::getenv("PROSPER_PT_DEBUG_BUILD_THREADS")) threads = (unsigned)std::max(1, std::atoi(forced));
-        threads = (unsigned)std::min<size_t>(threads, todo.size() ? todo.size() : 1);
-        std::atomic<size_t> nextJob{0};
-        std::exception_ptr failure;
-        std::mutex failureLock;
-        auto worker = [&]() {
-            for (size_t j = nextJob.fetch_add(1); j < todo.size(); j = nextJob.fetch_add(1))
-            {
-                try
-                {
-                    build_subtree(triangles, todo[j], depth0);
-                }
-                catch (...)
-                {
-                    std::lock_guard<std::mutex> g(failureLock);
-                    failure = std::current_exception();
-                }
-            }
-        };
-        std::vector<std::thread> pool;
-        for (unsigned t = 1; t < threads; ++t) pool.emplace_back(worker);
-        worker();
-        for (std::thread &t : pool) t.join();
-        if (failure) std::rethrow_exception(failure);
+        run_parallel(todo.size(), [&](size_t j) { build_subtree(triangles, todo[j], depth0); });
     }
 
     // Top level over the instances, spliced with their subtrees into one binary tree, emitted as 4-wide nodes.
@@ -623,6 +739,13 @@ struct InstancedBvh::Impl
     BvhBuildResult assemble()
     {
         BvhBuildResult out;
+        const bool timing = std::getenv("PROSPER_PT_DEBUG_BUILD_TIMING") != nullptr;
+        auto tick = std::chrono::steady_clock::now();
+        auto lap = [&](const char *what) {
+            const auto now = std::chrono::steady_clock::now();
+            if (timing) std::fprintf(stderr, "[bvh] %-14s %.1f ms\n", what, std::chrono::duration<double, std::milli>(now - tick).count());
+            tick = now;
+        };
         // merged node array: every subtree with its indices shifted (top-level nodes are appended afterwards)
         std::vector<TmpNode> merged;
         size_t total = 0;
@@ -651,6 +774,7 @@ struct InstancedBvh::Impl
             heap.push_back(Entry{merged[(size_t)(shift + st.root)].box.half_area(), shift + st.root});
         }
         if (heap.empty()) return build_bvh(nullptr, 0);
+        lap("merge");
         size_t target = std::min(std::max(kMinTopEntries, (size_t)(count / kTrianglesPerTopEntry)), kMaxTopEntries);
         if (const char *forced = std::getenv("PROSPER_PT_DEBUG_TOP_ENTRIES")) target = (size_t)std::max(1, std::atoi(forced));
         std::make_heap(heap.begin(), heap.end());
@@ -672,6 +796,7 @@ struct InstancedBvh::Impl
             std::push_heap(heap.begin(), heap.end());
         }
         for (const Entry &e : heap) entries.push_back(e.node);
+        lap("open");
 
         std::vector<Prim> top(entries.size());
         for (size_t i = 0; i < entries.size(); ++i)
@@ -682,7 +807,8 @@ struct InstancedBvh::Impl
         }
         Builder tb(top);
         tb.kMaxLeaf = 1; // a top-level leaf is exactly one entry
-        const int32_t topRoot = tb.build(0, (uint32_t)top.size(), 0);
+        const int32_t topRoot = tb.build_parallel(0, (uint32_t)top.size(), 0);
+        lap("top level");
         const int32_t shift = (int32_t)merged.size();
         auto entry_of = [&](int32_t topLeaf) { return entries[top[tb.nodes[(size_t)topLeaf].first].index]; };
         int32_t root;
@@ -702,7 +828,9 @@ struct InstancedBvh::Impl
                 merged.push_back(n); // (top-level leaves are copied too but nothing points at them any more)
             }
         }
+        lap("splice");
         emit_tree(merged, root, prims, count, out);
+        lap("emit");
         return out;
     }
 };

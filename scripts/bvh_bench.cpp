@@ -1,0 +1,96 @@
+// bvh_bench.cpp — host-side timing of the hierarchy builder (tooling): full build and rebuild after one moved instance on a
+// synthetic scene of tessellated patches (43 instances, ~262 k triangles).
+//   g++ -O3 -std=c++17 -I prosper_amd/csrc -I include scripts/bvh_bench.cpp prosper_amd/csrc/bvh_build.o -lpthread -o /tmp/bvh_bench
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#include "bvh_build.hpp"
+
+using namespace ppt;
+
+static uint32_t rngState = 12345u;
+static float rnd()
+{
+    rngState = rngState * 1664525u + 1013904223u;
+    return (float)(rngState >> 8) / 16777216.0f;
+}
+
+int main(int argc, char **argv)
+{
+    const int instances = 43, side = argc > 1 ? atoi(argv[1]) : 55;
+    std::vector<WorldTriangle> tris;
+    std::vector<InstancedBvh::Range> ranges;
+    for (int i = 0; i < instances; ++i)
+    {
+        const float cx = rnd() * 30.0f, cy = rnd() * 8.0f, cz = rnd() * 20.0f;
+        const float ux = rnd() - 0.5f, uy = rnd() - 0.5f, uz = rnd() - 0.5f, vx = rnd() - 0.5f, vy = rnd() - 0.5f, vz = rnd() - 0.5f;
+        const float size = 2.0f + 6.0f * rnd();
+        InstancedBvh::Range r{(uint32_t)tris.size(), 0};
+        for (int a = 0; a < side; ++a)
+            for (int b = 0; b < side; ++b)
+                for (int h = 0; h < 2; ++h)
+                {
+                    auto corner = [&](int da, int db, float out[3]) {
+                        const float s = ((a + da) / (float)side - 0.5f) * size, t = ((b + db) / (float)side - 0.5f) * size;
+                        const float bump = 0.05f * std::sin(7.0f * s) * std::cos(5.0f * t);
+                        out[0] = cx + s * ux + t * vx + bump;
+                        out[1] = cy + s * uy + t * vy + bump;
+                        out[2] = cz + s * uz + t * vz;
+                    };
+                    WorldTriangle w = {};
+                    if (h == 0)
+                    {
+                        corner(0, 0, w.v0);
+                        corner(1, 0, w.v1);
+                        corner(1, 1, w.v2);
+                    }
+                    else
+                    {
+                        corner(0, 0, w.v0);
+                        corner(1, 1, w.v1);
+                        corner(0, 1, w.v2);
+                    }
+                    tris.push_back(w);
+                }
+        r.count = (uint32_t)tris.size() - r.first;
+        ranges.push_back(r);
+    }
+    printf("%zu triangles in %d instances\n", tris.size(), instances);
+    auto now = [] { return std::chrono::steady_clock::now(); };
+    auto ms = [](auto a, auto b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+    InstancedBvh bvh;
+    auto t0 = now();
+    BvhBuildResult res = bvh.build(tris.data(), tris.size(), ranges);
+    auto t1 = now();
+    auto digest = [](const BvhBuildResult &r) {
+        unsigned long long h = 1469598103934665603ull;
+        auto mix = [&](const void *p, size_t n) {
+            const unsigned char *b = (const unsigned char *)p;
+            for (size_t i = 0; i < n; ++i) h = (h ^ b[i]) * 1099511628211ull;
+        };
+        mix(r.nodes.data(), r.nodes.size() * sizeof(BvhNode));
+        mix(r.permutation.data(), r.permutation.size() * 4);
+        return h;
+    };
+    printf("build: %.1f ms, %zu nodes, maxDepth %u, digest %016llx\n", ms(t0, t1), res.nodes.size(), res.maxDepth, digest(res));
+    for (int rep = 0; rep < 3; ++rep)
+    {
+        std::vector<uint8_t> changed(instances, 0);
+        changed[(size_t)(rep * 5 % instances)] = 1;
+        const InstancedBvh::Range &r = ranges[(size_t)(rep * 5 % instances)];
+        for (uint32_t i = r.first; i < r.first + r.count; ++i)
+            for (float *v : {tris[i].v0, tris[i].v1, tris[i].v2}) v[0] += 0.1f;
+        t0 = now();
+        res = bvh.rebuild(tris.data(), changed);
+        t1 = now();
+        printf("rebuild after moving 1 instance: %.1f ms, %zu nodes, digest %016llx\n", ms(t0, t1), res.nodes.size(), digest(res));
+    }
+    t0 = now();
+    res = build_bvh(tris.data(), tris.size());
+    t1 = now();
+    printf("flat build: %.1f ms, %zu nodes, digest %016llx\n", ms(t0, t1), res.nodes.size(), digest(res));
+    return 0;
+}
