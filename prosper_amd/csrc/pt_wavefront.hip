@@ -203,7 +203,6 @@ __global__ __launch_bounds__(256, PPT_GEN_WPE) void wf_generate_extend(
         bool slotValid = false; // of the slot the last fetch() decoded: commit() follows it in lockstep
         auto fetch = [&](uint32_t k) {
             const uint32_t at = id.base + k; // where the path's records live in this segment
-            const uint32_t slot = batchSlot + lane;
             SlotPixel sp;
             sp.frame = tileFrame;
             sp.lx = tileX * 8u + (lane & 7u);
@@ -226,7 +225,8 @@ __global__ __launch_bounds__(256, PPT_GEN_WPE) void wf_generate_extend(
                               st, cnt);
             if constexpr (COUNT) cnt.closestRays++;
             w.rayB[0][at] = make_float4(st.d.x, st.d.y, st.d.z, 0.0f);
-            w.pathT[0][at] = make_float4(1.0f, 1.0f, 1.0f, asf(slot));
+            // no pathT record for bounce 0: the throughput is (1, 1, 1) and wf_shade re-derives the slot from the path's
+            // place in its segment (32 B per camera path that HBM does not carry)
             w.pathR[0][at] = make_uint4(st.rng.x, st.rng.y, st.rng.z, 0u);
             r.o = st.o;
             r.d = st.d;
@@ -424,7 +424,10 @@ __global__ __launch_bounds__(256, PPT_SHADE_WPE) void wf_shade(
             const uint32_t i = w.hitIdx[id.base + j];
             const uint4 h = w.hit[id.base + j];
             const float4 b = w.rayB[cur][id.base + i];
-            const float4 t = w.pathT[cur][id.base + i];
+            // bounce 0: path i of the segment is lane i % 64 of the segment's tile number i / 64 (wf_generate_extend)
+            const float4 t = bounce == 0u
+                                 ? make_float4(1.0f, 1.0f, 1.0f, asf(((i >> 6) * w.nSeg + id.seg) * 64u + (i & 63u)))
+                                 : w.pathT[cur][id.base + i];
             const uint4 r = w.pathR[cur][id.base + i];
             slot = asu(t.w) & kSlotMask;
             rng = Rng{r.x, r.y, r.z};
