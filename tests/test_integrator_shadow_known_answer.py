@@ -1,0 +1,134 @@
+"""A third integrator-level known answer that does not go through oracle/oracle.c: the SHADOW ray through stochastic
+transparency.
+
+The scene of test_integrator_known_answer.py (a quad lit by a point and a spot light, maxBounces 1) with a BLEND quad
+(baseColorFactor.a = 0.4, no texture) hung between the ground and both lights, above the camera.  Every shadow ray crosses
+it exactly once, so a lit pixel keeps its unshadowed radiance or loses all of it:
+
+    visible  <=>  u > alpha,   u = float(pcg(seed)) / float(0xFFFFFFFF),   seed = pcg(pcg_state.x ^ pcg_state.y)
+
+with pcg_state the path's RNG state when shadow() is called - after the light-pick draw, not advanced by the trace
+(rt/reference/main.rgen:49-60,205-217; rt/scene.rahit:18-39; common/random.glsl:7-12,42-46).  Which pixels are lit is
+integer arithmetic, evaluated HERE in NumPy; their radiance is the float64 value of the first known answer.
+
+A second case looks at the veil from above with DrawType Position: whether a camera ray stops on it or goes through to
+the ground is the same rule with traceClosest's seed, pcg(pcg_state.x ^ pcg_state.z) (main.rgen:62-81).
+"""
+import numpy as np
+import pytest
+
+from conftest import default_pc, same_bits
+from prosper_amd import scenes, structs as S
+
+import test_integrator_known_answer as base
+
+W, H = base.W, base.H
+ALPHA = 0.4
+
+
+def build_world():
+    w = base.build_world()
+    mat = w.add_material(base_color=(1.0, 1.0, 1.0, ALPHA), metallic=0.0, roughness=1.0, alpha_mode=S.ALPHA_MODE_BLEND)
+    mesh = scenes._add(w, scenes.quad((-40, 2.5, 40), (40, 2.5, 40), (40, 2.5, -40), (-40, 2.5, -40)), mat)
+    w.add_instance(w.add_model([(mesh, mat)]))
+    assert w.camera["eye"][1] < 2.5  # the camera is below the veil: camera rays do not meet it
+    return w
+
+
+def pcg(v):
+    """random.glsl:7-12 on uint32 arrays."""
+    v = v.astype(np.uint64)
+    state = (v * 747796405 + 2891336453) & 0xFFFFFFFF
+    word = (((state >> ((state >> 28) + 4)) ^ state) * 277803737) & 0xFFFFFFFF
+    return ((word >> 22) ^ word).astype(np.uint32)
+
+
+def numpy_visibility(frame_index=1):
+    py, px = np.meshgrid(np.arange(H, dtype=np.uint32), np.arange(W, dtype=np.uint32), indexing="ij")
+    state = base.pcg3d(np.stack([px, py, np.full_like(px, frame_index)], axis=-1))  # jitter
+    state = base.pcg3d(state)                                                        # light pick: the state shadow() sees
+    seed = pcg(state[..., 0].astype(np.uint32) ^ state[..., 1].astype(np.uint32))    # main.rgen:55
+    u = base.rng_to_01(pcg(seed))                                                    # scene.rahit:35
+    return u > np.float32(ALPHA)                                                     # `u > alpha`: the candidate is ignored
+
+
+def _check(img, want, pick, cond, visible):
+    got = img[..., :3].astype(np.float64)
+    lit_unshadowed = want.sum(-1) > 0
+    blocked = lit_unshadowed & ~visible
+    assert (got[blocked] == 0.0).all(), "%d pixels behind an accepted candidate are lit" % (got[blocked].sum(-1) != 0).sum()
+    shown = np.where(visible[..., None], want, 0.0)
+    base._check_against_numpy(img, shown, pick, cond)
+    # the case is not degenerate: about 60 % of the lit pixels stay lit, thousands of each kind
+    frac = (lit_unshadowed & visible).sum() / lit_unshadowed.sum()
+    assert 0.55 < frac < 0.65 and blocked.sum() > 2000 and (lit_unshadowed & visible).sum() > 3000
+
+
+def test_oracle_matches_the_numpy_shadow_visibility(oracle):
+    world = build_world()
+    cam, fl = base._camera(oracle, world)
+    osc = oracle.OracleScene(world, brute_force=True)
+    for frame in (1, 2):
+        want, pick, cond = base.numpy_radiance(world, frame_index=frame)
+        img, counters = osc.render(default_pc(S, fl, frame_index=frame, max_bounces=1), cam, W, H)
+        _check(img, want, pick, cond, numpy_visibility(frame))
+        c = counters.as_dict()
+        assert c["closestHits"] == W * H and c["shadowRays"] > 0
+
+
+def build_world_seen_from_above():
+    """The same scene with the camera ABOVE the veil: a camera ray now meets it first, and traceClosest's any-hit decides
+    with its own seed, pcg(pcg_state.x ^ pcg_state.z) taken right after the jitter draw (main.rgen:62-81,229-238)."""
+    w = build_world()
+    w.camera = dict(w.camera, eye=(0.0, 5.0, 4.0))
+    return w
+
+
+def numpy_camera_ray_passes(frame_index=1):
+    py, px = np.meshgrid(np.arange(H, dtype=np.uint32), np.arange(W, dtype=np.uint32), indexing="ij")
+    state = base.pcg3d(np.stack([px, py, np.full_like(px, frame_index)], axis=-1))  # jitter: the state traceClosest sees
+    seed = pcg(state[..., 0].astype(np.uint32) ^ state[..., 2].astype(np.uint32))    # main.rgen:71
+    return base.rng_to_01(pcg(seed)) > np.float32(ALPHA)
+
+
+def _check_first_hit(img, passes):
+    """DrawType Position (debug.glsl:17-38): y of the first accepted hit is 2.5 on the veil, 0 on the ground."""
+    y = img[..., 1]
+    assert (np.abs(y[passes]) < 1e-3).all() and (np.abs(y[~passes] - 2.5) < 1e-3).all()
+    assert 0.55 < passes.mean() < 0.65
+
+
+def test_oracle_matches_the_numpy_camera_ray_transparency(oracle):
+    world = build_world_seen_from_above()
+    cam, fl = base._camera(oracle, world)
+    osc = oracle.OracleScene(world, brute_force=True)
+    for frame in (1, 2):
+        img, _ = osc.render(default_pc(S, fl, frame_index=frame, max_bounces=1, draw_type=S.DrawType["Position"]), cam, W, H)
+        _check_first_hit(img, numpy_camera_ray_passes(frame))
+
+
+@pytest.mark.gpu
+def test_hip_path_matches_oracle_bitwise_and_numpy_camera_ray_transparency(gpu_ctx, oracle):
+    world = build_world_seen_from_above()
+    cam, fl = base._camera(oracle, world)
+    pc = default_pc(S, fl, max_bounces=1, draw_type=S.DrawType["Position"])
+    gpu_ctx.upload_scene(world)
+    gpu_ctx.render(pc, cam, W, H)
+    got = gpu_ctx.read_hdr()
+    ref, _ = oracle.OracleScene(world, brute_force=True).render(pc, cam, W, H)
+    assert same_bits(got, ref).all()
+    _check_first_hit(got, numpy_camera_ray_passes())
+
+
+@pytest.mark.gpu
+def test_hip_path_matches_oracle_bitwise_and_numpy_shadow(gpu_ctx, oracle):
+    world = build_world()
+    want, pick, cond = base.numpy_radiance(world)
+    cam, fl = base._camera(oracle, world)
+    pc = default_pc(S, fl, max_bounces=1)
+    gpu_ctx.upload_scene(world)
+    gpu_ctx.render(pc, cam, W, H)
+    got = gpu_ctx.read_hdr()
+    ref, _ = oracle.OracleScene(world, brute_force=True).render(pc, cam, W, H)
+    assert same_bits(got, ref).all()
+    _check(got, want, pick, cond, numpy_visibility())
