@@ -120,6 +120,54 @@ def test_hip_path_matches_oracle_bitwise_and_numpy_camera_ray_transparency(gpu_c
     _check_first_hit(got, numpy_camera_ray_passes())
 
 
+def build_world_with_mask_veil(texel_alpha):
+    """A MASK veil (cutoff 0.5) whose base-colour texture has the same alpha in every texel, seen from above.  sampleAlpha
+    (materials.glsl:121-147) passes the sampled alpha through sRGBtoLinear before the cutoff - sampleMaterial does not
+     - so an alpha of 153 / 255 = 0.6 is 0.318 < 0.5: every camera ray goes through, although
+    0.6 >= 0.5; 200 / 255 = 0.784 is 0.578: every camera ray stops."""
+    w = base.build_world()
+    tex = np.full((8, 8, 4), 255, np.uint8)
+    tex[..., 3] = texel_alpha
+    t = w.add_texture(tex)
+    smp = w.add_sampler()
+    mat = w.add_material(base_color=(1.0, 1.0, 1.0, 1.0), metallic=0.0, roughness=1.0, alpha_cutoff=0.5,
+                         alpha_mode=S.ALPHA_MODE_MASK, base_tex=(t, smp))
+    mesh = scenes._add(w, scenes.quad((-40, 2.5, 40), (40, 2.5, 40), (40, 2.5, -40), (-40, 2.5, -40)), mat)
+    w.add_instance(w.add_model([(mesh, mat)]))
+    w.camera = dict(w.camera, eye=(0.0, 5.0, 4.0))
+    return w
+
+
+def srgb_to_linear(x):
+    """materials.glsl:26-35."""
+    return x / 12.92 if x <= 0.04045 else ((x + 0.055) / 1.055) ** 2.4
+
+
+@pytest.mark.parametrize("texel_alpha", [153, 200])
+def test_mask_cutoff_sees_the_alpha_after_srgb_to_linear(oracle, texel_alpha):
+    assert (texel_alpha / 255.0 >= 0.5) and ((srgb_to_linear(texel_alpha / 255.0) >= 0.5) == (texel_alpha == 200))
+    world = build_world_with_mask_veil(texel_alpha)
+    cam, fl = base._camera(oracle, world)
+    img, _ = oracle.OracleScene(world, brute_force=True).render(
+        default_pc(S, fl, max_bounces=1, draw_type=S.DrawType["Position"]), cam, W, H)
+    want_y = 2.5 if texel_alpha == 200 else 0.0
+    assert (np.abs(img[..., 1] - want_y) < 1e-3).all()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("texel_alpha", [153, 200])
+def test_hip_path_mask_cutoff_bitwise(gpu_ctx, oracle, texel_alpha):
+    world = build_world_with_mask_veil(texel_alpha)
+    cam, fl = base._camera(oracle, world)
+    pc = default_pc(S, fl, max_bounces=1, draw_type=S.DrawType["Position"])
+    gpu_ctx.upload_scene(world)
+    gpu_ctx.render(pc, cam, W, H)
+    got = gpu_ctx.read_hdr()
+    ref, _ = oracle.OracleScene(world, brute_force=True).render(pc, cam, W, H)
+    assert same_bits(got, ref).all()
+    assert (np.abs(got[..., 1] - (2.5 if texel_alpha == 200 else 0.0)) < 1e-3).all()
+
+
 @pytest.mark.gpu
 def test_hip_path_matches_oracle_bitwise_and_numpy_shadow(gpu_ctx, oracle):
     world = build_world()
