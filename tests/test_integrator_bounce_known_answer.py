@@ -34,7 +34,7 @@ from test_integrator_known_answer import normalize, pcg3d, rng_to_01, saturate
 
 W, H = 160, 120
 RTOL, ATOL = 5e-5, 1e-6
-SKY = (0.5, 0.75, 1.25)
+SKY = (0.5, 0.75, 2.0)  # 2 * albedo.z * sky.z = 2.4: the indirect clamp to [0, 2] (main.rgen:83-88) is active in one channel
 ALBEDO = (0.8, 0.7, 0.6)
 ROUGHNESS = 0.6
 METALLIC = 0.5  # fresnelZero = mix(0.04, albedo, metallic) is coloured: the specular weight differs per channel
