@@ -69,37 +69,9 @@ def onb_rows(n):
     return np.array([[1.0 + s * n[0] * n[0] * a, s * b, -s * n[0]], [b, s + n[1] * n[1] * a, -n[1]], n])
 
 
-def numpy_radiance(world, frame_index=1):
-    cam = world.camera
-    eye, target, up = (np.array(cam[k], np.float64) for k in ("eye", "target", "up"))
-    fwd = normalize(target - eye)
-    right = normalize(np.cross(fwd, up))
-    upv = np.cross(right, fwd)
-    tan_half = math.tan(cam["fov"] * 0.5)
-    aspect = W / H
-
-    py, px = np.meshgrid(np.arange(H, dtype=np.uint32), np.arange(W, dtype=np.uint32), indexing="ij")
-    state = pcg3d(np.stack([px, py, np.full_like(px, frame_index)], axis=-1))      # jitter
-    jitter = rng_to_01(state[..., :2]).astype(np.float64)
-    uv = (np.stack([px, py], axis=-1).astype(np.float64) + jitter) / np.array([W, H], np.float64)
-    nd = uv * 2.0 - 1.0
-    d = normalize(nd[..., :1] * right * (tan_half * aspect) - nd[..., 1:] * upv * tan_half + fwd)
-    n_geo = np.array([0.0, 0.8, 0.6])
-    assert ((d * n_geo).sum(-1) < -0.05).all(), "every primary ray must reach the plane"
-    assert (d * n_geo).sum(-1).max() > -0.12 and (d * n_geo).sum(-1).min() < -0.4  # grazing to moderately steep
-    t = -(eye * n_geo).sum() / (d * n_geo).sum(-1)
-    p = eye + t[..., None] * d
-    assert (np.abs(p[..., 0]) < 39).all() and (np.abs(p[..., 1]) > 2.0).all() and (np.abs(p[..., 1]) < 23).all()
-    assert (np.abs(p[..., 2]) > 3.0).all()
-    n = normalize(np.array([0.0, 409.0, 307.0]))  # packSnorm3x10_1x2(0, 0.8, 0.6) -> (0, 409, 307) / 511 -> normalize
-    v = -d
-
-    state = pcg3d(state)   # evaluateDirectLighting's light pick (main.rgen:205): the draw happens, the sun emits nothing
-    state = pcg3d(state)   # importanceSampleBounce: lobe pick (main.rgen:100)
-    pick_diffuse = rng_to_01(state[..., 0]) < np.float32(0.5)
-    state = pcg3d(state)   # direction (main.rgen:101)
-    u = rng_to_01(state[..., :2]).astype(np.float64)
-
+def sample_bounce(n, v, pick_diffuse, u):
+    """importanceSampleBounce (main.rgen:90-144) for a surface with shading normal n (3,), view vectors v [..., 3], the
+    lobe picks and the direction draws u [..., 2]: -> (direction [..., 3], weight brdf * NoL / pdf [..., 3]), float64."""
     albedo = np.array(ALBEDO, np.float64)
     alpha = ROUGHNESS * ROUGHNESS
     m = onb_rows(n)
@@ -154,6 +126,41 @@ def numpy_radiance(world, frame_index=1):
 
     rd = np.where(pick_diffuse[..., None], rd_diff, rd_spec)
     weight = np.where(pick_diffuse[..., None], w_diff, w_spec)
+    return rd, weight
+
+
+def numpy_radiance(world, frame_index=1):
+    cam = world.camera
+    eye, target, up = (np.array(cam[k], np.float64) for k in ("eye", "target", "up"))
+    fwd = normalize(target - eye)
+    right = normalize(np.cross(fwd, up))
+    upv = np.cross(right, fwd)
+    tan_half = math.tan(cam["fov"] * 0.5)
+    aspect = W / H
+
+    py, px = np.meshgrid(np.arange(H, dtype=np.uint32), np.arange(W, dtype=np.uint32), indexing="ij")
+    state = pcg3d(np.stack([px, py, np.full_like(px, frame_index)], axis=-1))      # jitter
+    jitter = rng_to_01(state[..., :2]).astype(np.float64)
+    uv = (np.stack([px, py], axis=-1).astype(np.float64) + jitter) / np.array([W, H], np.float64)
+    nd = uv * 2.0 - 1.0
+    d = normalize(nd[..., :1] * right * (tan_half * aspect) - nd[..., 1:] * upv * tan_half + fwd)
+    n_geo = np.array([0.0, 0.8, 0.6])
+    assert ((d * n_geo).sum(-1) < -0.05).all(), "every primary ray must reach the plane"
+    assert (d * n_geo).sum(-1).max() > -0.12 and (d * n_geo).sum(-1).min() < -0.4  # grazing to moderately steep
+    t = -(eye * n_geo).sum() / (d * n_geo).sum(-1)
+    p = eye + t[..., None] * d
+    assert (np.abs(p[..., 0]) < 39).all() and (np.abs(p[..., 1]) > 2.0).all() and (np.abs(p[..., 1]) < 23).all()
+    assert (np.abs(p[..., 2]) > 3.0).all()
+    n = normalize(np.array([0.0, 409.0, 307.0]))  # packSnorm3x10_1x2(0, 0.8, 0.6) -> (0, 409, 307) / 511 -> normalize
+    v = -d
+
+    state = pcg3d(state)   # evaluateDirectLighting's light pick (main.rgen:205): the draw happens, the sun emits nothing
+    state = pcg3d(state)   # importanceSampleBounce: lobe pick (main.rgen:100)
+    pick_diffuse = rng_to_01(state[..., 0]) < np.float32(0.5)
+    state = pcg3d(state)   # direction (main.rgen:101)
+    u = rng_to_01(state[..., :2]).astype(np.float64)
+
+    rd, weight = sample_bounce(n, v, pick_diffuse, u)
     leaves = (rd * n).sum(-1) > 0.0
     throughput = np.where(leaves[..., None], np.maximum(weight, 0.0), 0.0)
     radiance = np.clip(throughput * np.array(SKY, np.float64), 0.0, 2.0)
