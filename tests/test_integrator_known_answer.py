@@ -87,7 +87,9 @@ def eval_brdf_times_nol(l, n, v, albedo, roughness, metallic):
     return (c_diff / math.pi + spec) * NoL[..., None]
 
 
-def numpy_radiance(world, frame_index=1):
+def numpy_radiance(world, frame_index=1, lens=None):
+    """lens = (apertureDiameter, focusDistance): thinLensCameraRay (ray.glsl:46-78) instead of the pinhole ray - one more
+    rnd2d01 draw between the jitter and the light pick (main.rgen:236-240)."""
     f = world.freeze()
     cam = world.camera
     eye, target, up = (np.array(cam[k], np.float64) for k in ("eye", "target", "up"))
@@ -106,9 +108,20 @@ def numpy_radiance(world, frame_index=1):
     # ray.glsl:21-24 with Camera::perspective's Y flip: cameraToClip[1][1] < 0, so aspect and tanHalfFovY are both
     # negative - their product (the x term) is positive, the y term changes sign
     d = normalize(nd[..., :1] * right * (tan_half * aspect) - nd[..., 1:] * upv * tan_half + fwd)
+    origin = np.broadcast_to(eye, d.shape)
+    if lens is not None:
+        aperture, focus = lens
+        state = pcg3d(state)                               # main.rgen:238: the lens offset, rnd2d01
+        lo = rng_to_01(state[..., :2]).astype(np.float64)
+        theta = lo[..., 0] * 2.0 * 3.14159265
+        lu, lv = np.cos(theta) * np.sqrt(lo[..., 1]), np.sin(theta) * np.sqrt(lo[..., 1])
+        focus_point = eye + d * (focus / (d * fwd).sum(-1))[..., None]
+        coc = aperture / 2.0                               # focalLength / (2 * focalLength / aperture)
+        origin = eye + right * (lu * coc)[..., None] + upv * (lv * coc)[..., None]   # cameraToWorld * (lensPos, 1)
+        d = normalize(focus_point - origin)
     assert (d[..., 1] < 0).all(), "every primary ray must reach the plane"
-    t = -eye[1] / d[..., 1]
-    p = eye + t[..., None] * d
+    t = -origin[..., 1] / d[..., 1]
+    p = origin + t[..., None] * d
     assert (np.abs(p[..., 0]) < 40).all() and (np.abs(p[..., 2]) < 40).all()
     n = np.array([0.0, 1.0, 0.0])
     v = -d
@@ -171,11 +184,11 @@ def _camera(oracle, world):
     return oracle.camera_uniforms(c["eye"], c["target"], c["up"], c["fov"], c["zN"], c["zF"], W, H)
 
 
-def _check_against_numpy(img, want, pick, cond):
+def _check_against_numpy(img, want, pick, cond, rtol=RTOL):
     assert (img[..., 3] == 1.0).all()
     scale = want.max()
     err = np.abs(img[..., :3].astype(np.float64) - want)
-    bound = (RTOL + cond[..., None]) * np.abs(want) + ATOL_OF_MAX * scale
+    bound = (rtol + cond[..., None] * (rtol / RTOL)) * np.abs(want) + ATOL_OF_MAX * scale
     bad = err > bound
     assert not bad.any(), "%d channel values off; worst %g at %s (want %g)" % (
         bad.sum(), (err / np.maximum(np.abs(want), 1e-300)).max(), np.argwhere(bad)[0], want[tuple(np.argwhere(bad)[0])])
@@ -183,7 +196,7 @@ def _check_against_numpy(img, want, pick, cond):
     assert all((pick == k).sum() > 1000 for k in (0, 1, 2))
     assert (cond > 0).sum() > 200 and ((cond > 0) & (cond < 1e-4)).sum() > 0.9 * (cond > 0).sum()  # the falloff zone is small
     plain = (cond == 0) & (want.sum(-1) > 100 * ATOL_OF_MAX * scale)
-    assert (err[plain] / want[plain]).max() < RTOL  # everywhere else: 1e-5 relative, as stated
+    assert (err[plain] / want[plain]).max() < rtol  # everywhere else: 1e-5 relative, as stated
     assert ((want.sum(-1) > 0) & (pick == 1)).sum() > 1000 and ((want.sum(-1) > 0) & (pick == 2)).sum() > 500
 
 
@@ -215,3 +228,42 @@ def test_hip_path_matches_oracle_bitwise_and_numpy_within_tolerance(gpu_ctx, ora
     ref, _ = oracle.OracleScene(world, brute_force=True).render(pc, cam, W, H)
     assert same_bits(got, ref).all()
     _check_against_numpy(got, want, pick, cond)
+
+
+# ---- the same answer through the thin-lens camera (depth of field): ray.glsl:46-78, main.rgen:236-240 ----
+
+LENS = (0.3, 4.5)  # apertureDiameter, focusDistance: a 15 cm circle of confusion radius at the lens - rays move by centimetres
+RTOL_LENS = 5e-5   # the lens ray adds an fp32 normalize(focusPoint - origin) in front of everything: measured 2.4e-5 outside the spot's falloff zone
+
+
+def _lens_pc(fl, frame_index=1):
+    pc = default_pc(S, fl, frame_index=frame_index, max_bounces=1, dof=True)
+    pc.apertureDiameter, pc.focusDistance = LENS
+    return pc
+
+
+def test_oracle_matches_the_numpy_float64_integrator_with_depth_of_field(oracle):
+    world = build_world()
+    cam, fl = _camera(oracle, world)
+    osc = oracle.OracleScene(world, brute_force=True)
+    for frame in (1, 2):
+        want, pick, cond = numpy_radiance(world, frame_index=frame, lens=LENS)
+        img, _ = osc.render(_lens_pc(fl, frame), cam, W, H)
+        _check_against_numpy(img, want, pick, cond, RTOL_LENS)
+        # the lens matters: the pinhole answer is a different image (and a different light pick per pixel: one draw earlier)
+        pinhole, pinhole_pick, _ = numpy_radiance(world, frame_index=frame)
+        assert (pinhole_pick != pick).mean() > 0.5 and np.abs(pinhole - want).max() > 0.1 * want.max()
+
+
+@pytest.mark.gpu
+def test_hip_path_matches_oracle_bitwise_and_numpy_with_depth_of_field(gpu_ctx, oracle):
+    world = build_world()
+    want, pick, cond = numpy_radiance(world, lens=LENS)
+    cam, fl = _camera(oracle, world)
+    pc = _lens_pc(fl)
+    gpu_ctx.upload_scene(world)
+    gpu_ctx.render(pc, cam, W, H)
+    got = gpu_ctx.read_hdr()
+    ref, _ = oracle.OracleScene(world, brute_force=True).render(pc, cam, W, H)
+    assert same_bits(got, ref).all()
+    _check_against_numpy(got, want, pick, cond, RTOL_LENS)
