@@ -267,3 +267,57 @@ def test_hip_path_matches_oracle_bitwise_and_numpy_with_depth_of_field(gpu_ctx, 
     ref, _ = oracle.OracleScene(world, brute_force=True).render(pc, cam, W, H)
     assert same_bits(got, ref).all()
     _check_against_numpy(got, want, pick, cond, RTOL_LENS)
+
+
+# ---- accumulation (main.rgen:285-298): frames 1..4 of the same answer, running mean with the sample count in alpha ----
+
+def _running_mean(frames):
+    """new = hist + (c - hist) / (hist.a + 1), first frame (skipHistory) -> (c, 1)."""
+    hist, count = frames[0].copy(), 1.0
+    for c in frames[1:]:
+        hist = hist + (c - hist) / (count + 1.0)
+        count += 1.0
+    return hist, count
+
+
+def _check_accumulated(img, frames):
+    want, count = _running_mean([f[0] for f in frames])
+    assert (img[..., 3] == count).all()
+    scale = want.max()
+    cond = np.max([f[2] for f in frames], axis=0)
+    err = np.abs(img[..., :3].astype(np.float64) - want)
+    # each frame within (RTOL + its conditioning) of its float64 value, so the mean within that of the mean of magnitudes
+    mags = np.mean([np.abs(f[0]) for f in frames], axis=0)
+    assert (err <= (2 * RTOL + cond[..., None]) * mags + ATOL_OF_MAX * scale).all()
+    # and it IS a mean of different images: a pixel lit in one frame and unlit in another (another light pick) holds a fraction
+    lit = np.stack([f[0].sum(-1) > 0 for f in frames])
+    mixed = lit.any(0) & ~lit.all(0)
+    assert mixed.sum() > 1000 and (img[..., :3].sum(-1)[mixed] > 0).all()
+
+
+def test_oracle_accumulates_the_running_mean_of_the_numpy_frames(oracle):
+    world = build_world()
+    cam, fl = _camera(oracle, world)
+    osc = oracle.OracleScene(world, brute_force=True)
+    frames, img = [], None
+    for frame in (1, 2, 3, 4):
+        frames.append(numpy_radiance(world, frame_index=frame))
+        img, _ = osc.render(default_pc(S, fl, frame_index=frame, max_bounces=1, skip_history=(frame == 1)), cam, W, H, history=img)
+    _check_accumulated(img, frames)
+
+
+@pytest.mark.gpu
+def test_hip_path_accumulates_bitwise_like_the_oracle_and_the_numpy_mean(gpu_ctx, oracle):
+    world = build_world()
+    cam, fl = _camera(oracle, world)
+    osc = oracle.OracleScene(world, brute_force=True)
+    gpu_ctx.upload_scene(world)
+    frames, ref = [], None
+    for frame in (1, 2, 3, 4):
+        frames.append(numpy_radiance(world, frame_index=frame))
+        pc = default_pc(S, fl, frame_index=frame, max_bounces=1, skip_history=(frame == 1))
+        gpu_ctx.render(pc, cam, W, H)
+        ref, _ = osc.render(pc, cam, W, H, history=ref)
+    got = gpu_ctx.read_hdr()
+    assert same_bits(got, ref).all()
+    _check_accumulated(got, frames)
