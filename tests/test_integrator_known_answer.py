@@ -321,3 +321,82 @@ def test_hip_path_accumulates_bitwise_like_the_oracle_and_the_numpy_mean(gpu_ctx
     got = gpu_ctx.read_hdr()
     assert same_bits(got, ref).all()
     _check_accumulated(got, frames)
+
+
+# ---- the sun and an opaque shadow (lighting.glsl:58-70, main.rgen:49-60,195-223) ----
+
+PLATE = (3.0, 7.0, 6.0, 2.0, 6.5)  # x0, x1, y, z0, z1: an opaque plate above and behind the camera
+
+
+def build_world_sun():
+    w = World()
+    mat = w.add_material(base_color=(0.8, 0.7, 0.6, 1.0), metallic=0.0, roughness=1.0)
+    mesh = scenes._add(w, scenes.quad((-40, 0, 40), (40, 0, 40), (40, 0, -40), (-40, 0, -40)), mat)
+    w.add_instance(w.add_model([(mesh, mat)]))
+    x0, x1, y, z0, z1 = PLATE
+    plate = scenes._add(w, scenes.quad((x0, y, z1), (x1, y, z1), (x1, y, z0), (x0, y, z0)), mat)
+    w.add_instance(w.add_model([(plate, mat)]))
+    w.set_directional_light((1.0, 0.9, 0.8), 2.0, (-1.0, -1.0, -1.0))  # un-normalised, as prosper's default (lights.h:9,18-19)
+    w.camera = dict(eye=(0.0, 2.0, 4.0), target=(0.0, 0.0, 0.0), up=(0.0, 1.0, 0.0), fov=math.radians(40.0), zN=0.1, zF=100.0)
+    return w
+
+
+def numpy_radiance_sun(world, frame_index=1):
+    cam = world.camera
+    eye, target, up = (np.array(cam[k], np.float64) for k in ("eye", "target", "up"))
+    fwd = normalize(target - eye)
+    right = normalize(np.cross(fwd, up))
+    upv = np.cross(right, fwd)
+    tan_half = math.tan(cam["fov"] * 0.5)
+    py, px = np.meshgrid(np.arange(H, dtype=np.uint32), np.arange(W, dtype=np.uint32), indexing="ij")
+    state = pcg3d(np.stack([px, py, np.full_like(px, frame_index)], axis=-1))
+    jitter = rng_to_01(state[..., :2]).astype(np.float64)
+    uv = (np.stack([px, py], axis=-1).astype(np.float64) + jitter) / np.array([W, H], np.float64)
+    nd = uv * 2.0 - 1.0
+    d = normalize(nd[..., :1] * right * (tan_half * W / H) - nd[..., 1:] * upv * tan_half + fwd)
+    p = eye + (-eye[1] / d[..., 1])[..., None] * d
+    n = np.array([0.0, 1.0, 0.0])
+    sun = world.directional
+    irr = np.array([sun.irradiance.x, sun.irradiance.y, sun.irradiance.z], np.float64)
+    l = -normalize(np.array([sun.direction.x, sun.direction.y, sun.direction.z], np.float64))   # lighting.glsl:66
+    mat = world.freeze()["materials"][1]
+    albedo = np.array([mat.baseColorFactor.x, mat.baseColorFactor.y, mat.baseColorFactor.z], np.float64)
+    lv = np.broadcast_to(l, p.shape)
+    c = irr * 1.0 * eval_brdf_times_nol(lv, n, -d, albedo, max(float(mat.roughnessFactor), 0.05), float(mat.metallicFactor))
+    # the shadow ray p + t l, t in (0.1, 100), against the plate
+    x0, x1, y, z0, z1 = PLATE
+    t = y / l[1]
+    hx, hz = p[..., 0] + t * l[0], p[..., 2] + t * l[2]
+    inside = (hx > x0) & (hx < x1) & (hz > z0) & (hz < z1)
+    edge = np.minimum(np.minimum(np.abs(hx - x0), np.abs(hx - x1)), np.minimum(np.abs(hz - z0), np.abs(hz - z1)))
+    assert 0.1 < t < 100.0
+    return np.where(inside[..., None], 0.0, c), inside, edge > 1e-3
+
+
+def _check_sun(img, want, shadowed, compared):
+    err = np.abs(img[..., :3].astype(np.float64) - want)
+    assert (err[compared] <= RTOL * np.abs(want[compared]) + ATOL_OF_MAX * want.max()).all()
+    assert (img[..., :3][shadowed & compared] == 0.0).all()
+    assert shadowed.sum() > 1000 and (~shadowed).sum() > 5000 and compared.mean() > 0.99
+
+
+def test_oracle_matches_the_numpy_sun_and_its_shadow(oracle):
+    world = build_world_sun()
+    cam, fl = _camera(oracle, world)
+    osc = oracle.OracleScene(world, brute_force=True)
+    for frame in (1, 2):
+        img, _ = osc.render(default_pc(S, fl, frame_index=frame, max_bounces=1), cam, W, H)
+        _check_sun(img, *numpy_radiance_sun(world, frame_index=frame))
+
+
+@pytest.mark.gpu
+def test_hip_path_matches_oracle_bitwise_and_numpy_sun(gpu_ctx, oracle):
+    world = build_world_sun()
+    cam, fl = _camera(oracle, world)
+    pc = default_pc(S, fl, max_bounces=1)
+    gpu_ctx.upload_scene(world)
+    gpu_ctx.render(pc, cam, W, H)
+    got = gpu_ctx.read_hdr()
+    ref, _ = oracle.OracleScene(world, brute_force=True).render(pc, cam, W, H)
+    assert same_bits(got, ref).all()
+    _check_sun(got, *numpy_radiance_sun(world))
