@@ -87,9 +87,10 @@ def eval_brdf_times_nol(l, n, v, albedo, roughness, metallic):
     return (c_diff / math.pi + spec) * NoL[..., None]
 
 
-def numpy_radiance(world, frame_index=1, lens=None):
+def numpy_radiance(world, frame_index=1, lens=None, surface=None):
     """lens = (apertureDiameter, focusDistance): thinLensCameraRay (ray.glsl:46-78) instead of the pinhole ray - one more
-    rnd2d01 draw between the jitter and the light pick (main.rgen:236-240)."""
+    rnd2d01 draw between the jitter and the light pick (main.rgen:236-240).
+    surface(p) -> (albedo [..., 3], roughness, metallic) replaces the material factors (textured materials)."""
     f = world.freeze()
     cam = world.camera
     eye, target, up = (np.array(cam[k], np.float64) for k in ("eye", "target", "up"))
@@ -135,6 +136,8 @@ def numpy_radiance(world, frame_index=1, lens=None):
     albedo = np.array([mat.baseColorFactor.x, mat.baseColorFactor.y, mat.baseColorFactor.z], np.float64)
     rough = max(float(mat.roughnessFactor), 0.05)
     metal = float(mat.metallicFactor)
+    if surface is not None:
+        albedo, rough, metal = surface(p)
 
     pl = world.point_lights.lights[0]
     sl = world.spot_lights.lights[0]
@@ -400,3 +403,83 @@ def test_hip_path_matches_oracle_bitwise_and_numpy_sun(gpu_ctx, oracle):
     ref, _ = oracle.OracleScene(world, brute_force=True).render(pc, cam, W, H)
     assert same_bits(got, ref).all()
     _check_sun(got, *numpy_radiance_sun(world))
+
+
+# ---- textures in the shading (materials.glsl:47-119, geometry.glsl:246-295): which texel, which channel, which decode ----
+
+BASE_TEXELS = np.array([[(200, 50, 50, 255), (50, 200, 50, 255)],
+                        [(50, 50, 200, 255), (220, 220, 60, 255)]], np.uint8)   # [row j (v), column i (u)]
+MR_TEXEL = (0, 180, 90, 255)   # g = roughness, b = metallic (materials.glsl:86-96)
+UV_SCALE = 16.0                # the 2 x 2 texture repeats every 5 units: 2.5-unit texels
+
+
+def build_world_textured():
+    w = World()
+    nearest = w.add_sampler(S.FILTER_NEAREST, S.FILTER_NEAREST, S.WRAP_REPEAT, S.WRAP_REPEAT)
+    base = w.add_texture(BASE_TEXELS)
+    mr = w.add_texture(np.tile(np.array(MR_TEXEL, np.uint8), (2, 2, 1)))
+    mat = w.add_material(base_color=(1.0, 1.0, 1.0, 1.0), metallic=1.0, roughness=1.0, base_tex=(base, nearest), mr_tex=(mr, nearest))
+    mesh = scenes._add(w, scenes.quad((-40, 0, 40), (40, 0, 40), (40, 0, -40), (-40, 0, -40), uv_scale=UV_SCALE), mat)
+    w.add_instance(w.add_model([(mesh, mat)]))
+    w.add_point_light((1.0, 0.9, 0.8), 200.0, (1.0, 3.0, 0.5))
+    d = np.array([0.3, -1.0, -0.2])
+    w.add_spot_light((0.7, 0.8, 1.0), 300.0, (-2.0, 4.0, 1.0), d / np.linalg.norm(d), math.radians(20.0), math.radians(35.0))
+    w.camera = dict(eye=(0.0, 2.0, 4.0), target=(0.0, 0.0, 0.0), up=(0.0, 1.0, 0.0), fov=math.radians(40.0), zN=0.1, zF=100.0)
+    return w
+
+
+def _srgb_to_linear(x):
+    """materials.glsl:26-35."""
+    return np.where(x <= 0.04045, x / 12.92, ((x + 0.055) / 1.055) ** 2.4)
+
+
+def textured_surface(p, away):
+    """The quad's corners carry uv (0,0) at (-40, 0, 40), (1,0) at (40, 0, 40), (1,1) at (40, 0, -40), times UV_SCALE."""
+    u = (p[..., 0] + 40.0) / 80.0 * UV_SCALE
+    v = (40.0 - p[..., 2]) / 80.0 * UV_SCALE
+    fu, fv = u * 2.0, v * 2.0                          # nearest: texel = floor(uv * size) mod size (repeat)
+    i, j = np.floor(fu).astype(np.int64) % 2, np.floor(fv).astype(np.int64) % 2
+    away &= (np.abs(fu - np.round(fu)) > 1e-3) & (np.abs(fv - np.round(fv)) > 1e-3)
+    texel = BASE_TEXELS[j, i].astype(np.float64) / 255.0
+    albedo = _srgb_to_linear(texel[..., :3])           # sRGB decode of the colour, factor 1
+    return albedo, max(MR_TEXEL[1] / 255.0, 0.05), MR_TEXEL[2] / 255.0
+
+
+def _textured_answer(world, frame_index=1):
+    away = np.ones((H, W), bool)
+    want, pick, cond = numpy_radiance(world, frame_index=frame_index, surface=lambda p: textured_surface(p, away))
+    return want, pick, cond, away
+
+
+def _check_textured(img, want, pick, cond, away):
+    err = np.abs(img[..., :3].astype(np.float64) - want)
+    # 2e-5: the metallic surface's specular term and the fp32 pow of the sRGB decode double the plain case's error
+    bound = 2.0 * (RTOL + cond[..., None]) * np.abs(want) + ATOL_OF_MAX * want.max()
+    assert (err <= bound)[away].all(), "%d of %d compared channel values off" % ((err > bound)[away].sum(), away.sum() * 3)
+    assert away.mean() > 0.98
+    # all four texels are on screen and tint what they cover (red-ish, green-ish, blue-ish, yellow-ish)
+    lit = (want.sum(-1) > 0) & away
+    dominant = np.argmax(want, axis=-1)
+    assert all((lit & (dominant == c)).sum() > 300 for c in range(3))
+
+
+def test_oracle_matches_the_numpy_textured_surface(oracle):
+    world = build_world_textured()
+    cam, fl = _camera(oracle, world)
+    osc = oracle.OracleScene(world, brute_force=True)
+    for frame in (1, 2):
+        img, _ = osc.render(default_pc(S, fl, frame_index=frame, max_bounces=1), cam, W, H)
+        _check_textured(img, *_textured_answer(world, frame))
+
+
+@pytest.mark.gpu
+def test_hip_path_matches_oracle_bitwise_and_numpy_textured_surface(gpu_ctx, oracle):
+    world = build_world_textured()
+    cam, fl = _camera(oracle, world)
+    pc = default_pc(S, fl, max_bounces=1)
+    gpu_ctx.upload_scene(world)
+    gpu_ctx.render(pc, cam, W, H)
+    got = gpu_ctx.read_hdr()
+    ref, _ = oracle.OracleScene(world, brute_force=True).render(pc, cam, W, H)
+    assert same_bits(got, ref).all()
+    _check_textured(got, *_textured_answer(world))
