@@ -137,7 +137,10 @@ def numpy_radiance(world, frame_index=1, lens=None, surface=None):
     rough = max(float(mat.roughnessFactor), 0.05)
     metal = float(mat.metallicFactor)
     if surface is not None:
-        albedo, rough, metal = surface(p)
+        res = surface(p)
+        albedo, rough, metal = res[:3]
+        if len(res) > 3:
+            n = res[3]                                     # the shading normal (instance transform, normal map)
 
     pl = world.point_lights.lights[0]
     sl = world.spot_lights.lights[0]
@@ -154,11 +157,17 @@ def numpy_radiance(world, frame_index=1, lens=None, surface=None):
     d2 = (to_light * to_light).sum(-1)
     dist = np.sqrt(d2)
     l = to_light / dist[..., None]
-    att = np.maximum(np.minimum(1.0 - (dist / radius) ** 4, 1.0), 0.0)
+    q4 = (dist / radius) ** 4
+    att = np.maximum(np.minimum(1.0 - q4, 1.0), 0.0)
     irr = radiance * (att / d2)[..., None]
     lit = (l * n).sum(-1) > 0
     c = irr * light_count * eval_brdf_times_nol(l, n, v, albedo, rough, metal)
     out = np.where(((pick == 1) & lit)[..., None], c, out)
+    # conditioning of the range window near the light's radius: 1 - q^4 amplifies the fp32 rounding of q^4 (a few
+    # half-ulps, taken as 8 * 2^-24) by q^4 / (1 - q^4)
+    cond_point = np.where((pick == 1) & (att > 0) & (att < 1), 8.0 * 2.0 ** -24 * q4 / np.maximum(att, 1e-30), 0.0)
+    # ... and of a light within 3 degrees of the shading horizon: NoL = dot(n, l) carries ~8 * 2^-24 of absolute rounding
+    cond_point = np.maximum(cond_point, np.where((pick == 1) & lit & ((l * n).sum(-1) < 0.05), 8.0 * 2.0 ** -24 / np.maximum((l * n).sum(-1), 1e-30), 0.0))
 
     # spot light, lighting.glsl:39-56
     pos = np.array([sl.positionAndAngleOffset.x, sl.positionAndAngleOffset.y, sl.positionAndAngleOffset.z], np.float64)
@@ -179,7 +188,8 @@ def numpy_radiance(world, frame_index=1, lens=None, surface=None):
     # conditioning of the spot cone's edge: the fp32 shader's cd = dot(-direction, l) carries a few half-ulps of
     # rounding (taken as 4 * 2^-24 here), which att = saturate(cd * scale + offset)^2 amplifies by 2 * scale / x
     cond = np.where((pick == 2) & (x > 0) & (x < 1), 2.0 * scale * 4.0 * 2.0 ** -24 / np.maximum(x, 1e-30), 0.0)
-    return out, pick, cond
+    cond = np.maximum(cond, np.where((pick == 2) & lit & ((l * n).sum(-1) < 0.05), 8.0 * 2.0 ** -24 / np.maximum((l * n).sum(-1), 1e-30), 0.0))
+    return out, pick, np.maximum(cond, cond_point)
 
 
 def _camera(oracle, world):
@@ -483,3 +493,80 @@ def test_hip_path_matches_oracle_bitwise_and_numpy_textured_surface(gpu_ctx, ora
     ref, _ = oracle.OracleScene(world, brute_force=True).render(pc, cam, W, H)
     assert same_bits(got, ref).all()
     _check_textured(got, *_textured_answer(world))
+
+
+# ---- the shading frame: snorm10 normals and tangents, the instance's normal matrix, the normal map ----
+# geometry.glsl:95-127 (decode + normalize), instances.glsl:36-53 (normal * mat3(inverse(M)), tangent * mat3(M)),
+# main.rgen:37-45 (mappedNormal: B = sgn * cross(N, T)), materials.glsl:104-116 (normal = texel * 2 - 1)
+
+NORMAL_TEXEL = (200, 100, 230, 255)
+OBJECT_NORMAL = (0.6, 0.8, 0.0)      # tilted against the flat geometry: packs to (307, 409, 0) / 511
+OBJECT_TANGENT = (0.8, -0.6, 0.0)    # packs to (409, -307, 0) / 511, sign +1
+
+
+def _instance_matrix():
+    from prosper_amd.world import rotate_y, scale
+    return rotate_y(math.radians(30.0)) @ scale((2.0, 1.0, 0.5))
+
+
+def build_world_shading_frame():
+    w = World()
+    lin = w.add_sampler()
+    nt = w.add_texture(np.tile(np.array(NORMAL_TEXEL, np.uint8), (2, 2, 1)))
+    mat = w.add_material(base_color=(0.8, 0.7, 0.6, 1.0), metallic=0.0, roughness=0.7, normal_tex=(nt, lin))
+    pos = np.array([(-30, 0, 120), (30, 0, 120), (30, 0, -120), (-30, 0, -120)], np.float64)   # x2, x0.5 by the instance
+    nrm = np.tile(np.array(OBJECT_NORMAL), (4, 1))
+    tan = np.tile(np.array(OBJECT_TANGENT + (1.0,)), (4, 1))
+    uvs = np.array([[0, 0], [1, 0], [1, 1], [0, 1]], np.float64)
+    mesh = w.add_mesh(pos, np.array([0, 1, 2, 0, 2, 3], np.uint32), mat, normals=nrm, tangents=tan, uvs=uvs)
+    w.add_instance(w.add_model([(mesh, mat)]), _instance_matrix())
+    w.add_point_light((1.0, 0.9, 0.8), 200.0, (1.0, 3.0, 0.5))
+    d = np.array([0.3, -1.0, -0.2])
+    w.add_spot_light((0.7, 0.8, 1.0), 300.0, (-2.0, 4.0, 1.0), d / np.linalg.norm(d), math.radians(20.0), math.radians(35.0))
+    w.camera = dict(eye=(0.0, 2.0, 4.0), target=(0.0, 0.0, 0.0), up=(0.0, 1.0, 0.0), fov=math.radians(40.0), zN=0.1, zF=100.0)
+    return w
+
+
+def shading_normal():
+    m = _instance_matrix()[:3, :3]
+    n_o = normalize(np.array([307.0, 409.0, 0.0]))         # unpackSnorm10 / 511, clamp, normalize
+    t_o = normalize(np.array([409.0, -307.0, 0.0]))
+    n_w = normalize(np.linalg.inv(m).T @ n_o)              # n * mat3(inverse(M)): the inverse transpose
+    t_w = normalize(m @ t_o)                               # t * mat3(modelToWorld) with modelToWorld = transpose(M)
+    b_w = 1.0 * np.cross(n_w, t_w)
+    nt = np.array(NORMAL_TEXEL[:3], np.float64) / 255.0 * 2.0 - 1.0
+    return normalize(nt[0] * t_w + nt[1] * b_w + nt[2] * n_w)
+
+
+def _shading_frame_answer(world, frame_index=1):
+    n = shading_normal()
+    return numpy_radiance(world, frame_index=frame_index,
+                          surface=lambda p: (np.array([0.8, 0.7, 0.6]), 0.7, 0.0, n))
+
+
+def test_oracle_matches_the_numpy_shading_frame(oracle):
+    n = shading_normal()
+    assert n[1] > 0.5 and abs(n[0]) > 0.1 and abs(n[2]) > 0.1          # tilted off the geometric normal in both directions
+    wrong = normalize(_instance_matrix()[:3, :3] @ normalize(np.array([307.0, 409.0, 0.0])))
+    assert np.abs(wrong - normalize(np.linalg.inv(_instance_matrix()[:3, :3]).T @ normalize(np.array([307.0, 409.0, 0.0])))).max() > 0.2
+    world = build_world_shading_frame()
+    cam, fl = _camera(oracle, world)
+    osc = oracle.OracleScene(world, brute_force=True)
+    for frame in (1, 2):
+        want, pick, cond = _shading_frame_answer(world, frame)
+        img, _ = osc.render(default_pc(S, fl, frame_index=frame, max_bounces=1), cam, W, H)
+        _check_against_numpy(img, want, pick, cond, 5e-5)
+
+
+@pytest.mark.gpu
+def test_hip_path_matches_oracle_bitwise_and_numpy_shading_frame(gpu_ctx, oracle):
+    world = build_world_shading_frame()
+    want, pick, cond = _shading_frame_answer(world)
+    cam, fl = _camera(oracle, world)
+    pc = default_pc(S, fl, max_bounces=1)
+    gpu_ctx.upload_scene(world)
+    gpu_ctx.render(pc, cam, W, H)
+    got = gpu_ctx.read_hdr()
+    ref, _ = oracle.OracleScene(world, brute_force=True).render(pc, cam, W, H)
+    assert same_bits(got, ref).all()
+    _check_against_numpy(got, want, pick, cond, 5e-5)
