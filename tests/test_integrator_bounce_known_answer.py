@@ -41,7 +41,7 @@ METALLIC = 0.5  # fresnelZero = mix(0.04, albedo, metallic) is coloured: the spe
 PI = 3.14159265  # math.glsl:4
 
 
-def build_world():
+def build_world(sky_faces=None):
     w = World()
     mat = w.add_material(base_color=ALBEDO + (1.0,), metallic=METALLIC, roughness=ROUGHNESS)
     # corners +-40 u +- 40 v with u = (1, 0, 0), v = (0, -0.6, 0.8): exactly representable in binary16
@@ -49,7 +49,7 @@ def build_world():
     w.add_instance(w.add_model([(mesh, mat)]))
     w.set_directional_light((1.0, 1.0, 1.0), 0.0, (-1.0, -1.0, -1.0))
     sky = np.empty((6, 4, 4, 4), np.float16)
-    sky[..., :3] = np.asarray(SKY, np.float16)
+    sky[..., :3] = np.asarray(SKY, np.float16) if sky_faces is None else np.asarray(sky_faces, np.float16)[:, None, None, :]
     sky[..., 3] = np.float16(1.0)
     w.skybox = sky
     # A grazing view (17 degrees above the plane at the centre: NoV from 0.09 to 0.5, so the masking terms and the
@@ -129,7 +129,7 @@ def sample_bounce(n, v, pick_diffuse, u):
     return rd, weight
 
 
-def numpy_radiance(world, frame_index=1):
+def numpy_radiance(world, frame_index=1, sky_faces=None):
     cam = world.camera
     eye, target, up = (np.array(cam[k], np.float64) for k in ("eye", "target", "up"))
     fwd = normalize(target - eye)
@@ -163,11 +163,23 @@ def numpy_radiance(world, frame_index=1):
     rd, weight = sample_bounce(n, v, pick_diffuse, u)
     leaves = (rd * n).sum(-1) > 0.0
     throughput = np.where(leaves[..., None], np.maximum(weight, 0.0), 0.0)
-    radiance = np.clip(throughput * np.array(SKY, np.float64), 0.0, 2.0)
     # not compared: directions within 0.02 of the shading horizon (NoL -> 0: the specular weight is 0 / 0-like) or of
     # the geometric one (the bounce ray may or may not meet the plane again)
     margin = np.minimum(np.abs((rd * n).sum(-1)), np.abs((rd * n_geo).sum(-1)))
-    return radiance, pick_diffuse, margin > 0.02, leaves
+    compared = margin > 0.02
+    if sky_faces is None:
+        sky = np.array(SKY, np.float64)
+    else:
+        # cube faces +X, -X, +Y, -Y, +Z, -Z by the direction's major axis; every face one colour, so a lookup whose
+        # 2 x 2 footprint stays on the face returns it - directions whose second largest component exceeds 0.7 of the
+        # largest (within a texel of a 4 x 4 face's border) are not compared
+        face = sky_face_of(rd)
+        sky = np.asarray(sky_faces, np.float64)[face]
+        numpy_radiance.last_faces = np.where(compared & leaves, face, -1)
+        srt = np.sort(np.abs(rd), axis=-1)
+        compared &= srt[..., 1] < 0.7 * srt[..., 2]
+    radiance = np.clip(throughput * sky, 0.0, 2.0)
+    return radiance, pick_diffuse, compared, leaves
 
 
 def _camera(oracle, world):
@@ -219,3 +231,48 @@ def test_hip_path_matches_oracle_bitwise_and_numpy_bounce(gpu_ctx, oracle):
     ref, _ = oracle.OracleScene(world, brute_force=True).render(pc, cam, W, H)
     assert same_bits(got, ref).all()
     _check(got, want, pick, compared, leaves)
+
+
+SKY_FACES = [(1.0, 0.25, 0.25), (0.25, 1.0, 0.25), (0.25, 0.25, 1.0), (1.0, 1.0, 0.25), (1.0, 0.25, 1.0), (0.25, 1.0, 1.0)]
+
+
+def sky_face_of(rd):
+    a = np.abs(rd)
+    major = np.argmax(a, axis=-1)
+    return 2 * major + (np.take_along_axis(rd, major[..., None], axis=-1)[..., 0] < 0)
+
+
+def _check_faces(img, want, compared, leaves):
+    got = img[..., :3].astype(np.float64)
+    err = np.abs(got - want)
+    assert (err[compared] <= RTOL * np.abs(want[compared]) + ATOL).all()
+    assert compared.mean() > 0.5 and leaves[compared].mean() > 0.9
+
+
+def test_oracle_matches_the_numpy_sky_face_lookup(oracle):
+    """The same bounce under a sky whose six faces have six colours (skybox.glsl:4, main.rgen:249-253: textureLod on the
+    cube with the bounce direction): which face a direction reads."""
+    world = build_world(SKY_FACES)
+    cam, fl = _camera(oracle, world)
+    osc = oracle.OracleScene(world, brute_force=True)
+    for frame in (1, 2):
+        want, pick, compared, leaves = numpy_radiance(world, frame_index=frame, sky_faces=SKY_FACES)
+        img, _ = osc.render(default_pc(S, fl, frame_index=frame, max_bounces=2, ibl=True), cam, W, H)
+        _check_faces(img, want, compared, leaves)
+        # the bounce directions read at least four of the six faces, hundreds of compared pixels each
+        counts = np.bincount(numpy_radiance.last_faces[(numpy_radiance.last_faces >= 0) & compared], minlength=6)
+        assert (counts > 300).sum() >= 4, counts
+
+
+@pytest.mark.gpu
+def test_hip_path_matches_oracle_bitwise_and_numpy_sky_faces(gpu_ctx, oracle):
+    world = build_world(SKY_FACES)
+    want, pick, compared, leaves = numpy_radiance(world, sky_faces=SKY_FACES)
+    cam, fl = _camera(oracle, world)
+    pc = default_pc(S, fl, max_bounces=2, ibl=True)
+    gpu_ctx.upload_scene(world)
+    gpu_ctx.render(pc, cam, W, H)
+    got = gpu_ctx.read_hdr()
+    ref, _ = oracle.OracleScene(world, brute_force=True).render(pc, cam, W, H)
+    assert same_bits(got, ref).all()
+    _check_faces(got, want, compared, leaves)
