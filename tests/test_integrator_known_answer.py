@@ -570,3 +570,96 @@ def test_hip_path_matches_oracle_bitwise_and_numpy_shading_frame(gpu_ctx, oracle
     ref, _ = oracle.OracleScene(world, brute_force=True).render(pc, cam, W, H)
     assert same_bits(got, ref).all()
     _check_against_numpy(got, want, pick, cond, 5e-5)
+
+
+# ---- the debug draw types (debug.glsl:17-38, main.rgen:181-193,259-264, random.glsl:30-40) ----
+
+def _pcg(v):
+    """random.glsl:7-12."""
+    v = np.asarray(v, np.uint64)
+    state = (v * 747796405 + 2891336453) & 0xFFFFFFFF
+    word = (((state >> ((state >> 28) + 4)) ^ state) * 277803737) & 0xFFFFFFFF
+    return (word >> 22) ^ word
+
+
+def uint_to_color(x):
+    xr = _pcg(x)
+    return np.stack([(xr >> 20) & 0x3FF, (xr >> 10) & 0x3FF, xr & 0x3FF], axis=-1).astype(np.float64) / 0x3FF
+
+
+def _primary_hits(world, frame_index=1):
+    """Hit points of the jittered camera rays on the plane y = 0 (the first lines of numpy_radiance)."""
+    cam = world.camera
+    eye, target, up = (np.array(cam[k], np.float64) for k in ("eye", "target", "up"))
+    fwd = normalize(target - eye)
+    right = normalize(np.cross(fwd, up))
+    upv = np.cross(right, fwd)
+    tan_half = math.tan(cam["fov"] * 0.5)
+    py, px = np.meshgrid(np.arange(H, dtype=np.uint32), np.arange(W, dtype=np.uint32), indexing="ij")
+    state = pcg3d(np.stack([px, py, np.full_like(px, frame_index)], axis=-1))
+    uv = (np.stack([px, py], axis=-1).astype(np.float64) + rng_to_01(state[..., :2]).astype(np.float64)) / np.array([W, H], np.float64)
+    nd = uv * 2.0 - 1.0
+    d = normalize(nd[..., :1] * right * (tan_half * W / H) - nd[..., 1:] * upv * tan_half + fwd)
+    return eye + (-eye[1] / d[..., 1])[..., None] * d
+
+
+def numpy_debug_images(world_textured, world_frame):
+    """-> {draw type: (world, image [H, W, 3], compared [H, W])} for one frame."""
+    p = _primary_hits(world_textured)
+    away = np.ones((H, W), bool)
+    albedo, rough, metal = textured_surface(p, away)
+    everywhere = np.ones((H, W), bool)
+    u = (p[..., 0] + 40.0) / 80.0 * UV_SCALE
+    v = (40.0 - p[..., 2]) / 80.0 * UV_SCALE
+    tri = (p[..., 2] < -p[..., 0]).astype(np.uint32)       # the quad's triangles (0, 1, 2) and (0, 2, 3) meet on z = -x
+    ones = np.ones((H, W, 3))
+    return {
+        "Position": (world_textured, p, everywhere),
+        "TexCoord0": (world_textured, np.stack([u, v, np.zeros_like(u)], axis=-1), everywhere),
+        "Albedo": (world_textured, albedo, away),
+        "Roughness": (world_textured, ones * rough, everywhere),
+        "Metallic": (world_textured, ones * metal, everywhere),
+        "PrimitiveID": (world_textured, uint_to_color(tri), np.abs(p[..., 2] + p[..., 0]) > 1e-3),
+        "MeshID": (world_textured, ones * uint_to_color(0), everywhere),
+        "MaterialID": (world_textured, ones * uint_to_color(1), everywhere),
+        "ShadingNormal": (world_frame, ones * (shading_normal() * 0.5 + 0.5), everywhere),
+    }
+
+
+def _check_debug(name, img, want, compared):
+    assert (img[..., 3] == 1.0).all()
+    err = np.abs(img[..., :3].astype(np.float64) - want)
+    # positions and texture coordinates are interpolated from corners 40 units out: fp32 leaves a few 1e-6 of absolute error
+    atol = 2e-5 if name in ("Position", "TexCoord0") else 2e-6
+    assert (err[compared] <= 2e-5 * np.abs(want[compared]) + atol).all(), name
+    assert compared.mean() > 0.98, name
+
+
+def test_oracle_matches_the_numpy_debug_draw_types(oracle):
+    textured, frame = build_world_textured(), build_world_shading_frame()
+    scenes_ = {id(textured): oracle.OracleScene(textured, brute_force=True), id(frame): oracle.OracleScene(frame, brute_force=True)}
+    for name, (world, want, compared) in numpy_debug_images(textured, frame).items():
+        cam, fl = _camera(oracle, world)
+        img, _ = scenes_[id(world)].render(default_pc(S, fl, max_bounces=1, draw_type=S.DrawType[name]), cam, W, H)
+        _check_debug(name, img, want, compared)
+    tri = numpy_debug_images(textured, frame)["PrimitiveID"][1]
+    assert len(np.unique(tri.reshape(-1, 3), axis=0)) == 2          # both triangles are on screen
+
+
+@pytest.mark.gpu
+def test_hip_path_matches_oracle_bitwise_and_numpy_debug_draw_types(gpu_ctx, oracle):
+    textured, frame = build_world_textured(), build_world_shading_frame()
+    answers = numpy_debug_images(textured, frame)
+    for world in (textured, frame):
+        cam, fl = _camera(oracle, world)
+        gpu_ctx.upload_scene(world)
+        osc = oracle.OracleScene(world, brute_force=True)
+        for name, (wld, want, compared) in answers.items():
+            if wld is not world:
+                continue
+            pc = default_pc(S, fl, max_bounces=1, draw_type=S.DrawType[name])
+            gpu_ctx.render(pc, cam, W, H)
+            got = gpu_ctx.read_hdr()
+            ref, _ = osc.render(pc, cam, W, H)
+            assert same_bits(got, ref).all(), name
+            _check_debug(name, got, want, compared)
