@@ -423,9 +423,10 @@ MR_TEXEL = (0, 180, 90, 255)   # g = roughness, b = metallic (materials.glsl:86-
 UV_SCALE = 16.0                # the 2 x 2 texture repeats every 5 units: 2.5-unit texels
 
 
-def build_world_textured():
+def build_world_textured(linear=False):
     w = World()
-    nearest = w.add_sampler(S.FILTER_NEAREST, S.FILTER_NEAREST, S.WRAP_REPEAT, S.WRAP_REPEAT)
+    f = S.FILTER_LINEAR if linear else S.FILTER_NEAREST
+    nearest = w.add_sampler(f, f, S.WRAP_REPEAT, S.WRAP_REPEAT)
     base = w.add_texture(BASE_TEXELS)
     mr = w.add_texture(np.tile(np.array(MR_TEXEL, np.uint8), (2, 2, 1)))
     mat = w.add_material(base_color=(1.0, 1.0, 1.0, 1.0), metallic=1.0, roughness=1.0, base_tex=(base, nearest), mr_tex=(mr, nearest))
@@ -663,3 +664,47 @@ def test_hip_path_matches_oracle_bitwise_and_numpy_debug_draw_types(gpu_ctx, ora
             ref, _ = osc.render(pc, cam, W, H)
             assert same_bits(got, ref).all(), name
             _check_debug(name, got, want, compared)
+
+
+# ---- bilinear filtering of the base colour (LOD 0, repeat): the filtered UNORM value is decoded, not the texels ----
+
+def numpy_bilinear_albedo(p):
+    u = (p[..., 0] + 40.0) / 80.0 * UV_SCALE
+    v = (40.0 - p[..., 2]) / 80.0 * UV_SCALE
+    x, y = u * 2.0 - 0.5, v * 2.0 - 0.5                    # texel space of the 2 x 2 texture, texel centres at integers
+    x0, y0 = np.floor(x), np.floor(y)
+    a, b = (x - x0)[..., None], (y - y0)[..., None]
+    i0, j0 = x0.astype(np.int64) % 2, y0.astype(np.int64) % 2
+    i1, j1 = (i0 + 1) % 2, (j0 + 1) % 2
+    t = BASE_TEXELS.astype(np.float64)[..., :3] / 255.0
+    top = t[j0, i0] * (1.0 - a) + t[j0, i1] * a
+    bottom = t[j1, i0] * (1.0 - a) + t[j1, i1] * a
+    return _srgb_to_linear(top * (1.0 - b) + bottom * b)
+
+
+def test_oracle_matches_the_numpy_bilinear_albedo(oracle):
+    world = build_world_textured(linear=True)
+    cam, fl = _camera(oracle, world)
+    img, _ = oracle.OracleScene(world, brute_force=True).render(
+        default_pc(S, fl, max_bounces=1, draw_type=S.DrawType["Albedo"]), cam, W, H)
+    want = numpy_bilinear_albedo(_primary_hits(world))
+    err = np.abs(img[..., :3].astype(np.float64) - want)
+    # uv carries ~1e-6 of fp32 interpolation error, a texel is 2.5 units: the filtered value moves by up to ~3e-6 * contrast
+    assert (err <= 2e-5).all(), err.max()
+    # and the image is not one of flat texels: most pixels hold a blend no texel has
+    texels = _srgb_to_linear(BASE_TEXELS.reshape(-1, 4)[:, :3] / 255.0)
+    nearest_texel = np.abs(want[..., None, :] - texels).max(-1).min(-1)
+    assert (nearest_texel > 0.01).mean() > 0.8
+
+
+@pytest.mark.gpu
+def test_hip_path_matches_oracle_bitwise_and_numpy_bilinear_albedo(gpu_ctx, oracle):
+    world = build_world_textured(linear=True)
+    cam, fl = _camera(oracle, world)
+    pc = default_pc(S, fl, max_bounces=1, draw_type=S.DrawType["Albedo"])
+    gpu_ctx.upload_scene(world)
+    gpu_ctx.render(pc, cam, W, H)
+    got = gpu_ctx.read_hdr()
+    ref, _ = oracle.OracleScene(world, brute_force=True).render(pc, cam, W, H)
+    assert same_bits(got, ref).all()
+    assert (np.abs(got[..., :3].astype(np.float64) - numpy_bilinear_albedo(_primary_hits(world))) <= 2e-5).all()
