@@ -708,3 +708,104 @@ def test_hip_path_matches_oracle_bitwise_and_numpy_bilinear_albedo(gpu_ctx, orac
     ref, _ = oracle.OracleScene(world, brute_force=True).render(pc, cam, W, H)
     assert same_bits(got, ref).all()
     assert (np.abs(got[..., :3].astype(np.float64) - numpy_bilinear_albedo(_primary_hits(world))) <= 2e-5).all()
+
+
+# ---- a rank's tile of the image: the RNG is seeded with ABSOLUTE pixel coordinates (main.rgen:227-229) ----
+
+def _tile_columns(rank, ranks, stripe=16):
+    return np.array([x for x in range(W) if (x // stripe) % ranks == rank])
+
+
+@pytest.mark.parametrize("rank,ranks", [(1, 2), (3, 5)])
+def test_oracle_rank_tile_is_the_numpy_image_at_its_columns(oracle, rank, ranks):
+    from prosper_amd import tiling
+    world = build_world()
+    cam, fl = _camera(oracle, world)
+    want, pick, cond = numpy_radiance(world)
+    cols = _tile_columns(rank, ranks)
+    img, _ = oracle.OracleScene(world, brute_force=True).render(
+        default_pc(S, fl, max_bounces=1), cam, W, H, tile=tiling.tile_for_rank(rank, ranks))
+    assert img.shape == (H, len(cols), 4)
+    err = np.abs(img[..., :3].astype(np.float64) - want[:, cols])
+    assert (err <= (RTOL + cond[:, cols, None]) * np.abs(want[:, cols]) + ATOL_OF_MAX * want.max()).all()
+    # with local instead of absolute columns in the seed the picks - hence which pixels are lit - would differ
+    assert ((want[:, cols].sum(-1) > 0) != (want[:, :len(cols)].sum(-1) > 0)).mean() > 0.2
+
+
+@pytest.mark.gpu
+def test_hip_path_rank_tile_bitwise_and_numpy(gpu_ctx, oracle):
+    from prosper_amd import tiling
+    world = build_world()
+    cam, fl = _camera(oracle, world)
+    want, pick, cond = numpy_radiance(world)
+    tile = tiling.tile_for_rank(3, 5)
+    cols = _tile_columns(3, 5)
+    pc = default_pc(S, fl, max_bounces=1)
+    gpu_ctx.upload_scene(world)
+    gpu_ctx.render(pc, cam, W, H, tile=tile)
+    got = gpu_ctx.read_hdr()
+    ref, _ = oracle.OracleScene(world, brute_force=True).render(pc, cam, W, H, tile=tile)
+    assert same_bits(got, ref).all()
+    err = np.abs(got[..., :3].astype(np.float64) - want[:, cols])
+    assert (err <= (RTOL + cond[:, cols, None]) * np.abs(want[:, cols]) + ATOL_OF_MAX * want.max()).all()
+
+
+# ---- draw instances: model-instance order x sub-model order (World.cpp:480-513), ids through the debug draws ----
+
+def build_world_instances():
+    """Model A = two strips (meshes 0, 1 with materials 1, 2), model B = one strip (mesh 2, material 3); instances A, B, A
+    side by side along x.  DrawInstance i then carries (mesh, material) = (0,1) (1,2) (2,3) (0,1) (1,2)."""
+    from prosper_amd.world import translate
+    w = World()
+    mats = [w.add_material(base_color=(0.2 * (k + 1), 0.5, 0.5, 1.0), metallic=0.0, roughness=1.0) for k in range(3)]
+
+    def strip(x0, mat):
+        return scenes._add(w, scenes.quad((x0, 0, 40), (x0 + 1, 0, 40), (x0 + 1, 0, -40), (x0, 0, -40)), mat)
+    a = w.add_model([(strip(0.0, mats[0]), mats[0]), (strip(1.0, mats[1]), mats[1])])
+    b = w.add_model([(strip(0.0, mats[2]), mats[2])])
+    w.add_instance(a, translate((-3.0, 0.0, 0.0)))      # x in [-3, -1)
+    w.add_instance(b, translate((-1.0, 0.0, 0.0)))      # x in [-1, 0)
+    w.add_instance(a, translate((0.0, 0.0, 0.0)))       # x in [0, 2)
+    w.camera = dict(eye=(-0.5, 2.0, 4.0), target=(-0.5, 0.0, 0.0), up=(0.0, 1.0, 0.0), fov=math.radians(40.0), zN=0.1, zF=100.0)
+    return w, mats
+
+
+def numpy_instance_ids(world, mats):
+    p = _primary_hits(world)
+    x = p[..., 0]
+    strip = np.floor(x + 3.0).astype(np.int64)                # 0..4 across the five strips, anything else is a miss
+    on = (strip >= 0) & (strip <= 4)
+    mesh = np.array([0, 1, 2, 0, 1])[np.clip(strip, 0, 4)]
+    material = np.array([mats[0], mats[1], mats[2], mats[0], mats[1]])[np.clip(strip, 0, 4)]
+    compared = np.abs(x + 3.0 - np.round(x + 3.0)) > 1e-3
+    return on, mesh, material, compared
+
+
+def _check_ids(img_mesh, img_mat, on, mesh, material, compared):
+    for img, ids in ((img_mesh, mesh), (img_mat, material)):
+        want = np.where(on[..., None], uint_to_color(ids.astype(np.uint32)), 0.0)   # a miss is black (no sky)
+        assert (np.abs(img[..., :3] - want)[compared] < 2e-6).all()
+    assert all(((mesh == k) & on & compared).sum() > 200 for k in range(3)) and (~on).sum() > 200
+
+
+def test_oracle_matches_the_numpy_instance_and_material_ids(oracle):
+    world, mats = build_world_instances()
+    cam, fl = _camera(oracle, world)
+    osc = oracle.OracleScene(world, brute_force=True)
+    imgs = [osc.render(default_pc(S, fl, max_bounces=1, draw_type=S.DrawType[t]), cam, W, H)[0] for t in ("MeshID", "MaterialID")]
+    _check_ids(*imgs, *numpy_instance_ids(world, mats))
+
+
+@pytest.mark.gpu
+def test_hip_path_matches_oracle_bitwise_and_numpy_instance_ids(gpu_ctx, oracle):
+    world, mats = build_world_instances()
+    cam, fl = _camera(oracle, world)
+    gpu_ctx.upload_scene(world)
+    osc = oracle.OracleScene(world, brute_force=True)
+    imgs = []
+    for t in ("MeshID", "MaterialID"):
+        pc = default_pc(S, fl, max_bounces=1, draw_type=S.DrawType[t])
+        gpu_ctx.render(pc, cam, W, H)
+        imgs.append(gpu_ctx.read_hdr())
+        assert same_bits(imgs[-1], osc.render(pc, cam, W, H)[0]).all()
+    _check_ids(*imgs, *numpy_instance_ids(world, mats))
