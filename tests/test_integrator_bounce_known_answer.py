@@ -41,7 +41,7 @@ METALLIC = 0.5  # fresnelZero = mix(0.04, albedo, metallic) is coloured: the spe
 PI = 3.14159265  # math.glsl:4
 
 
-def build_world(sky_faces=None):
+def build_world(sky_faces=None, sky_texels=None):
     w = World()
     mat = w.add_material(base_color=ALBEDO + (1.0,), metallic=METALLIC, roughness=ROUGHNESS)
     # corners +-40 u +- 40 v with u = (1, 0, 0), v = (0, -0.6, 0.8): exactly representable in binary16
@@ -51,6 +51,8 @@ def build_world(sky_faces=None):
     sky = np.empty((6, 4, 4, 4), np.float16)
     sky[..., :3] = np.asarray(SKY, np.float16) if sky_faces is None else np.asarray(sky_faces, np.float16)[:, None, None, :]
     sky[..., 3] = np.float16(1.0)
+    if sky_texels is not None:
+        sky = np.asarray(sky_texels, np.float16)
     w.skybox = sky
     # A grazing view (17 degrees above the plane at the centre: NoV from 0.09 to 0.5, so the masking terms and the
     # Fresnel term vary) of the part of the plane around 12 v.  Every hit point has |y| > 2 and |z| > 3, so the bounce
@@ -129,7 +131,7 @@ def sample_bounce(n, v, pick_diffuse, u):
     return rd, weight
 
 
-def numpy_radiance(world, frame_index=1, sky_faces=None):
+def numpy_radiance(world, frame_index=1, sky_faces=None, sky_gradient=0):
     cam = world.camera
     eye, target, up = (np.array(cam[k], np.float64) for k in ("eye", "target", "up"))
     fwd = normalize(target - eye)
@@ -178,6 +180,9 @@ def numpy_radiance(world, frame_index=1, sky_faces=None):
         numpy_radiance.last_faces = np.where(compared & leaves, face, -1)
         srt = np.sort(np.abs(rd), axis=-1)
         compared &= srt[..., 1] < 0.7 * srt[..., 2]
+    if sky_gradient:
+        sky, inside = gradient_sky(rd, sky_gradient)
+        compared = (margin > 0.02) & inside
     radiance = np.clip(throughput * sky, 0.0, 2.0)
     return radiance, pick_diffuse, compared, leaves
 
@@ -276,3 +281,69 @@ def test_hip_path_matches_oracle_bitwise_and_numpy_sky_faces(gpu_ctx, oracle):
     ref, _ = oracle.OracleScene(world, brute_force=True).render(pc, cam, W, H)
     assert same_bits(got, ref).all()
     _check_faces(got, want, compared, leaves)
+
+
+# ---- where on a cube face a direction lands: faces that are ramps in s and t (Vulkan spec, cube map face selection) ----
+
+GRADIENT_N = 8
+
+
+def gradient_texels(n=GRADIENT_N):
+    """Face f, texel (i, j) = (i / (n - 1), j / (n - 1), f / 5): bilinear filtering reproduces a ramp exactly between texel centres."""
+    sky = np.empty((6, n, n, 4), np.float16)
+    j, i = np.meshgrid(np.arange(n), np.arange(n), indexing="ij")
+    for f in range(6):
+        sky[f, ..., 0] = i / (n - 1)
+        sky[f, ..., 1] = j / (n - 1)
+        sky[f, ..., 2] = f / 5
+    sky[..., 3] = 1
+    return sky
+
+
+def gradient_sky(rd, n):
+    """Major axis -> face and (sc, tc): +X (-z, -y), -X (z, -y), +Y (x, z), -Y (x, -z), +Z (x, -y), -Z (-x, -y); s, t = (c / |ma| + 1) / 2."""
+    x, y, z = rd[..., 0], rd[..., 1], rd[..., 2]
+    face = sky_face_of(rd)
+    sc = np.choose(face, [-z, z, x, x, x, -x])
+    tc = np.choose(face, [-y, -y, z, -z, -y, -y])
+    ma = np.abs(np.choose(face, [x, x, y, y, z, z]))
+    px = (sc / ma + 1.0) * 0.5 * n - 0.5          # texel space, centres at integers
+    py = (tc / ma + 1.0) * 0.5 * n - 0.5
+    inside = (px > 0.02) & (px < n - 1.02) & (py > 0.02) & (py < n - 1.02)   # all four taps on this face
+    colour = np.stack([px / (n - 1), py / (n - 1), face / 5.0], axis=-1)
+    # the texels are binary16: a ramp step of 1 / 7 is not exact, the filtered value is within 2^-11 relative of the ramp
+    return colour, inside
+
+
+def _check_gradient(img, want, compared, leaves):
+    got = img[..., :3].astype(np.float64)
+    err = np.abs(got - want)
+    assert (err[compared] <= 1.5e-3 * np.abs(want[compared]) + 1e-4).all(), err[compared].max()
+    assert compared.mean() > 0.5
+    # ramps, not constants: the red and green channels vary across the compared pixels of a face
+    lit = compared & leaves & (want[..., 0] > 0)
+    assert want[lit][:, 0].std() > 0.02 and want[lit][:, 1].std() > 0.02
+
+
+def test_oracle_matches_the_numpy_cube_face_coordinates(oracle):
+    world = build_world(sky_texels=gradient_texels())
+    cam, fl = _camera(oracle, world)
+    osc = oracle.OracleScene(world, brute_force=True)
+    for frame in (1, 2):
+        want, pick, compared, leaves = numpy_radiance(world, frame_index=frame, sky_gradient=GRADIENT_N)
+        img, _ = osc.render(default_pc(S, fl, frame_index=frame, max_bounces=2, ibl=True), cam, W, H)
+        _check_gradient(img, want, compared, leaves)
+
+
+@pytest.mark.gpu
+def test_hip_path_matches_oracle_bitwise_and_numpy_cube_face_coordinates(gpu_ctx, oracle):
+    world = build_world(sky_texels=gradient_texels())
+    want, pick, compared, leaves = numpy_radiance(world, sky_gradient=GRADIENT_N)
+    cam, fl = _camera(oracle, world)
+    pc = default_pc(S, fl, max_bounces=2, ibl=True)
+    gpu_ctx.upload_scene(world)
+    gpu_ctx.render(pc, cam, W, H)
+    got = gpu_ctx.read_hdr()
+    ref, _ = oracle.OracleScene(world, brute_force=True).render(pc, cam, W, H)
+    assert same_bits(got, ref).all()
+    _check_gradient(got, want, compared, leaves)
