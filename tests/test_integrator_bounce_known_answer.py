@@ -41,9 +41,9 @@ METALLIC = 0.5  # fresnelZero = mix(0.04, albedo, metallic) is coloured: the spe
 PI = 3.14159265  # math.glsl:4
 
 
-def build_world(sky_faces=None, sky_texels=None):
+def build_world(sky_faces=None, sky_texels=None, metallic=METALLIC):
     w = World()
-    mat = w.add_material(base_color=ALBEDO + (1.0,), metallic=METALLIC, roughness=ROUGHNESS)
+    mat = w.add_material(base_color=ALBEDO + (1.0,), metallic=metallic, roughness=ROUGHNESS)
     # corners +-40 u +- 40 v with u = (1, 0, 0), v = (0, -0.6, 0.8): exactly representable in binary16
     mesh = scenes._add(w, scenes.quad((-40, -24, 32), (40, -24, 32), (40, 24, -32), (-40, 24, -32)), mat)
     w.add_instance(w.add_model([(mesh, mat)]))
@@ -71,9 +71,11 @@ def onb_rows(n):
     return np.array([[1.0 + s * n[0] * n[0] * a, s * b, -s * n[0]], [b, s + n[1] * n[1] * a, -n[1]], n])
 
 
-def sample_bounce(n, v, pick_diffuse, u):
+def sample_bounce(n, v, pick_diffuse, u, metallic=METALLIC):
     """importanceSampleBounce (main.rgen:90-144) for a surface with shading normal n (3,), view vectors v [..., 3], the
     lobe picks and the direction draws u [..., 2]: -> (direction [..., 3], weight brdf * NoL / pdf [..., 3]), float64."""
+    specular_weight = 1.0 if metallic > 0.999 else 0.5             # main.rgen:92-95: a pure metal has no diffuse lobe
+    diffuse_weight = 1.0 - specular_weight
     albedo = np.array(ALBEDO, np.float64)
     alpha = ROUGHNESS * ROUGHNESS
     m = onb_rows(n)
@@ -85,7 +87,7 @@ def sample_bounce(n, v, pick_diffuse, u):
     rd_diff = normalize(n + np.stack([b * np.cos(phi), b * np.sin(phi), a], axis=-1))
     nol_diff = saturate((rd_diff * n).sum(-1))
     with np.errstate(divide="ignore", invalid="ignore"):
-        w_diff = (albedo / PI) * nol_diff[..., None] / (nol_diff / PI * 0.5)[..., None]
+        w_diff = (albedo / PI) * nol_diff[..., None] / (nol_diff / PI * diffuse_weight)[..., None]
 
     # specular lobe: sampling.glsl:53-93, brdf.glsl:12-64
     ve = v @ m.T
@@ -115,7 +117,7 @@ def sample_bounce(n, v, pick_diffuse, u):
 
     def g(nl, nv):
         return (nl / (nl * (1.0 - k) + k)) * (nv / (nv * (1.0 - k) + k))
-    f0 = 0.04 * (1.0 - METALLIC) + albedo * METALLIC              # brdf.glsl:60-64
+    f0 = 0.04 * (1.0 - metallic) + albedo * metallic              # brdf.glsl:60-64
     fterm = f0 + (1.0 - f0) * ((1.0 - voh) ** 5.0)[..., None]
     brdf = fterm * (dterm * g(nol, nov) / (4.0 * nol * nov + 0.0001))[..., None]
     # visibleTrowbridgeReitzPdf in the local frame (sampling.glsl:81-93)
@@ -123,7 +125,7 @@ def sample_bounce(n, v, pick_diffuse, u):
     nov_l, nol_l, noh_l = saturate(ve[..., 2]), saturate(le[..., 2]), saturate(hl[..., 2])
     d_l = a2 / (PI * (noh_l * noh_l * (a2 - 1.0) + 1.0) ** 2)
     with np.errstate(divide="ignore", invalid="ignore"):
-        pdf = g(nol_l, nov_l) * nov_l * d_l / ve[..., 2] / (4.0 * nov_l) * 0.5
+        pdf = g(nol_l, nov_l) * nov_l * d_l / ve[..., 2] / (4.0 * nov_l) * specular_weight
         w_spec = brdf * (nol / pdf)[..., None]
 
     rd = np.where(pick_diffuse[..., None], rd_diff, rd_spec)
@@ -131,7 +133,7 @@ def sample_bounce(n, v, pick_diffuse, u):
     return rd, weight
 
 
-def numpy_radiance(world, frame_index=1, sky_faces=None, sky_gradient=0):
+def numpy_radiance(world, frame_index=1, sky_faces=None, sky_gradient=0, metallic=METALLIC):
     cam = world.camera
     eye, target, up = (np.array(cam[k], np.float64) for k in ("eye", "target", "up"))
     fwd = normalize(target - eye)
@@ -158,11 +160,11 @@ def numpy_radiance(world, frame_index=1, sky_faces=None, sky_gradient=0):
 
     state = pcg3d(state)   # evaluateDirectLighting's light pick (main.rgen:205): the draw happens, the sun emits nothing
     state = pcg3d(state)   # importanceSampleBounce: lobe pick (main.rgen:100)
-    pick_diffuse = rng_to_01(state[..., 0]) < np.float32(0.5)
+    pick_diffuse = rng_to_01(state[..., 0]) < np.float32(0.0 if metallic > 0.999 else 0.5)   # rnd01() < diffuseWeight
     state = pcg3d(state)   # direction (main.rgen:101)
     u = rng_to_01(state[..., :2]).astype(np.float64)
 
-    rd, weight = sample_bounce(n, v, pick_diffuse, u)
+    rd, weight = sample_bounce(n, v, pick_diffuse, u, metallic)
     leaves = (rd * n).sum(-1) > 0.0
     throughput = np.where(leaves[..., None], np.maximum(weight, 0.0), 0.0)
     # not compared: directions within 0.02 of the shading horizon (NoL -> 0: the specular weight is 0 / 0-like) or of
@@ -347,3 +349,34 @@ def test_hip_path_matches_oracle_bitwise_and_numpy_cube_face_coordinates(gpu_ctx
     ref, _ = oracle.OracleScene(world, brute_force=True).render(pc, cam, W, H)
     assert same_bits(got, ref).all()
     _check_gradient(got, want, compared, leaves)
+
+
+# ---- a pure metal: metallic > 0.999 takes the specular lobe with weight 1, the lobe-pick draw still happens (main.rgen:92-100) ----
+
+def test_oracle_matches_the_numpy_bounce_of_a_pure_metal(oracle):
+    world = build_world(metallic=1.0)
+    cam, fl = _camera(oracle, world)
+    osc = oracle.OracleScene(world, brute_force=True)
+    for frame in (1, 2):
+        want, pick, compared, leaves = numpy_radiance(world, frame_index=frame, metallic=1.0)
+        assert not pick.any()
+        img, _ = osc.render(default_pc(S, fl, frame_index=frame, max_bounces=2, ibl=True), cam, W, H)
+        got = img[..., :3].astype(np.float64)
+        assert (np.abs(got - want)[compared] <= RTOL * np.abs(want[compared]) + ATOL).all()
+        assert compared.mean() > 0.95 and (want[compared & leaves].min(-1) > 0).mean() > 0.99
+        # twice the 50 / 50 material's specular weight would be 2x off: the weights are F G2 / G1 with F0 = albedo
+        assert 0.3 < np.median(want[compared & leaves][:, 0] / SKY[0]) < 1.0
+
+
+@pytest.mark.gpu
+def test_hip_path_matches_oracle_bitwise_and_numpy_pure_metal(gpu_ctx, oracle):
+    world = build_world(metallic=1.0)
+    want, pick, compared, leaves = numpy_radiance(world, metallic=1.0)
+    cam, fl = _camera(oracle, world)
+    pc = default_pc(S, fl, max_bounces=2, ibl=True)
+    gpu_ctx.upload_scene(world)
+    gpu_ctx.render(pc, cam, W, H)
+    got = gpu_ctx.read_hdr()
+    ref, _ = oracle.OracleScene(world, brute_force=True).render(pc, cam, W, H)
+    assert same_bits(got, ref).all()
+    assert (np.abs(got[..., :3].astype(np.float64) - want)[compared] <= RTOL * np.abs(want[compared]) + ATOL).all()
