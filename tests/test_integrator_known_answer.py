@@ -341,20 +341,22 @@ def test_hip_path_accumulates_bitwise_like_the_oracle_and_the_numpy_mean(gpu_ctx
 PLATE = (3.0, 7.0, 6.0, 2.0, 6.5)  # x0, x1, y, z0, z1: an opaque plate above and behind the camera
 
 
-def build_world_sun():
+def build_world_sun(plate=None):
+    plate = PLATE if plate is None else plate
     w = World()
     mat = w.add_material(base_color=(0.8, 0.7, 0.6, 1.0), metallic=0.0, roughness=1.0)
     mesh = scenes._add(w, scenes.quad((-40, 0, 40), (40, 0, 40), (40, 0, -40), (-40, 0, -40)), mat)
     w.add_instance(w.add_model([(mesh, mat)]))
-    x0, x1, y, z0, z1 = PLATE
-    plate = scenes._add(w, scenes.quad((x0, y, z1), (x1, y, z1), (x1, y, z0), (x0, y, z0)), mat)
-    w.add_instance(w.add_model([(plate, mat)]))
+    x0, x1, y, z0, z1 = plate
+    mesh2 = scenes._add(w, scenes.quad((x0, y, z1), (x1, y, z1), (x1, y, z0), (x0, y, z0)), mat)
+    w.add_instance(w.add_model([(mesh2, mat)]))
     w.set_directional_light((1.0, 0.9, 0.8), 2.0, (-1.0, -1.0, -1.0))  # un-normalised, as prosper's default (lights.h:9,18-19)
     w.camera = dict(eye=(0.0, 2.0, 4.0), target=(0.0, 0.0, 0.0), up=(0.0, 1.0, 0.0), fov=math.radians(40.0), zN=0.1, zF=100.0)
     return w
 
 
-def numpy_radiance_sun(world, frame_index=1):
+def numpy_radiance_sun(world, frame_index=1, plate=None):
+    plate = PLATE if plate is None else plate
     cam = world.camera
     eye, target, up = (np.array(cam[k], np.float64) for k in ("eye", "target", "up"))
     fwd = normalize(target - eye)
@@ -377,12 +379,12 @@ def numpy_radiance_sun(world, frame_index=1):
     lv = np.broadcast_to(l, p.shape)
     c = irr * 1.0 * eval_brdf_times_nol(lv, n, -d, albedo, max(float(mat.roughnessFactor), 0.05), float(mat.metallicFactor))
     # the shadow ray p + t l, t in (0.1, 100), against the plate
-    x0, x1, y, z0, z1 = PLATE
+    x0, x1, y, z0, z1 = plate
     t = y / l[1]
     hx, hz = p[..., 0] + t * l[0], p[..., 2] + t * l[2]
-    inside = (hx > x0) & (hx < x1) & (hz > z0) & (hz < z1)
+    inside = (hx > x0) & (hx < x1) & (hz > z0) & (hz < z1) & (t < 100.0)   # the sun's shadow ray ends at d = 100
     edge = np.minimum(np.minimum(np.abs(hx - x0), np.abs(hx - x1)), np.minimum(np.abs(hz - z0), np.abs(hz - z1)))
-    assert 0.1 < t < 100.0
+    assert t > 0.1
     return np.where(inside[..., None], 0.0, c), inside, edge > 1e-3
 
 
@@ -809,3 +811,36 @@ def test_hip_path_matches_oracle_bitwise_and_numpy_instance_ids(gpu_ctx, oracle)
         imgs.append(gpu_ctx.read_hdr())
         assert same_bits(imgs[-1], osc.render(pc, cam, W, H)[0]).all()
     _check_ids(*imgs, *numpy_instance_ids(world, mats))
+
+
+# ---- the sun's shadow ray is 100 units long (lighting.glsl:66): the same plate 121 units up the ray casts no shadow ----
+
+FAR_PLATE = (67.0, 71.0, 70.0, 66.0, 70.5)   # PLATE moved by (64, 64, 64) along the ray: t = 70 sqrt(3) = 121
+
+
+def test_oracle_sun_shadow_ray_ends_at_100(oracle):
+    world = build_world_sun(FAR_PLATE)
+    cam, fl = _camera(oracle, world)
+    img, _ = oracle.OracleScene(world, brute_force=True).render(default_pc(S, fl, max_bounces=1), cam, W, H)
+    want, shadowed, compared = numpy_radiance_sun(world, plate=FAR_PLATE)
+    assert not shadowed.any() and (want.sum(-1) > 0).all()
+    # the plate does lie on the shadow rays of the pixels the near plate shadows
+    l = -normalize(np.array([-1.0, -1.0, -1.0]))
+    p = _primary_hits(world)
+    t = FAR_PLATE[2] / l[1]
+    hx, hz = p[..., 0] + t * l[0], p[..., 2] + t * l[2]
+    assert ((hx > FAR_PLATE[0]) & (hx < FAR_PLATE[1]) & (hz > FAR_PLATE[3]) & (hz < FAR_PLATE[4])).sum() > 1000 and t > 100.0
+    err = np.abs(img[..., :3].astype(np.float64) - want)
+    assert (err <= RTOL * np.abs(want) + ATOL_OF_MAX * want.max()).all()
+
+
+@pytest.mark.gpu
+def test_hip_path_sun_shadow_ray_ends_at_100(gpu_ctx, oracle):
+    world = build_world_sun(FAR_PLATE)
+    cam, fl = _camera(oracle, world)
+    pc = default_pc(S, fl, max_bounces=1)
+    gpu_ctx.upload_scene(world)
+    gpu_ctx.render(pc, cam, W, H)
+    got = gpu_ctx.read_hdr()
+    ref, _ = oracle.OracleScene(world, brute_force=True).render(pc, cam, W, H)
+    assert same_bits(got, ref).all() and (got[..., :3].sum(-1) > 0).all()
