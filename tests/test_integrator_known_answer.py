@@ -844,3 +844,66 @@ def test_hip_path_sun_shadow_ray_ends_at_100(gpu_ctx, oracle):
     got = gpu_ctx.read_hdr()
     ref, _ = oracle.OracleScene(world, brute_force=True).render(pc, cam, W, H)
     assert same_bits(got, ref).all() and (got[..., :3].sum(-1) > 0).all()
+
+
+# ---- the shadow ray starts at tMin = 0.1 (main.rgen:217): a curb casts no shadow on the 5.8 cm of ground right behind it ----
+
+CURB_X, CURB_H = 0.5, 0.5
+
+
+def build_world_curb():
+    w = build_world_sun(FAR_PLATE)            # the sun, the ground, the (irrelevant) far plate
+    mat = 1
+    curb = scenes._add(w, scenes.quad((CURB_X, 0, 40), (CURB_X, 0, -40), (CURB_X, CURB_H, -40), (CURB_X, CURB_H, 40)), mat)
+    w.add_instance(w.add_model([(curb, mat)]))
+    return w
+
+
+def numpy_radiance_curb(world, frame_index=1):
+    want, _, _ = numpy_radiance_sun(world, frame_index=frame_index, plate=FAR_PLATE)
+    p = _primary_hits(world, frame_index)
+    cam = world.camera
+    eye = np.array(cam["eye"], np.float64)
+    d = normalize(p - eye)
+    # camera rays that meet the curb before the ground are not compared
+    with np.errstate(divide="ignore", invalid="ignore"):
+        tc = (CURB_X - eye[0]) / d[..., 0]
+    yc = eye[1] + tc * d[..., 1]
+    sees_curb = (tc > 0) & (yc > -1e-3) & (yc < CURB_H + 1e-3)
+    # the shadow ray p + t (1, 1, 1) / sqrt(3) meets the plane x = CURB_X at height CURB_X - p.x, at t = (CURB_X - p.x) sqrt(3)
+    gap = CURB_X - p[..., 0]
+    t = gap * math.sqrt(3.0)
+    shadowed = (gap > 0) & (gap < CURB_H) & (t > 0.1)
+    skipped = (gap > 0) & (t <= 0.1)                       # the curb is there, the ray starts beyond it: lit
+    edge = (np.abs(t - 0.1) > 2e-3) & (np.abs(gap - CURB_H) > 2e-3) & (np.abs(gap) > 2e-3)
+    return np.where(shadowed[..., None], 0.0, want), shadowed, skipped, edge & ~sees_curb
+
+
+def _check_curb(img, want, shadowed, skipped, compared):
+    got = img[..., :3].astype(np.float64)
+    err = np.abs(got - want)
+    assert (err[compared] <= RTOL * np.abs(want[compared]) + ATOL_OF_MAX * want.max()).all()
+    assert (got[shadowed & compared] == 0.0).all() and (got[skipped & compared].sum(-1) > 0).all()
+    assert (shadowed & compared).sum() > 1000 and (skipped & compared).sum() > 150 and compared.mean() > 0.8
+
+
+def test_oracle_shadow_ray_starts_at_tmin(oracle):
+    world = build_world_curb()
+    cam, fl = _camera(oracle, world)
+    osc = oracle.OracleScene(world, brute_force=True)
+    for frame in (1, 2):
+        img, _ = osc.render(default_pc(S, fl, frame_index=frame, max_bounces=1), cam, W, H)
+        _check_curb(img, *numpy_radiance_curb(world, frame))
+
+
+@pytest.mark.gpu
+def test_hip_path_shadow_ray_starts_at_tmin(gpu_ctx, oracle):
+    world = build_world_curb()
+    cam, fl = _camera(oracle, world)
+    pc = default_pc(S, fl, max_bounces=1)
+    gpu_ctx.upload_scene(world)
+    gpu_ctx.render(pc, cam, W, H)
+    got = gpu_ctx.read_hdr()
+    ref, _ = oracle.OracleScene(world, brute_force=True).render(pc, cam, W, H)
+    assert same_bits(got, ref).all()
+    _check_curb(got, *numpy_radiance_curb(world))
