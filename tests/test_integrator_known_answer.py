@@ -120,8 +120,8 @@ def numpy_radiance(world, frame_index=1, lens=None, surface=None):
         coc = aperture / 2.0                               # focalLength / (2 * focalLength / aperture)
         origin = eye + right * (lu * coc)[..., None] + upv * (lv * coc)[..., None]   # cameraToWorld * (lensPos, 1)
         d = normalize(focus_point - origin)
-    assert (d[..., 1] < 0).all(), "every primary ray must reach the plane"
     t = -origin[..., 1] / d[..., 1]
+    assert (t > 0).all(), "every primary ray must reach the plane"
     p = origin + t[..., None] * d
     assert (np.abs(p[..., 0]) < 40).all() and (np.abs(p[..., 2]) < 40).all()
     n = np.array([0.0, 1.0, 0.0])
@@ -907,3 +907,41 @@ def test_hip_path_shadow_ray_starts_at_tmin(gpu_ctx, oracle):
     ref, _ = oracle.OracleScene(world, brute_force=True).render(pc, cam, W, H)
     assert same_bits(got, ref).all()
     _check_curb(got, *numpy_radiance_curb(world))
+
+
+# ---- no face culling (main.rgen:62-81: gl_RayFlagsNoneEXT): the quad seen from BELOW is hit and shaded with its own normal ----
+
+def build_world_from_below():
+    w = build_world()
+    w.camera = dict(w.camera, eye=(0.0, -2.0, 4.0))
+    return w
+
+
+def test_oracle_matches_the_numpy_back_face(oracle):
+    """The view vector is on the far side of the normal: NoV = saturate(dot(n, v)) = 0 kills the specular term (its masking
+    factor), the diffuse term still sees the lights above the quad - the reference lights back faces from their front."""
+    world = build_world_from_below()
+    cam, fl = _camera(oracle, world)
+    osc = oracle.OracleScene(world, brute_force=True)
+    for frame in (1, 2):
+        want, pick, cond = numpy_radiance(world, frame_index=frame)
+        img, counters = osc.render(default_pc(S, fl, frame_index=frame, max_bounces=1), cam, W, H)
+        _check_against_numpy(img, want, pick, cond)
+        assert counters.as_dict()["closestHits"] == W * H
+    # and that is the diffuse term alone: c_diff / pi * NoL * irradiance, the same for every view direction
+    front, _, _ = numpy_radiance(build_world())
+    assert want.max() < front.max()
+
+
+@pytest.mark.gpu
+def test_hip_path_matches_oracle_bitwise_and_numpy_back_face(gpu_ctx, oracle):
+    world = build_world_from_below()
+    want, pick, cond = numpy_radiance(world)
+    cam, fl = _camera(oracle, world)
+    pc = default_pc(S, fl, max_bounces=1)
+    gpu_ctx.upload_scene(world)
+    gpu_ctx.render(pc, cam, W, H)
+    got = gpu_ctx.read_hdr()
+    ref, _ = oracle.OracleScene(world, brute_force=True).render(pc, cam, W, H)
+    assert same_bits(got, ref).all()
+    _check_against_numpy(got, want, pick, cond)
