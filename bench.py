@@ -374,9 +374,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pmc", action="store_true", help="skip the rocprofv3 child passes (roofline then quotes the "
                     "committed profile if it matches the kernel sources, else null)")
-    ap.add_argument("--no-subconfigs", action="store_true", help="skip the C3 / C4 sub-objects")
+    ap.add_argument("--no-subconfigs", action="store_true", help="skip the C3 / C4 / FlightHelmet sub-objects")
     ap.add_argument("--no-extras", action="store_true", help="skip the tone-map and ReSTIR-DI legs")
-    ap.add_argument("--subconfigs", default="c3,c4")
+    ap.add_argument("--subconfigs", default="c3,c4,helmet")
     ap.add_argument("--megakernel", action="store_true", help="use the one-lane-per-pixel kernel (A/B)")
     ap.add_argument("--persistent", action="store_true", help="use the persistent path-regeneration kernel (A/B)")
     ap.add_argument("--single-chain", action="store_true",

@@ -40,7 +40,7 @@
 extern "C" {
 #endif
 
-#define PROSPER_PT_ABI_VERSION 2
+#define PROSPER_PT_ABI_VERSION 3
 
 enum
 {
@@ -211,6 +211,7 @@ typedef struct prosper_pt_counters
     uint64_t shortIndexTriangleTests; /* of triangleTests: those on u16-indexed meshes */
     uint64_t nodePhaseSteps;     /* wavefront pipeline: wave-level steps of the node phase (x64 lanes = issue slots) */
     uint64_t trianglePhaseSteps; /* same for the triangle phase; lane utilisation = visits / (64 * steps) */
+    uint64_t anyHitTexelFetches; /* of anyHitCalls: those that fetched texels (not settled by the material's alpha bounds) */
 } prosper_pt_counters;
 
 /* Sizes the roofline model needs about the acceleration structure the library built. */
@@ -229,6 +230,9 @@ typedef struct prosper_pt_scene_stats
     double uploadSeconds;
     double bvhBuildSeconds;
     double textureSeconds;
+    /* (ABI 3) non-opaque triangles (each has a 32-byte any-hit record) and the bytes of the materials' alpha bounds */
+    uint64_t alphaTriangleCount;
+    uint64_t alphaBoundBytes;
 } prosper_pt_scene_stats;
 enum
 {
@@ -436,6 +440,13 @@ enum
     PROSPER_PT_FN_BC7_BLOCK = 16,     /* in: 4 words of a block (u32 bits)    out: 16 RGBA8 texels (u32 bits) */
     PROSPER_PT_FN_COUNT = 17,
 };
+
+/* Test hook for the alpha bounds (DESIGN.md "alpha bounds"): evaluates the device's sRGBtoLinear on EVERY float whose bit
+ * pattern lies in [first_bits, last_bits] (non-negative floats, increasing) and reports how far it is from monotone:
+ * *max_defect = max over x of (max of L over the inputs shortly before x) - L(x), 0 if monotone; *decreases = adjacent
+ * input pairs whose outputs decrease.  The bounds are valid while max_defect < 4e-6 (kAlphaCurveSlack). */
+int prosper_pt_debug_srgb_monotonicity(
+    prosper_pt_ctx *ctx, uint32_t first_bits, uint32_t last_bits, float *max_defect, uint64_t *decreases);
 
 /* Device self-test: evaluates device function `fn` (PROSPER_PT_FN_*) element-wise over `n`
  * records of `in_stride` floats and writes `out_stride` floats per record.  Test-only entry that

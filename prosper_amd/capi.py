@@ -74,6 +74,7 @@ def lib():
     L.prosper_pt_kernel_name.restype = C.c_char_p
     L.prosper_pt_set_kernel_timing.argtypes = [vp, C.c_int]
     L.prosper_pt_eval_device_fn.argtypes = [vp, u32, vp, u32, vp, u32, u32]
+    L.prosper_pt_debug_srgb_monotonicity.argtypes = [vp, u32, u32, C.POINTER(C.c_float), C.POINTER(C.c_uint64)]
     # multi-GPU: stripes + RCCL gather + de-interleave
     L.prosper_pt_comm_get_unique_id.argtypes = [vp]
     L.prosper_pt_comm_init.argtypes = [vp, vp, u32, u32]
@@ -324,6 +325,12 @@ class Context:
         """The root's kernel alone, on raw device pointers."""
         _check(lib().prosper_pt_deinterleave_tiles(self._h, C.c_void_p(tiles_ptr), ranks, stripe_width, width, height,
                                                    C.c_void_p(full_ptr), width * height * 16, C.c_void_p(stream)))
+
+    def srgb_monotonicity(self, first_bits, last_bits):
+        """(max defect, decreasing adjacent pairs) of the device's sRGBtoLinear over every float in the bit range."""
+        defect, decreases = C.c_float(0.0), C.c_uint64(0)
+        _check(lib().prosper_pt_debug_srgb_monotonicity(self._h, first_bits, last_bits, C.byref(defect), C.byref(decreases)))
+        return float(defect.value), int(decreases.value)
 
     def eval_device_fn(self, fn, inputs, in_stride, out_stride):
         a = np.ascontiguousarray(inputs, dtype=np.float32).reshape(-1, in_stride)

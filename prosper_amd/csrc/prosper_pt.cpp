@@ -8,11 +8,14 @@
 
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <chrono>
+#include <cmath>
 #include <cstdlib>
 #include <cstdio>
 #include <cstring>
 #include <exception>
+#include <stdexcept>
 #include <string>
 #include <vector>
 
@@ -358,6 +361,68 @@ int upload_scene_impl(prosper_pt_ctx *ctx, const prosper_pt_scene_view *v)
     acc->transforms.assign(v->modelInstanceTransforms, v->modelInstanceTransforms + v->modelInstanceCount);
     ctx->dTransforms = const_cast<prosper_ModelInstanceTransforms *>(s.modelInstanceTransforms);
 
+    // ---- what the any-hit shader reads: one 32-byte record per non-opaque triangle, one per material, and the
+    //      materials' alpha bounds (pt_scene.hpp AlphaTriangle / AlphaMaterial) ----
+    {
+        std::vector<uint32_t> alphaOffsets(v->drawInstanceCount ? v->drawInstanceCount : 1, 0u);
+        uint64_t alphaTotal = 0;
+        for (uint32_t i = 0; i < v->drawInstanceCount; ++i)
+            if (!(diFlags[i] & kTriFlagOpaque))
+            {
+                alphaOffsets[i] = (uint32_t)alphaTotal;
+                alphaTotal += acc->triOffsets[i + 1] - acc->triOffsets[i];
+            }
+        if ((rc = upload(ctx, alphaOffsets.data(), alphaOffsets.size() * 4, &d))) return rc;
+        s.alphaOffsets = static_cast<const uint32_t *>(d);
+        if ((rc = device_alloc(ctx, sizeof(AlphaTriangle) * (size_t)(alphaTotal ? alphaTotal : 1), &d))) return rc;
+        s.alphaTriangles = static_cast<const AlphaTriangle *>(d);
+        const bool noBounds = std::getenv("PROSPER_PT_DEBUG_NO_ALPHA_BOUNDS") != nullptr;
+        const char *cellEnv = std::getenv("PROSPER_PT_DEBUG_ALPHA_CELL");
+        std::vector<AlphaMaterial> alphaMaterials(v->materialCount ? v->materialCount : 1);
+        uint64_t boundBytes = 0;
+        for (uint32_t i = 0; i < v->materialCount; ++i)
+        {
+            const prosper_MaterialData &m = v->materials[i];
+            AlphaMaterial am{};
+            am.factorA = m.baseColorFactor.w;
+            am.cutoff = m.alphaCutoff;
+            am.bits = m.alphaMode & 3u;
+            const uint32_t tex = m.baseColorTextureSampler & 0xFFFFFFu;
+            if (m.alphaMode != PROSPER_ALPHA_MODE_OPAQUE && tex != 0)
+            {
+                const DeviceTexture &t = textures[tex];
+                const prosper_pt_sampler_desc &sd = v->samplers[m.baseColorTextureSampler >> 24];
+                if (t.width > 0xFFFFu || t.height > 0xFFFFu)
+                    return fail(PROSPER_PT_ERR_UNSUPPORTED, "base-colour texture of a MASK / BLEND material exceeds 65535 texels a side");
+                am.texels = t.texels;
+                am.width = (uint16_t)t.width;
+                am.height = (uint16_t)t.height;
+                am.bits |= (sd.wrapS & 3u) << 2 | (sd.wrapT & 3u) << 4 | (sd.magFilter == PROSPER_PT_FILTER_NEAREST ? 64u : 0u);
+                // cells of 2 x 2 texels: the table is an eighth of the texture (8 KB for 128^2: it lives in the L1 / L2
+                // the texels would have been read through); coarser for textures whose table would pass 2 MB
+                uint32_t shift = 1;
+                while (((uint64_t)(t.width >> shift) + 1u) * ((t.height >> shift) + 1u) * 2u > (2ull << 20)) ++shift;
+                if (cellEnv) shift = (uint32_t)std::min(15, std::max(0, std::atoi(cellEnv)));
+                const bool factorOk = std::isfinite(m.baseColorFactor.w) && m.baseColorFactor.w >= 0.0f;
+                if (!noBounds && factorOk)
+                {
+                    const uint32_t cellsX = (t.width + (1u << shift) - 1u) >> shift, cellsY = (t.height + (1u << shift) - 1u) >> shift;
+                    if ((rc = device_alloc(ctx, (size_t)cellsX * cellsY * 2u, &d))) return rc;
+                    launch_build_alpha_bounds(t, sd.wrapS, sd.wrapT, m.baseColorFactor.w, shift, static_cast<uint16_t *>(d), nullptr);
+                    am.bounds = static_cast<const uint16_t *>(d);
+                    am.bits |= shift << 8;
+                    boundBytes += (uint64_t)cellsX * cellsY * 2u;
+                }
+            }
+            alphaMaterials[i] = am;
+        }
+        PPT_HIP(hipGetLastError());
+        if ((rc = upload(ctx, alphaMaterials.data(), alphaMaterials.size() * sizeof(AlphaMaterial), &d))) return rc;
+        s.alphaMaterials = static_cast<const AlphaMaterial *>(d);
+        ctx->alphaTriangleCount = alphaTotal;
+        ctx->alphaBoundBytes = boundBytes;
+    }
+
     const size_t triBytes = sizeof(WorldTriangle) * (size_t)(total ? total : 1);
     if ((rc = device_alloc(ctx, triBytes, &d))) return rc;
     acc->dFlat = static_cast<WorldTriangle *>(d);
@@ -379,7 +444,8 @@ int upload_scene_impl(prosper_pt_ctx *ctx, const prosper_pt_scene_view *v)
     s.triangles = acc->dTris;
 
     launch_flatten_triangles(
-        s, acc->dOffsets, v->drawInstanceCount, acc->dFlags, acc->dFlat, static_cast<ShadeTriangle *>(dShade), (uint32_t)total, nullptr);
+        s, acc->dOffsets, v->drawInstanceCount, acc->dFlags, acc->dFlat, static_cast<ShadeTriangle *>(dShade),
+        const_cast<AlphaTriangle *>(s.alphaTriangles), (uint32_t)total, nullptr);
     PPT_HIP(hipGetLastError());
     acc->flat.resize((size_t)total);
     if (total) PPT_HIP(hipMemcpy(acc->flat.data(), acc->dFlat, sizeof(WorldTriangle) * (size_t)total, hipMemcpyDeviceToHost));
@@ -416,6 +482,8 @@ int upload_scene_impl(prosper_pt_ctx *ctx, const prosper_pt_scene_view *v)
     ctx->stats.bvhBuildSeconds = bvhBuildSeconds;
     ctx->stats.textureSeconds = textureSeconds;
     ctx->stats.uploadSeconds = seconds_since(tUpload);
+    ctx->stats.alphaTriangleCount = ctx->alphaTriangleCount;
+    ctx->stats.alphaBoundBytes = ctx->alphaBoundBytes;
     return PROSPER_PT_OK;
 }
 
@@ -609,8 +677,8 @@ int prosper_pt_create(const prosper_pt_device_desc *desc, prosper_pt_ctx **out_c
         eventsOk = eventsOk && hipEventCreateWithFlags(&slot.free, hipEventDisableTiming) == hipSuccess;
     }
     eventsOk = eventsOk && hipEventCreateWithFlags(&ctx->chainFork, hipEventDisableTiming) == hipSuccess;
-    if (!eventsOk || hipMalloc((void **)&ctx->dCounters, kStageCount * 16 * sizeof(unsigned long long)) != hipSuccess ||
-        hipMemset(ctx->dCounters, 0, kStageCount * 16 * sizeof(unsigned long long)) != hipSuccess ||
+    if (!eventsOk || hipMalloc((void **)&ctx->dCounters, kStageCount * kCounterCount * sizeof(unsigned long long)) != hipSuccess ||
+        hipMemset(ctx->dCounters, 0, kStageCount * kCounterCount * sizeof(unsigned long long)) != hipSuccess ||
         hipMalloc((void **)&ctx->dWorkCounter, 64) != hipSuccess)
     {
         prosper_pt_destroy(ctx);
@@ -693,21 +761,17 @@ int prosper_pt_update_lights(
     return PROSPER_PT_OK;
 }
 
-int prosper_pt_update_transforms(prosper_pt_ctx *ctx, const prosper_ModelInstanceTransforms *transforms, uint32_t count)
+static int update_transforms_impl(prosper_pt_ctx *ctx, const prosper_ModelInstanceTransforms *transforms, uint32_t count)
 {
-    if (!ctx || !transforms) return fail(PROSPER_PT_ERR_INVALID_ARGUMENT, "prosper_pt_update_transforms: null argument");
-    if (!ctx->haveScene || !ctx->accel) return fail(PROSPER_PT_ERR_NO_SCENE, "no scene uploaded");
     AccelState *acc = ctx->accel;
-    if (count != acc->transforms.size())
-        return fail(PROSPER_PT_ERR_INVALID_ARGUMENT, "prosper_pt_update_transforms: count differs from the scene's modelInstanceCount");
     const auto t0 = std::chrono::steady_clock::now();
     // which instances moved (World::updateScene rewrites every transform each frame, World.cpp:359-466; most are unchanged)
     std::vector<uint8_t> changed(acc->ranges.size(), 0);
-    bool any = false;
+    bool any = acc->stale;
     for (size_t r = 0; r < acc->ranges.size(); ++r)
     {
         const uint32_t mi = acc->rangeModelInstance[r];
-        if (std::memcmp(&transforms[mi], &acc->transforms[mi], sizeof(prosper_ModelInstanceTransforms)) != 0)
+        if (acc->stale || std::memcmp(&transforms[mi], &acc->transforms[mi], sizeof(prosper_ModelInstanceTransforms)) != 0)
         {
             changed[r] = 1;
             any = true;
@@ -715,37 +779,53 @@ int prosper_pt_update_transforms(prosper_pt_ctx *ctx, const prosper_ModelInstanc
     }
     PPT_HIP(hipSetDevice(ctx->device));
     PPT_HIP(hipDeviceSynchronize()); // renders in flight read the old transforms and the old hierarchy
+    // from here on the device state is in between two scenes until the last step has succeeded
+    acc->stale = true;
     PPT_HIP(hipMemcpy(ctx->dTransforms, transforms, sizeof(prosper_ModelInstanceTransforms) * count, hipMemcpyHostToDevice));
+    if (any)
+    {
+        // world-space triangles again (the shading and any-hit records hold object-space attributes and stay as they are)
+        launch_flatten_triangles(
+            ctx->scene, acc->dOffsets, acc->drawInstanceCount, acc->dFlags, acc->dFlat, nullptr, nullptr, (uint32_t)acc->total, nullptr);
+        PPT_HIP(hipGetLastError());
+        for (size_t r = 0; r < acc->ranges.size(); ++r)
+            if ((changed[r] || !acc->instanced) && acc->ranges[r].count)
+                PPT_HIP(hipMemcpy(
+                    acc->flat.data() + acc->ranges[r].first, acc->dFlat + acc->ranges[r].first,
+                    sizeof(WorldTriangle) * (size_t)acc->ranges[r].count, hipMemcpyDeviceToHost));
+        BvhBuildResult bvh;
+        const auto tBuild = std::chrono::steady_clock::now();
+        try
+        {
+            if (std::getenv("PROSPER_PT_DEBUG_FAIL_NEXT_UPDATE")) throw std::runtime_error("PROSPER_PT_DEBUG_FAIL_NEXT_UPDATE is set");
+            bvh = acc->instanced ? acc->bvh.rebuild(acc->flat.data(), changed) : build_bvh(acc->flat.data(), acc->total);
+        }
+        catch (const std::exception &ex)
+        {
+            return fail(PROSPER_PT_ERR_UNSUPPORTED, std::string("BVH rebuild failed: ") + ex.what());
+        }
+        const double buildSeconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - tBuild).count();
+        const int rc = upload_hierarchy(ctx, bvh);
+        if (rc != PROSPER_PT_OK) return rc;
+        ctx->stats.nodeCount = bvh.nodes.size();
+        ctx->stats.maxDepth = bvh.maxDepth;
+        ctx->stats.deviceBytes = ctx->sceneBytes;
+        ctx->stats.bvhBuildSeconds = buildSeconds;
+        ctx->stats.buildSeconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    }
+    // committed: what the context remembers now matches what the device holds
     acc->transforms.assign(transforms, transforms + count);
-    if (!any) return PROSPER_PT_OK;
-    // world-space triangles again (the shading records hold object-space attributes and stay as they are)
-    launch_flatten_triangles(
-        ctx->scene, acc->dOffsets, acc->drawInstanceCount, acc->dFlags, acc->dFlat, nullptr, (uint32_t)acc->total, nullptr);
-    PPT_HIP(hipGetLastError());
-    for (size_t r = 0; r < acc->ranges.size(); ++r)
-        if ((changed[r] || !acc->instanced) && acc->ranges[r].count)
-            PPT_HIP(hipMemcpy(
-                acc->flat.data() + acc->ranges[r].first, acc->dFlat + acc->ranges[r].first,
-                sizeof(WorldTriangle) * (size_t)acc->ranges[r].count, hipMemcpyDeviceToHost));
-    BvhBuildResult bvh;
-    const auto tBuild = std::chrono::steady_clock::now();
-    try
-    {
-        bvh = acc->instanced ? acc->bvh.rebuild(acc->flat.data(), changed) : build_bvh(acc->flat.data(), acc->total);
-    }
-    catch (const std::exception &ex)
-    {
-        return fail(PROSPER_PT_ERR_UNSUPPORTED, std::string("BVH rebuild failed: ") + ex.what());
-    }
-    const double buildSeconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - tBuild).count();
-    const int rc = upload_hierarchy(ctx, bvh);
-    if (rc != PROSPER_PT_OK) return rc;
-    ctx->stats.nodeCount = bvh.nodes.size();
-    ctx->stats.maxDepth = bvh.maxDepth;
-    ctx->stats.deviceBytes = ctx->sceneBytes;
-    ctx->stats.bvhBuildSeconds = buildSeconds;
-    ctx->stats.buildSeconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    acc->stale = false;
     return PROSPER_PT_OK;
+}
+
+int prosper_pt_update_transforms(prosper_pt_ctx *ctx, const prosper_ModelInstanceTransforms *transforms, uint32_t count)
+{
+    if (!ctx || !transforms) return fail(PROSPER_PT_ERR_INVALID_ARGUMENT, "prosper_pt_update_transforms: null argument");
+    if (!ctx->haveScene || !ctx->accel) return fail(PROSPER_PT_ERR_NO_SCENE, "no scene uploaded");
+    if (count != ctx->accel->transforms.size())
+        return fail(PROSPER_PT_ERR_INVALID_ARGUMENT, "prosper_pt_update_transforms: count differs from the scene's modelInstanceCount");
+    return update_transforms_impl(ctx, transforms, count);
 }
 
 int prosper_pt_get_scene_stats(prosper_pt_ctx *ctx, prosper_pt_scene_stats *out)
@@ -782,6 +862,8 @@ int prosper_pt_render_frames(
 {
     if (!ctx || !pc || !camera) return fail(PROSPER_PT_ERR_INVALID_ARGUMENT, "prosper_pt_render: null argument");
     if (!ctx->haveScene) return fail(PROSPER_PT_ERR_NO_SCENE, "prosper_pt_render called before prosper_pt_upload_scene");
+    if (ctx->accel && ctx->accel->stale)
+        return fail(PROSPER_PT_ERR_NO_SCENE, "the last prosper_pt_update_transforms failed: update the transforms again (or upload the scene) before rendering");
     if (width == 0 || height == 0 || frame_count == 0)
         return fail(PROSPER_PT_ERR_INVALID_ARGUMENT, "prosper_pt_render: empty extent or frame count");
     if (pc->drawType >= PROSPER_DRAW_TYPE_COUNT) return fail(PROSPER_PT_ERR_INVALID_ARGUMENT, "drawType out of range");
@@ -1016,6 +1098,8 @@ int prosper_pt_restir_di_trace(
     if (!ctx || !pc || !camera || !in || !in->albedoRoughness || !in->normalMetallic || !in->nonLinearDepth || !in->reservoirs)
         return fail(PROSPER_PT_ERR_INVALID_ARGUMENT, "prosper_pt_restir_di_trace: null argument");
     if (!ctx->haveScene) return fail(PROSPER_PT_ERR_NO_SCENE, "prosper_pt_restir_di_trace called before prosper_pt_upload_scene");
+    if (ctx->accel && ctx->accel->stale)
+        return fail(PROSPER_PT_ERR_NO_SCENE, "the last prosper_pt_update_transforms failed: update the transforms again (or upload the scene) before tracing");
     if (width == 0 || height == 0) return fail(PROSPER_PT_ERR_INVALID_ARGUMENT, "prosper_pt_restir_di_trace: empty extent");
     if (pc->drawType >= PROSPER_DRAW_TYPE_COUNT) return fail(PROSPER_PT_ERR_INVALID_ARGUMENT, "drawType out of range");
     PPT_HIP(hipSetDevice(ctx->device));
@@ -1138,11 +1222,11 @@ int prosper_pt_tone_map(
     return PROSPER_PT_OK;
 }
 
-static int read_stage_counters(prosper_pt_ctx *ctx, unsigned long long host[kStageCount * 16], void *stream)
+static int read_stage_counters(prosper_pt_ctx *ctx, unsigned long long host[kStageCount * kCounterCount], void *stream)
 {
     PPT_HIP(hipSetDevice(ctx->device));
     hipStream_t s = static_cast<hipStream_t>(stream);
-    PPT_HIP(hipMemcpyAsync(host, ctx->dCounters, kStageCount * 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+    PPT_HIP(hipMemcpyAsync(host, ctx->dCounters, kStageCount * kCounterCount * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
     PPT_HIP(hipStreamSynchronize(s));
     return PROSPER_PT_OK;
 }
@@ -1150,13 +1234,13 @@ static int read_stage_counters(prosper_pt_ctx *ctx, unsigned long long host[kSta
 int prosper_pt_get_counters(prosper_pt_ctx *ctx, prosper_pt_counters *out, void *stream)
 {
     if (!ctx || !out) return fail(PROSPER_PT_ERR_INVALID_ARGUMENT, "prosper_pt_get_counters: null argument");
-    unsigned long long host[kStageCount * 16] = {};
+    unsigned long long host[kStageCount * kCounterCount] = {};
     const int rc = read_stage_counters(ctx, host, stream);
     if (rc != PROSPER_PT_OK) return rc;
-    static_assert(sizeof(prosper_pt_counters) == 16 * sizeof(uint64_t), "counter layout");
-    unsigned long long sum[16] = {};
+    static_assert(sizeof(prosper_pt_counters) == kCounterCount * sizeof(uint64_t), "counter layout");
+    unsigned long long sum[kCounterCount] = {};
     for (uint32_t st = 0; st < kStageCount; ++st)
-        for (uint32_t i = 0; i < 16; ++i) sum[i] += host[st * 16 + i];
+        for (uint32_t i = 0; i < kCounterCount; ++i) sum[i] += host[st * kCounterCount + i];
     std::memcpy(out, sum, sizeof(*out));
     return PROSPER_PT_OK;
 }
@@ -1165,10 +1249,10 @@ int prosper_pt_get_stage_counters(prosper_pt_ctx *ctx, uint32_t stage, prosper_p
 {
     if (!ctx || !out || stage >= kStageCount)
         return fail(PROSPER_PT_ERR_INVALID_ARGUMENT, "prosper_pt_get_stage_counters: bad argument");
-    unsigned long long host[kStageCount * 16] = {};
+    unsigned long long host[kStageCount * kCounterCount] = {};
     const int rc = read_stage_counters(ctx, host, stream);
     if (rc != PROSPER_PT_OK) return rc;
-    std::memcpy(out, host + stage * 16, sizeof(*out));
+    std::memcpy(out, host + stage * kCounterCount, sizeof(*out));
     return PROSPER_PT_OK;
 }
 
@@ -1177,7 +1261,7 @@ int prosper_pt_reset_counters(prosper_pt_ctx *ctx, void *stream)
     if (!ctx) return fail(PROSPER_PT_ERR_INVALID_ARGUMENT, "prosper_pt_reset_counters: null context");
     PPT_HIP(hipSetDevice(ctx->device));
     PPT_HIP(hipMemsetAsync(
-        ctx->dCounters, 0, kStageCount * 16 * sizeof(unsigned long long), static_cast<hipStream_t>(stream)));
+        ctx->dCounters, 0, kStageCount * kCounterCount * sizeof(unsigned long long), static_cast<hipStream_t>(stream)));
     return PROSPER_PT_OK;
 }
 
@@ -1251,6 +1335,29 @@ int prosper_pt_get_last_render_timing(
         if (kernel_ms) kernel_ms[i] = perStage[i];
         if (kernel_launches) kernel_launches[i] = launches[i];
     }
+    return PROSPER_PT_OK;
+}
+
+int prosper_pt_debug_srgb_monotonicity(
+    prosper_pt_ctx *ctx, uint32_t first_bits, uint32_t last_bits, float *max_defect, uint64_t *decreases)
+{
+    if (!ctx || !max_defect || !decreases || first_bits > last_bits || last_bits >= 0x7F800000u)
+        return fail(PROSPER_PT_ERR_INVALID_ARGUMENT, "prosper_pt_debug_srgb_monotonicity: bad argument");
+    PPT_HIP(hipSetDevice(ctx->device));
+    uint32_t *d = nullptr;
+    PPT_HIP(hipMalloc((void **)&d, 8));
+    hipError_t e = hipMemset(d, 0, 8);
+    uint32_t host[2] = {0u, 0u};
+    if (e == hipSuccess)
+    {
+        launch_srgb_monotonicity(first_bits, last_bits, d, nullptr);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpy(host, d, 8, hipMemcpyDeviceToHost);
+    (void)hipFree(d);
+    PPT_HIP(e);
+    std::memcpy(max_defect, &host[0], 4);
+    *decreases = host[1];
     return PROSPER_PT_OK;
 }
 

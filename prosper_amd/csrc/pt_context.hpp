@@ -40,6 +40,9 @@ struct AccelState
     std::vector<prosper_ModelInstanceTransforms> transforms;
     InstancedBvh bvh;
     bool instanced = false;
+    // a prosper_pt_update_transforms that failed half way leaves transforms, world triangles and nodes out of step: renders
+    // are refused and the next update redoes every instance, whatever the transforms it is given
+    bool stale = false;
     uint64_t total = 0;
     uint32_t drawInstanceCount = 0;
 };
@@ -67,6 +70,7 @@ struct prosper_pt_ctx
     ppt::DeviceScene scene = {};
     prosper_pt_scene_stats stats = {};
     uint32_t packedMaterials = 0; // materials whose three textures are interleaved (MaterialPack)
+    uint64_t alphaTriangleCount = 0, alphaBoundBytes = 0; // any-hit records and bytes of alpha bounds (AlphaMaterial)
     // light buffers are re-uploaded every frame in prosper; keep their device addresses mutable
     prosper_DirectionalLightParameters *dDirectional = nullptr;
     prosper_PointLightsBuffer *dPointLights = nullptr;

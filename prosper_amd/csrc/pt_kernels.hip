@@ -21,7 +21,7 @@ namespace ppt
 __global__ void flatten_triangles_kernel(
     DeviceScene s, const uint32_t *__restrict__ triOffsets, uint32_t drawInstanceCount,
     const uint32_t *__restrict__ drawInstanceFlags, WorldTriangle *__restrict__ out,
-    ShadeTriangle *__restrict__ shadeOut, uint32_t total)
+    ShadeTriangle *__restrict__ shadeOut, AlphaTriangle *__restrict__ alphaOut, uint32_t total)
 {
     const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= total) return;
@@ -52,7 +52,10 @@ __global__ void flatten_triangles_kernel(
     t.v2[0] = v2.x; t.v2[1] = v2.y; t.v2[2] = v2.z;
     t.drawInstance = di;
     t.primitive = prim;
-    t.flags = drawInstanceFlags[di];
+    const uint32_t diFlags = drawInstanceFlags[di];
+    const bool nonOpaque = !(diFlags & kTriFlagOpaque);
+    const uint32_t alphaIndex = nonOpaque ? s.alphaOffsets[di] + prim : 0u;
+    t.flags = diFlags | (alphaIndex << kTriAlphaShift); // a non-opaque triangle names its alpha record
     out[g] = t;
     if (shadeOut == nullptr) return; // re-flatten after moved instances: the shading records are object-space
 
@@ -81,9 +84,20 @@ __global__ void flatten_triangles_kernel(
             sh.position[c][1] = pp.y;
         }
     }
-    sh.flags = drawInstanceFlags[di];
+    sh.flags = diFlags;
     sh.reserved = 0;
     shadeOut[g] = sh;
+    if (nonOpaque)
+    {
+        // what the any-hit shader reads of this triangle (pt_scene.hpp AlphaTriangle): scene.rahit:20-31
+        AlphaTriangle at;
+        for (int c = 0; c < 3; ++c) at.uv[c] = __builtin_bit_cast(uint32_t, sh.normalUv[c][3]);
+        at.materialIndex = inst.materialIndex;
+        at.drawInstance = di;
+        at.primitive = prim;
+        at.reserved[0] = at.reserved[1] = 0u;
+        alphaOut[alphaIndex] = at;
+    }
 }
 
 __global__ void permute_triangles_kernel(
@@ -101,12 +115,12 @@ __global__ void permute_triangles_kernel(
 
 void launch_flatten_triangles(
     const DeviceScene &s, const uint32_t *triOffsets, uint32_t drawInstanceCount, const uint32_t *drawInstanceFlags,
-    WorldTriangle *out, ShadeTriangle *shadeOut, uint32_t total, hipStream_t stream)
+    WorldTriangle *out, ShadeTriangle *shadeOut, AlphaTriangle *alphaOut, uint32_t total, hipStream_t stream)
 {
     if (total == 0) return;
     hipLaunchKernelGGL(
         flatten_triangles_kernel, dim3((total + 255) / 256), dim3(256), 0, stream, s, triOffsets, drawInstanceCount,
-        drawInstanceFlags, out, shadeOut, total);
+        drawInstanceFlags, out, shadeOut, alphaOut, total);
 }
 
 void launch_permute_triangles(
@@ -948,6 +962,108 @@ void launch_decode_bc7(
     hipLaunchKernelGGL(
         decode_bc7_kernel, dim3((n + 255u) / 256u), dim3(256), 0, stream, static_cast<const uint4 *>(blocks), blocksX, blocksY,
         tilesPerRow, static_cast<uint32_t *>(tiled));
+}
+
+// Alpha bounds of a non-opaque material (pt_scene.hpp AlphaMaterial): one thread per cell of 2^shift x 2^shift texels.
+// A sample whose footprint STARTS in the cell (i0, j0 of texel_taps / any_hit_record) reads texels (i0, j0), (i1, j0),
+// (i0, j1), (i1, j1) with i1 = the wrapped neighbour of i0: one of i0 - 1, i0, i0 + 1 (mirrored repeat can step back),
+// so the cell's range grown by one texel on every side - wrapped around for REPEAT, clamped otherwise - holds every
+// texel of every such footprint.  With tmin / tmax the extreme alpha bytes in that range, f the filtered value and
+// L = sRGBtoLinear:
+//     tmin/255 - e1 <= f <= tmax/255 + e1       (convex combination; e1 = kAlphaFilterSlack covers the rounding of the
+//                                                weights and of the fma chain, < 6e-7 for values <= 1)
+//     L(tmin/255 - e1) - e2 <= L(f) <= L(tmax/255 + e1) + e2   (L monotone up to e2 = kAlphaCurveSlack; the monotonicity
+//                                                defect of the device function is measured over every input, test_alpha_bounds)
+//     alpha = fl(L(f) * factorA): multiplication by a non-negative constant is monotone under round-to-nearest.
+// f >= 0 exactly (non-negative weights and texels), hence alpha >= 0.  lo = the largest byte whose decoded value is <=
+// the lower bound, hi = the smallest byte < 255 whose decoded value is >= the upper bound, 255 (= unbounded) if there is
+// none.  tmax == 0 makes f, L(f) and alpha exactly 0: hi = 0 without slack.
+__global__ __launch_bounds__(256) void build_alpha_bounds_kernel(
+    DeviceTexture tex, uint32_t wrapS, uint32_t wrapT, float factorA, uint32_t shift, uint32_t cellsX, uint32_t cellsY,
+    uint16_t *__restrict__ out)
+{
+    const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= cellsX * cellsY) return;
+    const int32_t cx = (int32_t)(c % cellsX), cy = (int32_t)(c / cellsX);
+    const int32_t size = 1 << shift;
+    const int32_t w = (int32_t)tex.width, h = (int32_t)tex.height;
+    uint32_t tmin = 255u, tmax = 0u;
+    for (int32_t dj = -1; dj <= size; ++dj)
+    {
+        int32_t j = cy * size + dj;
+        j = wrapT == PROSPER_PT_WRAP_REPEAT ? floor_mod(j, h) : (j < 0 ? 0 : (j >= h ? h - 1 : j));
+        for (int32_t di = -1; di <= size; ++di)
+        {
+            int32_t i = cx * size + di;
+            i = wrapS == PROSPER_PT_WRAP_REPEAT ? floor_mod(i, w) : (i < 0 ? 0 : (i >= w ? w - 1 : i));
+            const uint32_t a = reinterpret_cast<const uint32_t *>(tex.texels)[texel_offset(tex, i, j)] >> 24;
+            tmin = a < tmin ? a : tmin;
+            tmax = a > tmax ? a : tmax;
+        }
+    }
+    const float k = 1.0f / 255.0f;
+    uint32_t lo = 0u, hi = 0u;
+    if (tmax != 0u)
+    {
+        const float lower = fmax_(srgb_to_linear((float)tmin * k - kAlphaFilterSlack) - kAlphaCurveSlack, 0.0f) * factorA;
+        const float upper = (srgb_to_linear((float)tmax * k + kAlphaFilterSlack) + kAlphaCurveSlack) * factorA;
+        while (lo < 255u && (float)(lo + 1u) * k <= lower) ++lo;
+        hi = 255u;
+        for (uint32_t b = 0; b < 255u; ++b)
+            if ((float)b * k >= upper)
+            {
+                hi = b;
+                break;
+            }
+        if (hi == 0u) hi = 1u; // hi == 0 is reserved for "alpha is exactly 0" (factorA == 0 lands here: decided by u > hi or exact code)
+    }
+    out[c] = (uint16_t)(lo | (hi << 8));
+}
+
+void launch_build_alpha_bounds(
+    const DeviceTexture &tex, uint32_t wrapS, uint32_t wrapT, float factorA, uint32_t shift, uint16_t *out, hipStream_t stream)
+{
+    const uint32_t cellsX = (tex.width + (1u << shift) - 1u) >> shift, cellsY = (tex.height + (1u << shift) - 1u) >> shift;
+    const uint32_t n = cellsX * cellsY;
+    if (n == 0) return;
+    hipLaunchKernelGGL(
+        build_alpha_bounds_kernel, dim3((n + 255u) / 256u), dim3(256), 0, stream, tex, wrapS, wrapT, factorA, shift, cellsX,
+        cellsY, out);
+}
+
+// The monotonicity defect of the device's sRGBtoLinear over the float bit patterns [firstBits, lastBits] (non-negative
+// floats in increasing order): max over x of (max of L over the <= 4096 + 1024 inputs before x) - L(x), as float bits in
+// out[0] (0 = monotone), and the number of adjacent pairs with L(next) < L(x) in out[1].  One thread per run of 4096
+// inputs, started 1024 inputs early so that a defect across a run boundary is seen.
+__global__ __launch_bounds__(256) void srgb_monotonicity_kernel(uint32_t firstBits, uint32_t lastBits, uint32_t *__restrict__ out)
+{
+    const uint64_t run = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t begin = (uint64_t)firstBits + run * 4096ull;
+    if (begin > lastBits) return;
+    const uint64_t end = begin + 4095ull < lastBits ? begin + 4095ull : lastBits;
+    const uint64_t warm = begin >= (uint64_t)firstBits + 1024ull ? begin - 1024ull : firstBits;
+    float runMax = srgb_to_linear(__builtin_bit_cast(float, (uint32_t)warm));
+    float prev = runMax, defect = 0.0f;
+    uint32_t decreases = 0;
+    for (uint64_t b = warm + 1ull; b <= end; ++b)
+    {
+        const float y = srgb_to_linear(__builtin_bit_cast(float, (uint32_t)b));
+        if (b >= begin)
+        {
+            defect = fmax_(defect, runMax - y);
+            decreases += y < prev ? 1u : 0u;
+        }
+        runMax = fmax_(runMax, y);
+        prev = y;
+    }
+    if (defect > 0.0f) atomicMax(&out[0], __builtin_bit_cast(uint32_t, defect));
+    if (decreases) atomicAdd(&out[1], decreases);
+}
+
+void launch_srgb_monotonicity(uint32_t firstBits, uint32_t lastBits, uint32_t *out, hipStream_t stream)
+{
+    const uint64_t runs = ((uint64_t)lastBits - firstBits) / 4096ull + 1ull;
+    hipLaunchKernelGGL(srgb_monotonicity_kernel, dim3((uint32_t)((runs + 255ull) / 256ull)), dim3(256), 0, stream, firstBits, lastBits, out);
 }
 
 // Interleaves the three tiled RGBA8 textures of a material into a MaterialPack (pt_scene.hpp): one thread per texel of

@@ -43,7 +43,10 @@ struct LaunchTimer
 
 void launch_flatten_triangles(
     const DeviceScene &s, const uint32_t *triOffsets, uint32_t drawInstanceCount, const uint32_t *drawInstanceFlags,
-    WorldTriangle *out, ShadeTriangle *shadeOut, uint32_t total, hipStream_t stream);
+    WorldTriangle *out, ShadeTriangle *shadeOut, AlphaTriangle *alphaOut, uint32_t total, hipStream_t stream);
+void launch_build_alpha_bounds(
+    const DeviceTexture &tex, uint32_t wrapS, uint32_t wrapT, float factorA, uint32_t shift, uint16_t *out, hipStream_t stream);
+void launch_srgb_monotonicity(uint32_t firstBits, uint32_t lastBits, uint32_t *out, hipStream_t stream);
 void launch_permute_triangles(
     const WorldTriangle *in, const uint32_t *permutation, WorldTriangle *out, uint32_t total, hipStream_t stream);
 uint32_t restir_grid_blocks(uint32_t width, uint32_t height);

@@ -18,11 +18,11 @@ __device__ void flush_counters(const LaneCounters &c, unsigned long long *counte
     if constexpr (COUNT)
     {
         // order = prosper_pt_counters fields
-        const uint32_t vals[16] = {c.paths, c.closestRays, c.shadowRays, c.nodeVisits, c.triangleTests, c.closestHits,
-                                   c.anyHitCalls, c.lightSamples, c.spotLightSamples, c.skyLookups, c.pixelsWritten,
-                                   c.historyReads, c.shortIndexHits, c.shortIndexTriangleTests, c.nodePhaseSteps,
-                                   c.trianglePhaseSteps};
-        for (int i = 0; i < 16; ++i)
+        const uint32_t vals[kCounterCount] = {
+            c.paths, c.closestRays, c.shadowRays, c.nodeVisits, c.triangleTests, c.closestHits, c.anyHitCalls, c.lightSamples,
+            c.spotLightSamples, c.skyLookups, c.pixelsWritten, c.historyReads, c.shortIndexHits, c.shortIndexTriangleTests,
+            c.nodePhaseSteps, c.trianglePhaseSteps, c.anyHitTexelFetches};
+        for (uint32_t i = 0; i < kCounterCount; ++i)
         {
             const uint32_t sum = wave_sum(vals[i]);
             if ((threadIdx.x & 63) == 0 && sum) atomicAdd(&counters[i], (unsigned long long)sum);

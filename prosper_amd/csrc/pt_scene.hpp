@@ -47,11 +47,48 @@ struct alignas(16) WorldTriangle
     float v1[3];
     uint32_t primitive;
     float v2[3];
-    uint32_t flags; // bit 0: opaque geometry (World.cpp:646-651); bit 1: u16-indexed mesh
+    uint32_t flags; // bit 0: opaque geometry (World.cpp:646-651); bit 1: u16-indexed mesh; bits 2..31 of a
+                    // non-opaque triangle: its record in DeviceScene::alphaTriangles
 };
 static_assert(sizeof(WorldTriangle) == 48, "world triangle is 48 B");
 constexpr uint32_t kTriFlagOpaque = 1u;
 constexpr uint32_t kTriFlagShortIndices = 2u; // the mesh is u16-indexed (only the byte model cares)
+constexpr uint32_t kTriAlphaShift = 2u;
+
+// What the any-hit shader (rt/scene.rahit:18-39) needs of a non-opaque triangle, 32 B in one cache line instead of
+// draw instance -> 128-byte shading record -> material: the three texCoord0 (two halfs each, as the vertex stream
+// holds them), the material, and the ids an accepted candidate reports.  Written by flatten_triangles next to the
+// shading records, (non-opaque drawInstance, primitive) order.
+struct alignas(32) AlphaTriangle
+{
+    uint32_t uv[3];
+    uint32_t materialIndex;
+    uint32_t drawInstance;
+    uint32_t primitive;
+    uint32_t reserved[2];
+};
+static_assert(sizeof(AlphaTriangle) == 32, "alpha triangle is 32 B");
+
+// sampleAlpha (scene/materials.glsl:121-147) of one material as the any-hit needs it, 32 B: the base-colour texture
+// (tiled RGBA8, as DeviceTexture), its sampler's wrap / filter, baseColorFactor.a, the cutoff, the mode - and
+// `bounds`, the material's ALPHA BOUNDS: one {lo, hi} byte pair per cell of 2^cellShift x 2^cellShift texels, bounding
+// the final alpha (after the bilinear filter, sRGBtoLinear and the factor) of EVERY sample whose footprint starts in
+// that cell.  A candidate whose bounds already decide the test - MASK: hi < cutoff or lo >= cutoff; BLEND: hi == 0,
+// u > hi or u <= lo - needs no texel fetch and no pow(); the others run the exact code, so the result is the exact
+// code's in every case (DESIGN.md "alpha bounds").  bounds == nullptr: no table (no texture, or a factor outside
+// [0, inf)): always exact.
+struct alignas(16) AlphaMaterial
+{
+    const uint8_t *texels;  // nullptr: no base-colour texture, alpha = baseColorFactor.a
+    const uint16_t *bounds; // lo | hi << 8 per cell; hi == 255 means unbounded
+    uint16_t width, height;
+    float factorA;
+    float cutoff;
+    uint32_t bits; // 0-1 alphaMode, 2-3 wrapS, 4-5 wrapT, 6 nearest filter, 8-11 cellShift
+};
+static_assert(sizeof(AlphaMaterial) == 32, "alpha material is 32 B");
+constexpr float kAlphaFilterSlack = 4e-6f; // > 6x the rounding of the bilinear weights and the fma chain
+constexpr float kAlphaCurveSlack = 4e-6f;  // > any non-monotonicity of the device's sRGBtoLinear (tested over all inputs)
 
 // Decoded object-space corner attributes of one triangle, 128 B = eight 16-byte words, stored in
 // (drawInstance, primitive) order (record = triangleOffsets[drawInstance] + primitive).  What
@@ -118,6 +155,9 @@ struct DeviceScene
     const prosper_MaterialData *materials;
     const DeviceTexture *textures;
     const MaterialPack *materialPacks; // [materialCount]
+    const AlphaTriangle *alphaTriangles; // non-opaque triangles, (drawInstance, primitive) order
+    const uint32_t *alphaOffsets;        // [drawInstanceCount]: first alpha record of a non-opaque draw instance
+    const AlphaMaterial *alphaMaterials; // [materialCount]
     const prosper_pt_sampler_desc *samplers;
     const prosper_DirectionalLightParameters *directionalLight;
     const prosper_PointLightsBuffer *pointLights;
@@ -133,6 +173,10 @@ struct DeviceScene
     // for the caches, where the three dependent HBM round trips per hit are what the shade kernel waits for
     uint32_t batchedTextures;
 };
+
+// fields of prosper_pt_counters (uint64 each), per kernel stage
+constexpr uint32_t kCounterCount = 17;
+static_assert(sizeof(prosper_pt_counters) == kCounterCount * 8, "prosper_pt_counters and the device counter block differ");
 
 // Per-launch constants: push constants, the camera terms the path reads, extent and tile.
 struct RenderParams

@@ -76,8 +76,8 @@ PPT_D void trace_stream(
     int32_t node = 0, sp = 0;
     uint32_t triFirst = 0, triCount = 0;
     Hit hit = {};
-    // candidate waiting for its any-hit evaluation
-    uint32_t cDi = 0, cPrim = 0;
+    // candidate waiting for its any-hit evaluation: its alpha record (which also names drawInstance and primitive)
+    uint32_t cAlpha = 0;
     float cT = 0.0f, cBu = 0.0f, cBv = 0.0f;
 
     // after a leaf is exhausted or a node misses: pop the next entry or finish
@@ -253,8 +253,7 @@ PPT_D void trace_stream(
                             accept(di, prim, t, bu, bv);
                         else
                         {
-                            cDi = di;
-                            cPrim = prim;
+                            cAlpha = flags >> kTriAlphaShift;
                             cT = t;
                             cBu = bu;
                             cBv = bv;
@@ -274,7 +273,11 @@ PPT_D void trace_stream(
             if (state == kLaneAny)
             {
                 state = kLaneTri;
-                if (any_hit<COUNT>(s, cDi, cPrim, f2{cBu, cBv}, seed, cnt)) accept(cDi, cPrim, cT, cBu, cBv);
+                if (any_hit_record<COUNT>(s, cAlpha, f2{cBu, cBv}, seed, cnt))
+                {
+                    const AlphaTriangle *rec = s.alphaTriangles + cAlpha;
+                    accept(rec->drawInstance, rec->primitive, cT, cBu, cBv);
+                }
                 if (state == kLaneTri && triCount == 0) pop();
             }
         }

@@ -702,8 +702,8 @@ static void enqueue_wavefront(
     const WavefrontPlan &plan, uint32_t nodeCount, uint32_t triCount, int32_t *stackOverflow, LaunchTimer *timer,
     hipStream_t stream)
 {
-    unsigned long long *cGen = counters + kStageGenerate * 16u, *cShade = counters + kStageShade * 16u,
-                       *cTrace = counters + kStageTrace * 16u;
+    unsigned long long *cGen = counters + kStageGenerate * kCounterCount, *cShade = counters + kStageShade * kCounterCount,
+                       *cTrace = counters + kStageTrace * kCounterCount;
     auto mark = [&](uint32_t st) {
         if (timer) timer->mark(st, stream);
     };
@@ -864,7 +864,7 @@ void launch_render_wavefront(
         }
     }
     if (timer) timer->mark(kStageAccumulate, stream);
-    unsigned long long *cAcc = counters + kStageAccumulate * 16u;
+    unsigned long long *cAcc = counters + kStageAccumulate * kCounterCount;
     const dim3 grid((w.pixelsPadded + 255u) / 256u), block(256);
     if (countWork)
         hipLaunchKernelGGL(wf_accumulate<true>, grid, block, 0, stream, p, w, hdr, cAcc);

@@ -605,3 +605,57 @@ def transform_zoo():
     w.add_spot_light((0.8, 0.9, 1.0), 600.0, (-4.0, 3.0, 5.0), (0.6, -0.4, -0.7), math.radians(25.0), math.radians(45.0))
     w.camera = dict(eye=(0.0, 0.3, 9.0), target=(0.0, 0.2, 0.0), up=(0.0, 1.0, 0.0), fov=math.radians(50.0), zN=0.1, zF=100.0)
     return w
+
+
+def alpha_wall():
+    """MASK and BLEND quads in front of an opaque, lit wall: every wrap mode x filter, power-of-two and odd alpha
+    textures (hard-edged blobs, smooth ramps, noise, all-0 and all-255 regions), UVs several periods either side of 0,
+    baseColorFactor.a in {0, 0.5, 1, 1.7}, cutoffs in {0, 0.3, 0.5, 1}: the any-hit test scene (rt/scene.rahit:18-39,
+    materials.glsl:121-147) - in particular for the alpha bounds that settle most candidates without a texel fetch."""
+    w = World()
+    rng = np.random.default_rng(0xA1FA)
+
+    def alpha_texture(ww, h, kind):
+        ys, xs = np.mgrid[0:h, 0:ww]
+        u, v = (xs + 0.5) / ww, (ys + 0.5) / h
+        if kind == 0:    # hard-edged blob: 0 / 255 with a one-texel rim of in-between values
+            r = np.hypot(u - 0.5, v - 0.45)
+            a = np.clip((0.36 - r) * max(ww, h) * 0.7 + 0.5, 0.0, 1.0) * 255.0
+        elif kind == 1:  # smooth ramp with a zero band
+            a = np.clip(u * 1.3 - 0.15, 0.0, 1.0) * np.where((v > 0.4) & (v < 0.55), 0.0, 1.0) * 255.0
+        elif kind == 2:  # noise: nothing for the bounds to settle
+            a = rng.integers(0, 256, size=(h, ww)).astype(np.float64)
+        else:            # stripes of exact 0 / 255 / mid grey
+            a = np.choose((xs * 3 // max(1, ww)) % 3, [0.0, 255.0, 128.0])
+        t = rng.integers(0, 256, size=(h, ww, 4), dtype=np.uint8)
+        t[..., 3] = np.round(a).astype(np.uint8)
+        return t
+
+    sizes = [(64, 64), (37, 21), (128, 32), (5, 3), (1, 1), (16, 48)]
+    wraps = [S.WRAP_REPEAT, S.WRAP_MIRRORED_REPEAT, S.WRAP_CLAMP_TO_EDGE]
+    samplers = [w.add_sampler(f, f, ws, wt) for f in (S.FILTER_LINEAR, S.FILTER_NEAREST) for ws in wraps for wt in wraps]
+    back = w.add_material(base_color=(0.7, 0.7, 0.7, 1.0), metallic=0.0, roughness=0.9)
+    wall = _add(w, quad((-4.2, -2.4, -0.6), (4.2, -2.4, -0.6), (4.2, 2.4, -0.6), (-4.2, 2.4, -0.6)), back)
+    w.add_instance(w.add_model([(wall, back)]))
+    cols, k = 8, 0
+    factors, cutoffs = [1.0, 0.5, 1.7, 0.0, 1.0, 0.9], [0.5, 0.3, 1.0, 0.0, 0.5, 0.7]
+    for row in range(5):
+        for col in range(cols):
+            ww, h = sizes[k % len(sizes)]
+            tex = w.add_texture(alpha_texture(ww, h, k % 4))
+            mode = S.ALPHA_MODE_MASK if (k // 2) % 2 == 0 else S.ALPHA_MODE_BLEND
+            mat = w.add_material(base_color=(0.9, 0.6 + 0.05 * (k % 5), 0.3, factors[k % len(factors)]), metallic=0.0,
+                                 roughness=0.7, alpha_cutoff=cutoffs[(k // 3) % len(cutoffs)], alpha_mode=mode,
+                                 base_tex=(tex, samplers[k % len(samplers)]))
+            cx, cy = col - cols / 2.0, row - 2.5
+            z = 0.15 * (k % 3)  # three layers: shadow and bounce rays meet several candidates
+            p, n, t, uv, idx = quad((cx, cy, z), (cx + 1.05, cy, z), (cx + 1.05, cy + 1.05, z), (cx, cy + 1.05, z))
+            if k % 5 != 0:
+                uv = uv * (1.9 + 0.23 * (k % 7)) - (0.7 + 0.11 * (k % 9))  # several periods, negative too
+            q = _add(w, (p, n, t, uv, idx), mat)
+            w.add_instance(w.add_model([(q, mat)]))
+            k += 1
+    w.add_point_light((1.0, 1.0, 1.0), 80.0, (0.5, 0.3, 3.0))
+    w.add_spot_light((0.9, 0.9, 1.0), 200.0, (-2.0, 1.5, 3.5), (0.4, -0.3, -0.85), math.radians(30.0), math.radians(50.0))
+    w.camera = dict(eye=(0.2, 0.1, 6.2), target=(0.0, 0.0, 0.0), up=(0.0, 1.0, 0.0), fov=math.radians(48.0), zN=0.1, zF=100.0)
+    return w

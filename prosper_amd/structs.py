@@ -246,6 +246,7 @@ class Counters(C.Structure):
         ("shortIndexTriangleTests", C.c_uint64),
         ("nodePhaseSteps", C.c_uint64),
         ("trianglePhaseSteps", C.c_uint64),
+        ("anyHitTexelFetches", C.c_uint64),
     ]
 
     def as_dict(self):
@@ -265,6 +266,8 @@ class SceneStats(C.Structure):
         ("uploadSeconds", C.c_double),
         ("bvhBuildSeconds", C.c_double),
         ("textureSeconds", C.c_double),
+        ("alphaTriangleCount", C.c_uint64),
+        ("alphaBoundBytes", C.c_uint64),
     ]
 
 

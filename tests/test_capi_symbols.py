@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol():
     assert len(syms) >= 30
     for name in syms:
         assert hasattr(lib, name), name
-    assert lib.prosper_pt_abi_version() == 2
+    assert lib.prosper_pt_abi_version() == 3
 
 
 def test_create_fails_loudly_without_gpu():
