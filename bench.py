@@ -76,17 +76,44 @@ def algorithmic_bytes(c, stats):
             c["pixelsWritten"] * 16.0 + c["historyReads"] * 16.0)
 
 
-def valu_peak():
-    """The chip's measured issue rate of independent v_fma_f32 (wave-instructions/s, best over the occupancies the
-    calibration ran): profiles/r02_valu_calibration.json, scripts/valu_calibration.hip."""
+VALU_PEAK_GUIDE = 1024 * 2.4e9 / 2.0  # wave-instructions/s: 1024 SIMDs x 2.4 GHz / 2 cycles per wave64 VALU op (MI355X_MICROARCH.md)
+VALU_PEAK_GUIDE_SOURCE = "1024 SIMDs x 2.4 GHz / 2 cycles per wave64 instruction (MI355X_MICROARCH.md, cycle constants)"
+
+
+def valu_peak_calibrated():
+    """The chip's MEASURED issue rate of independent v_fma_f32 (wave-instructions/s, best over the occupancies the
+    calibration ran): profiles/r02_valu_calibration.json, scripts/valu_calibration.hip.  Reported beside the guide's
+    figure, never instead of it."""
     try:
         with open(os.path.join(ROOT, "profiles", "r02_valu_calibration.json")) as f:
             rows = json.load(f)["results"]
         best = max(r["wave_insts_per_s_chip"] for r in rows if r["inst"] in ("fma_f32", "v_fma_f32"))
-        return best, "profiles/r02_valu_calibration.json (v_fma_f32, best occupancy)"
+        return best, "profiles/r02_valu_calibration.json (v_fma_f32, best occupancy; the clock drops to 2.0-2.3 GHz under that load)"
     except (OSError, KeyError, ValueError):
-        # 1024 SIMDs x 2.4 GHz / 2 cycles per wave64 instruction (MI355X_MICROARCH.md, cycle constants)
-        return 1024 * 2.4e9 / 2.0, "1024 SIMDs x 2.4 GHz / 2 cycles (MI355X_MICROARCH.md; no calibration file)"
+        return None, "no calibration file"
+
+
+def unit_costs():
+    """Static VALU instructions per unit of work (scripts/unit_costs.py over scripts/unit_costs.hip ->
+    profiles/r03_unit_costs.json): the yardstick of the work-normalised figures."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r03_unit_costs.json")) as f:
+            d = json.load(f)
+        return {k: v["valu"] for k, v in d["units"].items()}, "profiles/r03_unit_costs.json (kernel sources sha16 %s)" % d.get("kernel_source_sha16")
+    except (OSError, KeyError, ValueError):
+        return None, "profiles/r03_unit_costs.json is missing"
+
+
+def priced_work(c, unit):
+    """Lane-instructions the work counters of one kernel stage are worth at the static unit costs: what the stage would
+    issue if every lane of every wave instruction did useful work and no scheduling code existed.  Both sides of each
+    branch are in the unit costs, so this is an upper estimate - the efficiency built on it is optimistic, never
+    pessimistic, and it cannot rise by issuing more instructions."""
+    finishes = c["closestHits"] + c["anyHitCalls"]  # triangles a ray went through (at least these ran the long half of the test)
+    return (c["paths"] * unit["camera_ray"] + c["nodeVisits"] * unit["node_visit_closest"] +
+            c["triangleTests"] * unit["triangle_edge_functions"] + finishes * unit["triangle_finish"] +
+            c["anyHitCalls"] * unit["any_hit_settle"] + c.get("anyHitTexelFetches", 0) * unit["any_hit_exact"] +
+            c["skyLookups"] * unit["sky_lookup"])
 
 
 def make_pc(focal, frame_index, max_bounces, ibl, skip_history):
@@ -203,13 +230,15 @@ def bench_restir_di(ctx, torch, world, cam, focal, width, height, stream, repeat
             "gbuffer_bytes_per_pixel": 60, "lights": int(lights)}
 
 
-def kernel_table(per_kernel, stage_bytes, ms_per_step, pmc, alone=None):
+def kernel_table(per_kernel, stage_bytes, ms_per_step, pmc, alone=None, stage_counters=None):
     """Per kernel: launches, the raw per-launch duration inside the pipelined step (hipEvents; launches of the frames in
     flight overlap and queue behind one another, so these sum to 2-3x the step), the duration of the same launch ALONE on
     the GPU (one chain, in order: `alone`), and its EXCLUSIVE share of the step = alone x (ms_per_step / sum of the alone
     durations of the step's launches): the shares add up to the step time.  (Without `alone`: raw x ms_per_step / sum
     raw.)  Then algorithmic bytes and - when PMC figures for this launch shape exist - VALU wave-instructions, lane
-    utilisation and HBM bytes, priced against the exclusive time."""
+    utilisation and HBM bytes, priced against the exclusive time; and the work-normalised figures (issue slots per unit
+    of work against the static cost of that work)."""
+    unit, _ = unit_costs()
     basis = {}
     for name, (sum_ms, launches) in per_kernel.items():
         if launches:
@@ -229,12 +258,32 @@ def kernel_table(per_kernel, stage_bytes, ms_per_step, pmc, alone=None):
             k.update({
                 "valu_insts_per_launch": p["valu_insts_per_launch"],
                 "valu_wave_insts_per_s": p["valu_insts_per_launch"] / t,
-                "lane_util": p["lane_util"],
+                # SQ_THREAD_CYCLES_VALU / (64 x SQ_INSTS_VALU) reads 1.036 for the fully converged wf_accumulate: the two
+                # counters do not weigh every instruction alike.  Clamped; the raw ratio is kept beside it.
+                "lane_util": min(1.0, p["lane_util"]),
+                "lane_util_raw": p["lane_util"],
                 "hbm_bytes_per_launch": p["hbm_bytes_per_launch"],
                 "hbm_GBps": p["hbm_bytes_per_launch"] / t / 1e9,
                 "traffic_over_algorithmic": p["hbm_bytes_per_launch"] / k["algorithmic_bytes_per_launch"]
                 if k["algorithmic_bytes_per_launch"] else None,
             })
+            c = stage_counters[i] if stage_counters else None
+            if unit and c:
+                slots = 64.0 * p["valu_insts_per_launch"] * launches  # lane issue slots of the stage per step
+                if name == "wf_shade":
+                    work, units_done, what = c["closestHits"] * unit["shade_hit"], c["closestHits"], "closest hit"
+                elif name == "wf_accumulate":
+                    work, units_done, what = None, c["pixelsWritten"], "texel-frame"
+                else:
+                    work, units_done, what = priced_work(c, unit), c["nodeVisits"] + c["triangleTests"] + c["anyHitCalls"], "node visit + triangle test + any-hit call"
+                k["work_normalised"] = {
+                    "unit": what,
+                    "units_per_step": units_done,
+                    "issue_slots_per_unit": slots / units_done if units_done else None,
+                    "active_lane_insts_per_unit": slots * min(1.0, p["lane_util"]) / units_done if units_done else None,
+                    "static_lane_insts_of_the_work": work,
+                    "efficiency": (work / slots) if (work is not None and slots) else None,
+                }
         kernels[name] = k
     return kernels, scale
 
@@ -262,45 +311,119 @@ def time_alone(alone_ctx, world, cam, pc, width, height, spp, stream, torch):
     return acc
 
 
-def roofline_object(kernels, pmc, pmc_source, peak, peak_source, ms_per_step, timed_note):
+def roofline_object(kernels, pmc_source, ms_per_step, timed_note, step_algorithmic_bytes):
+    """The roof that binds the dominant kernel is vector-ALU issue, so `bound` is "valu": `achieved` =
+    wave-instructions/s of that kernel, `peak` = the guide's figure (the calibrated, lower one beside it), `frac` = the
+    USEFUL fraction = achieved / peak x lane utilisation: issue slots whose lanes did something.  The contract's HBM
+    figures sit in `hbm`: measured (PMC) and algorithmic (SURVEY 8d byte model) bytes over the kernel's time against
+    8 TB/s; `cache_served` says when the byte model prices bytes that LDS / L2 / the Infinity Cache serve (its rate would
+    exceed the HBM peak at step level), i.e. when the algorithmic fraction is not a statement about HBM."""
     dominant = max(kernels, key=lambda k: kernels[k]["ms_per_launch"] * kernels[k]["launches_per_step"])
     d = kernels[dominant]
+    cal, cal_source = valu_peak_calibrated()
+    t = d["ms_per_launch"] * 1e-3
+    step_alg_GBps = step_algorithmic_bytes / (ms_per_step * 1e-3) / 1e9
     r = {
         "bound": "valu",
         "kernel": dominant,
         "unit": "Gwave-inst/s",
-        "peak": peak / 1e9,
-        "peak_source": peak_source,
+        "peak": VALU_PEAK_GUIDE / 1e9,
+        "peak_source": VALU_PEAK_GUIDE_SOURCE,
+        "peak_calibrated": cal / 1e9 if cal else None,
+        "peak_calibrated_source": cal_source,
         "kernel_ms": d["ms_per_launch"],
+        "kernel_ms_alone": d["ms_per_launch_alone"],
         "kernel_ms_raw": d["ms_per_launch_raw"],
         "kernel_ms_source": timed_note,
         "launches_per_step": d["launches_per_step"],
         "share_of_step": d["ms_per_launch"] * d["launches_per_step"] / ms_per_step,
-        "algorithmic_bytes_per_launch": d["algorithmic_bytes_per_launch"],
         "pmc_source": pmc_source,
     }
+    hbm = {"peak_GBps": HBM_PEAK_GBS,
+           "algorithmic_bytes_per_launch": d["algorithmic_bytes_per_launch"],
+           "algorithmic_GBps": d["algorithmic_bytes_per_launch"] / t / 1e9,
+           "algorithmic_frac": d["algorithmic_bytes_per_launch"] / t / 1e9 / HBM_PEAK_GBS,
+           "step_algorithmic_bytes": step_algorithmic_bytes,
+           "step_algorithmic_GBps": step_alg_GBps,
+           "cache_served": bool(step_alg_GBps > HBM_PEAK_GBS or d["algorithmic_bytes_per_launch"] / t / 1e9 > HBM_PEAK_GBS),
+           "note": "algorithmic = SURVEY 8d unit costs x the work counters, zero reuse assumed; measured = 2 x FETCH_SIZE + "
+                   "WRITE_SIZE (PMC, gfx950 correction); both over the kernel's exclusive time"}
     if "valu_wave_insts_per_s" in d:
         total_insts = sum(k["valu_insts_per_launch"] * k["launches_per_step"] for k in kernels.values() if "valu_insts_per_launch" in k)
+        total_hbm = sum(k["hbm_bytes_per_launch"] * k["launches_per_step"] for k in kernels.values() if "hbm_bytes_per_launch" in k)
+        issue = d["valu_wave_insts_per_s"] / VALU_PEAK_GUIDE
+        hbm.update({"measured_bytes_per_launch": d["hbm_bytes_per_launch"], "measured_GBps": d["hbm_GBps"],
+                    "measured_frac": d["hbm_GBps"] / HBM_PEAK_GBS, "measured_over_algorithmic": d["traffic_over_algorithmic"]})
         r.update({
             "achieved": d["valu_wave_insts_per_s"] / 1e9,
-            "frac": d["valu_wave_insts_per_s"] / peak,
+            "issue_frac": issue,
+            "issue_frac_of_calibrated_peak": d["valu_wave_insts_per_s"] / cal if cal else None,
             "lane_util": d["lane_util"],
-            "useful_frac": d["valu_wave_insts_per_s"] / peak * d["lane_util"],
+            "frac": issue * d["lane_util"],
+            "frac_is": "useful fraction = achieved / peak x lane_util (issue slots whose lanes worked); against the calibrated peak: "
+                       + ("%.3f" % (d["valu_wave_insts_per_s"] / cal * d["lane_util"]) if cal else "n/a"),
+            "work_normalised": d.get("work_normalised"),
             "traffic": d["hbm_bytes_per_launch"],
-            "hbm_measured": {"bytes_per_launch": d["hbm_bytes_per_launch"], "GBps": d["hbm_GBps"],
-                             "frac_of_peak": d["hbm_GBps"] / HBM_PEAK_GBS, "peak_GBps": HBM_PEAK_GBS},
-            "traffic_over_algorithmic": d["traffic_over_algorithmic"],
+            "hbm": hbm,
             # the whole step against the same roofs: every kernel's instructions and bytes over the step time
             "whole_step": {
                 "valu_Gwave_insts_per_s": total_insts / (ms_per_step * 1e-3) / 1e9,
-                "valu_frac": total_insts / (ms_per_step * 1e-3) / peak,
-                "hbm_bytes": sum(k["hbm_bytes_per_launch"] * k["launches_per_step"] for k in kernels.values() if "hbm_bytes_per_launch" in k),
+                "issue_frac": total_insts / (ms_per_step * 1e-3) / VALU_PEAK_GUIDE,
+                "issue_frac_of_calibrated_peak": total_insts / (ms_per_step * 1e-3) / cal if cal else None,
+                "useful_frac": sum(k["valu_insts_per_launch"] * k["launches_per_step"] * k["lane_util"] for k in kernels.values()
+                                   if "valu_insts_per_launch" in k) / (ms_per_step * 1e-3) / VALU_PEAK_GUIDE,
+                "hbm_bytes": total_hbm,
+                "hbm_measured_frac": total_hbm / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                "hbm_algorithmic_frac": step_alg_GBps / HBM_PEAK_GBS,
             },
         })
-        r["whole_step"]["hbm_frac_of_peak"] = r["whole_step"]["hbm_bytes"] / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS
     else:
-        r.update({"achieved": None, "frac": None, "lane_util": None, "traffic": None, "hbm_measured": None})
+        r.update({"achieved": None, "frac": None, "lane_util": None, "traffic": None, "hbm": hbm})
     return r
+
+
+def time_single_sample_frames(ctx, torch, cam, focal, width, height, max_bounces, ibl, stream, frames=96):
+    """One prosper_pt_render per accumulated frame, as RtReference::record makes them (RtReference.cpp:161-383: one path
+    per pixel per frame, the frame index advancing, history read back every frame), three frames in flight: what an
+    interactive prosper session sees, beside the batched 8-spp steps of `value`."""
+    def run(n, first):
+        for f in range(n):
+            pc = make_pc(focal, 1 + ((first + f) % 4000), max_bounces, ibl, first + f == 0)
+            ctx.render(pc, cam, width, height, frames=1, stream=stream, flags=S.RENDER_PIPELINED)
+    run(24, 0)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    run(frames, 24)
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) * 1e3 / frames
+    return {"frames": frames, "ms_per_frame": ms, "frames_per_s": 1e3 / ms, "Mpaths_per_s": width * height / ms / 1e3,
+            "what": "one render call per 1-spp frame (frame index advancing, history accumulated), 3 frames in flight"}
+
+
+def time_rank_share(ctx, torch, cam, focal, width, height, spp, max_bounces, ibl, stream, ranks, rank, steps, full_ms=None):
+    """What ONE rank of an N-rank job would do per step - its stripes of the frame, no gather - timed on this GPU: the
+    per-rank side of the strong-scaling figure while no multi-GPU node is at hand."""
+    tile = tiling.tile_for_rank(rank, ranks)
+    lw = tiling.local_width(width, rank, ranks)
+    buf = torch.zeros((height, lw, 4), dtype=torch.float32, device="cuda")
+    ctx.set_output_buffer(buf.data_ptr(), buf.numel() * 4)
+    pc = make_pc(focal, 1, max_bounces, ibl, True)
+    for _ in range(max(2, steps // 2)):
+        ctx.render(pc, cam, width, height, tile=tile, frames=spp, stream=stream, flags=S.RENDER_PIPELINED)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        ctx.render(pc, cam, width, height, tile=tile, frames=spp, stream=stream, flags=S.RENDER_PIPELINED)
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) * 1e3 / steps
+    ctx.set_output_buffer(0, 0)
+    out = {"ranks": ranks, "rank": rank, "local_width": lw, "steps": steps, "ms_per_step": ms,
+           "Mpaths_per_s_of_the_share": lw * height * spp / ms / 1e3,
+           "what": "rank %d of %d: its 16-pixel stripes of the %dx%d frame at %d spp, 3 frames in flight, no gather" % (rank, ranks, width, height, spp)}
+    if full_ms:
+        out["ideal_ms"] = full_ms / ranks
+        out["bound_on_scaling_efficiency"] = (full_ms / ranks) / ms
+    return out
 
 
 def time_config(ctx, alone_ctx, torch, name, world, width, height, spp, max_bounces, ibl, steps, warmup, stream, render_flags, pmc):
@@ -317,7 +440,8 @@ def time_config(ctx, alone_ctx, torch, name, world, width, height, spp, max_boun
     ctx.reset_counters(stream)
     ctx.render(pc, cam, width, height, frames=spp, flags=S.RENDER_COUNT_WORK, stream=stream)
     counters = ctx.counters(stream).as_dict()
-    stage_bytes = [algorithmic_bytes(ctx.stage_counters(i, stream).as_dict(), stats) for i in range(4)]
+    stage_counters = [ctx.stage_counters(i, stream).as_dict() for i in range(4)]
+    stage_bytes = [algorithmic_bytes(c, stats) for c in stage_counters]
     ctx.set_kernel_timing(False)
     preheat = max(2, min(PREHEAT_STEPS, int(round(4e8 / (width * height * spp)))))
     for _ in range(preheat + warmup):
@@ -333,7 +457,7 @@ def time_config(ctx, alone_ctx, torch, name, world, width, height, spp, max_boun
     _, per_kernel = ctx.last_render_timing()
     ctx.set_kernel_timing(False)
     alone = time_alone(alone_ctx, world, cam, pc, width, height, spp, stream, torch) if alone_ctx is not None else None
-    kernels, _ = kernel_table(per_kernel, stage_bytes, ms_per_step, pmc, alone)
+    kernels, _ = kernel_table(per_kernel, stage_bytes, ms_per_step, pmc, alone, stage_counters)
     dominant = max(kernels, key=lambda k: kernels[k]["ms_per_launch"] * kernels[k]["launches_per_step"])
     out = {
         "ms_per_step": ms_per_step, "Mpaths_per_s": width * height * spp / ms_per_step / 1e3, "steps": steps,
@@ -341,6 +465,8 @@ def time_config(ctx, alone_ctx, torch, name, world, width, height, spp, max_boun
         "upload_ms": stats.uploadSeconds * 1e3, "bvh_build_ms": stats.bvhBuildSeconds * 1e3,
         "texture_upload_ms": stats.textureSeconds * 1e3, "upload_wall_ms": upload_wall * 1e3,
         "scene_device_MB": stats.deviceBytes / 1e6,
+        "alpha_triangles": int(stats.alphaTriangleCount), "alpha_bound_bytes": int(stats.alphaBoundBytes),
+        "counters": counters,
         "dominant_kernel": dominant, "kernels": kernels,
         "algorithmic_bytes_per_step": algorithmic_bytes(counters, stats),
         "pmc_source": pmc["source"] if pmc else None,
@@ -352,16 +478,24 @@ def time_config(ctx, alone_ctx, torch, name, world, width, height, spp, max_boun
         out["lane_util"] = {k: v.get("lane_util") for k, v in kernels.items()}
     # the same roofline object as the headline's, for this configuration's dominant kernel, and the kernel nearest
     # the HBM roof beside it (C3's wf_shade is the one kernel of the pass that waits for memory)
-    peak, peak_source = valu_peak()
     out["roofline"] = roofline_object(
-        kernels, pmc, out["pmc_source"], peak, peak_source, ms_per_step,
-        "each launch alone on the GPU x ms_per_step / sum of the alone durations (as in the headline)")
+        kernels, out["pmc_source"], ms_per_step,
+        "each launch alone on the GPU x ms_per_step / sum of the alone durations (as in the headline)",
+        out["algorithmic_bytes_per_step"])
     hbm = {k: v["hbm_GBps"] for k, v in kernels.items() if "hbm_GBps" in v and k != "wf_accumulate"}
     if hbm:
         k = max(hbm, key=hbm.get)
         out["nearest_hbm_roof"] = {"kernel": k, "GBps": hbm[k], "frac_of_peak": hbm[k] / HBM_PEAK_GBS,
                                    "traffic_over_algorithmic": kernels[k].get("traffic_over_algorithmic")}
     ctx.set_output_buffer(0, 0)
+    if name == "c3":
+        # BASELINE C5 (this scene, 3840x2160, 64 spp, 8 GPUs) as one of its ranks sees it
+        try:
+            w5, h5 = 3840, 2160
+            cam5, focal5 = Camera.from_world(world, w5, h5).update_buffer()
+            out["c5_rank_share"] = time_rank_share(ctx, torch, cam5, focal5, w5, h5, 64, max_bounces, ibl, stream, 8, 3, 3)
+        except Exception as e:
+            out["c5_rank_share"] = {"error": str(e)[:300]}
     return out
 
 
@@ -538,7 +672,8 @@ def main():
     ctx.render(pc, cam, width, height, tile=tile, frames=spp, flags=S.RENDER_COUNT_WORK, stream=stream)
     counters = ctx.counters(stream).as_dict()
     bytes_per_step = algorithmic_bytes(counters, stats)
-    stage_bytes = [algorithmic_bytes(ctx.stage_counters(i, stream).as_dict(), stats) for i in range(4)]
+    stage_counters = [ctx.stage_counters(i, stream).as_dict() for i in range(4)]
+    stage_bytes = [algorithmic_bytes(c, stats) for c in stage_counters]
     ctx.set_kernel_timing(True)
 
     # Device wake-up: the clocks of an idle MI355X take ~40 ms of load to ramp (the first ten 2.5 ms steps after idle
@@ -586,12 +721,12 @@ def main():
         image = full if world_size > 1 else hdr
         paths_per_step = width * height * spp
         ms_per_step = elapsed * 1e3 / args.steps
-        peak, peak_source = valu_peak()
         alone = None
         if world_size == 1 and wavefront and render_flags:
             alone_ctx = capi.Context(device=local_rank, flags=S.CREATE_SINGLE_CHAIN)
             alone = time_alone(alone_ctx, world, cam, make_pc(focal, 1, max_bounces, ibl, True), width, height, spp, stream, torch)
-        kernels, scale = kernel_table(per_kernel, stage_bytes, ms_per_step, pmc if world_size == 1 else None, alone)
+        kernels, scale = kernel_table(per_kernel, stage_bytes, ms_per_step, pmc if world_size == 1 else None, alone,
+                                      stage_counters if world_size == 1 else None)
         if alone:
             timed_note = ("each launch ALONE on the GPU (one chain, in order, hipEvents, mean of 3 renders) x %.3f = ms_per_step / "
                           "sum of the alone durations of a step's launches: with three frames in flight the launches overlap, the "
@@ -628,7 +763,7 @@ def main():
                         else "wavefront, 2 concurrent launch chains"))),
                 "preheat_steps": preheat_steps,
             },
-            "roofline": roofline_object(kernels, pmc, pmc_source, peak, peak_source, ms_per_step, timed_note),
+            "roofline": roofline_object(kernels, pmc_source, ms_per_step, timed_note, bytes_per_step),
             "kernels": kernels,
             "scene": {"upload_ms": stats.uploadSeconds * 1e3, "bvh_build_ms": stats.bvhBuildSeconds * 1e3,
                       "texture_upload_ms": stats.textureSeconds * 1e3, "upload_wall_ms": upload_wall * 1e3,
@@ -639,6 +774,10 @@ def main():
         }
         if world_size == 1 and wavefront:
             if not args.no_extras:
+                result["single_sample_frames"] = time_single_sample_frames(ctx, torch, cam, focal, width, height, max_bounces, ibl, stream)
+                result["rank_share"] = time_rank_share(ctx, torch, cam, focal, width, height, spp, max_bounces, ibl, stream, 8, 3, 30, ms_per_step)
+                ctx.set_output_buffer(hdr.data_ptr(), hdr.numel() * 4)
+                ctx.render(make_pc(focal, 1, max_bounces, ibl, True), cam, width, height, frames=spp, stream=stream)
                 result["tone_map"] = bench_tone_map(ctx, torch, width, height, stream)
                 result["restir_di_trace"] = bench_restir_di(ctx, torch, world, cam, focal, width, height, stream)
             if sub_names:

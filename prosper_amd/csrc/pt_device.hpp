@@ -1084,96 +1084,33 @@ struct Hit
     float t;
 };
 
-// rt/scene.rahit:18-39 on the candidate whose record is alphaTriangles[alphaIndex]; true = accept it.
+// rt/scene.rahit:18-39 on the candidate whose record is alphaTriangles[alphaIndex].
 //
 // The decision is sampleAlpha's (materials.glsl:121-147) in every case.  What changes is how often its texel fetches,
 // filter and sRGBtoLinear run: the material's alpha bounds (pt_scene.hpp AlphaMaterial) hold, for the cell the sample's
 // footprint starts in, bytes lo <= alpha <= hi valid for every footprint of that cell.  The footprint is computed first
 // - the same uv interpolation, the same i0 / j0 the filter would use - and when the bounds settle the comparison the
 // exact code is skipped; otherwise it runs on that footprint.
-template <bool COUNT>
-PPT_D bool any_hit_record(const DeviceScene &s, uint32_t alphaIndex, f2 bary, uint32_t randomSeed, LaneCounters &cnt)
+//   any_hit_settle: kAlphaReject / kAlphaAccept when the bounds (or a material without texture) decide, else
+//                   kAlphaUndecided with the footprint in `fp`
+//   any_hit_exact:  the texel fetches, the filter, sRGBtoLinear and the comparison on that footprint
+struct AlphaFootprint
 {
-    const uint4 rec = *reinterpret_cast<const uint4 *>(s.alphaTriangles + alphaIndex); // uv0, uv1, uv2, material
-    const uint4 *mp = reinterpret_cast<const uint4 *>(s.alphaMaterials + rec.w);
-    const uint4 m0 = mp[0], m1 = mp[1];
-    const uint64_t texelBits = ((uint64_t)m0.y << 32) | m0.x, boundBits = ((uint64_t)m0.w << 32) | m0.z;
-    const float factorA = __builtin_bit_cast(float, m1.y), cutoff = __builtin_bit_cast(float, m1.z);
-    const uint32_t bits = m1.w;
-    const uint32_t mode = bits & 3u;
-    if constexpr (COUNT)
-    {
-        cnt.anyHitCalls++;
-        const uint32_t di = s.alphaTriangles[alphaIndex].drawInstance, prim = s.alphaTriangles[alphaIndex].primitive;
-        cnt.shortIndexHits += (s.shadeTriangles[s.triangleOffsets[di] + prim].flags & kTriFlagShortIndices) ? 1u : 0u;
-    }
-    const float u = (float)pcg(randomSeed) / 4294967296.0f; // the ray's one draw (scene.rahit:35); BLEND only
-    float linearAlpha = 1.0f;
-    if (texelBits != 0ull)
-    {
-        // geometry.glsl:246-256: texCoord0 at the hit
-        const f2 uv0 = unpack_half2(rec.x), uv1 = unpack_half2(rec.y), uv2 = unpack_half2(rec.z);
-        const float a = (1.0f - bary.x) - bary.y;
-        const f2 uv = f2{bary1(uv0.x, uv1.x, uv2.x, a, bary.x, bary.y), bary1(uv0.y, uv1.y, uv2.y, a, bary.x, bary.y)};
-        DeviceTexture t;
-        t.texels = reinterpret_cast<const uint8_t *>(texelBits);
-        t.width = m1.x & 0xFFFFu;
-        t.height = m1.x >> 16;
-        t.tilesPerRow = (t.width + kTexTileW - 1u) / kTexTileW;
-        const uint32_t wrapS = (bits >> 2) & 3u, wrapT = (bits >> 4) & 3u;
-        const int32_t w = (int32_t)t.width, h = (int32_t)t.height;
-        int32_t i0, i1, j0, j1;
-        float fa, fb;
-        if (bits & 64u) // nearest: the footprint is one texel (texel_taps)
-        {
-            i0 = i1 = wrap_coord(f2i(__builtin_floorf(uv.x * (float)w)), w, wrapS);
-            j0 = j1 = wrap_coord(f2i(__builtin_floorf(uv.y * (float)h)), h, wrapT);
-            fa = 0.0f;
-            fb = 0.0f;
-        }
-        else
-        {
-            const float tu = __builtin_fmaf(uv.x, (float)w, -0.5f);
-            const float tv = __builtin_fmaf(uv.y, (float)h, -0.5f);
-            const float fu = __builtin_floorf(tu);
-            const float fv = __builtin_floorf(tv);
-            fa = tu - fu;
-            fb = tv - fv;
-            wrap_pair(f2i(fu), w, wrapS, i0, i1);
-            wrap_pair(f2i(fv), h, wrapT, j0, j1);
-        }
-        if (boundBits != 0ull && (fa + fb) == (fa + fb)) // (a non-finite uv makes the weights NaN: exact code only)
-        {
-            const uint32_t shift = (bits >> 8) & 15u;
-            const uint32_t cellsPerRow = (t.width + (1u << shift) - 1u) >> shift;
-            const uint32_t cell = ((uint32_t)j0 >> shift) * cellsPerRow + ((uint32_t)i0 >> shift);
-            typedef const __attribute__((address_space(1))) uint16_t *global_u16_ptr;
-            const uint32_t b = ((global_u16_ptr)boundBits)[cell];
-            const float lo = (float)(b & 0xFFu) * (1.0f / 255.0f);
-            const float hi = (b >> 8) == 255u ? kInf : (float)(b >> 8) * (1.0f / 255.0f);
-            if (mode == PROSPER_ALPHA_MODE_BLEND)
-            {
-                if (b < 256u) return false;        // hi == 0: every texel of the cell is 0, alpha == 0 exactly
-                if (u > hi) return false;          // 0 <= alpha <= hi < u
-                if (lo > 0.0f && u <= lo) return true; // 0 < u <= lo <= alpha
-            }
-            else if (mode == PROSPER_ALPHA_MODE_MASK)
-            {
-                if (hi < cutoff) return false;
-                if (lo >= cutoff) return true;
-            }
-        }
-        if constexpr (COUNT) cnt.anyHitTexelFetches++;
-        TexelTaps k;
-        k.texels = (global_u32_ptr)t.texels;
-        k.o00 = texel_offset(t, i0, j0);
-        k.o10 = texel_offset(t, i1, j0);
-        k.o01 = texel_offset(t, i0, j1);
-        k.o11 = texel_offset(t, i1, j1);
-        k.a = fa;
-        k.b = fb;
-        linearAlpha = srgb_to_linear(filter_taps(k, fetch_taps(k)).w);
-    }
+    global_u32_ptr texels;
+    uint32_t o00, o10, o01, o11;
+    float a, b;
+    float factorA, cutoff, u;
+    uint32_t mode;
+};
+enum : uint32_t
+{
+    kAlphaReject = 0,
+    kAlphaAccept = 1,
+    kAlphaUndecided = 2,
+};
+
+PPT_D bool alpha_verdict(uint32_t mode, float linearAlpha, float factorA, float cutoff, float u)
+{
     linearAlpha *= factorA;
     float alpha = -1.0f;
     if (mode == PROSPER_ALPHA_MODE_BLEND)
@@ -1183,6 +1120,112 @@ PPT_D bool any_hit_record(const DeviceScene &s, uint32_t alphaIndex, f2 bary, ui
     if (alpha == 0.0f) return false;
     if (alpha > 0.0f && u > alpha) return false;
     return true;
+}
+
+template <bool COUNT>
+PPT_D uint32_t any_hit_settle(
+    const DeviceScene &s, uint32_t alphaIndex, f2 bary, uint32_t randomSeed, LaneCounters &cnt, AlphaFootprint &fp)
+{
+    const uint4 *rp = reinterpret_cast<const uint4 *>(s.alphaTriangles + alphaIndex);
+    const uint4 rec = rp[0];             // uv0, uv1, uv2, drawInstance
+    const uint4 m0 = rp[2], m1 = rp[3]; // the material's AlphaMaterial
+    const uint64_t texelBits = ((uint64_t)m0.y << 32) | m0.x, boundBits = ((uint64_t)m0.w << 32) | m0.z;
+    const uint32_t bits = m1.w;
+    fp.factorA = __builtin_bit_cast(float, m1.y);
+    fp.cutoff = __builtin_bit_cast(float, m1.z);
+    fp.mode = bits & 3u;
+    fp.u = (float)pcg(randomSeed) / 4294967296.0f; // the ray's one draw (scene.rahit:35); BLEND only
+    if constexpr (COUNT)
+    {
+        cnt.anyHitCalls++;
+        const uint32_t di = s.alphaTriangles[alphaIndex].drawInstance, prim = s.alphaTriangles[alphaIndex].primitive;
+        cnt.shortIndexHits += (s.shadeTriangles[s.triangleOffsets[di] + prim].flags & kTriFlagShortIndices) ? 1u : 0u;
+    }
+    if (texelBits == 0ull) return alpha_verdict(fp.mode, 1.0f, fp.factorA, fp.cutoff, fp.u) ? kAlphaAccept : kAlphaReject;
+
+    // geometry.glsl:246-256: texCoord0 at the hit
+    const f2 uv0 = unpack_half2(rec.x), uv1 = unpack_half2(rec.y), uv2 = unpack_half2(rec.z);
+    const float a = (1.0f - bary.x) - bary.y;
+    const f2 uv = f2{bary1(uv0.x, uv1.x, uv2.x, a, bary.x, bary.y), bary1(uv0.y, uv1.y, uv2.y, a, bary.x, bary.y)};
+    DeviceTexture t;
+    t.texels = reinterpret_cast<const uint8_t *>(texelBits);
+    t.width = m1.x & 0xFFFFu;
+    t.height = m1.x >> 16;
+    t.tilesPerRow = (t.width + kTexTileW - 1u) / kTexTileW;
+    const uint32_t wrapS = (bits >> 2) & 3u, wrapT = (bits >> 4) & 3u;
+    const int32_t w = (int32_t)t.width, h = (int32_t)t.height;
+    int32_t i0, i1, j0, j1;
+    if (bits & 64u) // nearest: the footprint is one texel (texel_taps)
+    {
+        i0 = i1 = wrap_coord(f2i(__builtin_floorf(uv.x * (float)w)), w, wrapS);
+        j0 = j1 = wrap_coord(f2i(__builtin_floorf(uv.y * (float)h)), h, wrapT);
+        fp.a = 0.0f;
+        fp.b = 0.0f;
+    }
+    else
+    {
+        const float tu = __builtin_fmaf(uv.x, (float)w, -0.5f);
+        const float tv = __builtin_fmaf(uv.y, (float)h, -0.5f);
+        const float fu = __builtin_floorf(tu);
+        const float fv = __builtin_floorf(tv);
+        fp.a = tu - fu;
+        fp.b = tv - fv;
+        wrap_pair(f2i(fu), w, wrapS, i0, i1);
+        wrap_pair(f2i(fv), h, wrapT, j0, j1);
+    }
+    if (boundBits != 0ull && (fp.a + fp.b) == (fp.a + fp.b)) // (a non-finite uv makes the weights NaN: exact code only)
+    {
+        const uint32_t shift = (bits >> 8) & 15u;
+        const uint32_t cellsPerRow = (t.width + (1u << shift) - 1u) >> shift;
+        const uint32_t cell = ((uint32_t)j0 >> shift) * cellsPerRow + ((uint32_t)i0 >> shift);
+        typedef const __attribute__((address_space(1))) uint16_t *global_u16_ptr;
+        const uint32_t b = ((global_u16_ptr)boundBits)[cell];
+        const float lo = (float)(b & 0xFFu) * (1.0f / 255.0f);
+        const float hi = (b >> 8) == 255u ? kInf : (float)(b >> 8) * (1.0f / 255.0f);
+        if (fp.mode == PROSPER_ALPHA_MODE_BLEND)
+        {
+            if (b < 256u) return kAlphaReject;                     // hi == 0: every texel of the cell is 0, alpha == 0 exactly
+            if (fp.u > hi) return kAlphaReject;                    // 0 <= alpha <= hi < u
+            if (lo > 0.0f && fp.u <= lo) return kAlphaAccept;      // 0 < u <= lo <= alpha
+        }
+        else if (fp.mode == PROSPER_ALPHA_MODE_MASK)
+        {
+            if (hi < fp.cutoff) return kAlphaReject;
+            if (lo >= fp.cutoff) return kAlphaAccept;
+        }
+    }
+    fp.texels = (global_u32_ptr)t.texels;
+    fp.o00 = texel_offset(t, i0, j0);
+    fp.o10 = texel_offset(t, i1, j0);
+    fp.o01 = texel_offset(t, i0, j1);
+    fp.o11 = texel_offset(t, i1, j1);
+    return kAlphaUndecided;
+}
+
+template <bool COUNT>
+PPT_D bool any_hit_exact(const AlphaFootprint &fp, LaneCounters &cnt)
+{
+    if constexpr (COUNT) cnt.anyHitTexelFetches++;
+    TexelTaps k;
+    k.texels = fp.texels;
+    k.o00 = fp.o00;
+    k.o10 = fp.o10;
+    k.o01 = fp.o01;
+    k.o11 = fp.o11;
+    k.a = fp.a;
+    k.b = fp.b;
+    const float linearAlpha = srgb_to_linear(filter_taps(k, fetch_taps(k)).w);
+    return alpha_verdict(fp.mode, linearAlpha, fp.factorA, fp.cutoff, fp.u);
+}
+
+// both steps; true = accept the candidate
+template <bool COUNT>
+PPT_D bool any_hit_record(const DeviceScene &s, uint32_t alphaIndex, f2 bary, uint32_t randomSeed, LaneCounters &cnt)
+{
+    AlphaFootprint fp;
+    const uint32_t v = any_hit_settle<COUNT>(s, alphaIndex, bary, randomSeed, cnt, fp);
+    if (v != kAlphaUndecided) return v == kAlphaAccept;
+    return any_hit_exact<COUNT>(fp, cnt);
 }
 
 // the same for callers that hold (drawInstance, primitive) instead of the triangle's flags word

@@ -92,10 +92,11 @@ __global__ void flatten_triangles_kernel(
         // what the any-hit shader reads of this triangle (pt_scene.hpp AlphaTriangle): scene.rahit:20-31
         AlphaTriangle at;
         for (int c = 0; c < 3; ++c) at.uv[c] = __builtin_bit_cast(uint32_t, sh.normalUv[c][3]);
-        at.materialIndex = inst.materialIndex;
         at.drawInstance = di;
         at.primitive = prim;
+        at.materialIndex = inst.materialIndex;
         at.reserved[0] = at.reserved[1] = 0u;
+        at.material = s.alphaMaterials[inst.materialIndex];
         alphaOut[alphaIndex] = at;
     }
 }

@@ -55,20 +55,6 @@ constexpr uint32_t kTriFlagOpaque = 1u;
 constexpr uint32_t kTriFlagShortIndices = 2u; // the mesh is u16-indexed (only the byte model cares)
 constexpr uint32_t kTriAlphaShift = 2u;
 
-// What the any-hit shader (rt/scene.rahit:18-39) needs of a non-opaque triangle, 32 B in one cache line instead of
-// draw instance -> 128-byte shading record -> material: the three texCoord0 (two halfs each, as the vertex stream
-// holds them), the material, and the ids an accepted candidate reports.  Written by flatten_triangles next to the
-// shading records, (non-opaque drawInstance, primitive) order.
-struct alignas(32) AlphaTriangle
-{
-    uint32_t uv[3];
-    uint32_t materialIndex;
-    uint32_t drawInstance;
-    uint32_t primitive;
-    uint32_t reserved[2];
-};
-static_assert(sizeof(AlphaTriangle) == 32, "alpha triangle is 32 B");
-
 // sampleAlpha (scene/materials.glsl:121-147) of one material as the any-hit needs it, 32 B: the base-colour texture
 // (tiled RGBA8, as DeviceTexture), its sampler's wrap / filter, baseColorFactor.a, the cutoff, the mode - and
 // `bounds`, the material's ALPHA BOUNDS: one {lo, hi} byte pair per cell of 2^cellShift x 2^cellShift texels, bounding
@@ -87,6 +73,21 @@ struct alignas(16) AlphaMaterial
     uint32_t bits; // 0-1 alphaMode, 2-3 wrapS, 4-5 wrapT, 6 nearest filter, 8-11 cellShift
 };
 static_assert(sizeof(AlphaMaterial) == 32, "alpha material is 32 B");
+
+// What the any-hit shader (rt/scene.rahit:18-39) needs of a non-opaque triangle, in ONE 64-byte line instead of
+// draw instance -> 128-byte shading record -> material -> texture -> sampler: the three texCoord0 (two halfs each, as
+// the vertex stream holds them), the ids an accepted candidate reports, and a copy of its material's AlphaMaterial.
+// Written by flatten_triangles next to the shading records, (non-opaque drawInstance, primitive) order.
+struct alignas(64) AlphaTriangle
+{
+    uint32_t uv[3];
+    uint32_t drawInstance;
+    uint32_t primitive;
+    uint32_t materialIndex;
+    uint32_t reserved[2];
+    AlphaMaterial material;
+};
+static_assert(sizeof(AlphaTriangle) == 64, "alpha triangle is 64 B");
 constexpr float kAlphaFilterSlack = 4e-6f; // > 6x the rounding of the bilinear weights and the fma chain
 constexpr float kAlphaCurveSlack = 4e-6f;  // > any non-monotonicity of the device's sRGBtoLinear (tested over all inputs)
 

@@ -253,11 +253,24 @@ PPT_D void trace_stream(
                             accept(di, prim, t, bu, bv);
                         else
                         {
-                            cAlpha = flags >> kTriAlphaShift;
-                            cT = t;
-                            cBu = bu;
-                            cBv = bv;
-                            state = kLaneAny;
+                            // rt/scene.rahit:18-39 runs in a phase of its own (kLaneAny)
+#ifdef PPT_EXPERIMENT_SETTLE_IN_TRI_PHASE
+                            // measured slower (profiles/r03_alpha_bounds.txt): the two dependent loads lengthen every
+                            // triangle step of the wave by more than the any-hit phases they save
+                            AlphaFootprint fp;
+                            const uint32_t verdict =
+                                any_hit_settle<COUNT>(s, flags >> kTriAlphaShift, f2{bu, bv}, seed, cnt, fp);
+                            if (verdict == kAlphaAccept)
+                                accept(di, prim, t, bu, bv);
+                            else if (verdict == kAlphaUndecided)
+#endif
+                            {
+                                cAlpha = flags >> kTriAlphaShift;
+                                cT = t;
+                                cBu = bu;
+                                cBv = bv;
+                                state = kLaneAny;
+                            }
                         }
                     }
                     if (state == kLaneTri && triCount == 0) pop();
@@ -273,7 +286,15 @@ PPT_D void trace_stream(
             if (state == kLaneAny)
             {
                 state = kLaneTri;
+#ifdef PPT_EXPERIMENT_SETTLE_IN_TRI_PHASE
+                // the footprint again (a lane keeps only the candidate between phases), then the exact evaluation
+                AlphaFootprint fp;
+                LaneCounters uncounted = {};
+                (void)any_hit_settle<false>(s, cAlpha, f2{cBu, cBv}, seed, uncounted, fp);
+                if (any_hit_exact<COUNT>(fp, cnt))
+#else
                 if (any_hit_record<COUNT>(s, cAlpha, f2{cBu, cBv}, seed, cnt))
+#endif
                 {
                     const AlphaTriangle *rec = s.alphaTriangles + cAlpha;
                     accept(rec->drawInstance, rec->primitive, cT, cBu, cBv);

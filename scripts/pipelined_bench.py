@@ -22,6 +22,7 @@ CONFIGS = {
     "c2": (scenes.cornell, False),
     "c3": (lambda: scenes.sponza_class(), True),
     "c4": (lambda: scenes.sponza_class(lights=True, foliage=True), True),
+    "helmet": (lambda: __import__("prosper_amd.flight_helmet", fromlist=["x"]).load_fixture(), True),
 }
 
 

@@ -13,7 +13,7 @@ the dispatches, so every launch runs alone):
 HBM bytes per launch = 2 x FETCH_SIZE + WRITE_SIZE (KB): the guide's gfx950 correction (FETCH_SIZE tallies a 128-B
 request of a 16 B/lane stream at 64 B).  lane_util = SQ_THREAD_CYCLES_VALU / (64 x SQ_INSTS_VALU).
 
-    python scripts/pmc_tools.py c2 [c3 c4 ...]      -> profiles/r02_<config>_pmc.json  (run on the GPU box)
+    python scripts/pmc_tools.py c2 [c3 c4 ...]      -> profiles/r03_<config>_pmc.json  (run on the GPU box)
 bench.py calls collect() itself for the headline configuration, so the figures in its line are measured in that run.
 """
 import collections
@@ -23,6 +23,7 @@ import hashlib
 import json
 import os
 import shutil
+import signal
 import subprocess
 import sys
 import tempfile
@@ -102,9 +103,20 @@ def run_pass(config, counters, out_dir, extra_args=(), timeout=600):
     cmd = ["rocprofv3", "--pmc"] + list(counters) + ["-d", out_dir, "-o", "pmc", "--output-format", "csv", "--",
                                                     sys.executable, os.path.join(ROOT, "scripts", "quick_bench.py"),
                                                     "--config", config, "--single-chain", "--steps", "1"] + list(extra_args)
-    p = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=timeout)
+    # its own process group: a pass that hangs (some counter sets do) is killed as a whole - profiler AND the profiled
+    # python child - before the caller goes on to its timed region; nothing of it may be left holding the GPU
+    p = subprocess.Popen(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, start_new_session=True)
+    try:
+        out, _ = p.communicate(timeout=timeout)
+    except subprocess.TimeoutExpired:
+        try:
+            os.killpg(p.pid, signal.SIGKILL)
+        except ProcessLookupError:
+            pass
+        p.wait()
+        raise RuntimeError("rocprofv3 pass timed out after %d s (its process group was killed)" % timeout)
     if p.returncode != 0:
-        raise RuntimeError("rocprofv3 pass failed (%d): %s" % (p.returncode, p.stdout[-800:]))
+        raise RuntimeError("rocprofv3 pass failed (%d): %s" % (p.returncode, out[-800:]))
 
 
 def collect(config, work_dir=None, extra_args=(), keep=False, timeout=600, with_mix=False):
@@ -163,8 +175,8 @@ def collect(config, work_dir=None, extra_args=(), keep=False, timeout=600, with_
 
 
 def load_committed(config):
-    """profiles/r02_<config>_pmc.json if it was taken on the current kernel sources, else None."""
-    path = os.path.join(ROOT, "profiles", "r02_%s_pmc.json" % config)
+    """profiles/r03_<config>_pmc.json if it was taken on the current kernel sources, else None."""
+    path = os.path.join(ROOT, "profiles", "r03_%s_pmc.json" % config)
     try:
         with open(path) as f:
             d = json.load(f)
@@ -172,7 +184,7 @@ def load_committed(config):
         return None
     if d.get("kernel_source_sha16") != kernel_source_hash():
         return None
-    d["source"] = "profiles/r02_%s_pmc.json (taken on these kernel sources: sha16 %s)" % (config, d["kernel_source_sha16"])
+    d["source"] = "profiles/r03_%s_pmc.json (taken on these kernel sources: sha16 %s)" % (config, d["kernel_source_sha16"])
     return d
 
 
@@ -180,7 +192,7 @@ def main():
     for config in sys.argv[1:]:
         extra = []
         out = collect(config, extra_args=extra, with_mix=True)
-        path = os.path.join(ROOT, "profiles", "r02_%s_pmc.json" % config)
+        path = os.path.join(ROOT, "profiles", "r03_%s_pmc.json" % config)
         with open(path, "w") as f:
             json.dump(out, f, indent=1)
             f.write("\n")
