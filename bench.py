@@ -105,15 +105,14 @@ def unit_costs():
 
 
 def priced_work(c, unit):
-    """Lane-instructions the work counters of one kernel stage are worth at the static unit costs: what the stage would
-    issue if every lane of every wave instruction did useful work and no scheduling code existed.  Both sides of each
-    branch are in the unit costs, so this is an upper estimate - the efficiency built on it is optimistic, never
-    pessimistic, and it cannot rise by issuing more instructions."""
+    """Lane-instructions the traversal work counters of one kernel stage are worth at the static unit costs: what the
+    stage would issue if every lane of every wave instruction did useful work and no scheduling code existed.  The unit
+    costs count both sides of each branch, so this is an upper estimate of the work (the efficiency built on it is
+    optimistic); being work / issued slots it cannot rise by issuing more instructions."""
     finishes = c["closestHits"] + c["anyHitCalls"]  # triangles a ray went through (at least these ran the long half of the test)
     return (c["paths"] * unit["camera_ray"] + c["nodeVisits"] * unit["node_visit_closest"] +
             c["triangleTests"] * unit["triangle_edge_functions"] + finishes * unit["triangle_finish"] +
-            c["anyHitCalls"] * unit["any_hit_settle"] + c.get("anyHitTexelFetches", 0) * unit["any_hit_exact"] +
-            c["skyLookups"] * unit["sky_lookup"])
+            c["anyHitCalls"] * unit["any_hit_settle"] + c.get("anyHitTexelFetches", 0) * unit["any_hit_exact"])
 
 
 def make_pc(focal, frame_index, max_bounces, ibl, skip_history):
@@ -271,7 +270,9 @@ def kernel_table(per_kernel, stage_bytes, ms_per_step, pmc, alone=None, stage_co
             if unit and c:
                 slots = 64.0 * p["valu_insts_per_launch"] * launches  # lane issue slots of the stage per step
                 if name == "wf_shade":
-                    work, units_done, what = c["closestHits"] * unit["shade_hit"], c["closestHits"], "closest hit"
+                    # (no static yardstick: the straight-line count of a hit's shading holds every texture-addressing,
+                    # light-type and lobe branch at once, three times what a lane executes)
+                    work, units_done, what = None, c["closestHits"], "closest hit"
                 elif name == "wf_accumulate":
                     work, units_done, what = None, c["pixelsWritten"], "texel-frame"
                 else:
@@ -408,7 +409,7 @@ def time_rank_share(ctx, torch, cam, focal, width, height, spp, max_bounces, ibl
     buf = torch.zeros((height, lw, 4), dtype=torch.float32, device="cuda")
     ctx.set_output_buffer(buf.data_ptr(), buf.numel() * 4)
     pc = make_pc(focal, 1, max_bounces, ibl, True)
-    for _ in range(max(2, steps // 2)):
+    for _ in range(max(3, steps // 2)):  # at least one render per workspace slot: their first use allocates
         ctx.render(pc, cam, width, height, tile=tile, frames=spp, stream=stream, flags=S.RENDER_PIPELINED)
     torch.cuda.synchronize()
     t0 = time.perf_counter()

@@ -271,13 +271,34 @@ int prosper_pt_update_lights(
     prosper_pt_ctx *ctx, const prosper_DirectionalLightParameters *directionalLight,
     const prosper_PointLightsBuffer *pointLights, const prosper_SpotLightsBuffer *spotLights);
 /* New instance transforms for the uploaded scene (the whole ModelInstanceTransforms table, `count` = the scene's
- * modelInstanceCount; World::updateScene rewrites it every frame, World.cpp:359-466).  prosper then rebuilds its TLAS
- * (World.cpp:749-802, 878-928); here the acceleration structure is one tree made of a subtree per model instance under a
- * top level over the instances, so only the instances whose transform changed are re-flattened to world space and
- * re-split, the top level is rebuilt and the nodes re-emitted - the cost of the moved instances' triangles, not the
- * scene's (prosper_pt_scene_stats.bvhBuildSeconds reports it).  Synchronises the device.  Same pixels as a fresh
- * prosper_pt_upload_scene of the moved scene (hits do not depend on the hierarchy). */
+ * modelInstanceCount; World::updateScene rewrites it every frame, World.cpp:359-466).  prosper then rebuilds its TLAS on
+ * the GPU (World.cpp:749-802, 878-928).  Here (ABI 3) the update is a REFIT enqueued on a stream: the transform table,
+ * the world-space triangles and new boxes for the unchanged tree (two small kernels per tree level) - no host-side build,
+ * no device-wide synchronisation; it runs behind the renders already in flight and the renders that follow wait for it
+ * inside the library.  Same pixels as a fresh prosper_pt_upload_scene of the moved scene (hits do not depend on the
+ * hierarchy).  A refit cannot keep the tree good when instances travel far: each one leaves the tree's surface-area
+ * measure behind, and when that has grown by 30 % (PROSPER_PT_REBUILD_COST_RATIO) over its value at the last build, the
+ * next update also rebuilds - synchronously, like prosper_pt_rebuild_hierarchy.  prosper_pt_update_transforms uses the
+ * null stream. */
 int prosper_pt_update_transforms(prosper_pt_ctx *ctx, const prosper_ModelInstanceTransforms *transforms, uint32_t count);
+int prosper_pt_update_transforms_async(
+    prosper_pt_ctx *ctx, const prosper_ModelInstanceTransforms *transforms, uint32_t count, void *stream);
+/* Re-splits the instances that moved since the last build and re-assembles the tree on the host (one subtree per model
+ * instance under a re-braided top level); synchronises the device.  prosper_pt_scene_stats.bvhBuildSeconds reports it. */
+int prosper_pt_rebuild_hierarchy(prosper_pt_ctx *ctx);
+typedef struct prosper_pt_hierarchy_state
+{
+    uint32_t refits;    /* since the scene was uploaded */
+    uint32_t rebuilds;
+    float costRatio;    /* surface-area measure of the tree after the last refit / after the last build */
+    float builtCost;
+    uint32_t nodeCount;
+    uint32_t levels;    /* kernel launches of a refit = levels + 1 */
+} prosper_pt_hierarchy_state;
+/* Waits for the last refit's measure if it is still on its way. */
+int prosper_pt_get_hierarchy_state(prosper_pt_ctx *ctx, prosper_pt_hierarchy_state *out);
+/* Test hook: the node array as the device holds it (prosper_pt_scene_stats.nodeCount x nodeBytes). */
+int prosper_pt_debug_read_nodes(prosper_pt_ctx *ctx, void *out, size_t byte_size);
 int prosper_pt_get_scene_stats(prosper_pt_ctx *ctx, prosper_pt_scene_stats *out);
 
 /* Optional: render into caller-owned device memory (localWidth*height RGBA32F texels, 16-byte

@@ -52,6 +52,10 @@ def lib():
         vp, C.POINTER(S.DirectionalLightParameters), C.POINTER(S.PointLightsBuffer), C.POINTER(S.SpotLightsBuffer)]
     L.prosper_pt_get_scene_stats.argtypes = [vp, C.POINTER(S.SceneStats)]
     L.prosper_pt_update_transforms.argtypes = [vp, vp, u32]
+    L.prosper_pt_update_transforms_async.argtypes = [vp, vp, u32, vp]
+    L.prosper_pt_rebuild_hierarchy.argtypes = [vp]
+    L.prosper_pt_get_hierarchy_state.argtypes = [vp, C.POINTER(S.HierarchyState)]
+    L.prosper_pt_debug_read_nodes.argtypes = [vp, vp, C.c_size_t]
     L.prosper_pt_set_output_buffer.argtypes = [vp, vp, C.c_size_t]
     L.prosper_pt_render.argtypes = [
         vp, C.POINTER(S.ReferencePC), C.POINTER(S.CameraUniforms), u32, u32, C.POINTER(S.TileDesc), u32, vp]
@@ -186,13 +190,30 @@ class Context:
         _check(lib().prosper_pt_update_lights(self._h, C.byref(world.directional), C.byref(world.point_lights),
                                               C.byref(world.spot_lights)))
 
-    def update_transforms(self, world):
-        """New ModelInstanceTransforms of the uploaded scene from `world` (same scene, moved instances)."""
+    def update_transforms(self, world, stream=None):
+        """New ModelInstanceTransforms of the uploaded scene from `world` (same scene, moved instances): a refit
+        enqueued on `stream`."""
         world._frozen = None
         f = world.freeze()
         t = f["transforms"]
-        _check(lib().prosper_pt_update_transforms(self._h, C.cast(t, C.c_void_p), len(world.model_instances)))
+        _check(lib().prosper_pt_update_transforms_async(self._h, C.cast(t, C.c_void_p), len(world.model_instances),
+                                                         C.c_void_p(stream)))
         self._world = world
+
+    def rebuild_hierarchy(self):
+        _check(lib().prosper_pt_rebuild_hierarchy(self._h))
+
+    def hierarchy_state(self):
+        st = S.HierarchyState()
+        _check(lib().prosper_pt_get_hierarchy_state(self._h, C.byref(st)))
+        return st
+
+    def read_nodes(self):
+        """The node array as the device holds it: (nodeCount, 20) uint32 (80-byte nodes)."""
+        n = int(self.scene_stats().nodeCount)
+        out = np.zeros((n, 20), np.uint32)
+        _check(lib().prosper_pt_debug_read_nodes(self._h, out.ctypes.data, out.nbytes))
+        return out
 
     def scene_stats(self):
         st = S.SceneStats()

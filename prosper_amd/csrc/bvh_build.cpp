@@ -2,6 +2,8 @@
 // parallel under a top level over the instances (InstancedBvh), both emitted as the same 4-wide nodes.
 #include "bvh_build.hpp"
 
+#include "bvh_encode.hpp"
+
 #include <algorithm>
 #include <atomic>
 #include <cstdio>
@@ -300,96 +302,23 @@ struct Builder
     }
 };
 
-// Conservative padding.  A valid hit (pt_device.hpp box_guard) lies in the ray's interval through the
-// triangle's bounds grown by 2^-16 of its largest |coordinate|; a node box must contain those guard
-// boxes (1.6e-5 > 2^-16 of the box's own largest |coordinate| does, and the term is monotone up the
-// tree).  On top of that the node test works on fl(o - nodeOrigin), off by up to 2^-24 of the distance
-// between the ray origin and the node: `slack` = 2e-6 * scene diagonal (32 * 2^-24) covers ray origins
-// up to ~16 scene diagonals away; the relative term covers the fp32 subtractions that form the offsets.
-// PROSPER_PT_DEBUG_PAD (>= 1.6e-5) fattens the boxes: a different hierarchy for the tests that check
-// that hits do not depend on it
+// PROSPER_PT_DEBUG_PAD (>= 1.6e-5) fattens the boxes (bvh_encode.hpp enc_padded): a different hierarchy for the tests
+// that check that hits do not depend on it
 float pad_coefficient()
 {
     const char *forced = std::getenv("PROSPER_PT_DEBUG_PAD");
     return forced ? std::max(1.6e-5f, (float)std::atof(forced)) : 1.6e-5f;
 }
 
-void padded(const Aabb &b, float coeff, float slack, float lo[3], float hi[3])
+EncBox enc_box(const Aabb &b)
 {
-    float mall = 0.0f;
-    for (int k = 0; k < 3; ++k) mall = std::max(mall, std::max(std::fabs(b.lo[k]), std::fabs(b.hi[k])));
+    EncBox e;
     for (int k = 0; k < 3; ++k)
     {
-        const float pad = coeff * mall + 1e-6f * (b.hi[k] - b.lo[k]) + slack;
-        lo[k] = b.lo[k] - pad;
-        hi[k] = b.hi[k] + pad;
+        e.lo[k] = b.lo[k];
+        e.hi[k] = b.hi[k];
     }
-}
-
-// binary32 -> binary16 rounded toward -inf / +inf: child boxes are stored as halfs and must stay
-// conservative (they may only grow).
-uint16_t half_rne(float f)
-{
-    uint32_t x;
-    std::memcpy(&x, &f, 4);
-    const uint32_t sign = (x >> 16) & 0x8000u;
-    const uint32_t ax = x & 0x7FFFFFFFu;
-    if (ax >= 0x7F800000u) return (uint16_t)(sign | 0x7C00u | ((ax > 0x7F800000u) ? 0x200u : 0u));
-    if (ax >= 0x477FF000u) return (uint16_t)(sign | 0x7C00u);
-    if (ax < 0x33000001u) return (uint16_t)sign;
-    const int32_t e = (int32_t)(ax >> 23) - 127;
-    const uint32_t m = (ax & 0x007FFFFFu) | 0x00800000u;
-    const uint32_t shift = e < -14 ? (uint32_t)(13 + (-14 - e)) : 13u;
-    const uint32_t he = e < -14 ? 0u : (uint32_t)(e + 15);
-    uint32_t hm = m >> shift;
-    const uint32_t rem = m & ((1u << shift) - 1u);
-    const uint32_t halfway = 1u << (shift - 1);
-    if (rem > halfway || (rem == halfway && (hm & 1u))) hm += 1;
-    return (uint16_t)(sign | ((he == 0) ? hm : (((he - 1u) << 10) + hm)));
-}
-float half_value(uint16_t h)
-{
-    const uint32_t sign = (uint32_t)(h & 0x8000u) << 16;
-    const uint32_t exp = (h >> 10) & 0x1Fu, man = h & 0x3FFu;
-    uint32_t bits;
-    if (exp == 0)
-    {
-        const float v = (float)man * 5.9604644775390625e-08f;
-        std::memcpy(&bits, &v, 4);
-        bits |= sign;
-    }
-    else if (exp == 31)
-        bits = sign | 0x7F800000u | (man << 13);
-    else
-        bits = sign | ((exp + 112u) << 23) | (man << 13);
-    float f;
-    std::memcpy(&f, &bits, 4);
-    return f;
-}
-// next representable half towards +inf / -inf (as ordered values, handling the sign-magnitude encoding)
-uint16_t half_next_up(uint16_t h)
-{
-    if ((h & 0x7FFFu) == 0) return 0x0001u;          // +-0 -> smallest positive
-    if (h & 0x8000u) return (uint16_t)(h - 1u);       // negative: magnitude shrinks
-    return (h == 0x7C00u) ? h : (uint16_t)(h + 1u);   // positive: magnitude grows (stop at +inf)
-}
-uint16_t half_next_down(uint16_t h)
-{
-    if ((h & 0x7FFFu) == 0) return 0x8001u;
-    if (h & 0x8000u) return (h == 0xFC00u) ? h : (uint16_t)(h + 1u);
-    return (uint16_t)(h - 1u);
-}
-uint16_t half_floor(float f)
-{
-    uint16_t h = half_rne(f);
-    if (half_value(h) > f) h = half_next_down(h);
-    return h;
-}
-uint16_t half_ceil(float f)
-{
-    uint16_t h = half_rne(f);
-    if (half_value(h) < f) h = half_next_up(h);
-    return h;
+    return e;
 }
 
 // Renumbers the nodes (speed only; the root stays node 0, leaf references do not change).  The emitter numbers them
@@ -547,35 +476,14 @@ struct Emitter
         const int32_t *kids = p.kids;
         const uint32_t k = p.k;
         BvhNode node;
-        node.reserved = 0;
-        // unused slots: lo = hi = +inf (half 0x7C00) can never be entered (see build_bvh)
-        for (int a = 0; a < 3; ++a)
-            for (int c = 0; c < 4; ++c)
-            {
-                node.lo[a][c] = 0x7C00u;
-                node.hi[a][c] = 0x7C00u;
-            }
-        float lo[4][3], hi[4][3];
-        for (int a = 0; a < 3; ++a) node.origin[a] = std::numeric_limits<float>::infinity();
-        for (uint32_t c = 0; c < k; ++c)
-        {
-            padded(tmp[kids[c]].box, padCoeff, slack, lo[c], hi[c]);
-            for (int a = 0; a < 3; ++a) node.origin[a] = std::min(node.origin[a], lo[c][a]);
-        }
+        EncBox boxes[4];
+        for (uint32_t c = 0; c < k; ++c) boxes[c] = enc_box(tmp[kids[c]].box);
+        enc_node_boxes(boxes, k, padCoeff, slack, node); // unused slots: lo = hi = +inf can never be entered (see build_bvh)
         uint32_t nextNode = self + 1u, nextTri = triBase;
         for (uint32_t c = 0; c < 4; ++c)
         {
             node.child[c] = ~0;
             if (c >= k) continue;
-            for (int a = 0; a < 3; ++a)
-            {
-                // offsets from the node origin; the fp32 subtraction is pushed one ulp outward before
-                // the outward half rounding, so origin + offset never lies inside the padded box
-                const float offLo = std::nextafter(lo[c][a] - node.origin[a], -std::numeric_limits<float>::infinity());
-                const float offHi = std::nextafter(hi[c][a] - node.origin[a], std::numeric_limits<float>::infinity());
-                node.lo[a][c] = half_floor(std::max(offLo, 0.0f));
-                node.hi[a][c] = half_ceil(offHi);
-            }
             const TmpNode &kid = tmp[kids[c]];
             if (kid.left < 0)
             {
@@ -604,9 +512,7 @@ struct Emitter
 void relayout_nodes(std::vector<BvhNode> &nodes);
 void emit_tree(const std::vector<TmpNode> &tmp, int32_t root, const std::vector<Prim> &prims, uint64_t count, BvhBuildResult &out)
 {
-    const Aabb &scene = tmp[(size_t)root].box;
-    const float dx = scene.hi[0] - scene.lo[0], dy = scene.hi[1] - scene.lo[1], dz = scene.hi[2] - scene.lo[2];
-    const float slack = 2e-6f * std::sqrt(dx * dx + dy * dy + dz * dz) + 1e-30f;
+    const float slack = enc_slack(enc_box(tmp[(size_t)root].box));
     const char *order = std::getenv("PROSPER_PT_DEBUG_CHILD_ORDER");
     Emitter emitter{tmp, prims, out, slack, pad_coefficient(), !order || std::atoi(order) != 0, {}};
     emitter.plans.resize(tmp.size());
@@ -626,6 +532,8 @@ void emit_tree(const std::vector<TmpNode> &tmp, int32_t root, const std::vector<
 }
 
 } // namespace
+
+float bvh_pad_coefficient() { return pad_coefficient(); }
 
 BvhBuildResult build_bvh(const WorldTriangle *triangles, uint64_t count)
 {
@@ -650,7 +558,7 @@ BvhBuildResult build_bvh(const WorldTriangle *triangles, uint64_t count)
     if (count == 0)
     {
         BvhNode root;
-        root.reserved = 0;
+        root.reserved = 0; // no child in use
         for (int a = 0; a < 3; ++a) root.origin[a] = 0.0f;
         for (int a = 0; a < 3; ++a)
             for (int c = 0; c < 4; ++c)

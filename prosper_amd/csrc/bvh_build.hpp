@@ -21,6 +21,9 @@ struct BvhBuildResult
     uint32_t maxDepth = 0;             // inner nodes on the longest root-to-leaf path
 };
 
+// box padding coefficient of the emitter (1.6e-5, or PROSPER_PT_DEBUG_PAD): the device refit pads with the same value
+float bvh_pad_coefficient();
+
 // `triangles` are the GPU-flattened world-space triangles in (drawInstance, primitive) order.
 // Throws std::runtime_error if the depth bound of the LDS traversal stack cannot be met.
 BvhBuildResult build_bvh(const WorldTriangle *triangles, uint64_t count);

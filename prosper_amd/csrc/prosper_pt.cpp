@@ -157,7 +157,24 @@ int validate_scene(const prosper_pt_scene_view *v)
     return PROSPER_PT_OK;
 }
 
-// Nodes + leaf-order triangles of a freshly built hierarchy to the device (the node array grows when it has to).
+// The refit's GPU work on `stream`: exact bounds level by level, every node re-encoded, the tree's surface-area measure
+// into acc->dCost (read back through acc->hCost / costEvent).
+int enqueue_refit(prosper_pt_ctx *ctx, hipStream_t stream)
+{
+    AccelState *acc = ctx->accel;
+    PPT_HIP(hipMemsetAsync(acc->dCost, 0, sizeof(float), stream));
+    launch_refit(
+        acc->dNodes, acc->dTris, acc->dNodeBounds, acc->dRefitOrder, acc->levelOffsets.data(),
+        (uint32_t)acc->levelOffsets.size() - 1u, acc->nodeCount, bvh_pad_coefficient(), acc->dCost, stream);
+    PPT_HIP(hipGetLastError());
+    PPT_HIP(hipMemcpyAsync(acc->hCost, acc->dCost, sizeof(float), hipMemcpyDeviceToHost, stream));
+    PPT_HIP(hipEventRecord(acc->costEvent, stream));
+    acc->costPending = true;
+    return PROSPER_PT_OK;
+}
+
+// Nodes + leaf-order triangles of a freshly built hierarchy to the device (the node array grows when it has to), and
+// what a later refit needs: the nodes ordered by height, every triangle's place in the leaf order, the bounds array.
 int upload_hierarchy(prosper_pt_ctx *ctx, const BvhBuildResult &bvh)
 {
     AccelState *acc = ctx->accel;
@@ -165,7 +182,7 @@ int upload_hierarchy(prosper_pt_ctx *ctx, const BvhBuildResult &bvh)
     if (nodeBytes > acc->nodeCapacityBytes)
     {
         void *d = nullptr;
-        const size_t capacity = nodeBytes + nodeBytes / 4 + 4096; // headroom: a moved instance changes the node count a little
+        const size_t capacity = nodeBytes + nodeBytes / 4 + 4096; // headroom: a rebuild changes the node count a little
         const int rc = device_alloc(ctx, capacity, &d);          // (the previous array stays in the scene's list until the next upload)
         if (rc != PROSPER_PT_OK) return rc;
         acc->dNodes = static_cast<BvhNode *>(d);
@@ -180,6 +197,74 @@ int upload_hierarchy(prosper_pt_ctx *ctx, const BvhBuildResult &bvh)
         PPT_HIP(hipGetLastError());
         PPT_HIP(hipDeviceSynchronize());
     }
+
+    // ---- refit tables ----
+    const size_t n = bvh.nodes.size();
+    acc->nodeCount = (uint32_t)n;
+    std::vector<uint32_t> height(n, 0u);
+    uint32_t levels = 1;
+    for (size_t i = n; i-- > 0;) // children are numbered after their parent (emit order and relayout_nodes both)
+    {
+        uint32_t h = 0;
+        for (uint32_t c = 0; c < bvh.nodes[i].reserved && c < 4u; ++c)
+        {
+            const int32_t ch = bvh.nodes[i].child[c];
+            if (ch < 0) continue;
+            if ((size_t)ch <= i) return fail(PROSPER_PT_ERR_UNSUPPORTED, "hierarchy: a child node precedes its parent");
+            h = std::max(h, height[(size_t)ch] + 1u);
+        }
+        height[i] = h;
+        levels = std::max(levels, h + 1u);
+    }
+    acc->levelOffsets.assign(levels + 1u, 0u);
+    for (size_t i = 0; i < n; ++i) acc->levelOffsets[height[i] + 1u]++;
+    for (uint32_t l = 0; l < levels; ++l) acc->levelOffsets[l + 1u] += acc->levelOffsets[l];
+    std::vector<uint32_t> order(n ? n : 1), cursor(acc->levelOffsets.begin(), acc->levelOffsets.end() - 1);
+    for (size_t i = 0; i < n; ++i) order[cursor[height[i]]++] = (uint32_t)i;
+    if (n > acc->refitCapacityNodes)
+    {
+        const size_t capacity = n + n / 4 + 64;
+        void *d = nullptr;
+        int rc;
+        if ((rc = device_alloc(ctx, capacity * 2 * sizeof(float4), &d))) return rc;
+        acc->dNodeBounds = static_cast<float4 *>(d);
+        if ((rc = device_alloc(ctx, capacity * sizeof(uint32_t), &d))) return rc;
+        acc->dRefitOrder = static_cast<uint32_t *>(d);
+        acc->refitCapacityNodes = capacity;
+    }
+    PPT_HIP(hipMemcpy(acc->dRefitOrder, order.data(), n * sizeof(uint32_t), hipMemcpyHostToDevice));
+    if (!acc->dLeafPosition)
+    {
+        void *d = nullptr;
+        int rc;
+        if ((rc = device_alloc(ctx, (size_t)(acc->total ? acc->total : 1) * sizeof(uint32_t), &d))) return rc;
+        acc->dLeafPosition = static_cast<uint32_t *>(d);
+        if ((rc = device_alloc(ctx, sizeof(float), &d))) return rc;
+        acc->dCost = static_cast<float *>(d);
+        PPT_HIP(hipHostMalloc((void **)&acc->hCost, sizeof(float), hipHostMallocDefault));
+        PPT_HIP(hipEventCreateWithFlags(&acc->costEvent, hipEventDisableTiming));
+        PPT_HIP(hipEventCreateWithFlags(&acc->sceneEvent, hipEventDisableTiming));
+    }
+    if (acc->total)
+    {
+        std::vector<uint32_t> position((size_t)acc->total);
+        for (size_t leaf = 0; leaf < bvh.permutation.size(); ++leaf) position[bvh.permutation[leaf]] = (uint32_t)leaf;
+        PPT_HIP(hipMemcpy(acc->dLeafPosition, position.data(), position.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    }
+    // one refit right away: the device encoder writes the bytes the emitter wrote (tested), and leaves the tree's
+    // surface-area measure to compare later refits with
+    // (PROSPER_PT_DEBUG_NO_UPLOAD_REFIT keeps the emitter's own bytes, for the test that compares the two; the bounds array
+    // and the measure are still computed)
+    const bool keepEmitted = std::getenv("PROSPER_PT_DEBUG_NO_UPLOAD_REFIT") != nullptr;
+    int rc = enqueue_refit(ctx, nullptr);
+    if (rc != PROSPER_PT_OK) return rc;
+    PPT_HIP(hipDeviceSynchronize());
+    if (keepEmitted) PPT_HIP(hipMemcpy(acc->dNodes, bvh.nodes.data(), nodeBytes, hipMemcpyHostToDevice));
+    acc->costPending = false;
+    acc->builtCost = *acc->hCost;
+    acc->lastCostRatio = 1.0f;
+    acc->movedSinceBuild.assign(acc->ranges.size(), 0);
+    acc->flatStale = false;
     return PROSPER_PT_OK;
 }
 
@@ -761,71 +846,188 @@ int prosper_pt_update_lights(
     return PROSPER_PT_OK;
 }
 
-static int update_transforms_impl(prosper_pt_ctx *ctx, const prosper_ModelInstanceTransforms *transforms, uint32_t count)
+// The synchronous path: re-split the instances that moved since the last build, re-assemble, upload (what
+// prosper_pt_update_transforms did before the refit existed; prosper's own TLAS build is of this kind, on the GPU).
+static int rebuild_hierarchy_impl(prosper_pt_ctx *ctx)
+{
+    AccelState *acc = ctx->accel;
+    const auto t0 = std::chrono::steady_clock::now();
+    PPT_HIP(hipSetDevice(ctx->device));
+    PPT_HIP(hipDeviceSynchronize()); // renders in flight read the old hierarchy
+    acc->stale = true;               // until the new hierarchy is up
+    bool any = false;
+    for (size_t r = 0; r < acc->ranges.size(); ++r)
+    {
+        if (!(acc->movedSinceBuild[r] || !acc->instanced) || !acc->ranges[r].count) continue;
+        any = any || acc->movedSinceBuild[r];
+        PPT_HIP(hipMemcpy(
+            acc->flat.data() + acc->ranges[r].first, acc->dFlat + acc->ranges[r].first,
+            sizeof(WorldTriangle) * (size_t)acc->ranges[r].count, hipMemcpyDeviceToHost));
+    }
+    BvhBuildResult bvh;
+    const auto tBuild = std::chrono::steady_clock::now();
+    try
+    {
+        if (std::getenv("PROSPER_PT_DEBUG_FAIL_NEXT_UPDATE")) throw std::runtime_error("PROSPER_PT_DEBUG_FAIL_NEXT_UPDATE is set");
+        bvh = acc->instanced ? acc->bvh.rebuild(acc->flat.data(), acc->movedSinceBuild) : build_bvh(acc->flat.data(), acc->total);
+    }
+    catch (const std::exception &ex)
+    {
+        return fail(PROSPER_PT_ERR_UNSUPPORTED, std::string("BVH rebuild failed: ") + ex.what());
+    }
+    const double buildSeconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - tBuild).count();
+    const int rc = upload_hierarchy(ctx, bvh);
+    if (rc != PROSPER_PT_OK) return rc;
+    acc->stale = false;
+    acc->rebuilds++;
+    ctx->stats.nodeCount = bvh.nodes.size();
+    ctx->stats.maxDepth = bvh.maxDepth;
+    ctx->stats.deviceBytes = ctx->sceneBytes;
+    ctx->stats.bvhBuildSeconds = buildSeconds;
+    ctx->stats.buildSeconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    return PROSPER_PT_OK;
+}
+
+static float rebuild_cost_ratio()
+{
+    if (const char *v = std::getenv("PROSPER_PT_REBUILD_COST_RATIO")) return std::max(1.0f, (float)std::atof(v));
+    return 1.3f;
+}
+
+// World::updateScene + the per-frame TLAS rebuild (World.cpp:359-466,749-802,878-928) as a REFIT: the new transforms, the
+// world triangles and new boxes for the unchanged tree, all enqueued on `stream` - no host build, no device-wide
+// synchronisation, nothing of the frames in flight is disturbed.  Hits do not depend on the hierarchy (hit contract), so
+// the image is the one a fresh upload gives.  What a refit cannot do is keep the tree GOOD when instances travel far:
+// every refit leaves the tree's surface-area measure behind, and once that has grown by 30 % over its value at the last
+// build the next update rebuilds (synchronously: prosper_pt_rebuild_hierarchy).
+static int update_transforms_impl(prosper_pt_ctx *ctx, const prosper_ModelInstanceTransforms *transforms, uint32_t count, hipStream_t stream)
 {
     AccelState *acc = ctx->accel;
     const auto t0 = std::chrono::steady_clock::now();
     // which instances moved (World::updateScene rewrites every transform each frame, World.cpp:359-466; most are unchanged)
-    std::vector<uint8_t> changed(acc->ranges.size(), 0);
     bool any = acc->stale;
     for (size_t r = 0; r < acc->ranges.size(); ++r)
     {
         const uint32_t mi = acc->rangeModelInstance[r];
         if (acc->stale || std::memcmp(&transforms[mi], &acc->transforms[mi], sizeof(prosper_ModelInstanceTransforms)) != 0)
         {
-            changed[r] = 1;
+            acc->movedSinceBuild[r] = 1;
             any = true;
         }
     }
+    if (!any && std::memcmp(transforms, acc->transforms.data(), sizeof(prosper_ModelInstanceTransforms) * count) == 0) return PROSPER_PT_OK;
     PPT_HIP(hipSetDevice(ctx->device));
-    PPT_HIP(hipDeviceSynchronize()); // renders in flight read the old transforms and the old hierarchy
-    // from here on the device state is in between two scenes until the last step has succeeded
+    // the measure the previous refit left behind, if it has arrived
+    if (acc->costPending && hipEventQuery(acc->costEvent) == hipSuccess)
+    {
+        acc->costPending = false;
+        if (acc->builtCost > 0.0f) acc->lastCostRatio = *acc->hCost / acc->builtCost;
+    }
+    // everything enqueued so far reads the old scene: the update goes behind the renders in flight ...
+    for (RenderSlot &slot : ctx->slots)
+        if (slot.freeRecorded) PPT_HIP(hipStreamWaitEvent(stream, slot.free, 0));
+    const uint32_t k = acc->stagingNext;
+    acc->stagingNext ^= 1u;
+    if (!acc->staging[k])
+    {
+        PPT_HIP(hipHostMalloc((void **)&acc->staging[k], sizeof(prosper_ModelInstanceTransforms) * (count ? count : 1), hipHostMallocDefault));
+        PPT_HIP(hipEventCreateWithFlags(&acc->stagingDone[k], hipEventDisableTiming));
+    }
+    if (acc->stagingUsed[k]) PPT_HIP(hipEventSynchronize(acc->stagingDone[k])); // the copy of two updates ago
+    std::memcpy(acc->staging[k], transforms, sizeof(prosper_ModelInstanceTransforms) * count);
+    // from here on the device state is in between two scenes until the last step has been enqueued
     acc->stale = true;
-    PPT_HIP(hipMemcpy(ctx->dTransforms, transforms, sizeof(prosper_ModelInstanceTransforms) * count, hipMemcpyHostToDevice));
+    PPT_HIP(hipMemcpyAsync(ctx->dTransforms, acc->staging[k], sizeof(prosper_ModelInstanceTransforms) * count, hipMemcpyHostToDevice, stream));
+    PPT_HIP(hipEventRecord(acc->stagingDone[k], stream));
+    acc->stagingUsed[k] = true;
     if (any)
     {
-        // world-space triangles again (the shading and any-hit records hold object-space attributes and stay as they are)
+        // world-space triangles again, in both orders (the shading and any-hit records hold object-space attributes and
+        // stay as they are), then the boxes
         launch_flatten_triangles(
-            ctx->scene, acc->dOffsets, acc->drawInstanceCount, acc->dFlags, acc->dFlat, nullptr, nullptr, (uint32_t)acc->total, nullptr);
+            ctx->scene, acc->dOffsets, acc->drawInstanceCount, acc->dFlags, acc->dFlat, nullptr, nullptr, (uint32_t)acc->total,
+            stream, acc->dLeafPosition, acc->dTris);
         PPT_HIP(hipGetLastError());
-        for (size_t r = 0; r < acc->ranges.size(); ++r)
-            if ((changed[r] || !acc->instanced) && acc->ranges[r].count)
-                PPT_HIP(hipMemcpy(
-                    acc->flat.data() + acc->ranges[r].first, acc->dFlat + acc->ranges[r].first,
-                    sizeof(WorldTriangle) * (size_t)acc->ranges[r].count, hipMemcpyDeviceToHost));
-        BvhBuildResult bvh;
-        const auto tBuild = std::chrono::steady_clock::now();
-        try
-        {
-            if (std::getenv("PROSPER_PT_DEBUG_FAIL_NEXT_UPDATE")) throw std::runtime_error("PROSPER_PT_DEBUG_FAIL_NEXT_UPDATE is set");
-            bvh = acc->instanced ? acc->bvh.rebuild(acc->flat.data(), changed) : build_bvh(acc->flat.data(), acc->total);
-        }
-        catch (const std::exception &ex)
-        {
-            return fail(PROSPER_PT_ERR_UNSUPPORTED, std::string("BVH rebuild failed: ") + ex.what());
-        }
-        const double buildSeconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - tBuild).count();
-        const int rc = upload_hierarchy(ctx, bvh);
+        acc->flatStale = true;
+        const int rc = enqueue_refit(ctx, stream);
         if (rc != PROSPER_PT_OK) return rc;
-        ctx->stats.nodeCount = bvh.nodes.size();
-        ctx->stats.maxDepth = bvh.maxDepth;
-        ctx->stats.deviceBytes = ctx->sceneBytes;
-        ctx->stats.bvhBuildSeconds = buildSeconds;
-        ctx->stats.buildSeconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        acc->refits++;
     }
-    // committed: what the context remembers now matches what the device holds
+    // ... and the renders to come behind the update
+    PPT_HIP(hipEventRecord(acc->sceneEvent, stream));
+    acc->sceneEventRecorded = true;
     acc->transforms.assign(transforms, transforms + count);
     acc->stale = false;
+    ctx->stats.bvhBuildSeconds = 0.0;
+    ctx->stats.buildSeconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    if (any && (acc->lastCostRatio > rebuild_cost_ratio() || std::getenv("PROSPER_PT_DEBUG_ALWAYS_REBUILD")))
+    {
+        const int rc = rebuild_hierarchy_impl(ctx);
+        if (rc != PROSPER_PT_OK) return rc;
+    }
     return PROSPER_PT_OK;
 }
 
-int prosper_pt_update_transforms(prosper_pt_ctx *ctx, const prosper_ModelInstanceTransforms *transforms, uint32_t count)
+static int check_update_arguments(prosper_pt_ctx *ctx, const prosper_ModelInstanceTransforms *transforms, uint32_t count)
 {
     if (!ctx || !transforms) return fail(PROSPER_PT_ERR_INVALID_ARGUMENT, "prosper_pt_update_transforms: null argument");
     if (!ctx->haveScene || !ctx->accel) return fail(PROSPER_PT_ERR_NO_SCENE, "no scene uploaded");
     if (count != ctx->accel->transforms.size())
         return fail(PROSPER_PT_ERR_INVALID_ARGUMENT, "prosper_pt_update_transforms: count differs from the scene's modelInstanceCount");
-    return update_transforms_impl(ctx, transforms, count);
+    return PROSPER_PT_OK;
+}
+
+int prosper_pt_update_transforms(prosper_pt_ctx *ctx, const prosper_ModelInstanceTransforms *transforms, uint32_t count)
+{
+    const int rc = check_update_arguments(ctx, transforms, count);
+    return rc != PROSPER_PT_OK ? rc : update_transforms_impl(ctx, transforms, count, nullptr);
+}
+
+int prosper_pt_update_transforms_async(
+    prosper_pt_ctx *ctx, const prosper_ModelInstanceTransforms *transforms, uint32_t count, void *stream)
+{
+    const int rc = check_update_arguments(ctx, transforms, count);
+    return rc != PROSPER_PT_OK ? rc : update_transforms_impl(ctx, transforms, count, static_cast<hipStream_t>(stream));
+}
+
+int prosper_pt_rebuild_hierarchy(prosper_pt_ctx *ctx)
+{
+    if (!ctx) return fail(PROSPER_PT_ERR_INVALID_ARGUMENT, "prosper_pt_rebuild_hierarchy: null argument");
+    if (!ctx->haveScene || !ctx->accel) return fail(PROSPER_PT_ERR_NO_SCENE, "no scene uploaded");
+    return rebuild_hierarchy_impl(ctx);
+}
+
+int prosper_pt_get_hierarchy_state(prosper_pt_ctx *ctx, prosper_pt_hierarchy_state *out)
+{
+    if (!ctx || !out) return fail(PROSPER_PT_ERR_INVALID_ARGUMENT, "prosper_pt_get_hierarchy_state: null argument");
+    if (!ctx->haveScene || !ctx->accel) return fail(PROSPER_PT_ERR_NO_SCENE, "no scene uploaded");
+    AccelState *acc = ctx->accel;
+    PPT_HIP(hipSetDevice(ctx->device));
+    if (acc->costPending)
+    {
+        PPT_HIP(hipEventSynchronize(acc->costEvent));
+        acc->costPending = false;
+        if (acc->builtCost > 0.0f) acc->lastCostRatio = *acc->hCost / acc->builtCost;
+    }
+    out->refits = acc->refits;
+    out->rebuilds = acc->rebuilds;
+    out->costRatio = acc->lastCostRatio;
+    out->builtCost = acc->builtCost;
+    out->nodeCount = acc->nodeCount;
+    out->levels = (uint32_t)acc->levelOffsets.size() - 1u;
+    return PROSPER_PT_OK;
+}
+
+int prosper_pt_debug_read_nodes(prosper_pt_ctx *ctx, void *out, size_t byte_size)
+{
+    if (!ctx || !out) return fail(PROSPER_PT_ERR_INVALID_ARGUMENT, "prosper_pt_debug_read_nodes: null argument");
+    if (!ctx->haveScene || !ctx->accel) return fail(PROSPER_PT_ERR_NO_SCENE, "no scene uploaded");
+    const size_t bytes = (size_t)ctx->accel->nodeCount * sizeof(BvhNode);
+    if (byte_size < bytes) return fail(PROSPER_PT_ERR_INVALID_ARGUMENT, "prosper_pt_debug_read_nodes: destination too small");
+    PPT_HIP(hipSetDevice(ctx->device));
+    PPT_HIP(hipDeviceSynchronize());
+    PPT_HIP(hipMemcpy(out, ctx->accel->dNodes, bytes, hipMemcpyDeviceToHost));
+    return PROSPER_PT_OK;
 }
 
 int prosper_pt_get_scene_stats(prosper_pt_ctx *ctx, prosper_pt_scene_stats *out)
@@ -903,6 +1105,8 @@ int prosper_pt_render_frames(
     // accumulate kernel, which writes the tile, is enqueued on `s` and must come after it; detached path stages
     // (PROSPER_PT_RENDER_PIPELINED) do not wait for `s` and overlap the gather
     wait_for_gather_before_writing_tile(ctx, s);
+    // a refit of moved instances may still be on its way on another stream (prosper_pt_update_transforms_async)
+    if (ctx->accel && ctx->accel->sceneEventRecorded) PPT_HIP(hipStreamWaitEvent(s, ctx->accel->sceneEvent, 0));
 
     RenderParams p = {};
     p.pc = *pc;
@@ -1015,6 +1219,7 @@ int prosper_pt_render_frames(
             // the slot's previous user (a render of two calls ago, or the previous chunk of this one) must be done
             // with the workspace: detached chains wait for that on their own stream, the others on the caller's
             chains.after = slot.freeRecorded ? slot.free : nullptr;
+            chains.scene = (ctx->accel && ctx->accel->sceneEventRecorded) ? ctx->accel->sceneEvent : nullptr;
             if (!pipelined) wait_for_slot(slot, s);
             if (tp) tp->mark(kStageChains, s);
             launch_render_wavefront(

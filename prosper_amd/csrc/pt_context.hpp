@@ -34,7 +34,7 @@ struct AccelState
     BvhNode *dNodes = nullptr;
     size_t nodeCapacityBytes = 0;
     std::vector<uint32_t> triOffsets;
-    std::vector<WorldTriangle> flat;
+    std::vector<WorldTriangle> flat; // host copy of dFlat as of the last BUILD (flatStale: instances moved since)
     std::vector<InstancedBvh::Range> ranges;      // one per run of draw instances of a model instance
     std::vector<uint32_t> rangeModelInstance;
     std::vector<prosper_ModelInstanceTransforms> transforms;
@@ -45,6 +45,43 @@ struct AccelState
     bool stale = false;
     uint64_t total = 0;
     uint32_t drawInstanceCount = 0;
+
+    // ---- refit of the tree after moved instances (pt_kernels.hip refit_bounds / encode_nodes) ----
+    float4 *dNodeBounds = nullptr;     // [2 * nodes]: exact bounds below every node
+    uint32_t *dRefitOrder = nullptr;   // node indices by height (leaves' parents first)
+    uint32_t *dLeafPosition = nullptr; // [total]: (drawInstance, primitive)-order triangle -> its place in dTris
+    size_t refitCapacityNodes = 0;
+    std::vector<uint32_t> levelOffsets; // [levels + 1] into dRefitOrder
+    uint32_t nodeCount = 0;
+    float *dCost = nullptr;             // surface-area measure of the refitted tree (encode_nodes_kernel)
+    float *hCost = nullptr;             // pinned; valid once costEvent has passed
+    hipEvent_t costEvent = nullptr;
+    bool costPending = false;
+    float builtCost = 0.0f;             // the same measure right after the last build
+    float lastCostRatio = 1.0f;
+    std::vector<uint8_t> movedSinceBuild; // per range: its subtree is out of date in `bvh` and `flat`
+    bool flatStale = false;
+    // the update's transforms go through pinned staging (a pageable source would make the async copy synchronous)
+    prosper_ModelInstanceTransforms *staging[2] = {nullptr, nullptr};
+    hipEvent_t stagingDone[2] = {nullptr, nullptr};
+    bool stagingUsed[2] = {false, false};
+    uint32_t stagingNext = 0;
+    // recorded on the updating stream behind the refit: every later render's path stages wait for it
+    hipEvent_t sceneEvent = nullptr;
+    bool sceneEventRecorded = false;
+    uint32_t refits = 0, rebuilds = 0;
+
+    ~AccelState()
+    {
+        for (int i = 0; i < 2; ++i)
+        {
+            if (staging[i]) (void)hipHostFree(staging[i]);
+            if (stagingDone[i]) (void)hipEventDestroy(stagingDone[i]);
+        }
+        if (hCost) (void)hipHostFree(hCost);
+        if (costEvent) (void)hipEventDestroy(costEvent);
+        if (sceneEvent) (void)hipEventDestroy(sceneEvent);
+    }
 };
 
 // multi-GPU state of a context (pt_tiling.cpp): the communicator, its stream and the root's staging buffer

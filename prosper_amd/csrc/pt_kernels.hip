@@ -7,6 +7,7 @@
 //   eval_fn             device self-test entry (prosper_pt_eval_device_fn)
 #include "pt_kernels.hpp"
 
+#include "bvh_encode.hpp"
 #include "pt_bc7.hpp"
 #include "pt_device.hpp"
 #include "pt_render_common.hpp"
@@ -21,7 +22,8 @@ namespace ppt
 __global__ void flatten_triangles_kernel(
     DeviceScene s, const uint32_t *__restrict__ triOffsets, uint32_t drawInstanceCount,
     const uint32_t *__restrict__ drawInstanceFlags, WorldTriangle *__restrict__ out,
-    ShadeTriangle *__restrict__ shadeOut, AlphaTriangle *__restrict__ alphaOut, uint32_t total)
+    ShadeTriangle *__restrict__ shadeOut, AlphaTriangle *__restrict__ alphaOut, uint32_t total,
+    const uint32_t *__restrict__ leafPosition, WorldTriangle *__restrict__ leafOrder)
 {
     const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= total) return;
@@ -57,6 +59,7 @@ __global__ void flatten_triangles_kernel(
     const uint32_t alphaIndex = nonOpaque ? s.alphaOffsets[di] + prim : 0u;
     t.flags = diFlags | (alphaIndex << kTriAlphaShift); // a non-opaque triangle names its alpha record
     out[g] = t;
+    if (leafOrder != nullptr) leafOrder[leafPosition[g]] = t; // moved instances: straight into the traversal's (leaf) order
     if (shadeOut == nullptr) return; // re-flatten after moved instances: the shading records are object-space
 
     // the shading record of this triangle (pt_scene.hpp ShadeTriangle): geometry.glsl:220-244 per corner
@@ -116,12 +119,13 @@ __global__ void permute_triangles_kernel(
 
 void launch_flatten_triangles(
     const DeviceScene &s, const uint32_t *triOffsets, uint32_t drawInstanceCount, const uint32_t *drawInstanceFlags,
-    WorldTriangle *out, ShadeTriangle *shadeOut, AlphaTriangle *alphaOut, uint32_t total, hipStream_t stream)
+    WorldTriangle *out, ShadeTriangle *shadeOut, AlphaTriangle *alphaOut, uint32_t total, hipStream_t stream,
+    const uint32_t *leafPosition, WorldTriangle *leafOrder)
 {
     if (total == 0) return;
     hipLaunchKernelGGL(
         flatten_triangles_kernel, dim3((total + 255) / 256), dim3(256), 0, stream, s, triOffsets, drawInstanceCount,
-        drawInstanceFlags, out, shadeOut, alphaOut, total);
+        drawInstanceFlags, out, shadeOut, alphaOut, total, leafPosition, leafOrder);
 }
 
 void launch_permute_triangles(
@@ -130,6 +134,119 @@ void launch_permute_triangles(
     if (total == 0) return;
     hipLaunchKernelGGL(
         permute_triangles_kernel, dim3((total + 255) / 256), dim3(256), 0, stream, in, permutation, out, total);
+}
+
+// ---- refit: new boxes for an unchanged tree after instances moved (prosper rebuilds its TLAS every frame,
+//      World.cpp:749-802,878-928; here the per-frame cost is two small kernels per tree level) ----
+//
+// bounds[i] = the exact bounds of the triangles below node i (two float4: lo, hi).  refit_bounds runs level by level from
+// the leaves' parents up (`order` lists the nodes by height); encode_nodes then rewrites every node's origin and child
+// boxes with the emitter's own code (bvh_encode.hpp), the slack taken from the root's new bounds.
+
+__device__ __forceinline__ EncBox leaf_bounds(const WorldTriangle *__restrict__ tris, int32_t ref)
+{
+    const uint32_t leaf = (uint32_t)~ref;
+    const uint32_t first = leaf >> 3, count = (leaf & 7u) + 1u;
+    EncBox b;
+    for (int a = 0; a < 3; ++a)
+    {
+        b.lo[a] = kInf;
+        b.hi[a] = -kInf;
+    }
+    for (uint32_t i = 0; i < count; ++i)
+    {
+        const WorldTriangle t = tris[first + i];
+        for (int a = 0; a < 3; ++a)
+        {
+            b.lo[a] = enc_min(b.lo[a], enc_min(t.v0[a], enc_min(t.v1[a], t.v2[a])));
+            b.hi[a] = enc_max(b.hi[a], enc_max(t.v0[a], enc_max(t.v1[a], t.v2[a])));
+        }
+    }
+    return b;
+}
+__device__ __forceinline__ EncBox child_bounds(
+    const BvhNode &n, uint32_t c, const WorldTriangle *__restrict__ tris, const float4 *__restrict__ bounds)
+{
+    if (n.child[c] < 0) return leaf_bounds(tris, n.child[c]);
+    const float4 lo = bounds[2 * (size_t)n.child[c]], hi = bounds[2 * (size_t)n.child[c] + 1];
+    return EncBox{{lo.x, lo.y, lo.z}, {hi.x, hi.y, hi.z}};
+}
+
+__global__ __launch_bounds__(256) void refit_bounds_kernel(
+    const BvhNode *__restrict__ nodes, const WorldTriangle *__restrict__ tris, float4 *__restrict__ bounds,
+    const uint32_t *__restrict__ order, uint32_t first, uint32_t count)
+{
+    const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= count) return;
+    const uint32_t i = order[first + g];
+    const BvhNode n = nodes[i];
+    EncBox u;
+    for (int a = 0; a < 3; ++a)
+    {
+        u.lo[a] = kInf;
+        u.hi[a] = -kInf;
+    }
+    for (uint32_t c = 0; c < n.reserved && c < 4u; ++c)
+    {
+        const EncBox b = child_bounds(n, c, tris, bounds);
+        for (int a = 0; a < 3; ++a)
+        {
+            u.lo[a] = enc_min(u.lo[a], b.lo[a]);
+            u.hi[a] = enc_max(u.hi[a], b.hi[a]);
+        }
+    }
+    bounds[2 * (size_t)i] = make_float4(u.lo[0], u.lo[1], u.lo[2], 0.0f);
+    bounds[2 * (size_t)i + 1] = make_float4(u.hi[0], u.hi[1], u.hi[2], 0.0f);
+}
+
+// `cost` (optional): sum over the nodes of the half-areas of their inner children's boxes relative to the root's - the
+// surface-area measure of how many node visits a random ray makes; the host compares it with the value right after the
+// last build to notice a tree that moved instances have degraded (a heuristic: the float sum is not deterministic).
+__global__ __launch_bounds__(256) void encode_nodes_kernel(
+    BvhNode *__restrict__ nodes, const WorldTriangle *__restrict__ tris, const float4 *__restrict__ bounds,
+    uint32_t nodeCount, float padCoeff, float *__restrict__ cost)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nodeCount) return;
+    BvhNode n = nodes[i];
+    const uint32_t k = n.reserved < 4u ? n.reserved : 4u;
+    const float4 rlo = bounds[0], rhi = bounds[1];
+    const EncBox scene{{rlo.x, rlo.y, rlo.z}, {rhi.x, rhi.y, rhi.z}};
+    EncBox boxes[4];
+    float area = 0.0f;
+    for (uint32_t c = 0; c < k; ++c)
+    {
+        boxes[c] = child_bounds(n, c, tris, bounds);
+        if (n.child[c] >= 0)
+        {
+            const float dx = boxes[c].hi[0] - boxes[c].lo[0], dy = boxes[c].hi[1] - boxes[c].lo[1], dz = boxes[c].hi[2] - boxes[c].lo[2];
+            area += dx * dy + dy * dz + dz * dx;
+        }
+    }
+    enc_node_boxes(boxes, k, padCoeff, enc_slack(scene), n);
+    nodes[i] = n;
+    if (cost != nullptr)
+    {
+        const float sx = scene.hi[0] - scene.lo[0], sy = scene.hi[1] - scene.lo[1], sz = scene.hi[2] - scene.lo[2];
+        const float rootArea = sx * sy + sy * sz + sz * sx;
+        float v = rootArea > 0.0f ? area / rootArea : 0.0f;
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+        if ((threadIdx.x & 63u) == 0u && v != 0.0f) atomicAdd(cost, v);
+    }
+}
+
+void launch_refit(
+    BvhNode *nodes, const WorldTriangle *tris, float4 *bounds, const uint32_t *order, const uint32_t *levelOffsets,
+    uint32_t levels, uint32_t nodeCount, float padCoeff, float *cost, hipStream_t stream)
+{
+    for (uint32_t l = 0; l < levels; ++l)
+    {
+        const uint32_t first = levelOffsets[l], count = levelOffsets[l + 1] - first;
+        if (count == 0) continue;
+        hipLaunchKernelGGL(refit_bounds_kernel, dim3((count + 255u) / 256u), dim3(256), 0, stream, nodes, tris, bounds, order, first, count);
+    }
+    if (nodeCount)
+        hipLaunchKernelGGL(encode_nodes_kernel, dim3((nodeCount + 255u) / 256u), dim3(256), 0, stream, nodes, tris, bounds, nodeCount, padCoeff, cost);
 }
 
 // ------------------------------------------------------------------------------------------

@@ -43,7 +43,13 @@ struct LaunchTimer
 
 void launch_flatten_triangles(
     const DeviceScene &s, const uint32_t *triOffsets, uint32_t drawInstanceCount, const uint32_t *drawInstanceFlags,
-    WorldTriangle *out, ShadeTriangle *shadeOut, AlphaTriangle *alphaOut, uint32_t total, hipStream_t stream);
+    WorldTriangle *out, ShadeTriangle *shadeOut, AlphaTriangle *alphaOut, uint32_t total, hipStream_t stream,
+    const uint32_t *leafPosition = nullptr, WorldTriangle *leafOrder = nullptr);
+// refit of an unchanged tree after moved instances: exact bounds level by level (`order` = nodes by height,
+// levelOffsets[levels + 1] on the HOST), then every node's boxes re-encoded; *cost += the tree's surface-area measure
+void launch_refit(
+    BvhNode *nodes, const WorldTriangle *tris, float4 *bounds, const uint32_t *order, const uint32_t *levelOffsets,
+    uint32_t levels, uint32_t nodeCount, float padCoeff, float *cost, hipStream_t stream);
 void launch_build_alpha_bounds(
     const DeviceTexture &tex, uint32_t wrapS, uint32_t wrapT, float factorA, uint32_t shift, uint16_t *out, hipStream_t stream);
 void launch_srgb_monotonicity(uint32_t firstBits, uint32_t lastBits, uint32_t *out, hipStream_t stream);
@@ -80,6 +86,7 @@ struct WavefrontChains
     uint32_t count = 1;
     bool detached = false;
     hipEvent_t after = nullptr;
+    hipEvent_t scene = nullptr; // the last prosper_pt_update_transforms: every chain waits for it
     hipStream_t streams[kMaxChains] = {};
     hipEvent_t fork = nullptr;
     hipEvent_t join[kMaxChains] = {};

@@ -25,7 +25,7 @@ namespace ppt
 struct alignas(16) BvhNode
 {
     float origin[3];
-    uint32_t reserved;
+    uint32_t reserved; // number of children in use (slots 0 .. reserved - 1); the traversal does not read it
     uint16_t lo[3][4];
     uint16_t hi[3][4];
     int32_t child[4];

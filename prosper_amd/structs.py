@@ -271,6 +271,11 @@ class SceneStats(C.Structure):
     ]
 
 
+class HierarchyState(C.Structure):
+    _fields_ = [("refits", C.c_uint32), ("rebuilds", C.c_uint32), ("costRatio", C.c_float), ("builtCost", C.c_float),
+                ("nodeCount", C.c_uint32), ("levels", C.c_uint32)]
+
+
 GATHER_IN_STREAM = 1
 VARIANT_LDS_SCENE = 1
 VARIANT_LDS_TABLES = 2

@@ -31,8 +31,7 @@ extern "C" __global__ void unit_node_visit_closest(DeviceScene s, const RayIn *i
     __shared__ int32_t lds[16 * 256];
     const RayIn r = in[tid()];
     const TraversalStack stack{(lds_int32 *)lds + (threadIdx.x >> 6) * (16u * 64u) + (threadIdx.x & 63u), stackMem + tid(), 16u, gridDim.x * 256u, 64u};
-    const f3 o = f3{r.a.x, r.a.y, r.a.z}, d = f3{r.b.x, r.b.y, r.b.z};
-    const f3 invd = f3{safe_rcp_dir(d.x), safe_rcp_dir(d.y), safe_rcp_dir(d.z)};
+    const f3 o = f3{r.a.x, r.a.y, r.a.z}, invd = f3{r.b.x, r.b.y, r.b.z}; // 1 / direction is per-ray work, not per visit
     const GlobalGeom g{s.nodes, s.triangles};
     const NodeData nd = g.node(nodeIdx[tid()]);
     float e[4];
@@ -51,8 +50,7 @@ extern "C" __global__ void unit_node_visit_shadow(DeviceScene s, const RayIn *in
     __shared__ int32_t lds[16 * 256];
     const RayIn r = in[tid()];
     const TraversalStack stack{(lds_int32 *)lds + (threadIdx.x >> 6) * (16u * 64u) + (threadIdx.x & 63u), stackMem + tid(), 16u, gridDim.x * 256u, 64u};
-    const f3 o = f3{r.a.x, r.a.y, r.a.z}, d = f3{r.b.x, r.b.y, r.b.z};
-    const f3 invd = f3{safe_rcp_dir(d.x), safe_rcp_dir(d.y), safe_rcp_dir(d.z)};
+    const f3 o = f3{r.a.x, r.a.y, r.a.z}, invd = f3{r.b.x, r.b.y, r.b.z};
     const GlobalGeom g{s.nodes, s.triangles};
     const NodeData nd = g.node(nodeIdx[tid()]);
     float e[4];
@@ -105,9 +103,10 @@ extern "C" __global__ void unit_any_hit_with_texels(DeviceScene s, const RayIn *
     out[tid()] = make_float4(v ? 1.0f : 0.0f, 0.0f, 0.0f, 0.0f);
 }
 
-// one camera path start: RNG, jitter, pinhole / thin-lens ray (start_path)
+// one camera path start: RNG, jitter, pinhole ray (start_path without depth of field, the configurations' case)
 extern "C" __global__ void unit_camera_ray(RenderParams p, const RayIn *in, float4 *out, uint4 *outRng)
 {
+    p.pc.flags &= ~(uint32_t)PROSPER_PC_FLAG_DEPTH_OF_FIELD;
     const RayIn r = in[tid()];
     PathState st;
     LaneCounters cnt = {};

@@ -864,9 +864,9 @@ def test_texture_packs_equal_separate_textures(gpu_ctx, oracle, sponza_small, mo
 
 def test_moved_instances_refit_equals_fresh_upload(gpu_ctx, oracle, monkeypatch):
     """prosper_pt_update_transforms (prosper: World::updateScene + the per-frame TLAS rebuild, World.cpp:359-466,749-802):
-    the acceleration structure is one subtree per model instance under a top level, so a moved instance re-splits only
-    its own triangles.  After moving two instances the image equals a fresh upload of the moved scene, the flat
-    (round-1) hierarchy's image and the oracle's, bit for bit; and the refit is cheaper than the full build."""
+    a refit on the GPU - new world triangles and new boxes for the unchanged tree, no host build.  After moving two
+    instances the image equals a fresh upload of the moved scene, the flat (round-1) hierarchy's image and the
+    oracle's, bit for bit; so does the image after the explicit host-side rebuild."""
     from prosper_amd import capi
     from prosper_amd.world import rotate_y, translate
 
@@ -883,11 +883,14 @@ def test_moved_instances_refit_equals_fresh_upload(gpu_ctx, oracle, monkeypatch)
     pc = default_pc(S, fl, max_bounces=3, ibl=True)
     gpu_ctx.upload_scene(still)
     full_build = gpu_ctx.scene_stats().bvhBuildSeconds
+    nodes_at_upload = gpu_ctx.read_nodes()
     gpu_ctx.render(pc, cam, w, h, frames=2)
     before = gpu_ctx.read_hdr()
     gpu_ctx.update_transforms(moved)
     st = gpu_ctx.scene_stats()
-    assert st.triangleCount == moved.triangle_count() and st.bvhBuildSeconds < full_build
+    hs = gpu_ctx.hierarchy_state()
+    assert st.triangleCount == moved.triangle_count() and st.bvhBuildSeconds == 0.0 and st.buildSeconds < full_build
+    assert hs.refits == 1 and hs.rebuilds == 0 and hs.costRatio > 1.0 and hs.levels >= 3
     gpu_ctx.render(pc, cam, w, h, frames=2)
     refit = gpu_ctx.read_hdr()
     assert not same_bits(refit, before).all()  # the instances are in view: something moved
@@ -910,25 +913,103 @@ def test_moved_instances_refit_equals_fresh_upload(gpu_ctx, oracle, monkeypatch)
         want, _ = osc.render(default_pc(S, fl, frame_index=frame, max_bounces=3, ibl=True, skip_history=(frame == 1)),
                              cam, w, h, history=want)
     assert same_bits(refit, want).all()
+    # the host-side rebuild (re-split of the two moved instances): same image, a tree as good as a fresh one
+    gpu_ctx.rebuild_hierarchy()
+    hs = gpu_ctx.hierarchy_state()
+    assert hs.rebuilds == 1 and abs(hs.costRatio - 1.0) < 1e-6 and gpu_ctx.scene_stats().bvhBuildSeconds > 0.0
+    gpu_ctx.render(pc, cam, w, h, frames=2)
+    assert same_bits(gpu_ctx.read_hdr(), refit).all()
     # moving them back restores the first image
     gpu_ctx.update_transforms(still)
     gpu_ctx.render(pc, cam, w, h, frames=2)
     assert same_bits(gpu_ctx.read_hdr(), before).all()
     # an unchanged table is a no-op; a table of the wrong length is refused
+    refits = gpu_ctx.hierarchy_state().refits
     gpu_ctx.update_transforms(still)
+    assert gpu_ctx.hierarchy_state().refits == refits
     with pytest.raises(capi.ProsperPtError):
         capi._check(capi.lib().prosper_pt_update_transforms(gpu_ctx._h, None, 3))
-    # an update that fails half way (forced) must not be mistaken for done: renders are refused until a retry - with the
-    # very same transforms - has gone through, and then show the moved scene
+    # a rebuild that fails half way (forced) must not be mistaken for done: renders are refused until an update has gone
+    # through, and then show the moved scene
     monkeypatch.setenv("PROSPER_PT_DEBUG_FAIL_NEXT_UPDATE", "1")
+    monkeypatch.setenv("PROSPER_PT_DEBUG_ALWAYS_REBUILD", "1")
     with pytest.raises(capi.ProsperPtError):
         gpu_ctx.update_transforms(moved)
     monkeypatch.delenv("PROSPER_PT_DEBUG_FAIL_NEXT_UPDATE")
+    monkeypatch.delenv("PROSPER_PT_DEBUG_ALWAYS_REBUILD")
     with pytest.raises(capi.ProsperPtError):
         gpu_ctx.render(pc, cam, w, h, frames=2)
     gpu_ctx.update_transforms(moved)
     gpu_ctx.render(pc, cam, w, h, frames=2)
     assert same_bits(gpu_ctx.read_hdr(), refit).all()
+    # upload: the refit that runs right after the build rewrote every node with the bytes the emitter had written
+    gpu_ctx.upload_scene(still)
+    assert np.array_equal(gpu_ctx.read_nodes(), nodes_at_upload)
+
+
+def test_refit_writes_the_emitters_bytes(gpu_ctx, monkeypatch):
+    """The device encoder of a node's child boxes (bvh_encode.hpp through encode_nodes_kernel) and the host emitter are
+    the same code: with the refit at upload switched off (PROSPER_PT_DEBUG_NO_UPLOAD_REFIT) the node array is the
+    emitter's own, and it equals the refitted one byte for byte - on a scene with instancing, scaling and a skewed
+    transform, and on the big one."""
+    for world in (scenes.transform_zoo(), scenes.sponza_class(foliage=True, texture_size=64, sky_size=32, detail=0.5)):
+        monkeypatch.setenv("PROSPER_PT_DEBUG_NO_UPLOAD_REFIT", "1")
+        gpu_ctx.upload_scene(world)
+        emitted = gpu_ctx.read_nodes()
+        monkeypatch.delenv("PROSPER_PT_DEBUG_NO_UPLOAD_REFIT")
+        gpu_ctx.upload_scene(world)
+        refitted = gpu_ctx.read_nodes()
+        assert emitted.shape == refitted.shape and emitted.shape[0] > 8
+        differing = np.argwhere(emitted != refitted)
+        assert differing.size == 0, "node %d word %d: emitter %08x, refit %08x" % (
+            differing[0][0], differing[0][1], emitted[tuple(differing[0])], refitted[tuple(differing[0])])
+
+
+def test_moving_instances_between_frames_in_flight(gpu_ctx, oracle):
+    """Updates interleaved with pipelined renders on one stream, as a frame loop makes them (App.cpp:516-578: update the
+    scene, then record the pass): every frame shows the scene of ITS update - frames in flight neither see the next
+    update nor delay it.  Each image equals a fresh context's render of that pose."""
+    from prosper_amd import capi
+    from prosper_amd.world import rotate_y, translate
+
+    def pose(k):
+        world = scenes.sponza_class(lights=(4, 4), texture_size=64, sky_size=32, detail=0.25)
+        model, m = world.model_instances[5]
+        world.model_instances[5] = (model, translate((0.15 * k, 0.05 * k, 0.0)) @ rotate_y(0.2 * k) @ m)
+        return world
+    poses = [pose(k) for k in range(4)]
+    w, h = 256, 144
+    cam, fl = _camera(oracle, poses[0], w, h)
+    pc = default_pc(S, fl, max_bounces=3, ibl=True)
+    import ctypes
+    hip = ctypes.CDLL("libamdhip64.so")  # the runtime the library itself uses: plain device buffers for the four images
+    nbytes = w * h * 16
+    outs = []
+    for _ in poses:
+        ptr = ctypes.c_void_p()
+        assert hip.hipMalloc(ctypes.byref(ptr), ctypes.c_size_t(nbytes)) == 0
+        outs.append(ptr)
+    gpu_ctx.upload_scene(poses[0])
+    for k, world in enumerate(poses):
+        gpu_ctx.update_transforms(world)
+        gpu_ctx.set_output_buffer(outs[k].value, nbytes)
+        gpu_ctx.render(pc, cam, w, h, frames=2, flags=S.RENDER_PIPELINED)
+    assert hip.hipDeviceSynchronize() == 0
+    gpu_ctx.set_output_buffer(0, 0)
+    images = []
+    for ptr in outs:
+        img = np.zeros((h, w, 4), np.float32)
+        assert hip.hipMemcpy(ctypes.c_void_p(img.ctypes.data), ptr, ctypes.c_size_t(nbytes), 2) == 0  # hipMemcpyDeviceToHost
+        assert hip.hipFree(ptr) == 0
+        images.append(img)
+    fresh = capi.Context(device=0)
+    try:
+        for k, world in enumerate(poses):
+            fresh.upload_scene(world)
+            fresh.render(pc, cam, w, h, frames=2)
+            assert same_bits(images[k], fresh.read_hdr()).all(), "pose %d" % k
+    finally:
+        fresh.close()
 
 
 def test_pipelined_renders_survive_changing_extents(gpu_ctx, oracle, cornell_world):
