@@ -577,6 +577,10 @@ def main():
             os.close(saved_stdout)
 
     workload, builder, width, height, spp, max_bounces, ibl = CONFIGS[args.config]
+    if world_size > 1 and not tiling.check_divisible(width, world_size):
+        # equal tiles -> the one ncclGather the design names; the grouped send/recv path for uneven stripe counts exists
+        # in the library but has never run on more than one GPU, so the bench does not time it
+        raise SystemExit("--gpus %d: %d stripes of %d pixels do not divide over the ranks" % (world_size, width // STRIPE_WIDTH, STRIPE_WIDTH))
     world = builder()
     camera = Camera.from_world(world, width, height)
     cam, focal = camera.update_buffer()

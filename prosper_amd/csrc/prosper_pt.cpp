@@ -54,6 +54,19 @@ int device_alloc(prosper_pt_ctx *ctx, size_t bytes, void **out)
     return PROSPER_PT_OK;
 }
 
+// returns a scene allocation early (a texture only its material pack still mirrors, a node array that was outgrown)
+void device_free(prosper_pt_ctx *ctx, const void *p)
+{
+    for (size_t i = 0; i < ctx->sceneAllocations.size(); ++i)
+        if (ctx->sceneAllocations[i].ptr == p)
+        {
+            (void)hipFree(ctx->sceneAllocations[i].ptr);
+            ctx->sceneBytes -= ctx->sceneAllocations[i].bytes;
+            ctx->sceneAllocations.erase(ctx->sceneAllocations.begin() + (long)i);
+            return;
+        }
+}
+
 int upload(prosper_pt_ctx *ctx, const void *src, size_t bytes, void **out)
 {
     const int rc = device_alloc(ctx, bytes, out);
@@ -183,8 +196,9 @@ int upload_hierarchy(prosper_pt_ctx *ctx, const BvhBuildResult &bvh)
     {
         void *d = nullptr;
         const size_t capacity = nodeBytes + nodeBytes / 4 + 4096; // headroom: a rebuild changes the node count a little
-        const int rc = device_alloc(ctx, capacity, &d);          // (the previous array stays in the scene's list until the next upload)
+        const int rc = device_alloc(ctx, capacity, &d);
         if (rc != PROSPER_PT_OK) return rc;
+        if (acc->dNodes) device_free(ctx, acc->dNodes); // (callers have synchronised the device: nothing reads it any more)
         acc->dNodes = static_cast<BvhNode *>(d);
         acc->nodeCapacityBytes = capacity;
     }
@@ -344,8 +358,6 @@ int upload_scene_impl(prosper_pt_ctx *ctx, const prosper_pt_scene_view *v)
         if ((rc = upload(ctx, tiled.data(), tiled.size() * 4u, &d))) return rc;
         textures[i] = DeviceTexture{static_cast<const uint8_t *>(d), t.width, t.height, tilesX, 0u};
     }
-    if ((rc = upload(ctx, textures.data(), textures.size() * sizeof(DeviceTexture), &d))) return rc;
-    s.textures = static_cast<const DeviceTexture *>(d);
     // beyond the 8 x 4 MB of L2 the texels of a hit come from the Infinity Cache or HBM: overlap their fetches
     // (PROSPER_PT_DEBUG_BATCHED_TEXTURES = 0 / 1 forces either path: same pixels, tested)
     s.batchedTextures = texelBytes > (32ull << 20) ? 1u : 0u;
@@ -384,6 +396,30 @@ int upload_scene_impl(prosper_pt_ctx *ctx, const prosper_pt_scene_view *v)
     if ((rc = upload(ctx, packs.data(), packs.size() * sizeof(MaterialPack), &d))) return rc;
     s.materialPacks = static_cast<const MaterialPack *>(d);
     ctx->packedMaterials = packedMaterials;
+    // A texture that only packed materials use is never sampled by itself again (sample_material takes the pack): its
+    // own copy goes - half of a packed scene's texel memory.  What keeps a texture: an unpacked material, or the any-hit
+    // of a MASK / BLEND material, which reads the base colour's alpha out of the texture itself.
+    {
+        std::vector<uint8_t> needed(textures.size(), 0);
+        needed[0] = 1;
+        for (uint32_t i = 0; i < v->materialCount; ++i)
+        {
+            const prosper_MaterialData &m = v->materials[i];
+            const uint32_t t3[3] = {m.baseColorTextureSampler & 0xFFFFFFu, m.metallicRoughnessTextureSampler & 0xFFFFFFu,
+                                    m.normalTextureSampler & 0xFFFFFFu};
+            if (packs[i].texels == nullptr)
+                for (uint32_t t : t3) needed[t] = 1;
+            if (m.alphaMode != PROSPER_ALPHA_MODE_OPAQUE) needed[t3[0]] = 1;
+        }
+        for (uint32_t i = 1; i < v->textureCount; ++i)
+            if (!needed[i] && textures[i].texels)
+            {
+                device_free(ctx, textures[i].texels);
+                textures[i].texels = nullptr;
+            }
+    }
+    if ((rc = upload(ctx, textures.data(), textures.size() * sizeof(DeviceTexture), &d))) return rc;
+    s.textures = static_cast<const DeviceTexture *>(d);
     const double textureSeconds = seconds_since(tTextures);
 
     // lights
@@ -545,8 +581,17 @@ int upload_scene_impl(prosper_pt_ctx *ctx, const prosper_pt_scene_view *v)
             bvh = build_bvh(acc->flat.data(), total);
         else
         {
-            bvh = acc->bvh.build(acc->flat.data(), total, acc->ranges);
-            acc->instanced = true;
+            try
+            {
+                bvh = acc->bvh.build(acc->flat.data(), total, acc->ranges);
+                acc->instanced = true;
+            }
+            catch (const std::exception &)
+            {
+                // the subtrees are split without knowing how deep the re-braided top level above them gets: a spliced
+                // tree can pass the traversal's stack bound where one tree over everything does not
+                bvh = build_bvh(acc->flat.data(), total);
+            }
         }
     }
     catch (const std::exception &ex)

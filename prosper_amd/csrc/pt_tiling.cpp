@@ -10,6 +10,7 @@
 
 #include <cstring>
 #include <mutex>
+#include <string>
 
 using namespace ppt;
 
@@ -110,6 +111,7 @@ void destroy_tiling(prosper_pt_ctx *ctx)
 {
     TilingState *t = ctx->tiling;
     if (!t) return;
+    (void)hipSetDevice(ctx->device); // one thread may drive several contexts: everything below belongs to this one's GPU
     if (t->commStream) (void)hipStreamSynchronize(t->commStream);
     if (t->comm && t->ownsComm && rccl().commDestroy) (void)rccl().commDestroy(t->comm);
     if (t->staging) (void)hipFree(t->staging);
@@ -138,10 +140,21 @@ int ensure_state(prosper_pt_ctx *ctx)
     PPT_HIP(hipSetDevice(ctx->device));
     TilingState *t = new (std::nothrow) TilingState();
     if (!t) return fail(PROSPER_PT_ERR_INVALID_ARGUMENT, "out of host memory");
+    // published only once it is whole: a half-made state (no stream, null events) must never be seen by a later call
+    // (the communication stream is a fifth stream beside the caller's and the three work streams: it shares a hardware
+    // queue with one of them, so a gather can queue behind a path stage - it still overlaps the other frames' stages)
+    hipError_t e = hipStreamCreateWithFlags(&t->commStream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&t->tileReady, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&t->gatherDone, hipEventDisableTiming);
+    if (e != hipSuccess)
+    {
+        if (t->tileReady) (void)hipEventDestroy(t->tileReady);
+        if (t->gatherDone) (void)hipEventDestroy(t->gatherDone);
+        if (t->commStream) (void)hipStreamDestroy(t->commStream);
+        delete t;
+        return fail(PROSPER_PT_ERR_HIP, std::string("multi-GPU state: ") + hipGetErrorString(e));
+    }
     ctx->tiling = t;
-    PPT_HIP(hipStreamCreateWithFlags(&t->commStream, hipStreamNonBlocking));
-    PPT_HIP(hipEventCreateWithFlags(&t->tileReady, hipEventDisableTiming));
-    PPT_HIP(hipEventCreateWithFlags(&t->gatherDone, hipEventDisableTiming));
     return PROSPER_PT_OK;
 }
 

@@ -2,7 +2,7 @@
 """Randomised parity sweep: random camera poses, push constants, extents, frame counts and rank tiles over the
 synthetic scenes, HIP path (through the C-ABI) against the CPU oracle, every pixel bit for bit.
 
-    python scripts/parity_fuzz.py [--cases 60] [--seed 1] [--scenes cornell,sponza,foliage,wall,zoo]
+    python scripts/parity_fuzz.py [--cases 60] [--seed 1] [--scenes cornell,sponza,foliage,wall,zoo,alpha,helmet]
 
 Prints one line per case and a summary; exit code 1 if any pixel differs.  (tests/test_gpu_parity.py holds the
 fixed cases; this is the wide net: profiles/r01_parity_fuzz.txt keeps a run.)
@@ -32,6 +32,8 @@ def run(cases, seed, scene_names, log=print):
         "foliage": lambda: scenes.sponza_class(lights=True, foliage=True, texture_size=64, sky_size=32, detail=0.35),
         "wall": scenes.texture_wall,
         "zoo": scenes.transform_zoo,
+        "alpha": scenes.alpha_wall,     # MASK / BLEND quads: every wrap mode, filter, factor, cutoff (alpha bounds)
+        "helmet": lambda: __import__("prosper_amd.flight_helmet", fromlist=["x"]).load_fixture(),
     }
     names = list(scene_names)
     rng = np.random.default_rng(seed)
@@ -44,9 +46,28 @@ def run(cases, seed, scene_names, log=print):
         name = names[case % len(names)]
         if name not in worlds:
             worlds[name] = builders[name]()
-            oracles[name] = O.OracleScene(worlds[name], brute_force=name in ("cornell", "wall", "zoo"))
+            oracles[name] = O.OracleScene(worlds[name], brute_force=name in ("cornell", "wall", "zoo", "alpha"))
         world = worlds[name]
         ctx.upload_scene(world)
+        # a third of the cases on instanced scenes: some instances moved by prosper_pt_update_transforms (the GPU refit)
+        # after the upload, against the oracle's own scene built at the moved pose
+        oracle_scene = oracles[name]
+        moved_note = ""
+        if len(world.model_instances) >= 3 and rng.random() < 0.33:
+            import copy
+            from prosper_amd.world import rotate_y, rotate_x, translate
+            moved = copy.copy(world)
+            moved.model_instances = list(world.model_instances)
+            moved._frozen = None
+            size = float(np.linalg.norm(np.array(world.camera["eye"]) - np.array(world.camera["target"])))
+            picks = rng.choice(len(world.model_instances), size=int(rng.integers(1, 4)), replace=False)
+            for k in picks:
+                model, m = moved.model_instances[int(k)]
+                delta = translate(tuple(rng.normal(0, 0.05 * size, 3))) @ rotate_y(rng.uniform(-0.8, 0.8)) @ rotate_x(rng.uniform(-0.3, 0.3))
+                moved.model_instances[int(k)] = (model, delta @ m)
+            ctx.update_transforms(moved)
+            oracle_scene = O.OracleScene(moved, brute_force=name in ("cornell", "wall", "zoo", "alpha"))
+            moved_note = " moved %d" % len(picks)
         base = world.camera
         eye0, tgt0 = np.array(base["eye"], np.float64), np.array(base["target"], np.float64)
         dist = np.linalg.norm(eye0 - tgt0)
@@ -92,7 +113,9 @@ def run(cases, seed, scene_names, log=print):
                 ctx.render(p, cam, w, h, tile=tile, flags=pipelined)
         got = ctx.read_hdr()
         for p in pcs:
-            want, _ = oracles[name].render(p, cam, w, h, history=want)
+            want, _ = oracle_scene.render(p, cam, w, h, history=want)
+        if oracle_scene is not oracles[name]:
+            oracle_scene.close()
         if tile is not None:  # this rank's stripes, in ascending order
             cols = [x for x in range(w) if (x // tile.stripeWidth) % tile.stripeCount == tile.stripeIndex]
             want = want[:, cols]
@@ -102,7 +125,7 @@ def run(cases, seed, scene_names, log=print):
         total_px += ok.size
         nan = int(np.isnan(got[..., :3]).any(axis=2).sum())
         log("case %3d %-8s %3dx%-3d draw %2d flags %02x bounces %d rr %d frames %d%s%s  eye-dist %.2g fov %3.0f  -> %s (%d NaN px)" % (
-            case, name, w, h, draw, flags, bounces, roulette, frames, (" batched" if batched else "") + (" pipelined" if pipelined else ""),
+            case, name, w, h, draw, flags, bounces, roulette, frames, (" batched" if batched else "") + (" pipelined" if pipelined else "") + moved_note,
             " tile %d/%d" % (tile.stripeIndex, tile.stripeCount) if tile is not None else "", r, math.degrees(fov),
             "ok" if nbad == 0 else "%d PIXELS DIFFER" % nbad, nan))
     ctx.close()
@@ -114,7 +137,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--cases", type=int, default=60)
     ap.add_argument("--seed", type=int, default=1)
-    ap.add_argument("--scenes", default="cornell,sponza,foliage,wall,zoo")
+    ap.add_argument("--scenes", default="cornell,sponza,foliage,wall,zoo,alpha,helmet")
     args = ap.parse_args()
     bad, _ = run(args.cases, args.seed, [n for n in args.scenes.split(",") if n],
                  log=lambda *a: print(*a, flush=True))

@@ -1161,15 +1161,15 @@ def test_full_sponza_class_scene_parity(gpu_ctx, oracle):
 
 
 def test_random_configurations_bit_exact():
-    """A fixed-seed slice of scripts/parity_fuzz.py (random poses, flags, bounces, frame counts, extents and rank
-    tiles over five scenes); profiles/r01_parity_fuzz.txt keeps an 860-case run."""
+    """A fixed-seed slice of scripts/parity_fuzz.py (random poses, flags, bounces, frame counts, extents, rank tiles and
+    moved instances over seven scenes); profiles/r03_parity_fuzz.txt keeps the long runs."""
     import importlib.util
     path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scripts", "parity_fuzz.py")
     spec = importlib.util.spec_from_file_location("parity_fuzz", path)
     fuzz = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(fuzz)
     lines = []
-    bad, pixels = fuzz.run(25, 11, ["cornell", "sponza", "foliage", "wall", "zoo"], log=lines.append)
+    bad, pixels = fuzz.run(28, 11, ["cornell", "sponza", "foliage", "wall", "zoo", "alpha", "helmet"], log=lines.append)
     assert bad == 0, "\n".join(l for l in lines if "DIFFER" in l)
     assert pixels > 100000
 
