@@ -102,6 +102,72 @@ __device__ __forceinline__ SlotPixel decode_slot(const WavefrontBuffers &w, cons
     return r;
 }
 
+// Which (frame, pixel) lane `lane` of batch `q` of a render's camera rays is.  A batch is 64 paths: NOT one 8x8 tile of one
+// frame but a block of 64 / g pixels of a tile in g consecutive frames (g = 64 while that many frames remain, then 32,
+// 16, ... 1 - a single frame is the 8x8 tile again).  The g camera rays of a pixel differ by their sub-pixel jitter
+// only: they walk the same nodes and mostly hit the same triangle, so the lockstep traversal of the batch diverges far
+// less than 64 different pixels do (a dense mesh has a triangle every few pixels), and in wf_shade the hits of a pixel
+// sit next to each other - one shading record, one texel footprint for all of them.  Slots keep their meaning (frame *
+// pixelsPadded + tile * 64 + pixel in tile): only the order the camera rays are generated in changes.
+// (FlightHelmet, 8 spp: wf_generate_extend 1249 -> 918 us; C3 1536 -> 1449 and wf_shade 1004 -> 934; C4 6860 -> 6056.)
+struct BatchLane
+{
+    uint32_t slot, lx, py, frame;
+    bool valid;
+};
+#ifndef PPT_BATCH_MAX_FRAMES
+#define PPT_BATCH_MAX_FRAMES 64u
+#endif
+__device__ __forceinline__ BatchLane batch_lane(const WavefrontBuffers &w, const RenderParams &p, uint32_t q, uint32_t lane)
+{
+    constexpr uint32_t kMax = PPT_BATCH_MAX_FRAMES, kMaxShift = kMax == 64u ? 6u : (kMax == 32u ? 5u : (kMax == 16u ? 4u : (kMax == 8u ? 3u : 0u)));
+    static_assert(kMaxShift != 0u || kMax == 1u, "PPT_BATCH_MAX_FRAMES is 1, 8, 16, 32 or 64");
+    const uint32_t tiles = w.pixelsPadded >> 6;
+    const uint32_t frames = p.frameCount;
+    uint32_t shift = kMaxShift, firstFrame = 0u, rem = q;
+    const uint32_t fullGroups = frames >> kMaxShift;
+    const uint32_t fullBatches = (fullGroups << kMaxShift) * tiles; // batches of the groups of kMax frames
+    bool inRange = true;
+    if (rem < fullBatches)
+    {
+        const uint32_t group = rem / (tiles << kMaxShift);
+        firstFrame = group << kMaxShift;
+        rem -= group * (tiles << kMaxShift);
+    }
+    else
+    {
+        rem -= fullBatches;
+        firstFrame = fullGroups << kMaxShift;
+        inRange = false;
+        for (shift = kMaxShift; shift-- != 0u;)
+            if (frames & (1u << shift))
+            {
+                if (rem < (tiles << shift))
+                {
+                    inRange = true;
+                    break;
+                }
+                rem -= tiles << shift;
+                firstFrame += 1u << shift;
+            }
+        if (!inRange) shift = 0u;
+    }
+    // 2^shift batches per tile, each a block of 64 >> shift pixels: 8x8, 8x4, 4x4, 4x2, 2x2, 2x1, 1x1
+    const uint32_t tile = rem >> shift, part = rem & ((1u << shift) - 1u);
+    const uint32_t wShift = (7u - shift) >> 1, hShift = (6u - shift) >> 1; // log2 of the block's width and height
+    const uint32_t pixel = lane & ((64u >> shift) - 1u);
+    const uint32_t bx = part & ((8u >> wShift) - 1u), by = part >> (3u - wShift);
+    const uint32_t ix = (bx << wShift) + (pixel & ((1u << wShift) - 1u)), iy = (by << hShift) + (pixel >> wShift);
+    BatchLane r;
+    r.frame = firstFrame + (lane >> (6u - shift));
+    const uint32_t ty = tile / w.tilesX;
+    r.lx = (tile - ty * w.tilesX) * 8u + ix;
+    r.py = ty * 8u + iy;
+    r.slot = r.frame * w.pixelsPadded + tile * 64u + iy * 8u + ix;
+    r.valid = inRange && r.frame < frames && r.lx < p.localWidth && r.py < p.height;
+    return r;
+}
+
 // addBounce (main.rgen:83-88) into the path's radiance slot
 __device__ __forceinline__ void add_to_slot(float4 *color, uint32_t slot, uint32_t flags, f3 value, uint32_t bounce)
 {
@@ -186,31 +252,14 @@ __global__ __launch_bounds__(256, PPT_GEN_WPE) void wf_generate_extend(
     }
     else
     {
-        // A batch of 64 consecutive slots is one 8x8 tile of one frame (segment bases and the frame stride are
-        // multiples of 64), so frame / tile row / tile column are wave-uniform: decoded once per segment with
-        // the two integer divisions, then stepped tile by tile.
-        // Batch b of segment s is tile number b * nSeg + s of the (frame, tile) sequence: every segment gets
-        // tiles from all over the image (and all frames), so the waves of a launch carry statistically equal
-        // work and finish together; consecutive segments still start on neighbouring tiles.
-        const SlotPixel first = decode_slot(w, p, id.seg * 64u);
-        uint32_t tileFrame = first.frame, tileX = first.lx >> 3, tileY = first.py >> 3;
-        // one step of nSeg tiles, split into whole frames, tile rows and tile columns
-        const uint32_t tilesPerFrame = w.pixelsPadded >> 6;
-        const uint32_t stepFrames = w.nSeg / tilesPerFrame;
-        const uint32_t stepRem = w.nSeg - stepFrames * tilesPerFrame;
-        const uint32_t stepRows = stepRem / w.tilesX, stepCols = stepRem - stepRows * w.tilesX;
-        uint32_t batchSlot = id.seg * 64u; // image slot of lane 0 of the current batch
-        bool slotValid = false; // of the slot the last fetch() decoded: commit() follows it in lockstep
+        // Batch b of segment s is batch number q = b * nSeg + s of the frame's batch sequence (batch_lane): every segment
+        // gets batches from all over the image (and all frame groups), so the waves of a launch carry statistically
+        // equal work and finish together; consecutive segments still start on neighbouring batches.
+        BatchLane bl = {};
         auto fetch = [&](uint32_t k) {
             const uint32_t at = id.base + k; // where the path's records live in this segment
-            SlotPixel sp;
-            sp.frame = tileFrame;
-            sp.lx = tileX * 8u + (lane & 7u);
-            sp.py = tileY * 8u + (lane >> 3);
-            sp.valid = sp.frame < p.frameCount && sp.lx < p.localWidth && sp.py < p.height;
-            slotValid = sp.valid;
             StreamRay r;
-            if (!sp.valid)
+            if (!bl.valid)
             {
                 // slot outside the image / batch: a ray that cannot hit anything
                 r.o = f3{0.0f, 0.0f, 0.0f};
@@ -221,12 +270,12 @@ __global__ __launch_bounds__(256, PPT_GEN_WPE) void wf_generate_extend(
                 return r;
             }
             PathState st;
-            start_path<COUNT>(p, local_to_global_x(p, sp.lx), sp.py, (p.pc.frameIndex + sp.frame) % PROSPER_RT_FRAME_PERIOD,
+            start_path<COUNT>(p, local_to_global_x(p, bl.lx), bl.py, (p.pc.frameIndex + bl.frame) % PROSPER_RT_FRAME_PERIOD,
                               st, cnt);
             if constexpr (COUNT) cnt.closestRays++;
-            w.rayB[0][at] = make_float4(st.d.x, st.d.y, st.d.z, 0.0f);
-            // no pathT record for bounce 0: the throughput is (1, 1, 1) and wf_shade re-derives the slot from the path's
-            // place in its segment (32 B per camera path that HBM does not carry)
+            // no pathT record for bounce 0: the throughput is (1, 1, 1) and the path's radiance slot rides in the spare
+            // word of its direction record (32 B per camera path that HBM does not carry)
+            w.rayB[0][at] = make_float4(st.d.x, st.d.y, st.d.z, asf(bl.slot));
             w.pathR[0][at] = make_uint4(st.rng.x, st.rng.y, st.rng.z, 0u);
             r.o = st.o;
             r.d = st.d;
@@ -236,8 +285,7 @@ __global__ __launch_bounds__(256, PPT_GEN_WPE) void wf_generate_extend(
             return r;
         };
         auto commit = [&](bool pred, uint32_t k, bool found, const Hit &hit, const f3 &dir) {
-            const uint32_t slot = batchSlot + lane;
-            const bool valid = pred && slotValid;
+            const bool valid = pred && bl.valid;
             if (valid)
             {
                 f3 color = f3{0.0f, 0.0f, 0.0f};
@@ -246,7 +294,7 @@ __global__ __launch_bounds__(256, PPT_GEN_WPE) void wf_generate_extend(
                     if constexpr (COUNT) cnt.skyLookups++;
                     add_bounce(p.pc.flags, color, sample_skybox(s, dir), 0u); // throughput is (1,1,1)
                 }
-                w.color[slot] = make_float4(color.x, color.y, color.z, 0.0f);
+                w.color[bl.slot] = make_float4(color.x, color.y, color.z, 0.0f);
             }
             const bool isHit = valid && found;
             uint32_t total;
@@ -259,13 +307,14 @@ __global__ __launch_bounds__(256, PPT_GEN_WPE) void wf_generate_extend(
             }
             nHit += total;
         };
-        // Camera rays of an 8x8 tile are coherent: 64 of them in lockstep keep ~96 % of the lanes busy on C2 (0.73 on
-        // C3, 0.56 on C4: measured), so they skip the stream scheduler and its bookkeeping.  Running them through
-        // trace_stream() instead was measured slower on every configuration (profiles/r02_scheduler_experiments.txt:
-        // C2 365 -> 572 us, C3 1551 -> 1922, C4 7119 -> 9805, FlightHelmet 1438 -> 1562).
+        // Camera rays of a batch are coherent: 64 of them in lockstep keep ~96 % of the lanes busy on C2, so they skip the
+        // stream scheduler and its bookkeeping.  Running them through trace_stream() instead was measured slower on
+        // every configuration (profiles/r02_scheduler_experiments.txt: C2 365 -> 572 us, C3 1551 -> 1922, C4 7119 ->
+        // 9805, FlightHelmet 1438 -> 1562).
         for (uint32_t k0 = 0; k0 < w.segLen; k0 += 64u)
         {
             const uint32_t k = k0 + lane;
+            bl = batch_lane(w, p, (k0 >> 6) * w.nSeg + id.seg, lane);
             const StreamRay r = fetch(k);
             Hit hit;
             bool found;
@@ -274,21 +323,6 @@ __global__ __launch_bounds__(256, PPT_GEN_WPE) void wf_generate_extend(
             else
                 found = trace_in<false, COUNT>(gg, s, r.o, r.d, r.tMin, r.tMax, r.seed, stack, hit, cnt);
             commit(true, k, found, hit, r.d);
-            // nSeg tiles on: columns, rows, frames, with carries
-            batchSlot += w.nSeg * 64u;
-            tileX += stepCols;
-            if (tileX >= w.tilesX)
-            {
-                tileX -= w.tilesX;
-                ++tileY;
-            }
-            tileY += stepRows;
-            if (tileY >= w.tilesY)
-            {
-                tileY -= w.tilesY;
-                ++tileFrame;
-            }
-            tileFrame += stepFrames;
         }
     }
     if (lane == 0) w.segHits[id.seg] = nHit;
@@ -424,10 +458,8 @@ __global__ __launch_bounds__(256, PPT_SHADE_WPE) void wf_shade(
             const uint32_t i = w.hitIdx[id.base + j];
             const uint4 h = w.hit[id.base + j];
             const float4 b = w.rayB[cur][id.base + i];
-            // bounce 0: path i of the segment is lane i % 64 of the segment's tile number i / 64 (wf_generate_extend)
-            const float4 t = bounce == 0u
-                                 ? make_float4(1.0f, 1.0f, 1.0f, asf(((i >> 6) * w.nSeg + id.seg) * 64u + (i & 63u)))
-                                 : w.pathT[cur][id.base + i];
+            // bounce 0: no throughput record - it is (1, 1, 1) - and the slot rides in the direction record's spare word
+            const float4 t = bounce == 0u ? make_float4(1.0f, 1.0f, 1.0f, b.w) : w.pathT[cur][id.base + i];
             const uint4 r = w.pathR[cur][id.base + i];
             slot = asu(t.w) & kSlotMask;
             rng = Rng{r.x, r.y, r.z};
