@@ -272,14 +272,17 @@ int prosper_pt_update_lights(
     const prosper_PointLightsBuffer *pointLights, const prosper_SpotLightsBuffer *spotLights);
 /* New instance transforms for the uploaded scene (the whole ModelInstanceTransforms table, `count` = the scene's
  * modelInstanceCount; World::updateScene rewrites it every frame, World.cpp:359-466).  prosper then rebuilds its TLAS on
- * the GPU (World.cpp:749-802, 878-928).  Here (ABI 3) the update is a REFIT enqueued on a stream: the transform table,
- * the world-space triangles and new boxes for the unchanged tree (two small kernels per tree level) - no host-side build,
- * no device-wide synchronisation; it runs behind the renders already in flight and the renders that follow wait for it
- * inside the library.  Same pixels as a fresh prosper_pt_upload_scene of the moved scene (hits do not depend on the
- * hierarchy).  A refit cannot keep the tree good when instances travel far: each one leaves the tree's surface-area
- * measure behind, and when that has grown by 30 % (PROSPER_PT_REBUILD_COST_RATIO) over its value at the last build, the
- * next update also rebuilds - synchronously, like prosper_pt_rebuild_hierarchy.  prosper_pt_update_transforms uses the
- * null stream. */
+ * the GPU (World.cpp:749-802, 878-928).  Here (ABI 3) the update is a REFIT on the GPU: the transform table, the
+ * world-space triangles and new boxes for the unchanged tree (one small kernel per tree level + one over all nodes) - no
+ * host-side build, no device-wide synchronisation.  prosper_pt_update_transforms only STAGES the table (it returns in
+ * microseconds; an unchanged table is a no-op); the refit runs at the head of the next render's own chain of launches,
+ * into the next of three versions of the transform / triangle / node arrays - like the per-frame TLAS of a Vulkan frame
+ * loop - so the frames in flight (PROSPER_PT_RENDER_PIPELINED) go on reading theirs and nothing waits for them.
+ * prosper_pt_update_transforms_async with a non-null stream enqueues the refit on that stream right away instead.  Same
+ * pixels as a fresh prosper_pt_upload_scene of the moved scene (hits do not depend on the hierarchy).  A refit cannot keep
+ * the tree good when instances travel far: each one leaves the tree's surface-area measure behind, and when that has
+ * grown by 30 % (PROSPER_PT_REBUILD_COST_RATIO) over its value at the last build, the next update also rebuilds -
+ * synchronously, like prosper_pt_rebuild_hierarchy. */
 int prosper_pt_update_transforms(prosper_pt_ctx *ctx, const prosper_ModelInstanceTransforms *transforms, uint32_t count);
 int prosper_pt_update_transforms_async(
     prosper_pt_ctx *ctx, const prosper_ModelInstanceTransforms *transforms, uint32_t count, void *stream);

@@ -198,10 +198,18 @@ int upload_hierarchy(prosper_pt_ctx *ctx, const BvhBuildResult &bvh)
         const size_t capacity = nodeBytes + nodeBytes / 4 + 4096; // headroom: a rebuild changes the node count a little
         const int rc = device_alloc(ctx, capacity, &d);
         if (rc != PROSPER_PT_OK) return rc;
-        if (acc->dNodes) device_free(ctx, acc->dNodes); // (callers have synchronised the device: nothing reads it any more)
+        // (callers have synchronised the device: nothing reads the old arrays any more)
+        for (uint32_t ver = 0; ver < AccelState::kVersions; ++ver)
+            if (acc->dNodesV[ver])
+            {
+                device_free(ctx, acc->dNodesV[ver]);
+                acc->dNodesV[ver] = nullptr;
+            }
         acc->dNodes = static_cast<BvhNode *>(d);
+        acc->dNodesV[acc->cur] = acc->dNodes;
         acc->nodeCapacityBytes = capacity;
     }
+    for (uint32_t ver = 0; ver < AccelState::kVersions; ++ver) acc->nodesCurrent[ver] = ver == acc->cur;
     PPT_HIP(hipMemcpy(acc->dNodes, bvh.nodes.data(), nodeBytes, hipMemcpyHostToDevice));
     ctx->scene.nodes = acc->dNodes;
     if (acc->total)
@@ -481,6 +489,7 @@ int upload_scene_impl(prosper_pt_ctx *ctx, const prosper_pt_scene_view *v)
     acc->drawInstanceCount = v->drawInstanceCount;
     acc->transforms.assign(v->modelInstanceTransforms, v->modelInstanceTransforms + v->modelInstanceCount);
     ctx->dTransforms = const_cast<prosper_ModelInstanceTransforms *>(s.modelInstanceTransforms);
+    acc->dTransformsV[0] = ctx->dTransforms;
 
     // ---- what the any-hit shader reads: one 32-byte record per non-opaque triangle, one per material, and the
     //      materials' alpha bounds (pt_scene.hpp AlphaTriangle / AlphaMaterial) ----
@@ -562,6 +571,7 @@ int upload_scene_impl(prosper_pt_ctx *ctx, const prosper_pt_scene_view *v)
     if ((rc = device_alloc(ctx, triBytes, &dTris))) return rc;
     PPT_HIP(hipMemset(dTris, 0, triBytes));
     acc->dTris = static_cast<WorldTriangle *>(dTris);
+    acc->dTrisV[0] = acc->dTris;
     s.triangles = acc->dTris;
 
     launch_flatten_triangles(
@@ -893,11 +903,16 @@ int prosper_pt_update_lights(
 
 // The synchronous path: re-split the instances that moved since the last build, re-assemble, upload (what
 // prosper_pt_update_transforms did before the refit existed; prosper's own TLAS build is of this kind, on the GPU).
+static int flush_pending_update(prosper_pt_ctx *ctx, hipStream_t stream);
 static int rebuild_hierarchy_impl(prosper_pt_ctx *ctx)
 {
     AccelState *acc = ctx->accel;
     const auto t0 = std::chrono::steady_clock::now();
     PPT_HIP(hipSetDevice(ctx->device));
+    {
+        const int frc = flush_pending_update(ctx, nullptr); // the moved triangles must be in the flat array
+        if (frc != PROSPER_PT_OK) return frc;
+    }
     PPT_HIP(hipDeviceSynchronize()); // renders in flight read the old hierarchy
     acc->stale = true;               // until the new hierarchy is up
     bool any = false;
@@ -940,12 +955,83 @@ static float rebuild_cost_ratio()
 }
 
 // World::updateScene + the per-frame TLAS rebuild (World.cpp:359-466,749-802,878-928) as a REFIT: the new transforms, the
-// world triangles and new boxes for the unchanged tree, all enqueued on `stream` - no host build, no device-wide
-// synchronisation, nothing of the frames in flight is disturbed.  Hits do not depend on the hierarchy (hit contract), so
-// the image is the one a fresh upload gives.  What a refit cannot do is keep the tree GOOD when instances travel far:
-// every refit leaves the tree's surface-area measure behind, and once that has grown by 30 % over its value at the last
-// build the next update rebuilds (synchronously: prosper_pt_rebuild_hierarchy).
-static int update_transforms_impl(prosper_pt_ctx *ctx, const prosper_ModelInstanceTransforms *transforms, uint32_t count, hipStream_t stream)
+// world triangles and new boxes for the unchanged tree - no host build, no device-wide synchronisation.  Hits do not
+// depend on the hierarchy (hit contract), so the image is the one a fresh upload gives.  Two steps:
+//   stage_transforms      the call itself: which instances moved, the table into pinned staging; nothing on the GPU
+//   flush_pending_update  run by the next consumer of the scene on ITS stream - a pipelined render's own chain - into the
+//                         NEXT scene version: the frames in flight go on reading theirs, nothing waits for them
+// What a refit cannot do is keep the tree GOOD when instances travel far: every refit leaves the tree's surface-area
+// measure behind, and once that has grown by 30 % over its value at the last build the next update rebuilds
+// (synchronously: prosper_pt_rebuild_hierarchy).
+static int rebuild_hierarchy_impl(prosper_pt_ctx *ctx);
+
+static int flush_pending_update(prosper_pt_ctx *ctx, hipStream_t stream)
+{
+    AccelState *acc = ctx->accel;
+    if (!acc || !acc->pending) return PROSPER_PT_OK;
+    const uint32_t v = (acc->cur + 1u) % AccelState::kVersions;
+    const size_t transformBytes = sizeof(prosper_ModelInstanceTransforms) * (acc->pendingCount ? acc->pendingCount : 1);
+    const size_t triBytes = sizeof(WorldTriangle) * (size_t)(acc->total ? acc->total : 1);
+    void *d = nullptr;
+    int rc;
+    if (!acc->dTransformsV[v])
+    {
+        if ((rc = device_alloc(ctx, transformBytes, &d))) return rc;
+        acc->dTransformsV[v] = static_cast<prosper_ModelInstanceTransforms *>(d);
+    }
+    if (!acc->dTrisV[v])
+    {
+        if ((rc = device_alloc(ctx, triBytes, &d))) return rc;
+        acc->dTrisV[v] = static_cast<WorldTriangle *>(d);
+    }
+    if (!acc->dNodesV[v])
+    {
+        if ((rc = device_alloc(ctx, acc->nodeCapacityBytes, &d))) return rc;
+        acc->dNodesV[v] = static_cast<BvhNode *>(d);
+        acc->nodesCurrent[v] = false;
+    }
+    if (!acc->versionFree[v]) PPT_HIP(hipEventCreateWithFlags(&acc->versionFree[v], hipEventDisableTiming));
+    // from here on the context is in between two scenes until the last step has been enqueued
+    acc->stale = true;
+    // the version's last readers (three updates ago), and the previous update: it wrote the node array copied below,
+    // and it shares the flat triangle array and the bounds scratch with this one
+    if (acc->versionUsed[v]) PPT_HIP(hipStreamWaitEvent(stream, acc->versionFree[v], 0));
+    if (acc->sceneEventRecorded) PPT_HIP(hipStreamWaitEvent(stream, acc->sceneEvent, 0));
+    if (!acc->nodesCurrent[v])
+    {
+        PPT_HIP(hipMemcpyAsync(acc->dNodesV[v], acc->dNodes, (size_t)acc->nodeCount * sizeof(BvhNode), hipMemcpyDeviceToDevice, stream));
+        acc->nodesCurrent[v] = true;
+    }
+    const uint32_t k = acc->pendingStaging;
+    PPT_HIP(hipMemcpyAsync(acc->dTransformsV[v], acc->staging[k], sizeof(prosper_ModelInstanceTransforms) * acc->pendingCount, hipMemcpyHostToDevice, stream));
+    PPT_HIP(hipEventRecord(acc->stagingDone[k], stream));
+    acc->stagingUsed[k] = true;
+    // the new version becomes the scene
+    acc->cur = v;
+    acc->dNodes = acc->dNodesV[v];
+    acc->dTris = acc->dTrisV[v];
+    ctx->dTransforms = acc->dTransformsV[v];
+    ctx->scene.nodes = acc->dNodes;
+    ctx->scene.triangles = acc->dTris;
+    ctx->scene.modelInstanceTransforms = ctx->dTransforms;
+    // world-space triangles again, in both orders (the shading and any-hit records hold object-space attributes and stay
+    // as they are), then the boxes.  (Also when only transforms of instances without geometry changed: a version must be
+    // whole.)
+    launch_flatten_triangles(
+        ctx->scene, acc->dOffsets, acc->drawInstanceCount, acc->dFlags, acc->dFlat, nullptr, nullptr, (uint32_t)acc->total, stream,
+        acc->dLeafPosition, acc->dTris);
+    PPT_HIP(hipGetLastError());
+    acc->flatStale = true;
+    if ((rc = enqueue_refit(ctx, stream))) return rc;
+    acc->refits++;
+    PPT_HIP(hipEventRecord(acc->sceneEvent, stream));
+    acc->sceneEventRecorded = true;
+    acc->pending = false;
+    acc->stale = false;
+    return PROSPER_PT_OK;
+}
+
+static int stage_transforms(prosper_pt_ctx *ctx, const prosper_ModelInstanceTransforms *transforms, uint32_t count)
 {
     AccelState *acc = ctx->accel;
     const auto t0 = std::chrono::steady_clock::now();
@@ -968,49 +1054,34 @@ static int update_transforms_impl(prosper_pt_ctx *ctx, const prosper_ModelInstan
         acc->costPending = false;
         if (acc->builtCost > 0.0f) acc->lastCostRatio = *acc->hCost / acc->builtCost;
     }
-    // everything enqueued so far reads the old scene: the update goes behind the renders in flight ...
-    for (RenderSlot &slot : ctx->slots)
-        if (slot.freeRecorded) PPT_HIP(hipStreamWaitEvent(stream, slot.free, 0));
-    const uint32_t k = acc->stagingNext;
-    acc->stagingNext ^= 1u;
+    // into pinned staging (a pageable source would make the later copy synchronous).  An update that was never consumed
+    // is simply replaced: its staging buffer is reused.
+    const uint32_t k = acc->pending ? acc->pendingStaging : acc->stagingNext;
+    if (!acc->pending) acc->stagingNext ^= 1u;
     if (!acc->staging[k])
     {
         PPT_HIP(hipHostMalloc((void **)&acc->staging[k], sizeof(prosper_ModelInstanceTransforms) * (count ? count : 1), hipHostMallocDefault));
         PPT_HIP(hipEventCreateWithFlags(&acc->stagingDone[k], hipEventDisableTiming));
     }
     if (acc->stagingUsed[k]) PPT_HIP(hipEventSynchronize(acc->stagingDone[k])); // the copy of two updates ago
+    acc->stagingUsed[k] = false;
     std::memcpy(acc->staging[k], transforms, sizeof(prosper_ModelInstanceTransforms) * count);
-    // from here on the device state is in between two scenes until the last step has been enqueued
-    acc->stale = true;
-    PPT_HIP(hipMemcpyAsync(ctx->dTransforms, acc->staging[k], sizeof(prosper_ModelInstanceTransforms) * count, hipMemcpyHostToDevice, stream));
-    PPT_HIP(hipEventRecord(acc->stagingDone[k], stream));
-    acc->stagingUsed[k] = true;
-    if (any)
-    {
-        // world-space triangles again, in both orders (the shading and any-hit records hold object-space attributes and
-        // stay as they are), then the boxes
-        launch_flatten_triangles(
-            ctx->scene, acc->dOffsets, acc->drawInstanceCount, acc->dFlags, acc->dFlat, nullptr, nullptr, (uint32_t)acc->total,
-            stream, acc->dLeafPosition, acc->dTris);
-        PPT_HIP(hipGetLastError());
-        acc->flatStale = true;
-        const int rc = enqueue_refit(ctx, stream);
-        if (rc != PROSPER_PT_OK) return rc;
-        acc->refits++;
-    }
-    // ... and the renders to come behind the update
-    PPT_HIP(hipEventRecord(acc->sceneEvent, stream));
-    acc->sceneEventRecorded = true;
+    acc->pending = true;
+    acc->pendingStaging = k;
+    acc->pendingCount = count;
     acc->transforms.assign(transforms, transforms + count);
-    acc->stale = false;
     ctx->stats.bvhBuildSeconds = 0.0;
     ctx->stats.buildSeconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     if (any && (acc->lastCostRatio > rebuild_cost_ratio() || std::getenv("PROSPER_PT_DEBUG_ALWAYS_REBUILD")))
-    {
-        const int rc = rebuild_hierarchy_impl(ctx);
-        if (rc != PROSPER_PT_OK) return rc;
-    }
+        return rebuild_hierarchy_impl(ctx);
     return PROSPER_PT_OK;
+}
+
+static int update_transforms_impl(prosper_pt_ctx *ctx, const prosper_ModelInstanceTransforms *transforms, uint32_t count, hipStream_t stream, bool flushNow)
+{
+    const int rc = stage_transforms(ctx, transforms, count);
+    if (rc != PROSPER_PT_OK || !flushNow) return rc;
+    return flush_pending_update(ctx, stream);
 }
 
 static int check_update_arguments(prosper_pt_ctx *ctx, const prosper_ModelInstanceTransforms *transforms, uint32_t count)
@@ -1025,14 +1096,16 @@ static int check_update_arguments(prosper_pt_ctx *ctx, const prosper_ModelInstan
 int prosper_pt_update_transforms(prosper_pt_ctx *ctx, const prosper_ModelInstanceTransforms *transforms, uint32_t count)
 {
     const int rc = check_update_arguments(ctx, transforms, count);
-    return rc != PROSPER_PT_OK ? rc : update_transforms_impl(ctx, transforms, count, nullptr);
+    return rc != PROSPER_PT_OK ? rc : update_transforms_impl(ctx, transforms, count, nullptr, false);
 }
 
 int prosper_pt_update_transforms_async(
     prosper_pt_ctx *ctx, const prosper_ModelInstanceTransforms *transforms, uint32_t count, void *stream)
 {
+    // `stream`: where the refit runs when the caller wants it enqueued NOW (PROSPER_PT_UPDATE_NOW semantics of the header);
+    // a null stream argument defers it to the next render's own chain like prosper_pt_update_transforms
     const int rc = check_update_arguments(ctx, transforms, count);
-    return rc != PROSPER_PT_OK ? rc : update_transforms_impl(ctx, transforms, count, static_cast<hipStream_t>(stream));
+    return rc != PROSPER_PT_OK ? rc : update_transforms_impl(ctx, transforms, count, static_cast<hipStream_t>(stream), stream != nullptr);
 }
 
 int prosper_pt_rebuild_hierarchy(prosper_pt_ctx *ctx)
@@ -1048,6 +1121,10 @@ int prosper_pt_get_hierarchy_state(prosper_pt_ctx *ctx, prosper_pt_hierarchy_sta
     if (!ctx->haveScene || !ctx->accel) return fail(PROSPER_PT_ERR_NO_SCENE, "no scene uploaded");
     AccelState *acc = ctx->accel;
     PPT_HIP(hipSetDevice(ctx->device));
+    {
+        const int frc = flush_pending_update(ctx, nullptr);
+        if (frc != PROSPER_PT_OK) return frc;
+    }
     if (acc->costPending)
     {
         PPT_HIP(hipEventSynchronize(acc->costEvent));
@@ -1070,6 +1147,10 @@ int prosper_pt_debug_read_nodes(prosper_pt_ctx *ctx, void *out, size_t byte_size
     const size_t bytes = (size_t)ctx->accel->nodeCount * sizeof(BvhNode);
     if (byte_size < bytes) return fail(PROSPER_PT_ERR_INVALID_ARGUMENT, "prosper_pt_debug_read_nodes: destination too small");
     PPT_HIP(hipSetDevice(ctx->device));
+    {
+        const int frc = flush_pending_update(ctx, nullptr);
+        if (frc != PROSPER_PT_OK) return frc;
+    }
     PPT_HIP(hipDeviceSynchronize());
     PPT_HIP(hipMemcpy(out, ctx->accel->dNodes, bytes, hipMemcpyDeviceToHost));
     return PROSPER_PT_OK;
@@ -1109,7 +1190,7 @@ int prosper_pt_render_frames(
 {
     if (!ctx || !pc || !camera) return fail(PROSPER_PT_ERR_INVALID_ARGUMENT, "prosper_pt_render: null argument");
     if (!ctx->haveScene) return fail(PROSPER_PT_ERR_NO_SCENE, "prosper_pt_render called before prosper_pt_upload_scene");
-    if (ctx->accel && ctx->accel->stale)
+    if (ctx->accel && ctx->accel->stale && !ctx->accel->pending) // (a staged update gets its chance below)
         return fail(PROSPER_PT_ERR_NO_SCENE, "the last prosper_pt_update_transforms failed: update the transforms again (or upload the scene) before rendering");
     if (width == 0 || height == 0 || frame_count == 0)
         return fail(PROSPER_PT_ERR_INVALID_ARGUMENT, "prosper_pt_render: empty extent or frame count");
@@ -1150,8 +1231,6 @@ int prosper_pt_render_frames(
     // accumulate kernel, which writes the tile, is enqueued on `s` and must come after it; detached path stages
     // (PROSPER_PT_RENDER_PIPELINED) do not wait for `s` and overlap the gather
     wait_for_gather_before_writing_tile(ctx, s);
-    // a refit of moved instances may still be on its way on another stream (prosper_pt_update_transforms_async)
-    if (ctx->accel && ctx->accel->sceneEventRecorded) PPT_HIP(hipStreamWaitEvent(s, ctx->accel->sceneEvent, 0));
 
     RenderParams p = {};
     p.pc = *pc;
@@ -1189,6 +1268,19 @@ int prosper_pt_render_frames(
     timer.stage = ctx->eventStage;
     timer.capacity = prosper_pt_ctx::kMaxTimedLaunches;
     LaunchTimer *tp = ctx->kernelTiming ? &timer : nullptr;
+    // a staged prosper_pt_update_transforms runs now, on the stream this render's path stages use: a pipelined render's own
+    // chain (beside the frames in flight, which keep reading their scene version), else the caller's stream
+    const bool wavefrontPipelined = !(ctx->flags & (PROSPER_PT_CREATE_MEGAKERNEL | PROSPER_PT_CREATE_PERSISTENT)) &&
+                                    (render_flags & PROSPER_PT_RENDER_PIPELINED) != 0 && !countWork;
+    {
+        const uint32_t nextSlot = wavefrontPipelined ? (ctx->lastSlot + 1u) % prosper_pt_ctx::kRenderSlots : 0u;
+        hipStream_t us = wavefrontPipelined ? ctx->workStreams[nextSlot] : s;
+        const int frc = flush_pending_update(ctx, us);
+        if (frc != PROSPER_PT_OK) return frc;
+        // a refit enqueued on another stream (another render's chain, or prosper_pt_update_transforms_async) must be
+        // done before anything on the caller's stream reads the scene
+        if (ctx->accel && ctx->accel->sceneEventRecorded) PPT_HIP(hipStreamWaitEvent(s, ctx->accel->sceneEvent, 0));
+    }
     if (ctx->flags & PROSPER_PT_CREATE_MEGAKERNEL)
     {
         int32_t *ovf = nullptr;
@@ -1276,6 +1368,15 @@ int prosper_pt_render_frames(
         if (tp) ctx->timedSlot = slotIndex;
     }
     PPT_HIP(hipGetLastError());
+    if (ctx->accel)
+    {
+        // the scene version this render read is free again behind its last kernel (the accumulate kernel follows the
+        // path stages on the caller's stream)
+        AccelState *acc = ctx->accel;
+        if (!acc->versionFree[acc->cur]) PPT_HIP(hipEventCreateWithFlags(&acc->versionFree[acc->cur], hipEventDisableTiming));
+        PPT_HIP(hipEventRecord(acc->versionFree[acc->cur], s));
+        acc->versionUsed[acc->cur] = true;
+    }
     if (tp)
     {
         tp->close(s);
@@ -1348,12 +1449,17 @@ int prosper_pt_restir_di_trace(
     if (!ctx || !pc || !camera || !in || !in->albedoRoughness || !in->normalMetallic || !in->nonLinearDepth || !in->reservoirs)
         return fail(PROSPER_PT_ERR_INVALID_ARGUMENT, "prosper_pt_restir_di_trace: null argument");
     if (!ctx->haveScene) return fail(PROSPER_PT_ERR_NO_SCENE, "prosper_pt_restir_di_trace called before prosper_pt_upload_scene");
-    if (ctx->accel && ctx->accel->stale)
+    if (ctx->accel && ctx->accel->stale && !ctx->accel->pending)
         return fail(PROSPER_PT_ERR_NO_SCENE, "the last prosper_pt_update_transforms failed: update the transforms again (or upload the scene) before tracing");
     if (width == 0 || height == 0) return fail(PROSPER_PT_ERR_INVALID_ARGUMENT, "prosper_pt_restir_di_trace: empty extent");
     if (pc->drawType >= PROSPER_DRAW_TYPE_COUNT) return fail(PROSPER_PT_ERR_INVALID_ARGUMENT, "drawType out of range");
     PPT_HIP(hipSetDevice(ctx->device));
     hipStream_t s = static_cast<hipStream_t>(stream);
+    {
+        const int frc = flush_pending_update(ctx, s);
+        if (frc != PROSPER_PT_OK) return frc;
+        if (ctx->accel && ctx->accel->sceneEventRecorded) PPT_HIP(hipStreamWaitEvent(s, ctx->accel->sceneEvent, 0));
+    }
     const size_t pixels = (size_t)width * height;
     const size_t bytes = pixels * sizeof(float4);
     if (ctx->externalHdr)

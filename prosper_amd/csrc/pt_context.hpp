@@ -71,6 +71,23 @@ struct AccelState
     bool sceneEventRecorded = false;
     uint32_t refits = 0, rebuilds = 0;
 
+    // ---- scene versions: what a refit rewrites - transform table, leaf-order triangles, nodes - exists up to three
+    // times, like the per-frame TLAS / instance buffers of a Vulkan frame loop: an update writes the NEXT version while
+    // the frames in flight go on reading theirs.  dNodes / dTris / ctx->dTransforms alias version `cur`.  The other
+    // versions are allocated by the first update that needs them. ----
+    static constexpr uint32_t kVersions = 3;
+    WorldTriangle *dTrisV[kVersions] = {};
+    BvhNode *dNodesV[kVersions] = {};
+    prosper_ModelInstanceTransforms *dTransformsV[kVersions] = {};
+    bool nodesCurrent[kVersions] = {}; // the version's node array holds the tree of the last build (child references)
+    hipEvent_t versionFree[kVersions] = {}; // behind the last render that read the version
+    bool versionUsed[kVersions] = {};
+    uint32_t cur = 0;
+    // an update waits here until the next consumer of the scene - normally the next render, which runs it at the head of
+    // its own chain of launches, beside the frames in flight
+    bool pending = false, pendingGeometry = false;
+    uint32_t pendingStaging = 0, pendingCount = 0;
+
     ~AccelState()
     {
         for (int i = 0; i < 2; ++i)
@@ -81,6 +98,8 @@ struct AccelState
         if (hCost) (void)hipHostFree(hCost);
         if (costEvent) (void)hipEventDestroy(costEvent);
         if (sceneEvent) (void)hipEventDestroy(sceneEvent);
+        for (hipEvent_t e : versionFree)
+            if (e) (void)hipEventDestroy(e);
     }
 };
 
