@@ -212,6 +212,9 @@ int main(int argc, char **argv)
         area.height = height;
         for (uint32_t f = 0; f < frames; ++f)
         {
+            // App::drawFrame: the scene's transforms every frame, then the acceleration structures, then the pass
+            // (App.cpp:516-578).  Nothing moves here: the update is a no-op, as it is on most of prosper's frames.
+            world.updateScene(pass.pass().context(), transforms, 3);
             camera.updateBuffer();
             (void)pass.record(nullptr, world, camera, area, options, f & 1u, 1, PROSPER_PT_RENDER_PIPELINED);
             camera.endFrame();

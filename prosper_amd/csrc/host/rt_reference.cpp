@@ -39,6 +39,13 @@ void World::buildAccelerationStructures(prosper_pt_ctx *ctx)
     m_dirty = false;
 }
 
+void World::updateScene(prosper_pt_ctx *ctx, const prosper_ModelInstanceTransforms *transforms, uint32_t count)
+{
+    PROSPER_ASSERT(uploadedTo(ctx));
+    if (prosper_pt_update_transforms(ctx, transforms, count) != PROSPER_PT_OK)
+        throw std::runtime_error(std::string("World::updateScene: ") + prosper_pt_last_error());
+}
+
 } // namespace scene
 
 namespace render

@@ -32,6 +32,10 @@ class World
     // Uploads scene + builds the BVH on `ctx` when the view changed since the last build.
     // Throws std::runtime_error on failure.
     void buildAccelerationStructures(prosper_pt_ctx *ctx);
+    // World::updateScene + the per-frame TLAS build (src/scene/World.cpp:359-466,749-802,878-928; App.cpp:516-578 calls
+    // them every frame): the whole transform table of the uploaded scene.  Cheap to call unconditionally - an unchanged
+    // table is a no-op, a changed one a GPU refit run by the next record().  Throws std::runtime_error on failure.
+    void updateScene(prosper_pt_ctx *ctx, const prosper_ModelInstanceTransforms *transforms, uint32_t count);
     [[nodiscard]] bool uploadedTo(const prosper_pt_ctx *ctx) const { return m_ctx == ctx && !m_dirty; }
 
   private:
