@@ -862,6 +862,7 @@ void launch_render_wavefront(
     LaunchTimer *timer, const WavefrontChains &chains, hipStream_t stream)
 {
     if (w.nSeg == 0) return;
+    static const bool graphExperiment = std::getenv("PROSPER_PT_DEBUG_GRAPH") != nullptr;
     static_assert(kTraversalStackDepth == 32, "largest LDS stack variant");
     const uint32_t groups = (w.nSeg + 3u) / 4u;
     // Two chains only pay when each still fills the machine a few times over (>= 1024 workgroups each).
@@ -886,6 +887,33 @@ void launch_render_wavefront(
         int32_t *ovf = stackOverflow ? stackOverflow + (size_t)blocksBefore * plan.scratchDwordsPerBlock : nullptr;
         if (countWork)
             enqueue_for_stack<true>(s, p, counters, part, plan, ovf, nodeCount, triCount, ct, cs);
+        else if (graphExperiment && !ct)
+        {
+            // EXPERIMENT (PROSPER_PT_DEBUG_GRAPH=1, profiles/r03_hip_graph.txt): the chain's launches captured into a HIP
+            // graph and submitted as one; captured and instantiated anew every time (the kernel arguments change with
+            // every frame), so only the DEVICE side of the comparison means anything
+            static thread_local hipGraphExec_t previous[8] = {};
+            static thread_local uint32_t turn = 0;
+            hipGraph_t graph = nullptr;
+            hipGraphExec_t exec = nullptr;
+            bool ok = hipStreamBeginCapture(cs, hipStreamCaptureModeRelaxed) == hipSuccess;
+            if (ok)
+            {
+                enqueue_for_stack<false>(s, p, counters, part, plan, ovf, nodeCount, triCount, nullptr, cs);
+                ok = hipStreamEndCapture(cs, &graph) == hipSuccess && graph != nullptr;
+            }
+            if (ok) ok = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) == hipSuccess;
+            if (ok) ok = hipGraphLaunch(exec, cs) == hipSuccess;
+            if (graph) (void)hipGraphDestroy(graph);
+            if (!ok)
+            {
+                (void)hipGetLastError();
+                enqueue_for_stack<false>(s, p, counters, part, plan, ovf, nodeCount, triCount, ct, cs);
+            }
+            // an executable graph may go once its launch has finished: eight launches later it has
+            if (previous[turn & 7u]) (void)hipGraphExecDestroy(previous[turn & 7u]);
+            previous[turn++ & 7u] = ok ? exec : nullptr;
+        }
         else
             enqueue_for_stack<false>(s, p, counters, part, plan, ovf, nodeCount, triCount, ct, cs);
         blocksBefore += ((part.groupCount + 7u) / 8u) * 8u;

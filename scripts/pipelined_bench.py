@@ -47,10 +47,11 @@ def main():
                 t0 = time.perf_counter()
                 for _ in range(steps):
                     ctx.render(pc, cam, width, height, frames=SPP, tile=tile, flags=render_flags)
+                host_ms = (time.perf_counter() - t0) / steps * 1e3  # until the calls have returned: the host's share
                 hip.hipDeviceSynchronize()
                 ms = (time.perf_counter() - t0) / steps * 1e3
-                print("%s ranks %d %-9s: %.3f ms/frame  %.0f Mpaths/s" % (
-                    name, ranks, label, ms, width * height * SPP / ranks / ms / 1e3), flush=True)
+                print("%s ranks %d %-9s: %.3f ms/frame  %.0f Mpaths/s  (host %.3f ms/frame)" % (
+                    name, ranks, label, ms, width * height * SPP / ranks / ms / 1e3, host_ms), flush=True)
         ctx.close()
 
 
