@@ -34,6 +34,15 @@
 #ifndef PPT_CONTINUE
 #define PPT_CONTINUE(c, c0, other) (3u * (c) > (c0))
 #endif
+// The any-hit phase (rt/scene.rahit on the lanes holding a non-opaque candidate) used to run when those lanes
+// outnumbered the node and triangle lanes.  Since the alpha bounds settle most candidates in a few dozen instructions the
+// phase is cheap, and a lane it returns to the triangle phase early is worth more than a fuller any-hit step: it runs
+// once a quarter as many lanes wait for it as for the fullest other phase.  wf_trace on C4, alone: 6603 us (a > best),
+// 6291 (2a), 6223 (4a, kept), 6250 (8a), 6316 (16a), 6350 (a > 0); FlightHelmet 381 -> 365; C2 unchanged
+// (profiles/r03_alpha_bounds.txt).
+#ifndef PPT_ANY_BEATS
+#define PPT_ANY_BEATS(a, best) (4u * (a) > (best))
+#endif
 
 namespace ppt
 {
@@ -126,7 +135,7 @@ PPT_D void trace_stream(
             best = nTri;
             pick = kLaneTri;
         }
-        if (nAny > best)
+        if (PPT_ANY_BEATS(nAny, best))
         {
             best = nAny;
             pick = kLaneAny;

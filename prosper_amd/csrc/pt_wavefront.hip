@@ -385,13 +385,14 @@ __device__ __forceinline__ void extend_segment(
 // per hit through the 16 KB vector L1, which keeps evicting them otherwise (an L2 round trip per table on the
 // dependent chain hit -> instance -> material / transform -> light).
 constexpr uint32_t kLdsTableBytes = 16u * 1024u;
-__host__ __device__ inline uint32_t shade_table_bytes(const DeviceScene &s)
+__host__ __device__ inline uint32_t shade_table_bytes(const DeviceScene &s, bool withLights)
 {
-    return s.drawInstanceCount * (uint32_t)sizeof(prosper_DrawInstance) +
-           s.modelInstanceCount * (uint32_t)sizeof(prosper_ModelInstanceTransforms) +
-           s.materialCount * (uint32_t)(sizeof(prosper_MaterialData) + sizeof(MaterialPack)) +
-           s.pointLightCount * (uint32_t)sizeof(prosper_PointLight) +
-           s.spotLightCount * (uint32_t)sizeof(prosper_SpotLight) + (uint32_t)sizeof(prosper_DirectionalLightParameters) + 64u;
+    const uint32_t scene = s.drawInstanceCount * (uint32_t)sizeof(prosper_DrawInstance) +
+                           s.modelInstanceCount * (uint32_t)sizeof(prosper_ModelInstanceTransforms) +
+                           s.materialCount * (uint32_t)(sizeof(prosper_MaterialData) + sizeof(MaterialPack)) +
+                           (uint32_t)sizeof(prosper_DirectionalLightParameters) + 64u;
+    const uint32_t lights = s.pointLightCount * (uint32_t)sizeof(prosper_PointLight) + s.spotLightCount * (uint32_t)sizeof(prosper_SpotLight);
+    return scene + (withLights ? lights : 0u);
 }
 // copies `bytes` (a multiple of 4) from global memory to the next 16-byte aligned LDS offset
 __device__ __forceinline__ const void *stage_table(uint32_t *lds, uint32_t &offsetWords, const void *src, uint32_t bytes)
@@ -405,13 +406,15 @@ __device__ __forceinline__ const void *stage_table(uint32_t *lds, uint32_t &offs
     return dst;
 }
 
-template <bool COUNT, bool LDS_TABLES, bool BATCHED_TEXTURES>
+// LDS_TABLES: 0 = every table from global memory, 1 = all of them staged in LDS, 2 = all but the light lists (a
+// compile-time choice: a pointer that may be either makes every access through it a flat one)
+template <bool COUNT, int LDS_TABLES, bool BATCHED_TEXTURES>
 __global__ __launch_bounds__(256, PPT_SHADE_WPE) void wf_shade(
     DeviceScene s, RenderParams p, WavefrontBuffers w, uint32_t bounce, uint32_t cur, uint32_t lastBounce,
     unsigned long long *__restrict__ counters)
 {
-    __shared__ uint32_t ldsTables[LDS_TABLES ? kLdsTableBytes / 4u : 4u];
-    if constexpr (LDS_TABLES)
+    __shared__ uint32_t ldsTables[LDS_TABLES != 0 ? kLdsTableBytes / 4u : 4u];
+    if constexpr (LDS_TABLES != 0)
     {
         uint32_t off = 0;
         s.drawInstances = static_cast<const prosper_DrawInstance *>(
@@ -424,11 +427,15 @@ __global__ __launch_bounds__(256, PPT_SHADE_WPE) void wf_shade(
             stage_table(ldsTables, off, s.materialPacks, s.materialCount * (uint32_t)sizeof(MaterialPack)));
         s.directionalLight = static_cast<const prosper_DirectionalLightParameters *>(
             stage_table(ldsTables, off, s.directionalLight, (uint32_t)sizeof(prosper_DirectionalLightParameters)));
-        // only the first `count` lights of each list are ever indexed (sample_light)
-        s.pointLights = static_cast<const prosper_PointLightsBuffer *>(
-            stage_table(ldsTables, off, s.pointLights, s.pointLightCount * (uint32_t)sizeof(prosper_PointLight)));
-        s.spotLights = static_cast<const prosper_SpotLightsBuffer *>(
-            stage_table(ldsTables, off, s.spotLights, s.spotLightCount * (uint32_t)sizeof(prosper_SpotLight)));
+        // only the first `count` lights of each list are ever indexed (sample_light); a thousand lights (C4: 40 KB) do not
+        // fit beside the rest and stay in global memory - the instance / transform / material chain still comes from LDS
+        if constexpr (LDS_TABLES == 1)
+        {
+            s.pointLights = static_cast<const prosper_PointLightsBuffer *>(
+                stage_table(ldsTables, off, s.pointLights, s.pointLightCount * (uint32_t)sizeof(prosper_PointLight)));
+            s.spotLights = static_cast<const prosper_SpotLightsBuffer *>(
+                stage_table(ldsTables, off, s.spotLights, s.spotLightCount * (uint32_t)sizeof(prosper_SpotLight)));
+        }
         __syncthreads();
     }
     const SegmentId id = my_segment(w);
@@ -754,12 +761,12 @@ static void enqueue_wavefront(
         const uint32_t cur = b & 1u;
         const uint32_t last = (b + 1u == bounces) ? 1u : 0u;
         mark(kStageShade);
-        const bool ldsTables = wavefront_shade_tables_in_lds(s);
+        const int ldsTables = !wavefront_shade_tables_in_lds(s) ? 0 : (shade_table_bytes(s, true) <= kLdsTableBytes ? 1 : 2);
         auto shade = [&](auto kernel) { hipLaunchKernelGGL(kernel, grid, block, 0, stream, s, p, w, b, cur, last, cShade); };
         if (s.batchedTextures)
-            ldsTables ? shade(wf_shade<COUNT, true, true>) : shade(wf_shade<COUNT, false, true>);
+            ldsTables == 1 ? shade(wf_shade<COUNT, 1, true>) : (ldsTables == 2 ? shade(wf_shade<COUNT, 2, true>) : shade(wf_shade<COUNT, 0, true>));
         else
-            ldsTables ? shade(wf_shade<COUNT, true, false>) : shade(wf_shade<COUNT, false, false>);
+            ldsTables == 1 ? shade(wf_shade<COUNT, 1, false>) : (ldsTables == 2 ? shade(wf_shade<COUNT, 2, false>) : shade(wf_shade<COUNT, 0, false>));
         if (!debugDraw)
         {
             mark(kStageTrace);
@@ -800,7 +807,7 @@ uint32_t wavefront_lds_stack_entries(uint32_t stackBound)
 // test of a variant can assert it is the one that ran).
 bool wavefront_shade_tables_in_lds(const DeviceScene &s)
 {
-    return shade_table_bytes(s) <= kLdsTableBytes && !std::getenv("PROSPER_PT_DEBUG_NO_LDS_TABLES");
+    return shade_table_bytes(s, false) <= kLdsTableBytes && !std::getenv("PROSPER_PT_DEBUG_NO_LDS_TABLES");
 }
 bool wavefront_scene_in_lds(uint32_t ldsStackEntries, uint32_t nodeCount, uint32_t triCount)
 {

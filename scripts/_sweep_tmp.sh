@@ -1,5 +1,2 @@
-python scripts/pipelined_bench.py c2 | grep "ranks 8"
-SPP=1 python scripts/pipelined_bench.py c2 | grep "ranks 1 "
-echo "== PROSPER_PT_DEBUG_GRAPH=1"
-PROSPER_PT_DEBUG_GRAPH=1 python scripts/pipelined_bench.py c2 | grep "ranks 8"
-SPP=1 PROSPER_PT_DEBUG_GRAPH=1 python scripts/pipelined_bench.py c2 | grep "ranks 1 "
+for c in c2 c3 c4 helmet; do python scripts/quick_bench.py --config $c --single-chain --steps 6 | tail -2; done
+python scripts/pipelined_bench.py helmet c3 c4 | grep pipelined

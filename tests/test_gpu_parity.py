@@ -807,10 +807,19 @@ def test_lds_staged_tables_equal_global_memory_tables(gpu_ctx, oracle, monkeypat
         want, _ = osc.render(default_pc(S, fl, frame_index=frame, max_bounces=4, ibl=True, skip_history=(frame == 1)),
                              cam, w, h, history=want)
     assert same_bits(base, want).all()
-    # and C4's 1024 lights (40 KB of light tables) take the global-memory variant
+    # C4's 1024 lights (40 KB of light tables) do not fit: they stay in global memory while the instance / transform /
+    # material tables are staged (the third variant of the kernel) - same bits again
     big = scenes.sponza_class(lights=True, foliage=False, texture_size=64, sky_size=32, detail=0.25)
+    cam, fl = _camera(oracle, big, w, h)
+    pc = default_pc(S, fl, max_bounces=4, ibl=True)
     gpu_ctx.upload_scene(big)
-    assert not (gpu_ctx.scene_stats().variantFlags & S.VARIANT_LDS_TABLES)
+    assert gpu_ctx.scene_stats().variantFlags & S.VARIANT_LDS_TABLES
+    gpu_ctx.render(pc, cam, w, h, frames=2)
+    staged = gpu_ctx.read_hdr()
+    monkeypatch.setenv("PROSPER_PT_DEBUG_NO_LDS_TABLES", "1")
+    gpu_ctx.render(pc, cam, w, h, frames=2)
+    monkeypatch.delenv("PROSPER_PT_DEBUG_NO_LDS_TABLES")
+    assert same_bits(gpu_ctx.read_hdr(), staged).all()
 
 
 def test_texture_packs_equal_separate_textures(gpu_ctx, oracle, sponza_small, monkeypatch):
@@ -963,6 +972,32 @@ def test_refit_writes_the_emitters_bytes(gpu_ctx, monkeypatch):
         differing = np.argwhere(emitted != refitted)
         assert differing.size == 0, "node %d word %d: emitter %08x, refit %08x" % (
             differing[0][0], differing[0][1], emitted[tuple(differing[0])], refitted[tuple(differing[0])])
+
+
+def test_refit_of_a_flat_tree_and_of_alpha_geometry(gpu_ctx, oracle, monkeypatch):
+    """The refit does not care how the tree was built: on the one-tree-over-everything hierarchy (PROSPER_PT_DEBUG_FLAT_BVH)
+    moved instances give the oracle's image of the moved scene too - here on the instance-transform zoo (mirrors, shears,
+    non-uniform scales) and with MASK / BLEND quads among the movers (their any-hit records are object-space and stay)."""
+    from prosper_amd.world import rotate_z, translate
+    monkeypatch.setenv("PROSPER_PT_DEBUG_FLAT_BVH", "1")
+    for builder, picks in ((scenes.transform_zoo, (1, 4, 6)), (scenes.alpha_wall, (0, 3, 17, 30))):
+        still, moved = builder(), builder()
+        for k in picks:
+            model, m = moved.model_instances[k]
+            moved.model_instances[k] = (model, translate((0.3, -0.2, 0.25)) @ rotate_z(0.4) @ m)
+        w, h = 256, 160
+        cam, fl = _camera(oracle, still, w, h)
+        gpu_ctx.upload_scene(still)
+        gpu_ctx.update_transforms(moved)
+        want = None
+        osc = oracle.OracleScene(moved, brute_force=True)
+        for frame in (1, 2):
+            pc = default_pc(S, fl, frame_index=frame, max_bounces=3, skip_history=(frame == 1))
+            gpu_ctx.render(pc, cam, w, h)
+            want, _ = osc.render(pc, cam, w, h, history=want)
+        assert gpu_ctx.hierarchy_state().refits == 1
+        ok = same_bits(gpu_ctx.read_hdr(), want).all(axis=2)
+        assert ok.all(), "%s: %d of %d pixels differ" % (builder.__name__, (~ok).sum(), ok.size)
 
 
 def test_moving_instances_between_frames_in_flight(gpu_ctx, oracle):
