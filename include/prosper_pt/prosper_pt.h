@@ -266,7 +266,9 @@ void prosper_pt_destroy(prosper_pt_ctx *ctx);
 /* Copies the whole scene to HBM, flattens instances x triangles into world space from the
  * fp16 positions (the BVH must see the decoded halfs: World.cpp:635-644) and builds the BVH. */
 int prosper_pt_upload_scene(prosper_pt_ctx *ctx, const prosper_pt_scene_view *scene);
-/* Re-uploads the three light buffers only (they are rewritten every frame: World.cpp:531-535). */
+/* The three light buffers only (prosper rewrites them every frame: World.cpp:531-535).  An unchanged set costs a memcmp.
+ * A changed one is staged by the call and copied by the next render at the head of its own chain of launches into the
+ * next of three device versions (ABI 3): the frames in flight keep theirs, nothing synchronises the device. */
 int prosper_pt_update_lights(
     prosper_pt_ctx *ctx, const prosper_DirectionalLightParameters *directionalLight,
     const prosper_PointLightsBuffer *pointLights, const prosper_SpotLightsBuffer *spotLights);

@@ -187,6 +187,7 @@ class Context:
         self._world = world
 
     def update_lights(self, world):
+        world.freeze()  # "honor scene lighting": a scene with punctual lights and no sun of its own has none (WorldData.cpp:1537-1542)
         _check(lib().prosper_pt_update_lights(self._h, C.byref(world.directional), C.byref(world.point_lights),
                                               C.byref(world.spot_lights)))
 

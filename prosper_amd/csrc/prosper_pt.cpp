@@ -81,6 +81,8 @@ void free_scene(prosper_pt_ctx *ctx)
     ctx->sceneAllocations.clear();
     delete ctx->accel; // its device arrays are in the list above
     ctx->accel = nullptr;
+    delete ctx->lights;
+    ctx->lights = nullptr;
     ctx->dTransforms = nullptr;
     ctx->sceneBytes = 0;
     ctx->haveScene = false;
@@ -430,16 +432,25 @@ int upload_scene_impl(prosper_pt_ctx *ctx, const prosper_pt_scene_view *v)
     s.textures = static_cast<const DeviceTexture *>(d);
     const double textureSeconds = seconds_since(tTextures);
 
-    // lights
-    if ((rc = upload(ctx, v->directionalLight, sizeof(prosper_DirectionalLightParameters), &d))) return rc;
-    ctx->dDirectional = static_cast<prosper_DirectionalLightParameters *>(d);
-    if ((rc = upload(ctx, v->pointLights, sizeof(prosper_PointLightsBuffer), &d))) return rc;
-    ctx->dPointLights = static_cast<prosper_PointLightsBuffer *>(d);
-    if ((rc = upload(ctx, v->spotLights, sizeof(prosper_SpotLightsBuffer), &d))) return rc;
-    ctx->dSpotLights = static_cast<prosper_SpotLightsBuffer *>(d);
-    s.directionalLight = ctx->dDirectional;
-    s.pointLights = ctx->dPointLights;
-    s.spotLights = ctx->dSpotLights;
+    // lights: one block (directional, point list, spot list), the first of up to three versions
+    {
+        LightState *ls = new (std::nothrow) LightState();
+        if (ls) ls->mirror = new (std::nothrow) LightBlock();
+        if (!ls || !ls->mirror)
+        {
+            delete ls;
+            return fail(PROSPER_PT_ERR_INVALID_ARGUMENT, "out of host memory");
+        }
+        ctx->lights = ls;
+        ls->mirror->directional = *v->directionalLight;
+        ls->mirror->points = *v->pointLights;
+        ls->mirror->spots = *v->spotLights;
+        if ((rc = upload(ctx, ls->mirror, sizeof(LightBlock), &d))) return rc;
+        ls->dBlocks[0] = static_cast<LightBlock *>(d);
+        s.directionalLight = &ls->dBlocks[0]->directional;
+        s.pointLights = &ls->dBlocks[0]->points;
+        s.spotLights = &ls->dBlocks[0]->spots;
+    }
     s.pointLightCount = v->pointLights->count;
     s.spotLightCount = v->spotLights->count;
     s.materialCount = v->materialCount;
@@ -882,22 +893,70 @@ int prosper_pt_upload_scene(prosper_pt_ctx *ctx, const prosper_pt_scene_view *sc
     return PROSPER_PT_OK;
 }
 
+// the staged light set into the next device version, on the stream of the render that is about to read it
+static int flush_pending_lights(prosper_pt_ctx *ctx, hipStream_t stream)
+{
+    LightState *ls = ctx->lights;
+    if (!ls || !ls->pending) return PROSPER_PT_OK;
+    const uint32_t v = (ls->cur + 1u) % LightState::kVersions;
+    if (!ls->dBlocks[v])
+    {
+        void *d = nullptr;
+        const int rc = device_alloc(ctx, sizeof(LightBlock), &d);
+        if (rc != PROSPER_PT_OK) return rc;
+        ls->dBlocks[v] = static_cast<LightBlock *>(d);
+    }
+    if (!ls->versionFree[v]) PPT_HIP(hipEventCreateWithFlags(&ls->versionFree[v], hipEventDisableTiming));
+    if (!ls->ready) PPT_HIP(hipEventCreateWithFlags(&ls->ready, hipEventDisableTiming));
+    if (ls->versionUsed[v]) PPT_HIP(hipStreamWaitEvent(stream, ls->versionFree[v], 0));
+    const uint32_t k = ls->pendingStaging;
+    PPT_HIP(hipMemcpyAsync(ls->dBlocks[v], ls->staging[k], sizeof(LightBlock), hipMemcpyHostToDevice, stream));
+    PPT_HIP(hipEventRecord(ls->stagingDone[k], stream));
+    ls->stagingUsed[k] = true;
+    PPT_HIP(hipEventRecord(ls->ready, stream));
+    ls->readyRecorded = true;
+    ls->cur = v;
+    ctx->scene.directionalLight = &ls->dBlocks[v]->directional;
+    ctx->scene.pointLights = &ls->dBlocks[v]->points;
+    ctx->scene.spotLights = &ls->dBlocks[v]->spots;
+    ctx->scene.pointLightCount = ls->staging[k]->points.count;
+    ctx->scene.spotLightCount = ls->staging[k]->spots.count;
+    ls->pending = false;
+    ls->updates++;
+    return PROSPER_PT_OK;
+}
+
 int prosper_pt_update_lights(
     prosper_pt_ctx *ctx, const prosper_DirectionalLightParameters *directionalLight,
     const prosper_PointLightsBuffer *pointLights, const prosper_SpotLightsBuffer *spotLights)
 {
     if (!ctx || !directionalLight || !pointLights || !spotLights)
         return fail(PROSPER_PT_ERR_INVALID_ARGUMENT, "prosper_pt_update_lights: null argument");
-    if (!ctx->haveScene) return fail(PROSPER_PT_ERR_NO_SCENE, "no scene uploaded");
+    if (!ctx->haveScene || !ctx->lights) return fail(PROSPER_PT_ERR_NO_SCENE, "no scene uploaded");
     if (pointLights->count > PROSPER_MAX_POINT_LIGHT_COUNT || spotLights->count > PROSPER_MAX_SPOT_LIGHT_COUNT)
         return fail(PROSPER_PT_ERR_SCENE, "light count exceeds 1024");
+    LightState *ls = ctx->lights;
+    // prosper rewrites the buffers every frame (World.cpp:531-535) and mostly with what they held: that costs a memcmp
+    if (std::memcmp(&ls->mirror->directional, directionalLight, sizeof(*directionalLight)) == 0 &&
+        std::memcmp(&ls->mirror->points, pointLights, sizeof(*pointLights)) == 0 &&
+        std::memcmp(&ls->mirror->spots, spotLights, sizeof(*spotLights)) == 0)
+        return PROSPER_PT_OK;
     PPT_HIP(hipSetDevice(ctx->device));
-    PPT_HIP(hipDeviceSynchronize());
-    PPT_HIP(hipMemcpy(ctx->dDirectional, directionalLight, sizeof(*directionalLight), hipMemcpyHostToDevice));
-    PPT_HIP(hipMemcpy(ctx->dPointLights, pointLights, sizeof(*pointLights), hipMemcpyHostToDevice));
-    PPT_HIP(hipMemcpy(ctx->dSpotLights, spotLights, sizeof(*spotLights), hipMemcpyHostToDevice));
-    ctx->scene.pointLightCount = pointLights->count;
-    ctx->scene.spotLightCount = spotLights->count;
+    const uint32_t k = ls->pending ? ls->pendingStaging : ls->stagingNext;
+    if (!ls->pending) ls->stagingNext ^= 1u;
+    if (!ls->staging[k])
+    {
+        PPT_HIP(hipHostMalloc((void **)&ls->staging[k], sizeof(LightBlock), hipHostMallocDefault));
+        PPT_HIP(hipEventCreateWithFlags(&ls->stagingDone[k], hipEventDisableTiming));
+    }
+    if (ls->stagingUsed[k]) PPT_HIP(hipEventSynchronize(ls->stagingDone[k])); // the copy of two updates ago
+    ls->stagingUsed[k] = false;
+    ls->staging[k]->directional = *directionalLight;
+    ls->staging[k]->points = *pointLights;
+    ls->staging[k]->spots = *spotLights;
+    *ls->mirror = *ls->staging[k];
+    ls->pending = true;
+    ls->pendingStaging = k;
     return PROSPER_PT_OK;
 }
 
@@ -1275,8 +1334,10 @@ int prosper_pt_render_frames(
     {
         const uint32_t nextSlot = wavefrontPipelined ? (ctx->lastSlot + 1u) % prosper_pt_ctx::kRenderSlots : 0u;
         hipStream_t us = wavefrontPipelined ? ctx->workStreams[nextSlot] : s;
-        const int frc = flush_pending_update(ctx, us);
+        int frc = flush_pending_update(ctx, us);
+        if (frc == PROSPER_PT_OK) frc = flush_pending_lights(ctx, us);
         if (frc != PROSPER_PT_OK) return frc;
+        if (ctx->lights && ctx->lights->readyRecorded) PPT_HIP(hipStreamWaitEvent(s, ctx->lights->ready, 0));
         // a refit enqueued on another stream (another render's chain, or prosper_pt_update_transforms_async) must be
         // done before anything on the caller's stream reads the scene
         if (ctx->accel && ctx->accel->sceneEventRecorded) PPT_HIP(hipStreamWaitEvent(s, ctx->accel->sceneEvent, 0));
@@ -1357,6 +1418,7 @@ int prosper_pt_render_frames(
             // with the workspace: detached chains wait for that on their own stream, the others on the caller's
             chains.after = slot.freeRecorded ? slot.free : nullptr;
             chains.scene = (ctx->accel && ctx->accel->sceneEventRecorded) ? ctx->accel->sceneEvent : nullptr;
+            chains.lights = (ctx->lights && ctx->lights->readyRecorded) ? ctx->lights->ready : nullptr;
             if (!pipelined) wait_for_slot(slot, s);
             if (tp) tp->mark(kStageChains, s);
             launch_render_wavefront(
@@ -1376,6 +1438,13 @@ int prosper_pt_render_frames(
         if (!acc->versionFree[acc->cur]) PPT_HIP(hipEventCreateWithFlags(&acc->versionFree[acc->cur], hipEventDisableTiming));
         PPT_HIP(hipEventRecord(acc->versionFree[acc->cur], s));
         acc->versionUsed[acc->cur] = true;
+    }
+    if (ctx->lights)
+    {
+        LightState *ls = ctx->lights;
+        if (!ls->versionFree[ls->cur]) PPT_HIP(hipEventCreateWithFlags(&ls->versionFree[ls->cur], hipEventDisableTiming));
+        PPT_HIP(hipEventRecord(ls->versionFree[ls->cur], s));
+        ls->versionUsed[ls->cur] = true;
     }
     if (tp)
     {
@@ -1456,9 +1525,11 @@ int prosper_pt_restir_di_trace(
     PPT_HIP(hipSetDevice(ctx->device));
     hipStream_t s = static_cast<hipStream_t>(stream);
     {
-        const int frc = flush_pending_update(ctx, s);
+        int frc = flush_pending_update(ctx, s);
+        if (frc == PROSPER_PT_OK) frc = flush_pending_lights(ctx, s);
         if (frc != PROSPER_PT_OK) return frc;
         if (ctx->accel && ctx->accel->sceneEventRecorded) PPT_HIP(hipStreamWaitEvent(s, ctx->accel->sceneEvent, 0));
+        if (ctx->lights && ctx->lights->readyRecorded) PPT_HIP(hipStreamWaitEvent(s, ctx->lights->ready, 0));
     }
     const size_t pixels = (size_t)width * height;
     const size_t bytes = pixels * sizeof(float4);

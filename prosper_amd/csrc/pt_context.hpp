@@ -26,6 +26,45 @@ int fail(int code, const std::string &msg);
 // Host + device state of the acceleration structure that outlives prosper_pt_upload_scene, so that moved instances can
 // be re-fitted without rebuilding the scene (prosper_pt_update_transforms): the world triangles in (drawInstance,
 // primitive) order on both sides, the per-instance subtrees (bvh_build.hpp InstancedBvh), the instance table.
+// The three light buffers of the scene (World.cpp:531-535 rewrites them every frame), versioned like the instance
+// transforms: an update is staged by the call (an unchanged set is a no-op) and copied by the next render's own chain
+// into the next of three device copies, so the frames in flight keep theirs and nothing synchronises the device.
+struct LightBlock
+{
+    alignas(16) prosper_DirectionalLightParameters directional;
+    alignas(16) prosper_PointLightsBuffer points; // (16-byte aligned: the kernels read the lights as vec4s)
+    alignas(16) prosper_SpotLightsBuffer spots;
+};
+struct LightState
+{
+    static constexpr uint32_t kVersions = 3;
+    LightBlock *dBlocks[kVersions] = {}; // [0] is the upload's own allocation
+    hipEvent_t versionFree[kVersions] = {};
+    bool versionUsed[kVersions] = {};
+    uint32_t cur = 0;
+    LightBlock *mirror = nullptr;         // host copy of what the device holds (or will hold once `pending` is flushed)
+    LightBlock *staging[2] = {nullptr, nullptr}; // pinned
+    hipEvent_t stagingDone[2] = {nullptr, nullptr};
+    bool stagingUsed[2] = {false, false};
+    uint32_t stagingNext = 0, pendingStaging = 0;
+    bool pending = false;
+    hipEvent_t ready = nullptr; // behind the last flush: every later render's chains wait for it
+    bool readyRecorded = false;
+    uint32_t updates = 0;
+    ~LightState()
+    {
+        delete mirror;
+        for (int i = 0; i < 2; ++i)
+        {
+            if (staging[i]) (void)hipHostFree(staging[i]);
+            if (stagingDone[i]) (void)hipEventDestroy(stagingDone[i]);
+        }
+        for (hipEvent_t e : versionFree)
+            if (e) (void)hipEventDestroy(e);
+        if (ready) (void)hipEventDestroy(ready);
+    }
+};
+
 struct AccelState
 {
     WorldTriangle *dFlat = nullptr; // (drawInstance, primitive) order: what flatten_triangles writes
@@ -128,9 +167,7 @@ struct prosper_pt_ctx
     uint32_t packedMaterials = 0; // materials whose three textures are interleaved (MaterialPack)
     uint64_t alphaTriangleCount = 0, alphaBoundBytes = 0; // any-hit records and bytes of alpha bounds (AlphaMaterial)
     // light buffers are re-uploaded every frame in prosper; keep their device addresses mutable
-    prosper_DirectionalLightParameters *dDirectional = nullptr;
-    prosper_PointLightsBuffer *dPointLights = nullptr;
-    prosper_SpotLightsBuffer *dSpotLights = nullptr;
+    ppt::LightState *lights = nullptr; // the scene's light buffers (device copies in the scene's allocation list)
 
     float4 *hdr = nullptr; // current HDR buffer (internal or caller-owned)
     float4 *ownedHdr = nullptr;

@@ -87,6 +87,7 @@ struct WavefrontChains
     bool detached = false;
     hipEvent_t after = nullptr;
     hipEvent_t scene = nullptr; // the last prosper_pt_update_transforms: every chain waits for it
+    hipEvent_t lights = nullptr; // the last prosper_pt_update_lights
     hipStream_t streams[kMaxChains] = {};
     hipEvent_t fork = nullptr;
     hipEvent_t join[kMaxChains] = {};

@@ -1047,6 +1047,63 @@ def test_moving_instances_between_frames_in_flight(gpu_ctx, oracle):
         fresh.close()
 
 
+def test_lights_updated_between_frames_in_flight(gpu_ctx, oracle):
+    """prosper rewrites the three light buffers every frame (World.cpp:531-535).  prosper_pt_update_lights stages a
+    changed set (an unchanged one is a no-op) and the next render copies it into the next of three device versions at the
+    head of its own chain: every frame of a pipelined sequence shows the lights of ITS update - equal to the oracle's
+    image of that light set - and nothing synchronises the device."""
+    import ctypes
+    import copy
+
+    def lit(k):
+        world = scenes.cornell(with_skybox=True)
+        if k >= 1:
+            world.add_point_light((0.2, 0.9, 0.3), 30.0 + 10.0 * k, (0.4 - 0.3 * k, 1.2, 0.6))
+        if k >= 2:
+            world.add_spot_light((0.9, 0.3, 0.2), 120.0, (-0.6, 1.7, 0.9), (0.3, -0.8, -0.4), 0.3, 0.6)
+        if k >= 3:
+            world.set_directional_light((1.0, 0.9, 0.8), 1.5, (-0.4, -1.0, -0.3))
+        return world
+    worlds = [lit(k) for k in range(4)]
+    w, h = 224, 160
+    cam, fl = _camera(oracle, worlds[0], w, h)
+    pc = default_pc(S, fl, max_bounces=3)
+    hip = ctypes.CDLL("libamdhip64.so")
+    nbytes = w * h * 16
+    outs = []
+    for _ in worlds:
+        ptr = ctypes.c_void_p()
+        assert hip.hipMalloc(ctypes.byref(ptr), ctypes.c_size_t(nbytes)) == 0
+        outs.append(ptr)
+    gpu_ctx.upload_scene(worlds[0])
+    for k, world in enumerate(worlds):
+        gpu_ctx.update_lights(world)
+        gpu_ctx.update_lights(world)  # again: nothing changed, nothing happens
+        gpu_ctx.set_output_buffer(outs[k].value, nbytes)
+        gpu_ctx.render(pc, cam, w, h, frames=2, flags=S.RENDER_PIPELINED)
+    assert hip.hipDeviceSynchronize() == 0
+    gpu_ctx.set_output_buffer(0, 0)
+    for k, world in enumerate(worlds):
+        img = np.zeros((h, w, 4), np.float32)
+        assert hip.hipMemcpy(ctypes.c_void_p(img.ctypes.data), outs[k], ctypes.c_size_t(nbytes), 2) == 0
+        assert hip.hipFree(outs[k]) == 0
+        osc = oracle.OracleScene(world, brute_force=True)
+        want = None
+        for frame in (1, 2):
+            want, _ = osc.render(default_pc(S, fl, frame_index=frame, max_bounces=3, skip_history=(frame == 1)), cam, w, h,
+                                 history=want)
+        ok = same_bits(img, want).all(axis=2)
+        assert ok.all(), "light set %d: %d of %d pixels differ" % (k, (~ok).sum(), ok.size)
+    # in-order renders and the counting kernels see the staged set too
+    gpu_ctx.update_lights(worlds[1])
+    gpu_ctx.render(pc, cam, w, h, frames=2)
+    osc = oracle.OracleScene(worlds[1], brute_force=True)
+    want = None
+    for frame in (1, 2):
+        want, _ = osc.render(default_pc(S, fl, frame_index=frame, max_bounces=3, skip_history=(frame == 1)), cam, w, h, history=want)
+    assert same_bits(gpu_ctx.read_hdr(), want).all()
+
+
 def test_pipelined_renders_survive_changing_extents(gpu_ctx, oracle, cornell_world):
     """Frames in flight while the image extent (and with it every slot's workspace size) changes from call to call,
     growing and shrinking: each image equals the in-order render of the same call."""
