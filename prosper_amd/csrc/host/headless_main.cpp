@@ -215,6 +215,7 @@ int main(int argc, char **argv)
             // App::drawFrame: the scene's transforms every frame, then the acceleration structures, then the pass
             // (App.cpp:516-578).  Nothing moves here: the update is a no-op, as it is on most of prosper's frames.
             world.updateScene(pass.pass().context(), transforms, 3);
+            world.updateBuffers(pass.pass().context());
             camera.updateBuffer();
             (void)pass.record(nullptr, world, camera, area, options, f & 1u, 1, PROSPER_PT_RENDER_PIPELINED);
             camera.endFrame();

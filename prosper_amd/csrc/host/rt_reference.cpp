@@ -46,6 +46,13 @@ void World::updateScene(prosper_pt_ctx *ctx, const prosper_ModelInstanceTransfor
         throw std::runtime_error(std::string("World::updateScene: ") + prosper_pt_last_error());
 }
 
+void World::updateBuffers(prosper_pt_ctx *ctx)
+{
+    PROSPER_ASSERT(uploadedTo(ctx));
+    if (prosper_pt_update_lights(ctx, m_view.directionalLight, m_view.pointLights, m_view.spotLights) != PROSPER_PT_OK)
+        throw std::runtime_error(std::string("World::updateBuffers: ") + prosper_pt_last_error());
+}
+
 } // namespace scene
 
 namespace render

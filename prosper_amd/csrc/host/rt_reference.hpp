@@ -36,6 +36,9 @@ class World
     // them every frame): the whole transform table of the uploaded scene.  Cheap to call unconditionally - an unchanged
     // table is a no-op, a changed one a GPU refit run by the next record().  Throws std::runtime_error on failure.
     void updateScene(prosper_pt_ctx *ctx, const prosper_ModelInstanceTransforms *transforms, uint32_t count);
+    // World::updateBuffers' light writes (src/scene/World.cpp:468-536, :531-535: the three light buffers, every frame), from
+    // the light pointers of the scene view.  An unchanged set is a no-op.
+    void updateBuffers(prosper_pt_ctx *ctx);
     [[nodiscard]] bool uploadedTo(const prosper_pt_ctx *ctx) const { return m_ctx == ctx && !m_dirty; }
 
   private:
