@@ -240,6 +240,7 @@ enum
     PROSPER_PT_VARIANT_LDS_TABLES = 1u << 1,      /* wf_shade stages instances/transforms/materials/lights in LDS */
     PROSPER_PT_VARIANT_BATCHED_TEXTURES = 1u << 2, /* the twelve texel loads of a hit issued together */
     PROSPER_PT_VARIANT_TEXTURE_PACKS = 1u << 3,  /* some material's base / MR / normal texels are interleaved per texel */
+    PROSPER_PT_VARIANT_RAW_RECORDS = 1u << 4,    /* 64-byte raw shading records decoded per hit (PROSPER_PT_DEBUG_RAW_RECORDS=1: an experiment) */
     PROSPER_PT_VARIANT_STACK_SHIFT = 8,           /* bits 8..15: LDS traversal-stack entries (16/24/32) */
 };
 

@@ -574,9 +574,22 @@ int upload_scene_impl(prosper_pt_ctx *ctx, const prosper_pt_scene_view *v)
     if ((rc = device_alloc(ctx, (size_t)(total ? total : 1) * 4, &d))) return rc;
     acc->dPerm = static_cast<uint32_t *>(d);
     // persistent (scene-lifetime) arrays the flatten kernel fills: shading records + their per-instance bases
-    void *dShade = nullptr;
-    if ((rc = device_alloc(ctx, sizeof(ShadeTriangle) * (size_t)(total ? total : 1), &dShade))) return rc;
+    // decoded 128-byte records; PROSPER_PT_DEBUG_RAW_RECORDS=1 keeps the raw 64-byte form instead, decoded per hit (same
+    // pixels, tested).  Measured and not made a default for any scene size (profiles/r03_raw_records.txt): even on
+    // S-sponza-class, whose 33.6 MB of records outgrow the L2 and whose wf_shade runs at 6.7 TB/s, the ~150 instructions of
+    // decoding cost more than the 64 bytes save (wf_shade 910 -> 931 us; C4 687 -> 721, C2 220 -> 248, FlightHelmet 97 -> 104)
+    bool rawRecords = false;
+    if (const char *forced = std::getenv("PROSPER_PT_DEBUG_RAW_RECORDS")) rawRecords = std::atoi(forced) != 0;
+    void *dShade = nullptr, *dRaw = nullptr;
+    if (rawRecords)
+    {
+        if ((rc = device_alloc(ctx, sizeof(RawShadeTriangle) * (size_t)(total ? total : 1), &dRaw))) return rc;
+    }
+    else if ((rc = device_alloc(ctx, sizeof(ShadeTriangle) * (size_t)(total ? total : 1), &dShade)))
+        return rc;
     s.shadeTriangles = static_cast<const ShadeTriangle *>(dShade);
+    s.rawShadeTriangles = static_cast<const RawShadeTriangle *>(dRaw);
+    ctx->rawRecords = rawRecords;
     s.triangleOffsets = acc->dOffsets;
     void *dTris = nullptr;
     if ((rc = device_alloc(ctx, triBytes, &dTris))) return rc;
@@ -587,7 +600,8 @@ int upload_scene_impl(prosper_pt_ctx *ctx, const prosper_pt_scene_view *v)
 
     launch_flatten_triangles(
         s, acc->dOffsets, v->drawInstanceCount, acc->dFlags, acc->dFlat, static_cast<ShadeTriangle *>(dShade),
-        const_cast<AlphaTriangle *>(s.alphaTriangles), (uint32_t)total, nullptr);
+        const_cast<AlphaTriangle *>(s.alphaTriangles), (uint32_t)total, nullptr, nullptr, nullptr,
+        static_cast<RawShadeTriangle *>(dRaw));
     PPT_HIP(hipGetLastError());
     acc->flat.resize((size_t)total);
     if (total) PPT_HIP(hipMemcpy(acc->flat.data(), acc->dFlat, sizeof(WorldTriangle) * (size_t)total, hipMemcpyDeviceToHost));
@@ -1229,7 +1243,8 @@ int prosper_pt_get_scene_stats(prosper_pt_ctx *ctx, prosper_pt_scene_stats *out)
              : 0u) |
         (wavefront_shade_tables_in_lds(ctx->scene) ? PROSPER_PT_VARIANT_LDS_TABLES : 0u) |
         (ctx->scene.batchedTextures ? PROSPER_PT_VARIANT_BATCHED_TEXTURES : 0u) |
-        (ctx->packedMaterials ? PROSPER_PT_VARIANT_TEXTURE_PACKS : 0u) | (ldsEntries << PROSPER_PT_VARIANT_STACK_SHIFT);
+        (ctx->packedMaterials ? PROSPER_PT_VARIANT_TEXTURE_PACKS : 0u) | (ctx->rawRecords ? PROSPER_PT_VARIANT_RAW_RECORDS : 0u) |
+        (ldsEntries << PROSPER_PT_VARIANT_STACK_SHIFT);
     return PROSPER_PT_OK;
 }
 

@@ -165,6 +165,7 @@ struct prosper_pt_ctx
     ppt::DeviceScene scene = {};
     prosper_pt_scene_stats stats = {};
     uint32_t packedMaterials = 0; // materials whose three textures are interleaved (MaterialPack)
+    bool rawRecords = false;      // the scene keeps 64-byte raw shading records (RawShadeTriangle)
     uint64_t alphaTriangleCount = 0, alphaBoundBytes = 0; // any-hit records and bytes of alpha bounds (AlphaMaterial)
     // light buffers are re-uploaded every frame in prosper; keep their device addresses mutable
     ppt::LightState *lights = nullptr; // the scene's light buffers (device copies in the scene's allocation list)

@@ -1139,7 +1139,9 @@ PPT_D uint32_t any_hit_settle(
     {
         cnt.anyHitCalls++;
         const uint32_t di = s.alphaTriangles[alphaIndex].drawInstance, prim = s.alphaTriangles[alphaIndex].primitive;
-        cnt.shortIndexHits += (s.shadeTriangles[s.triangleOffsets[di] + prim].flags & kTriFlagShortIndices) ? 1u : 0u;
+        const uint32_t record = s.triangleOffsets[di] + prim;
+        const uint32_t recordFlags = s.rawShadeTriangles ? s.rawShadeTriangles[record].flags : s.shadeTriangles[record].flags;
+        cnt.shortIndexHits += (recordFlags & kTriFlagShortIndices) ? 1u : 0u;
     }
     if (texelBits == 0ull) return alpha_verdict(fp.mode, 1.0f, fp.factorA, fp.cutoff, fp.u) ? kAlphaAccept : kAlphaReject;
 
@@ -1567,30 +1569,57 @@ PPT_D f3 mapped_normal(f3 tsn, f3 normal, f3 tangent, float sgn)
 template <bool COUNT, bool BATCHED_TEXTURES = false>
 PPT_D Surface evaluate_surface(const DeviceScene &s, f3 rayDir, const Hit &hit, LaneCounters &cnt)
 {
-    // loadVertexThroughIndexBuffer x 3 (geometry.glsl:220-244) from the triangle's precomputed record
+    // loadVertexThroughIndexBuffer x 3 (geometry.glsl:220-244) from the triangle's record: decoded at upload (128 B), or
+    // - big scenes - the raw stream values (64 B) decoded here by the same functions
     const prosper_DrawInstance inst = s.drawInstances[hit.drawInstance];
-    const float4 *rec =
-        reinterpret_cast<const float4 *>(s.shadeTriangles + (s.triangleOffsets[hit.drawInstance] + hit.primitive));
-    const float4 q0 = rec[0], q1 = rec[1], q2 = rec[2], q3 = rec[3], q4 = rec[4], q5 = rec[5], q6 = rec[6], q7 = rec[7];
+    const uint32_t record = s.triangleOffsets[hit.drawInstance] + hit.primitive;
     Vertex v0, v1, v2;
-    v0.normal = f3{q0.x, q0.y, q0.z};
-    v1.normal = f3{q1.x, q1.y, q1.z};
-    v2.normal = f3{q2.x, q2.y, q2.z};
-    v0.uv = unpack_half2(__builtin_bit_cast(uint32_t, q0.w));
-    v1.uv = unpack_half2(__builtin_bit_cast(uint32_t, q1.w));
-    v2.uv = unpack_half2(__builtin_bit_cast(uint32_t, q2.w));
-    v0.tangent = f4{q3.x, q3.y, q3.z, q3.w};
-    v1.tangent = f4{q4.x, q4.y, q4.z, q4.w};
-    v2.tangent = f4{q5.x, q5.y, q5.z, q5.w};
-    v0.position = unpack_half3(__builtin_bit_cast(uint32_t, q6.x), __builtin_bit_cast(uint32_t, q6.y));
-    v1.position = unpack_half3(__builtin_bit_cast(uint32_t, q6.z), __builtin_bit_cast(uint32_t, q6.w));
-    v2.position = unpack_half3(__builtin_bit_cast(uint32_t, q7.x), __builtin_bit_cast(uint32_t, q7.y));
+    uint32_t recordFlags;
+    if (s.rawShadeTriangles != nullptr)
+    {
+        const uint4 *rec = reinterpret_cast<const uint4 *>(s.rawShadeTriangles + record);
+        const uint4 q0 = rec[0], q1 = rec[1], q2 = rec[2], q3 = rec[3];
+        recordFlags = q3.w;
+        v0.position = unpack_half3(q0.x, q0.y);
+        v1.position = unpack_half3(q0.z, q0.w);
+        v2.position = unpack_half3(q1.x, q1.y);
+        const f3 zero = f3{0.0f, 0.0f, 0.0f};
+        const bool noNormals = (recordFlags & kRawNoNormals) != 0u, noTangents = (recordFlags & kRawNoTangents) != 0u;
+        v0.normal = noNormals ? zero : unpack_snorm_r10g10b10(q1.z);
+        v1.normal = noNormals ? zero : unpack_snorm_r10g10b10(q1.w);
+        v2.normal = noNormals ? zero : unpack_snorm_r10g10b10(q2.x);
+        const f3 t0 = unpack_snorm_r10g10b10(q2.y), t1 = unpack_snorm_r10g10b10(q2.z), t2 = unpack_snorm_r10g10b10(q2.w);
+        v0.tangent = noTangents ? f4{0.0f, 0.0f, 0.0f, 0.0f} : f4{t0.x, t0.y, t0.z, (float)((int32_t)q2.y >> 30)};
+        v1.tangent = noTangents ? f4{0.0f, 0.0f, 0.0f, 0.0f} : f4{t1.x, t1.y, t1.z, (float)((int32_t)q2.z >> 30)};
+        v2.tangent = noTangents ? f4{0.0f, 0.0f, 0.0f, 0.0f} : f4{t2.x, t2.y, t2.z, (float)((int32_t)q2.w >> 30)};
+        v0.uv = unpack_half2(q3.x);
+        v1.uv = unpack_half2(q3.y);
+        v2.uv = unpack_half2(q3.z);
+    }
+    else
+    {
+        const float4 *rec = reinterpret_cast<const float4 *>(s.shadeTriangles + record);
+        const float4 q0 = rec[0], q1 = rec[1], q2 = rec[2], q3 = rec[3], q4 = rec[4], q5 = rec[5], q6 = rec[6], q7 = rec[7];
+        recordFlags = __builtin_bit_cast(uint32_t, q7.z);
+        v0.normal = f3{q0.x, q0.y, q0.z};
+        v1.normal = f3{q1.x, q1.y, q1.z};
+        v2.normal = f3{q2.x, q2.y, q2.z};
+        v0.uv = unpack_half2(__builtin_bit_cast(uint32_t, q0.w));
+        v1.uv = unpack_half2(__builtin_bit_cast(uint32_t, q1.w));
+        v2.uv = unpack_half2(__builtin_bit_cast(uint32_t, q2.w));
+        v0.tangent = f4{q3.x, q3.y, q3.z, q3.w};
+        v1.tangent = f4{q4.x, q4.y, q4.z, q4.w};
+        v2.tangent = f4{q5.x, q5.y, q5.z, q5.w};
+        v0.position = unpack_half3(__builtin_bit_cast(uint32_t, q6.x), __builtin_bit_cast(uint32_t, q6.y));
+        v1.position = unpack_half3(__builtin_bit_cast(uint32_t, q6.z), __builtin_bit_cast(uint32_t, q6.w));
+        v2.position = unpack_half3(__builtin_bit_cast(uint32_t, q7.x), __builtin_bit_cast(uint32_t, q7.y));
+    }
     const Vertex vi = interpolate(v0, v1, v2, hit.bary);
     const Vertex v = transform(vi, s.modelInstanceTransforms[inst.modelInstanceIndex]);
     if constexpr (COUNT)
     {
         cnt.closestHits++;
-        cnt.shortIndexHits += (__builtin_bit_cast(uint32_t, q7.z) & kTriFlagShortIndices) ? 1u : 0u;
+        cnt.shortIndexHits += (recordFlags & kTriFlagShortIndices) ? 1u : 0u;
     }
     Surface sf;
     sf.positionWS = v.position;

@@ -23,7 +23,7 @@ __global__ void flatten_triangles_kernel(
     DeviceScene s, const uint32_t *__restrict__ triOffsets, uint32_t drawInstanceCount,
     const uint32_t *__restrict__ drawInstanceFlags, WorldTriangle *__restrict__ out,
     ShadeTriangle *__restrict__ shadeOut, AlphaTriangle *__restrict__ alphaOut, uint32_t total,
-    const uint32_t *__restrict__ leafPosition, WorldTriangle *__restrict__ leafOrder)
+    const uint32_t *__restrict__ leafPosition, WorldTriangle *__restrict__ leafOrder, RawShadeTriangle *__restrict__ rawOut)
 {
     const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= total) return;
@@ -60,41 +60,67 @@ __global__ void flatten_triangles_kernel(
     t.flags = diFlags | (alphaIndex << kTriAlphaShift); // a non-opaque triangle names its alpha record
     out[g] = t;
     if (leafOrder != nullptr) leafOrder[leafPosition[g]] = t; // moved instances: straight into the traversal's (leaf) order
-    if (shadeOut == nullptr) return; // re-flatten after moved instances: the shading records are object-space
+    if (shadeOut == nullptr && rawOut == nullptr) return; // re-flatten after moved instances: the shading records are object-space
 
-    // the shading record of this triangle (pt_scene.hpp ShadeTriangle): geometry.glsl:220-244 per corner
-    ShadeTriangle sh;
+    // the shading record of this triangle: decoded (pt_scene.hpp ShadeTriangle: geometry.glsl:220-244 per corner) or, for
+    // scenes that keep the 64-byte form, the raw stream values (RawShadeTriangle)
     const uint32_t vi[3] = {i0, i1, i2};
+    uint32_t uvBits[3];
     for (int c = 0; c < 3; ++c)
+        uvBits[c] = m.texCoord0sOffset == PROSPER_PT_ABSENT ? 0u : geo_u32(s, m.bufferIndex)[m.texCoord0sOffset + vi[c]];
+    if (rawOut != nullptr)
     {
-        const Vertex vtx = load_vertex_through_index_buffer(s, m, prim * 3 + c);
-        sh.normalUv[c][0] = vtx.normal.x;
-        sh.normalUv[c][1] = vtx.normal.y;
-        sh.normalUv[c][2] = vtx.normal.z;
-        const uint32_t uvBits =
-            m.texCoord0sOffset == PROSPER_PT_ABSENT ? 0u : geo_u32(s, m.bufferIndex)[m.texCoord0sOffset + vi[c]];
-        sh.normalUv[c][3] = __builtin_bit_cast(float, uvBits);
-        sh.tangent[c][0] = vtx.tangent.x;
-        sh.tangent[c][1] = vtx.tangent.y;
-        sh.tangent[c][2] = vtx.tangent.z;
-        sh.tangent[c][3] = vtx.tangent.w;
-        if (m.positionsOffset == PROSPER_PT_ABSENT)
-            sh.position[c][0] = sh.position[c][1] = 0u;
-        else
+        RawShadeTriangle raw;
+        for (int c = 0; c < 3; ++c)
         {
-            const u32x2 pp = *(global_u32x2_ptr)(geo_u32(s, m.bufferIndex) + m.positionsOffset + vi[c] * 2);
-            sh.position[c][0] = pp.x;
-            sh.position[c][1] = pp.y;
+            if (m.positionsOffset == PROSPER_PT_ABSENT)
+                raw.position[c][0] = raw.position[c][1] = 0u;
+            else
+            {
+                const u32x2 pp = *(global_u32x2_ptr)(geo_u32(s, m.bufferIndex) + m.positionsOffset + vi[c] * 2);
+                raw.position[c][0] = pp.x;
+                raw.position[c][1] = pp.y;
+            }
+            raw.normal[c] = m.normalsOffset == PROSPER_PT_ABSENT ? 0u : geo_u32(s, m.bufferIndex)[m.normalsOffset + vi[c]];
+            raw.tangent[c] = m.tangentsOffset == PROSPER_PT_ABSENT ? 0u : geo_u32(s, m.bufferIndex)[m.tangentsOffset + vi[c]];
+            raw.uv[c] = uvBits[c];
         }
+        raw.flags = (diFlags & kTriFlagShortIndices) | (m.normalsOffset == PROSPER_PT_ABSENT ? kRawNoNormals : 0u) |
+                    (m.tangentsOffset == PROSPER_PT_ABSENT ? kRawNoTangents : 0u);
+        rawOut[g] = raw;
     }
-    sh.flags = diFlags;
-    sh.reserved = 0;
-    shadeOut[g] = sh;
+    if (shadeOut != nullptr)
+    {
+        ShadeTriangle sh;
+        for (int c = 0; c < 3; ++c)
+        {
+            const Vertex vtx = load_vertex_through_index_buffer(s, m, prim * 3 + c);
+            sh.normalUv[c][0] = vtx.normal.x;
+            sh.normalUv[c][1] = vtx.normal.y;
+            sh.normalUv[c][2] = vtx.normal.z;
+            sh.normalUv[c][3] = __builtin_bit_cast(float, uvBits[c]);
+            sh.tangent[c][0] = vtx.tangent.x;
+            sh.tangent[c][1] = vtx.tangent.y;
+            sh.tangent[c][2] = vtx.tangent.z;
+            sh.tangent[c][3] = vtx.tangent.w;
+            if (m.positionsOffset == PROSPER_PT_ABSENT)
+                sh.position[c][0] = sh.position[c][1] = 0u;
+            else
+            {
+                const u32x2 pp = *(global_u32x2_ptr)(geo_u32(s, m.bufferIndex) + m.positionsOffset + vi[c] * 2);
+                sh.position[c][0] = pp.x;
+                sh.position[c][1] = pp.y;
+            }
+        }
+        sh.flags = diFlags;
+        sh.reserved = 0;
+        shadeOut[g] = sh;
+    }
     if (nonOpaque)
     {
         // what the any-hit shader reads of this triangle (pt_scene.hpp AlphaTriangle): scene.rahit:20-31
         AlphaTriangle at;
-        for (int c = 0; c < 3; ++c) at.uv[c] = __builtin_bit_cast(uint32_t, sh.normalUv[c][3]);
+        for (int c = 0; c < 3; ++c) at.uv[c] = uvBits[c];
         at.drawInstance = di;
         at.primitive = prim;
         at.materialIndex = inst.materialIndex;
@@ -120,12 +146,12 @@ __global__ void permute_triangles_kernel(
 void launch_flatten_triangles(
     const DeviceScene &s, const uint32_t *triOffsets, uint32_t drawInstanceCount, const uint32_t *drawInstanceFlags,
     WorldTriangle *out, ShadeTriangle *shadeOut, AlphaTriangle *alphaOut, uint32_t total, hipStream_t stream,
-    const uint32_t *leafPosition, WorldTriangle *leafOrder)
+    const uint32_t *leafPosition, WorldTriangle *leafOrder, RawShadeTriangle *rawOut)
 {
     if (total == 0) return;
     hipLaunchKernelGGL(
         flatten_triangles_kernel, dim3((total + 255) / 256), dim3(256), 0, stream, s, triOffsets, drawInstanceCount,
-        drawInstanceFlags, out, shadeOut, alphaOut, total, leafPosition, leafOrder);
+        drawInstanceFlags, out, shadeOut, alphaOut, total, leafPosition, leafOrder, rawOut);
 }
 
 void launch_permute_triangles(

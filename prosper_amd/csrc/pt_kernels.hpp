@@ -44,7 +44,7 @@ struct LaunchTimer
 void launch_flatten_triangles(
     const DeviceScene &s, const uint32_t *triOffsets, uint32_t drawInstanceCount, const uint32_t *drawInstanceFlags,
     WorldTriangle *out, ShadeTriangle *shadeOut, AlphaTriangle *alphaOut, uint32_t total, hipStream_t stream,
-    const uint32_t *leafPosition = nullptr, WorldTriangle *leafOrder = nullptr);
+    const uint32_t *leafPosition = nullptr, WorldTriangle *leafOrder = nullptr, RawShadeTriangle *rawOut = nullptr);
 // refit of an unchanged tree after moved instances: exact bounds level by level (`order` = nodes by height,
 // levelOffsets[levels + 1] on the HOST), then every node's boxes re-encoded; *cost += the tree's surface-area measure
 void launch_refit(

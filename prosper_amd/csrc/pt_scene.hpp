@@ -109,6 +109,24 @@ struct alignas(16) ShadeTriangle
 };
 static_assert(sizeof(ShadeTriangle) == 128, "shade triangle is 128 B");
 
+// The same three corners as the vertex streams hold them, 64 B, kept INSTEAD of ShadeTriangle under
+// PROSPER_PT_DEBUG_RAW_RECORDS=1 (DeviceScene::rawShadeTriangles) and decoded per hit by the very functions
+// flatten_triangles runs for the decoded record: same bits.  An experiment (round-2 verdict item 6): half the record bytes
+// against ~150 more instructions per hit (six unpackSnorm + normalize) - slower on every configuration, also on
+// S-sponza-class whose 33.6 MB of records outgrow the L2 (profiles/r03_raw_records.txt).
+//   q0: position halfs of corner 0 (xy, z_) and 1;  q1: corner 2, normal 0, normal 1 (snorm10);
+//   q2: normal 2, tangents 0..2 (snorm10, sign in the top two bits);  q3: texCoord0 0..2 (two halfs), flags
+struct alignas(64) RawShadeTriangle
+{
+    uint32_t position[3][2];
+    uint32_t normal[3];
+    uint32_t tangent[3];
+    uint32_t uv[3];
+    uint32_t flags; // bit 1: u16-indexed mesh; bit 2: the mesh has no normals; bit 3: no tangents
+};
+static_assert(sizeof(RawShadeTriangle) == 64, "raw shade triangle is 64 B");
+constexpr uint32_t kRawNoNormals = 4u, kRawNoTangents = 8u;
+
 // RGBA8 texels in 8 x 4 tiles of one 128-byte cache line each (texel (i, j) at tile (i >> 3, j >> 2),
 // row-major inside the tile; the allocation is padded to whole tiles).  The 2 x 2 footprint of a bilinear
 // fetch then falls into one line two times out of three instead of always two (rows are `width * 4` bytes
@@ -147,7 +165,8 @@ struct DeviceScene
 {
     const BvhNode *nodes;
     const WorldTriangle *triangles;
-    const ShadeTriangle *shadeTriangles; // (drawInstance, primitive) order
+    const ShadeTriangle *shadeTriangles; // (drawInstance, primitive) order; nullptr when the scene keeps raw records
+    const RawShadeTriangle *rawShadeTriangles; // the 64-byte form (PROSPER_PT_DEBUG_RAW_RECORDS=1), else nullptr
     const uint32_t *triangleOffsets;     // first record of each draw instance
     const void *const *geometryBuffers;  // device array of device pointers
     const prosper_GeometryMetadata *geometryMetadatas;

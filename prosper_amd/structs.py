@@ -281,6 +281,7 @@ VARIANT_LDS_SCENE = 1
 VARIANT_LDS_TABLES = 2
 VARIANT_BATCHED_TEXTURES = 4
 VARIANT_TEXTURE_PACKS = 8
+VARIANT_RAW_RECORDS = 16
 VARIANT_STACK_SHIFT = 8
 
 

@@ -1,6 +1,2 @@
-for lib in build/variants/lib_tri1.so build/variants/lib_tri2.so build/variants/lib_refill24.so build/variants/lib_cont2.so; do
-  echo "== lib $lib"
-  for c in c4 c3 c2; do
-    python scripts/quick_bench.py --config $c --single-chain --steps 6 --lib $lib | tail -2 | head -1
-  done
-done
+for raw in 0 1; do echo "== PROSPER_PT_DEBUG_RAW_RECORDS=$raw"; for c in c3 c4 c2 helmet; do PROSPER_PT_DEBUG_RAW_RECORDS=$raw python scripts/quick_bench.py --config $c --single-chain --steps 6 | tail -2 | head -1; done; done
+for raw in 0 1; do echo "== pipelined, RAW=$raw"; PROSPER_PT_DEBUG_RAW_RECORDS=$raw python scripts/pipelined_bench.py c3 c4 | grep pipelined; done

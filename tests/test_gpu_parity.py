@@ -729,6 +729,48 @@ def test_gltf_scene_bit_exact(gpu_ctx, oracle, draw_type):
     assert ok.all(), "%s: %d of %d pixels differ" % (draw_type, (~ok).sum(), ok.size)
 
 
+def test_raw_shading_records_equal_decoded_ones(gpu_ctx, oracle, sponza_small, monkeypatch):
+    """Big scenes keep a triangle's three corners as the vertex streams hold them (64 B, RawShadeTriangle) and decode them
+    per hit; small ones keep the decoded 128-byte record.  PROSPER_PT_DEBUG_RAW_RECORDS forces either: the same bits, on
+    scenes with normal maps and instancing, on meshes without tangents or normals (a hand-made one), through every
+    pipeline and the counting kernels - and the oracle's."""
+    import os
+    from prosper_amd import gltf
+    from prosper_amd.world import World
+    bare = World()                       # a mesh with positions only, one with normals but no tangents, one with everything
+    mat = bare.add_material(base_color=(0.8, 0.7, 0.6, 1.0), metallic=0.2, roughness=0.6)
+    p, n, t, uv, idx = scenes.quad((-1.5, 0.0, -1.0), (1.5, 0.0, -1.0), (1.5, 0.0, 1.0), (-1.5, 0.0, 1.0))
+    for k, kw in enumerate((dict(), dict(normals=n), dict(normals=n, tangents=t, uvs=uv))):
+        mesh = bare.add_mesh(p + np.array([0.0, 0.4 * k, -0.8 * k]), idx, mat, **kw)
+        bare.add_instance(bare.add_model([(mesh, mat)]))
+    bare.add_point_light((1.0, 1.0, 1.0), 60.0, (0.0, 2.5, 1.0))
+    bare.camera = dict(eye=(0.0, 2.2, 3.5), target=(0.0, 0.3, -0.5), up=(0.0, 1.0, 0.0), fov=0.9, zN=0.1, zF=100.0)
+    tiny = gltf.load_gltf(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "tiny_scene.gltf"))
+    for world, brute in ((sponza_small, False), (scenes.transform_zoo(), True), (bare, True), (tiny, True)):
+        w, h = 240, 136
+        cam, fl = _camera(oracle, world, w, h)
+        images = {}
+        for raw in ("0", "1"):
+            monkeypatch.setenv("PROSPER_PT_DEBUG_RAW_RECORDS", raw)
+            gpu_ctx.upload_scene(world)
+            assert bool(gpu_ctx.scene_stats().variantFlags & S.VARIANT_RAW_RECORDS) == (raw == "1")
+            out = []
+            for name in ("Default", "ShadingNormal", "TexCoord0", "Position"):
+                pc = default_pc(S, fl, draw_type=S.DrawType[name], max_bounces=3, ibl=world.skybox is not None)
+                gpu_ctx.render(pc, cam, w, h, frames=2, flags=S.RENDER_COUNT_WORK if name == "Default" else 0)
+                out.append(gpu_ctx.read_hdr())
+            images[raw] = out
+        monkeypatch.delenv("PROSPER_PT_DEBUG_RAW_RECORDS")
+        for a, b in zip(images["0"], images["1"]):
+            assert same_bits(a, b).all()
+        osc = oracle.OracleScene(world, brute_force=brute)
+        want = None
+        for frame in (1, 2):
+            want, _ = osc.render(default_pc(S, fl, frame_index=frame, max_bounces=3, ibl=world.skybox is not None,
+                                            skip_history=(frame == 1)), cam, w, h, history=want)
+        assert same_bits(images["1"][0], want).all()
+
+
 def test_all_pipelines_produce_identical_pixels(gpu_ctx, oracle, cornell_world):
     """Default wavefront pipeline, PROSPER_PT_CREATE_PERSISTENT and PROSPER_PT_CREATE_MEGAKERNEL are
     the same function of (pixel, frame): identical images, identical counters, all equal to the oracle."""
