@@ -647,6 +647,7 @@ int upload_scene_impl(prosper_pt_ctx *ctx, const prosper_pt_scene_view *v)
     ctx->stats.bvhBuildSeconds = bvhBuildSeconds;
     ctx->stats.textureSeconds = textureSeconds;
     ctx->stats.uploadSeconds = seconds_since(tUpload);
+    ctx->sceneStamp++;
     ctx->stats.alphaTriangleCount = ctx->alphaTriangleCount;
     ctx->stats.alphaBoundBytes = ctx->alphaBoundBytes;
     return PROSPER_PT_OK;
@@ -867,6 +868,7 @@ void prosper_pt_destroy(prosper_pt_ctx *ctx)
     {
         if (slot.wfBlock) (void)hipFree(slot.wfBlock);
         if (slot.stackOverflow) (void)hipFree(slot.stackOverflow);
+        if (slot.tileOrder) (void)hipFree(slot.tileOrder);
     }
     if (ctx->restirScratch) (void)hipFree(ctx->restirScratch);
     if (ctx->toneLut) (void)hipFree(ctx->toneLut);
@@ -1013,6 +1015,7 @@ static int rebuild_hierarchy_impl(prosper_pt_ctx *ctx)
     if (rc != PROSPER_PT_OK) return rc;
     acc->stale = false;
     acc->rebuilds++;
+    ctx->sceneStamp++;
     ctx->stats.nodeCount = bvh.nodes.size();
     ctx->stats.maxDepth = bvh.maxDepth;
     ctx->stats.deviceBytes = ctx->sceneBytes;
@@ -1097,6 +1100,7 @@ static int flush_pending_update(prosper_pt_ctx *ctx, hipStream_t stream)
     acc->flatStale = true;
     if ((rc = enqueue_refit(ctx, stream))) return rc;
     acc->refits++;
+    ctx->sceneStamp++;
     PPT_HIP(hipEventRecord(acc->sceneEvent, stream));
     acc->sceneEventRecorded = true;
     acc->pending = false;
@@ -1429,6 +1433,50 @@ int prosper_pt_render_frames(
             int32_t *ovf = nullptr;
             const int orc = ensure_scratch_dwords(ctx, slot, plan.scratchDwordsPerBlock, wavefront_grid_blocks(w), s, &ovf);
             if (orc != PROSPER_PT_OK) return orc;
+            // EXPERIMENT (PROSPER_PT_DEBUG_TILE_ORDER=1; measured slower, profiles/r03_tile_order.txt): the camera-ray batches
+            // take the tiles by cost, heaviest first, so that every segment's stride through the sequence gets the same mix;
+            // recomputed when the view or the geometry changed since this slot's last order
+            static const bool tileOrderExperiment = std::getenv("PROSPER_PT_DEBUG_TILE_ORDER") != nullptr;
+            w.tileOrder = nullptr;
+            if (frames >= 4u && tileOrderExperiment)
+            {
+                const size_t tiles = (size_t)tilesX * tilesY;
+                RenderSlot::OrderKey key = {};
+                std::memcpy(key.camera, pp.eye, sizeof(float) * 12);
+                key.camera[12] = pp.aspect;
+                key.camera[13] = pp.tanHalfFovY;
+                key.width = pp.width;
+                key.height = pp.height;
+                key.stripeWidth = pp.stripeWidth;
+                key.stripeIndex = pp.stripeIndex;
+                key.stripeCount = pp.stripeCount;
+                key.localWidth = pp.localWidth;
+                key.sceneStamp = ctx->sceneStamp;
+                hipStream_t os = pipelined ? ctx->workStreams[slotIndex] : s;
+                if (slot.tileOrderTiles < tiles)
+                {
+                    PPT_HIP(hipDeviceSynchronize());
+                    if (slot.tileOrder) PPT_HIP(hipFree(slot.tileOrder));
+                    slot.tileOrder = nullptr;
+                    slot.tileOrderTiles = 0;
+                    PPT_HIP(hipMalloc((void **)&slot.tileOrder, (2 * tiles + 512) * sizeof(uint32_t)));
+                    slot.tileOrderTiles = tiles;
+                    slot.orderValid = false;
+                }
+                if (!slot.orderValid || std::memcmp(&key, &slot.orderKey, sizeof(key)) != 0)
+                {
+                    // behind the slot's previous user (it reads the old order) and behind a refit on another stream
+                    if (pipelined && slot.freeRecorded) PPT_HIP(hipStreamWaitEvent(os, slot.free, 0));
+                    if (!pipelined) wait_for_slot(slot, s);
+                    if (pipelined && ctx->accel && ctx->accel->sceneEventRecorded) PPT_HIP(hipStreamWaitEvent(os, ctx->accel->sceneEvent, 0));
+                    launch_tile_order(
+                        ctx->scene, pp, tilesX, tilesY, plan.ldsStackEntries, ovf, slot.tileOrder, slot.tileOrder + slot.tileOrderTiles, os);
+                    PPT_HIP(hipGetLastError());
+                    slot.orderKey = key;
+                    slot.orderValid = true;
+                }
+                w.tileOrder = slot.tileOrder;
+            }
             // the slot's previous user (a render of two calls ago, or the previous chunk of this one) must be done
             // with the workspace: detached chains wait for that on their own stream, the others on the caller's
             chains.after = slot.freeRecorded ? slot.free : nullptr;

@@ -166,6 +166,7 @@ struct prosper_pt_ctx
     prosper_pt_scene_stats stats = {};
     uint32_t packedMaterials = 0; // materials whose three textures are interleaved (MaterialPack)
     bool rawRecords = false;      // the scene keeps 64-byte raw shading records (RawShadeTriangle)
+    uint64_t sceneStamp = 0;      // bumped whenever the geometry the rays see changes (upload, refit, rebuild)
     uint64_t alphaTriangleCount = 0, alphaBoundBytes = 0; // any-hit records and bytes of alpha bounds (AlphaMaterial)
     // light buffers are re-uploaded every frame in prosper; keep their device addresses mutable
     ppt::LightState *lights = nullptr; // the scene's light buffers (device copies in the scene's allocation list)
@@ -213,6 +214,16 @@ struct prosper_pt_ctx
         uint32_t chainLaunches[ppt::kMaxChains] = {};
         hipEvent_t free = nullptr; // recorded after the accumulate kernel of the slot's last render
         bool freeRecorded = false;
+        // tiles by the cost of a probe ray (pt_wavefront.hip "tile order"), valid for the view in `orderKey`
+        uint32_t *tileOrder = nullptr; // [tiles] + scratch [tiles + 512]
+        size_t tileOrderTiles = 0;
+        struct OrderKey
+        {
+            float camera[14];
+            uint32_t width, height, stripeWidth, stripeIndex, stripeCount, localWidth;
+            uint64_t sceneStamp;
+        } orderKey = {};
+        bool orderValid = false;
     };
     // prosper keeps two frames in flight; a third one fills the machine better at the batch sizes of a multi-GPU
     // rank share (1/4 share 0.71 -> 0.66 ms, C3 19.3 -> 18.9 ms; profiles/r01_pipelined.txt)

@@ -66,6 +66,11 @@ void launch_tone_map(
 uint32_t megakernel_grid_blocks(const RenderParams &p);
 uint32_t persistent_grid_blocks();
 uint32_t wavefront_grid_blocks(const WavefrontBuffers &w);
+// tiles ordered by the cost of a probe ray (heaviest first) into order[tilesX * tilesY]; `scratch` holds
+// tilesX * tilesY + 512 more uint32s; `stackOverflow` as for the render's traversal kernels (the probe's grid is smaller)
+void launch_tile_order(
+    const DeviceScene &s, const RenderParams &p, uint32_t tilesX, uint32_t tilesY, uint32_t ldsStackEntries, int32_t *stackOverflow,
+    uint32_t *order, uint32_t *scratch, hipStream_t stream);
 // `stackOverflow`: global array of (stack bound - LDS entries) x (grid lanes) ints, or nullptr when the
 // BVH's stack bound fits the kernel's LDS stack
 void launch_render_megakernel(

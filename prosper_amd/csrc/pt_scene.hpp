@@ -246,6 +246,9 @@ struct WavefrontBuffers
     uint32_t pixelsPadded; // tilesX * tilesY * 64
     uint32_t tilesX;
     uint32_t tilesY;
+    // tiles in the order the camera-ray batches take them: heaviest first, by the cost of a probe ray through the tile's
+    // centre (pt_wavefront.hip tile order); nullptr = raster order
+    const uint32_t *tileOrder;
     uint32_t groupBase;  // this launch covers segment groups [groupBase, groupBase + groupCount)
     uint32_t groupCount; // (a group = the 4 segments of one workgroup)
 };

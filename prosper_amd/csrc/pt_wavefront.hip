@@ -153,7 +153,8 @@ __device__ __forceinline__ BatchLane batch_lane(const WavefrontBuffers &w, const
         if (!inRange) shift = 0u;
     }
     // 2^shift batches per tile, each a block of 64 >> shift pixels: 8x8, 8x4, 4x4, 4x2, 2x2, 2x1, 1x1
-    const uint32_t tile = rem >> shift, part = rem & ((1u << shift) - 1u);
+    const uint32_t rank = rem >> shift, part = rem & ((1u << shift) - 1u);
+    const uint32_t tile = (w.tileOrder != nullptr && rank < tiles) ? w.tileOrder[rank] : rank; // (wave-uniform: a scalar load)
     const uint32_t wShift = (7u - shift) >> 1, hShift = (6u - shift) >> 1; // log2 of the block's width and height
     const uint32_t pixel = lane & ((64u >> shift) - 1u);
     const uint32_t bx = part & ((8u >> wShift) - 1u), by = part >> (3u - wShift);
@@ -213,6 +214,90 @@ __device__ __forceinline__ LdsGeom stage_scene_in_lds(const DeviceScene &s, floa
 }
 
 } // namespace
+
+// ------------------------------------------------------------------------------------------
+// tile order: which tiles are expensive?
+// ------------------------------------------------------------------------------------------
+//
+// EXPERIMENT (PROSPER_PT_DEBUG_TILE_ORDER=1), measured and NOT the default (profiles/r03_tile_order.txt).
+// A segment takes every nSeg-th batch of the render's batch sequence.  In raster order its share of expensive tiles
+// (FlightHelmet: a fifth of the tiles see the mesh and cost 15-20x a sky tile) varies from segment to segment like any
+// systematic sample of a patchy image - the slowest wave sets the launch's tail (cu_busy 0.78).  Sorted by cost, the
+// sequence is monotone and every stride through it gets the same mix.  The cost of a tile = node visits + triangle tests
+// + any-hit calls of ONE probe ray through its centre (32 400 rays for a 1920x1080 frame, a few microseconds), binned to
+// 256 levels; a counting sort (histogram by the probe kernel, a one-workgroup scan, a scatter) orders the tiles heaviest
+// first.  Within a bin the order is whatever the atomics give: it decides which wave traces which tile, never a pixel.
+// Result: the waves' loads do even out, and the kernels get SLOWER (FlightHelmet wf_generate_extend 888 -> 977 us, C4 5667 ->
+// 6047; steps +2 to +4 %): neighbouring workgroups no longer work on neighbouring tiles, and every wave meets its heavy
+// tiles at the same time.  The strided raster order - a stratified sample of the image already - stays.
+
+template <int STACK>
+__global__ __launch_bounds__(256) void probe_tiles_kernel(
+    DeviceScene s, RenderParams p, uint32_t tilesX, uint32_t tiles, int32_t *__restrict__ stackOverflow, uint32_t overflowStride,
+    uint32_t *__restrict__ bins, uint32_t *__restrict__ histogram)
+{
+    __shared__ int32_t ldsStack[STACK * 256];
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    const TraversalStack stack{(lds_int32 *)ldsStack + (threadIdx.x >> 6) * (STACK * 64u) + (threadIdx.x & 63u),
+                               stackOverflow + blockIdx.x * 256u + threadIdx.x, (uint32_t)STACK, overflowStride, 64u};
+    if (t >= tiles) return;
+    const uint32_t ty = t / tilesX, tx = t - ty * tilesX;
+    const uint32_t lx = tx * 8u + 4u, py = ty * 8u + 4u;
+    uint32_t cost = 0u;
+    if (lx < p.localWidth + 4u && py < p.height + 4u)
+    {
+        const f2 uv = f2{((float)local_to_global_x(p, lx < p.localWidth ? lx : p.localWidth - 1u)) / (float)p.width,
+                         ((float)(py < p.height ? py : p.height - 1u)) / (float)p.height};
+        const Ray ray = pinhole_camera_ray(p, uv);
+        LaneCounters cnt = {};
+        Hit hit;
+        (void)trace_in<false, true>(GlobalGeom{s.nodes, s.triangles}, s, ray.o, ray.d, 0.0f, kInf, 0x9E3779B9u, stack, hit, cnt);
+        cost = cnt.nodeVisits + cnt.triangleTests + cnt.anyHitCalls;
+    }
+    const uint32_t bin = cost > 255u ? 255u : cost;
+    bins[t] = bin;
+    atomicAdd(&histogram[bin], 1u);
+}
+
+// histogram[256] -> cursor[b] = tiles in heavier bins (one workgroup of 256)
+__global__ __launch_bounds__(256) void tile_order_scan_kernel(const uint32_t *__restrict__ histogram, uint32_t *__restrict__ cursor)
+{
+    __shared__ uint32_t counts[256];
+    counts[threadIdx.x] = histogram[threadIdx.x];
+    __syncthreads();
+    uint32_t before = 0;
+    for (uint32_t b = threadIdx.x + 1u; b < 256u; ++b) before += counts[b];
+    cursor[threadIdx.x] = before;
+}
+
+__global__ __launch_bounds__(256) void tile_order_scatter_kernel(
+    const uint32_t *__restrict__ bins, uint32_t *__restrict__ cursor, uint32_t *__restrict__ order, uint32_t tiles)
+{
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= tiles) return;
+    order[atomicAdd(&cursor[bins[t]], 1u)] = t;
+}
+
+// scratch: bins[tiles], histogram[256], cursor[256] (uint32 each) behind order[tiles]
+void launch_tile_order(
+    const DeviceScene &s, const RenderParams &p, uint32_t tilesX, uint32_t tilesY, uint32_t ldsStackEntries, int32_t *stackOverflow,
+    uint32_t *order, uint32_t *scratch, hipStream_t stream)
+{
+    const uint32_t tiles = tilesX * tilesY;
+    if (tiles == 0) return;
+    uint32_t *bins = scratch, *histogram = scratch + tiles, *cursor = histogram + 256;
+    (void)hipMemsetAsync(histogram, 0, 256 * sizeof(uint32_t), stream);
+    const dim3 grid((tiles + 255u) / 256u), block(256);
+    const uint32_t stride = grid.x * 256u;
+    if (ldsStackEntries == 16u)
+        hipLaunchKernelGGL(probe_tiles_kernel<16>, grid, block, 0, stream, s, p, tilesX, tiles, stackOverflow, stride, bins, histogram);
+    else if (ldsStackEntries == 24u)
+        hipLaunchKernelGGL(probe_tiles_kernel<24>, grid, block, 0, stream, s, p, tilesX, tiles, stackOverflow, stride, bins, histogram);
+    else
+        hipLaunchKernelGGL(probe_tiles_kernel<32>, grid, block, 0, stream, s, p, tilesX, tiles, stackOverflow, stride, bins, histogram);
+    hipLaunchKernelGGL(tile_order_scan_kernel, dim3(1), dim3(256), 0, stream, histogram, cursor);
+    hipLaunchKernelGGL(tile_order_scatter_kernel, grid, block, 0, stream, bins, cursor, order, tiles);
+}
 
 // ------------------------------------------------------------------------------------------
 // generate + first extend
