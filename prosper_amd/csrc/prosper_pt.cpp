@@ -1436,7 +1436,7 @@ int prosper_pt_render_frames(
             // EXPERIMENT (PROSPER_PT_DEBUG_TILE_ORDER=1; measured slower, profiles/r03_tile_order.txt): the camera-ray batches
             // take the tiles by cost, heaviest first, so that every segment's stride through the sequence gets the same mix;
             // recomputed when the view or the geometry changed since this slot's last order
-            static const bool tileOrderExperiment = std::getenv("PROSPER_PT_DEBUG_TILE_ORDER") != nullptr;
+            const bool tileOrderExperiment = std::getenv("PROSPER_PT_DEBUG_TILE_ORDER") != nullptr;
             w.tileOrder = nullptr;
             if (frames >= 4u && tileOrderExperiment)
             {

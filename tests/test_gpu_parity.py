@@ -771,6 +771,46 @@ def test_raw_shading_records_equal_decoded_ones(gpu_ctx, oracle, sponza_small, m
         assert same_bits(images["1"][0], want).all()
 
 
+def test_tiles_dealt_by_cost_give_the_same_pixels(gpu_ctx, oracle, monkeypatch):
+    """PROSPER_PT_DEBUG_TILE_ORDER=1 (an experiment, profiles/r03_tile_order.txt): the camera-ray batches take the tiles by
+    the cost of a probe ray instead of in raster order.  Which wave traces which tile never decides a pixel: the same
+    bits on the FlightHelmet fixture (mostly sky) and on a rank's stripes of S-sponza-class, in order and with frames in
+    flight, after the view changed and after an instance moved."""
+    from prosper_amd import flight_helmet, tiling
+    from prosper_amd.world import translate
+    helmet = flight_helmet.load_fixture()
+    sponza = scenes.sponza_class(lights=(4, 4), foliage=True, texture_size=64, sky_size=32, detail=0.25)
+    for world, tile in ((helmet, None), (sponza, tiling.tile_for_rank(1, 2))):
+        w, h = 512, 288
+        cam, fl = _camera(oracle, world, w, h)
+        pc = default_pc(S, fl, max_bounces=3, ibl=True)
+        images = {}
+        for on in (False, True):
+            if on:
+                monkeypatch.setenv("PROSPER_PT_DEBUG_TILE_ORDER", "1")
+            gpu_ctx.upload_scene(world)
+            out = []
+            for flags in (0, S.RENDER_PIPELINED, S.RENDER_PIPELINED):
+                gpu_ctx.render(pc, cam, w, h, tile=tile, frames=8, flags=flags)
+                out.append(gpu_ctx.read_hdr())
+            cam2, fl2 = oracle.camera_uniforms((0.5, 0.3, 0.6) if world is helmet else (-8.0, 3.0, 1.5), world.camera["target"],
+                                               world.camera["up"], world.camera["fov"], world.camera["zN"], world.camera["zF"], w, h)
+            gpu_ctx.render(default_pc(S, fl2, max_bounces=3, ibl=True), cam2, w, h, tile=tile, frames=5, flags=S.RENDER_PIPELINED)
+            out.append(gpu_ctx.read_hdr())
+            if world is sponza:
+                moved = scenes.sponza_class(lights=(4, 4), foliage=True, texture_size=64, sky_size=32, detail=0.25)
+                model, m = moved.model_instances[4]
+                moved.model_instances[4] = (model, translate((0.3, 0.2, -0.2)) @ m)
+                gpu_ctx.update_transforms(moved)
+                gpu_ctx.render(pc, cam, w, h, tile=tile, frames=8, flags=S.RENDER_PIPELINED)
+                out.append(gpu_ctx.read_hdr())
+            images[on] = out
+        monkeypatch.delenv("PROSPER_PT_DEBUG_TILE_ORDER")
+        assert same_bits(images[False][0], images[False][1]).all()
+        for a, b in zip(images[False], images[True]):
+            assert same_bits(a, b).all()
+
+
 def test_all_pipelines_produce_identical_pixels(gpu_ctx, oracle, cornell_world):
     """Default wavefront pipeline, PROSPER_PT_CREATE_PERSISTENT and PROSPER_PT_CREATE_MEGAKERNEL are
     the same function of (pixel, frame): identical images, identical counters, all equal to the oracle."""
