@@ -296,7 +296,7 @@ typedef struct prosper_pt_hierarchy_state
 {
     uint32_t refits;    /* since the scene was uploaded */
     uint32_t rebuilds;
-    float costRatio;    /* surface-area measure of the tree after the last refit / after the last build */
+    float costRatio;    /* sum of the inner boxes' half-areas after the last refit / right after the last build */
     float builtCost;
     uint32_t nodeCount;
     uint32_t levels;    /* kernel launches of a refit = levels + 1 */

@@ -225,9 +225,11 @@ __global__ __launch_bounds__(256) void refit_bounds_kernel(
     bounds[2 * (size_t)i + 1] = make_float4(u.hi[0], u.hi[1], u.hi[2], 0.0f);
 }
 
-// `cost` (optional): sum over the nodes of the half-areas of their inner children's boxes relative to the root's - the
-// surface-area measure of how many node visits a random ray makes; the host compares it with the value right after the
-// last build to notice a tree that moved instances have degraded (a heuristic: the float sum is not deterministic).
+// `cost` (optional): sum over the nodes of the half-areas of their inner children's boxes - the surface-area measure of how
+// many node visits a ray through the scene makes (absolute, not relative to the root's box: an instance that leaves the
+// scene's old bounds must not hide the growth of the nodes it stretches); the host compares it with the value right
+// after the last build to notice a tree that moved instances have degraded (a heuristic: the float sum is not
+// deterministic).
 __global__ __launch_bounds__(256) void encode_nodes_kernel(
     BvhNode *__restrict__ nodes, const WorldTriangle *__restrict__ tris, const float4 *__restrict__ bounds,
     uint32_t nodeCount, float padCoeff, float *__restrict__ cost)
@@ -253,9 +255,7 @@ __global__ __launch_bounds__(256) void encode_nodes_kernel(
     nodes[i] = n;
     if (cost != nullptr)
     {
-        const float sx = scene.hi[0] - scene.lo[0], sy = scene.hi[1] - scene.lo[1], sz = scene.hi[2] - scene.lo[2];
-        const float rootArea = sx * sy + sy * sz + sz * sx;
-        float v = rootArea > 0.0f ? area / rootArea : 0.0f;
+        float v = area;
         for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
         if ((threadIdx.x & 63u) == 0u && v != 0.0f) atomicAdd(cost, v);
     }

@@ -1056,6 +1056,41 @@ def test_refit_writes_the_emitters_bytes(gpu_ctx, monkeypatch):
             differing[0][0], differing[0][1], emitted[tuple(differing[0])], refitted[tuple(differing[0])])
 
 
+def test_far_moves_trigger_the_host_side_rebuild(gpu_ctx, oracle):
+    """A refit keeps the tree's shape: instances that travel far leave it with fat boxes.  The refit's surface-area measure
+    notices (costRatio well above 1.3 after three instances crossed the hall), and the NEXT update re-splits them on the
+    host (rebuilds == 1, the measure back at 1): the image is the oracle's before and after."""
+    from prosper_amd.world import translate
+
+    def pose(shift):
+        world = scenes.sponza_class(lights=(4, 4), texture_size=64, sky_size=32, detail=0.25)
+        for k in (2, 9, 14):
+            model, m = world.model_instances[k]
+            world.model_instances[k] = (model, translate((shift, 0.3 * shift, -0.5 * shift)) @ m)
+        return world
+    still, far, farther = pose(0.0), pose(14.0), pose(14.05)
+    w, h = 256, 144
+    cam, fl = _camera(oracle, still, w, h)
+    pc = default_pc(S, fl, max_bounces=3, ibl=True)
+    gpu_ctx.upload_scene(still)
+    for world, rebuilds in ((far, 0), (farther, 1)):
+        gpu_ctx.update_transforms(world)
+        gpu_ctx.render(pc, cam, w, h, frames=2)
+        got = gpu_ctx.read_hdr()
+        hs = gpu_ctx.hierarchy_state()
+        assert hs.rebuilds == rebuilds, (hs.rebuilds, hs.costRatio)
+        if rebuilds == 0:
+            assert hs.costRatio > 1.3, hs.costRatio
+        else:
+            assert hs.costRatio < 1.05, hs.costRatio
+        osc = oracle.OracleScene(world)
+        want = None
+        for frame in (1, 2):
+            want, _ = osc.render(default_pc(S, fl, frame_index=frame, max_bounces=3, ibl=True, skip_history=(frame == 1)),
+                                 cam, w, h, history=want)
+        assert same_bits(got, want).all()
+
+
 def test_refit_of_a_flat_tree_and_of_alpha_geometry(gpu_ctx, oracle, monkeypatch):
     """The refit does not care how the tree was built: on the one-tree-over-everything hierarchy (PROSPER_PT_DEBUG_FLAT_BVH)
     moved instances give the oracle's image of the moved scene too - here on the instance-transform zoo (mirrors, shears,
