@@ -1056,6 +1056,42 @@ def test_refit_writes_the_emitters_bytes(gpu_ctx, monkeypatch):
             differing[0][0], differing[0][1], emitted[tuple(differing[0])], refitted[tuple(differing[0])])
 
 
+def test_update_enqueued_on_a_stream_of_the_callers(gpu_ctx, oracle):
+    """prosper_pt_update_transforms_async with a stream: the refit is enqueued by the call itself on that stream (not left
+    to the next render), the renders that follow - on the same stream or, pipelined, on the library's own - wait for it."""
+    import ctypes
+    from prosper_amd.world import rotate_y, translate
+    hip = ctypes.CDLL("libamdhip64.so")
+    stream = ctypes.c_void_p()
+    assert hip.hipStreamCreate(ctypes.byref(stream)) == 0
+    try:
+        still, moved = scenes.transform_zoo(), scenes.transform_zoo()
+        for k in (0, 5):
+            model, m = moved.model_instances[k]
+            moved.model_instances[k] = (model, translate((0.5, 0.4, 0.3)) @ rotate_y(0.7) @ m)
+        w, h = 256, 160
+        cam, fl = _camera(oracle, still, w, h)
+        pc = default_pc(S, fl, max_bounces=3)
+        gpu_ctx.upload_scene(still)
+        gpu_ctx.render(pc, cam, w, h, frames=2, flags=S.RENDER_PIPELINED, stream=stream.value)
+        gpu_ctx.update_transforms(moved, stream=stream.value)
+        assert gpu_ctx._world is moved
+        images = []
+        for flags in (S.RENDER_PIPELINED, 0):
+            gpu_ctx.render(pc, cam, w, h, frames=2, flags=flags, stream=stream.value)
+            images.append(gpu_ctx.read_hdr(stream.value))
+        osc = oracle.OracleScene(moved, brute_force=True)
+        want = None
+        for frame in (1, 2):
+            want, _ = osc.render(default_pc(S, fl, frame_index=frame, max_bounces=3, skip_history=(frame == 1)), cam, w, h,
+                                 history=want)
+        assert same_bits(images[0], want).all() and same_bits(images[1], want).all()
+        assert gpu_ctx.hierarchy_state().refits == 1
+    finally:
+        assert hip.hipStreamSynchronize(stream) == 0
+        assert hip.hipStreamDestroy(stream) == 0
+
+
 def test_far_moves_trigger_the_host_side_rebuild(gpu_ctx, oracle):
     """A refit keeps the tree's shape: instances that travel far leave it with fat boxes.  The refit's surface-area measure
     notices (costRatio well above 1.3 after three instances crossed the hall), and the NEXT update re-splits them on the
