@@ -532,18 +532,22 @@ def main():
     # ---- PMC passes of the headline configuration, as child processes, BEFORE this process touches the GPU ----
     sub_names = [c for c in args.subconfigs.split(",") if c] if (args.config == "c2" and not args.no_subconfigs) else []
     pmc_by_config = {}
+    pmc_gave_up = False
     if world_size == 1 and wavefront:
         for name in [args.config] + sub_names:
             if name not in ("c2", "c3", "c4", "c5", "helmet"):
                 continue
             got = None
-            if not args.no_pmc:
+            if not args.no_pmc and not pmc_gave_up:
                 try:
                     t0 = time.perf_counter()
-                    got = pmc_tools.collect(name, timeout=420)
+                    got = pmc_tools.collect(name, timeout=240)
                     got["source"] = "rocprofv3 --pmc child passes of this run (%.0f s; scripts/pmc_tools.py)" % (time.perf_counter() - t0)
                 except Exception as e:  # no profiler, a refused counter, a timeout: the line says so instead of failing
                     print("bench: live PMC passes unavailable for %s (%s)" % (name, str(e)[:300]), file=sys.stderr)
+                    # one failure is the box's answer: no further passes are tried (a hanging profiler must not cost the
+                    # run a timeout per pass and configuration); the committed profiles serve if they match the sources
+                    pmc_gave_up = True
             if got is None:
                 got = pmc_tools.load_committed(name)
             pmc_by_config[name] = got
