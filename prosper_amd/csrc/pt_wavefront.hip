@@ -189,6 +189,32 @@ struct StreamTracer
         trace_stream<ANY, COUNT>(g, s, n, stack, cnt, fetch, commit);
     }
 };
+// 64 rays at a time in lockstep (trace_in's while-while loop), as the camera rays are traced: no phases, no refill.
+struct LockstepTracer
+{
+    TraversalStack stack;
+    template <bool ANY, bool COUNT, class Geom, class Fetch, class Commit>
+    __device__ __forceinline__ void run(
+        const Geom &g, const DeviceScene &s, uint32_t n, float, LaneCounters &cnt, Fetch &&fetch, Commit &&commit) const
+    {
+        const uint32_t lane = threadIdx.x & 63u;
+        for (uint32_t k0 = 0; k0 < n; k0 += 64u)
+        {
+            const uint32_t k = k0 + lane;
+            const bool valid = k < n;
+            StreamRay r;
+            r.o = f3{0.0f, 0.0f, 0.0f};
+            r.d = f3{0.0f, 0.0f, 1.0f};
+            r.tMin = 0.0f;
+            r.tMax = -1.0f; // a ray that cannot hit anything
+            r.seed = 0u;
+            if (valid) r = fetch(k);
+            Hit hit;
+            const bool found = trace_in<ANY, COUNT>(g, s, r.o, r.d, r.tMin, r.tMax, r.seed, stack, hit, cnt);
+            commit(valid, k, valid && found, hit, r.d);
+        }
+    }
+};
 template <uint32_t P, uint32_t S, uint32_t B>
 struct PoolTracer
 {
@@ -699,8 +725,15 @@ __global__ __launch_bounds__(256, PPT_TRACE_WPE(STACK)) void wf_trace(
                                             stackOverflow + blockIdx.x * 256u + threadIdx.x, (uint32_t)STACK,
                                             gridDim.x * 256u, 64u}};
     LaneCounters cnt = {};
+#ifdef PPT_EXPERIMENT_LDS_SCENE_LOCKSTEP
+    const LockstepTracer lockstep{stack.stack};
+#endif
     if constexpr (LDS_SCENE)
+#ifdef PPT_EXPERIMENT_LDS_SCENE_LOCKSTEP
+        shadow_segment<COUNT>(lg, s, p, w, id, bounce, lockstep, cnt);
+#else
         shadow_segment<COUNT>(lg, s, p, w, id, bounce, stack, cnt);
+#endif
     else
         shadow_segment<COUNT>(gg, s, p, w, id, bounce, stack, cnt);
     if (doExtend)
@@ -709,7 +742,11 @@ __global__ __launch_bounds__(256, PPT_TRACE_WPE(STACK)) void wf_trace(
         // radiance stores before the extend phase's loads; the vector L1 is write-through
         __threadfence_block();
         if constexpr (LDS_SCENE)
+#ifdef PPT_EXPERIMENT_LDS_SCENE_LOCKSTEP
+            extend_segment<COUNT>(lg, s, p, w, id, bounce + 1u, nextCur, lockstep, cnt);
+#else
             extend_segment<COUNT>(lg, s, p, w, id, bounce + 1u, nextCur, stack, cnt);
+#endif
         else
             extend_segment<COUNT>(gg, s, p, w, id, bounce + 1u, nextCur, stack, cnt);
     }
