@@ -686,7 +686,12 @@ int ensure_wavefront_workspace(
     uint64_t batches = (slots / target + 32u) / 64u;
     if (batches < 2u) batches = 2u; // small renders: 128-slot segments
     if (batches > 2u && batches % 2u == 0u) batches += 1u;
-    if (batches > 33u) batches = 33u;
+    // At most 49 batches (3136 slots) per segment.  Re-swept in round 3 (profiles/r03_seglen_sweep.txt; the cap was 33 since
+    // round 1): longer per-wave streams keep the later stages' waves fuller - what a sparse image (FlightHelmet: one camera
+    // ray in seven hits anything) and expensive, uneven rays (C4's foliage) need - while a dense, texture-heavy scene (C3)
+    // prefers short segments, whose waves work on neighbouring tiles.  8 spp, three frames in flight, 33 -> 49 -> 65 batches:
+    // FlightHelmet 2.04 -> 1.91 -> 1.87 ms, C4 27.9 -> 27.05 -> 27.15, C2 1.95 -> 1.96 -> 1.94, C3 12.93 -> 13.07 -> 13.14.
+    if (batches > 49u) batches = 49u;
     uint64_t segLen = batches * 64u;
     if (const char *forced = std::getenv("PROSPER_PT_DEBUG_SEGLEN")) // tuning/test hook
     {
