@@ -677,7 +677,9 @@ int ensure_wavefront_workspace(
     // profiles/r01_seglen_sweep.txt).  The length is an ODD multiple of 64 slots: at even multiples the waves'
     // concurrent accesses to their segments' records, `segLen * 16` bytes apart, pile onto a few HBM channels.
     // (frames in flight, one chain each: the same total split over the kRenderSlots frames - 3 700)
-    uint64_t target = pipelined ? 3700u : 11500u;
+    // (round 3, small batches re-swept - profiles/r03_seglen_sweep.txt: a 1-spp frame of C2 0.326 -> 0.317 ms at 2560 instead of
+    // 3700 segments, FlightHelmet 0.524 -> 0.499, a 1/8 rank share 0.330 -> 0.317, C3 1.826 -> 1.867: 3000)
+    uint64_t target = pipelined ? 3000u : 11500u;
     if (const char *forced = std::getenv("PROSPER_PT_DEBUG_SEGMENTS")) // tuning hook
     {
         const uint64_t v = (uint64_t)std::atoll(forced);
