@@ -640,18 +640,7 @@ PPT_D Material sample_material(const DeviceScene &s, uint32_t index, f2 uv)
     return ret;
 }
 
-// materials.glsl:121-147
-PPT_D float sample_alpha(const DeviceScene &s, uint32_t index, f2 uv)
-{
-    const prosper_MaterialData data = s.materials[index];
-    float linearAlpha = 1.0f;
-    const uint32_t baseTex = data.baseColorTextureSampler & 0xFFFFFFu;
-    if (baseTex > 0) linearAlpha = srgb_to_linear(sample_texture(s, baseTex, data.baseColorTextureSampler >> 24, uv).w);
-    linearAlpha *= data.baseColorFactor.w;
-    if (data.alphaMode == PROSPER_ALPHA_MODE_BLEND) return linearAlpha;
-    if (data.alphaMode == PROSPER_ALPHA_MODE_MASK && linearAlpha < data.alphaCutoff) return 0.0f;
-    return -1.0f;
-}
+// (sampleAlpha, materials.glsl:121-147, lives with the any-hit shader below: any_hit_settle / any_hit_exact / alpha_verdict)
 
 // ------------------------------------------------------------------------------------------
 // F15 BRDF — brdf.glsl
