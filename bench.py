@@ -13,10 +13,15 @@ accumulate and its gather complete inside the timed region, which is bracketed b
 What the one JSON line carries besides the contract fields:
   roofline   the roof that binds the dominant kernel: VALU issue.  achieved = wave-instructions/s of that kernel
              (SQ_INSTS_VALU per launch, measured IN THIS RUN by rocprofv3 child passes over the same launch shape, /
-             the kernel's exclusive share of the step time), peak = the chip's measured v_fma_f32 issue rate
-             (profiles/r02_valu_calibration.json), lane_util beside it; hbm_measured = PMC bytes / that time / 8 TB/s
-  configs    C3 and C4 (the configurations where bytes matter), each with ms/step, Mpaths/s, dominant kernel,
-             upload and BVH build time, measured / algorithmic traffic
+             the kernel's exclusive share of the step time); peak = the guide's 1024 SIMDs x 2.4 GHz / 2 cycles, the
+             chip's measured v_fma_f32 rate (profiles/r02_valu_calibration.json) beside it; frac = the USEFUL fraction =
+             achieved / peak x lane utilisation; hbm = measured (PMC) and algorithmic bytes over that time
+             against 8 TB/s, with cache_served where the byte model prices bytes the caches serve; work_normalised =
+             issue slots per node visit / triangle test / any-hit call against their static cost (profiles/r03_unit_costs.json)
+  single_sample_frames, rank_share   one render per 1-spp frame as RtReference::record makes them; one rank's stripes of
+             the frame of an 8-rank job, alone on this GPU
+  configs    C3 (+ the C5 rank share), C4 and the reference's bundled FlightHelmet, each with ms/step, Mpaths/s, the same
+             roofline object, per-kernel table, counters, upload and BVH build time
   cpu_baseline  the oracle (a scalar port) on this box's host cores, bounded sample
 
     python bench.py --gpus 1 --steps 20 --warmup 3
