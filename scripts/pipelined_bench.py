@@ -40,8 +40,7 @@ def main():
         for ranks in ((8, 4, 2, 1) if name == "c2" else (1,)):
             tile = tiling.tile_for_rank(0, ranks) if ranks > 1 else None
             for render_flags, label in ((0, "in order"), (S.RENDER_PIPELINED, "pipelined")):
-                # (a big pipelined batch spends its first 28 renders measuring segment lengths: prosper_pt.cpp tuner_pick)
-                for _ in range(36 if (render_flags and SPP >= 4) else 4):
+                for _ in range(4):
                     ctx.render(pc, cam, width, height, frames=SPP, tile=tile, flags=render_flags)
                 hip.hipDeviceSynchronize()
                 steps = 30 if name == "c2" else 6
