@@ -250,6 +250,12 @@ int upload_hierarchy(prosper_pt_ctx *ctx, const BvhBuildResult &bvh)
         const size_t capacity = n + n / 4 + 64;
         void *d = nullptr;
         int rc;
+        // (callers have synchronised the device: no refit is reading the old tables)
+        if (acc->dNodeBounds) device_free(ctx, acc->dNodeBounds);
+        if (acc->dRefitOrder) device_free(ctx, acc->dRefitOrder);
+        acc->dNodeBounds = nullptr;
+        acc->dRefitOrder = nullptr;
+        acc->refitCapacityNodes = 0;
         if ((rc = device_alloc(ctx, capacity * 2 * sizeof(float4), &d))) return rc;
         acc->dNodeBounds = static_cast<float4 *>(d);
         if ((rc = device_alloc(ctx, capacity * sizeof(uint32_t), &d))) return rc;
@@ -1269,6 +1275,32 @@ int prosper_pt_set_output_buffer(prosper_pt_ctx *ctx, void *device_rgba32f, size
     return PROSPER_PT_OK;
 }
 
+// The scene and light versions a render (or a ReSTIR trace) read are free again behind its last kernel on `s` (the
+// accumulate kernel follows the path stages on the caller's stream).  One event per version: a reader on ANOTHER stream
+// than the previous reader's first waits for that one, so the newest record always stands for every reader so far.
+static int mark_versions_read(prosper_pt_ctx *ctx, hipStream_t s)
+{
+    auto mark = [&](hipEvent_t &event, bool &used, hipStream_t &last) -> int {
+        if (!event) PPT_HIP(hipEventCreateWithFlags(&event, hipEventDisableTiming));
+        if (used && last != s) PPT_HIP(hipStreamWaitEvent(s, event, 0));
+        PPT_HIP(hipEventRecord(event, s));
+        used = true;
+        last = s;
+        return PROSPER_PT_OK;
+    };
+    if (AccelState *acc = ctx->accel)
+    {
+        const int rc = mark(acc->versionFree[acc->cur], acc->versionUsed[acc->cur], acc->versionStream[acc->cur]);
+        if (rc != PROSPER_PT_OK) return rc;
+    }
+    if (LightState *ls = ctx->lights)
+    {
+        const int rc = mark(ls->versionFree[ls->cur], ls->versionUsed[ls->cur], ls->versionStream[ls->cur]);
+        if (rc != PROSPER_PT_OK) return rc;
+    }
+    return PROSPER_PT_OK;
+}
+
 int prosper_pt_render_frames(
     prosper_pt_ctx *ctx, const prosper_ReferencePC *pc, const prosper_CameraUniforms *camera, uint32_t width,
     uint32_t height, const prosper_pt_tile_desc *tile, uint32_t frame_count, uint32_t render_flags, void *stream)
@@ -1500,21 +1532,9 @@ int prosper_pt_render_frames(
         if (tp) ctx->timedSlot = slotIndex;
     }
     PPT_HIP(hipGetLastError());
-    if (ctx->accel)
     {
-        // the scene version this render read is free again behind its last kernel (the accumulate kernel follows the
-        // path stages on the caller's stream)
-        AccelState *acc = ctx->accel;
-        if (!acc->versionFree[acc->cur]) PPT_HIP(hipEventCreateWithFlags(&acc->versionFree[acc->cur], hipEventDisableTiming));
-        PPT_HIP(hipEventRecord(acc->versionFree[acc->cur], s));
-        acc->versionUsed[acc->cur] = true;
-    }
-    if (ctx->lights)
-    {
-        LightState *ls = ctx->lights;
-        if (!ls->versionFree[ls->cur]) PPT_HIP(hipEventCreateWithFlags(&ls->versionFree[ls->cur], hipEventDisableTiming));
-        PPT_HIP(hipEventRecord(ls->versionFree[ls->cur], s));
-        ls->versionUsed[ls->cur] = true;
+        const int mrc = mark_versions_read(ctx, s);
+        if (mrc != PROSPER_PT_OK) return mrc;
     }
     if (tp)
     {
@@ -1665,7 +1685,7 @@ int prosper_pt_restir_di_trace(
         ctx->scene, pc->drawType, pc->frameIndex, pc->flags, width, height, eye, c2w, ar, nm, depth, res, ctx->hdr, ovf, s);
     release_slot(ctx->slots[0], s);
     PPT_HIP(hipGetLastError());
-    return PROSPER_PT_OK;
+    return mark_versions_read(ctx, s);
 }
 
 int prosper_pt_set_tone_map_lut(prosper_pt_ctx *ctx, const uint32_t *lut, uint32_t dim)

@@ -41,6 +41,7 @@ struct LightState
     LightBlock *dBlocks[kVersions] = {}; // [0] is the upload's own allocation
     hipEvent_t versionFree[kVersions] = {};
     bool versionUsed[kVersions] = {};
+    hipStream_t versionStream[kVersions] = {}; // the stream versionFree was last recorded on
     uint32_t cur = 0;
     LightBlock *mirror = nullptr;         // host copy of what the device holds (or will hold once `pending` is flushed)
     LightBlock *staging[2] = {nullptr, nullptr}; // pinned
@@ -121,6 +122,7 @@ struct AccelState
     bool nodesCurrent[kVersions] = {}; // the version's node array holds the tree of the last build (child references)
     hipEvent_t versionFree[kVersions] = {}; // behind the last render that read the version
     bool versionUsed[kVersions] = {};
+    hipStream_t versionStream[kVersions] = {}; // the stream versionFree was last recorded on
     uint32_t cur = 0;
     // an update waits here until the next consumer of the scene - normally the next render, which runs it at the head of
     // its own chain of launches, beside the frames in flight
