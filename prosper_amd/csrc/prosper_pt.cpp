@@ -383,6 +383,11 @@ int upload_scene_impl(prosper_pt_ctx *ctx, const prosper_pt_scene_view *v)
     std::vector<MaterialPack> packs(v->materialCount);
     uint32_t packedMaterials = 0;
     const bool noPacks = std::getenv("PROSPER_PT_DEBUG_NO_TEXTURE_PACKS") != nullptr;
+    // compact packs where the texels outgrow the caches (the threshold of the batched loads above): on a small texture set
+    // the bytes are not what the shade kernel waits for, and two kinds of pack in one wave cost a divergent branch
+    // (FlightHelmet fixture: +1 % on the step).  PROSPER_PT_DEBUG_WIDE_PACKS = 1 / 0 forces the 16-byte / the compact pack.
+    bool widePacks = texelBytes <= (32ull << 20);
+    if (const char *forced = std::getenv("PROSPER_PT_DEBUG_WIDE_PACKS")) widePacks = std::atoi(forced) != 0;
     for (uint32_t i = 0; i < v->materialCount; ++i)
     {
         packs[i] = MaterialPack{nullptr, 0u, 0u, 0u, 0u};
@@ -399,10 +404,12 @@ int upload_scene_impl(prosper_pt_ctx *ctx, const prosper_pt_scene_view *v)
         pk.width = b.width;
         pk.height = b.height;
         pk.tilesPerRow = (b.width + kPackTileW - 1u) / kPackTileW;
-        pk.sampler = sb;
+        // an OPAQUE material never reads base.a: the 8-byte texel
+        const bool compact = m.alphaMode == PROSPER_ALPHA_MODE_OPAQUE && !widePacks;
+        pk.sampler = sb | (compact ? kPackCompactBit : 0u);
         const size_t texelCount = (size_t)pk.tilesPerRow * kPackTileW * (((size_t)b.height + kPackTileH - 1u) / kPackTileH) * kPackTileH;
-        if ((rc = device_alloc(ctx, texelCount * sizeof(uint4), &d))) return rc;
-        pk.texels = static_cast<const uint4 *>(d);
+        if ((rc = device_alloc(ctx, texelCount * (compact ? sizeof(uint2) : sizeof(uint4)), &d))) return rc;
+        pk.texels = d;
         launch_pack_material_textures(b, r, n, pk, nullptr);
         packs[i] = pk;
         ++packedMaterials;
@@ -468,8 +475,16 @@ int upload_scene_impl(prosper_pt_ctx *ctx, const prosper_pt_scene_view *v)
     s.skyboxFaceSize = 0;
     if (v->skybox.texels)
     {
+        // kept with a one-texel seamless border per face (pt_device.hpp fetch_cube_rgb); the plain copy is only the source
         const size_t bytes = 6ull * v->skybox.faceSize * v->skybox.faceSize * 4u * sizeof(uint16_t);
-        if ((rc = upload(ctx, v->skybox.texels, bytes, &d))) return rc;
+        const size_t n2 = (size_t)v->skybox.faceSize + 2u;
+        void *plain = nullptr;
+        if ((rc = upload(ctx, v->skybox.texels, bytes, &plain))) return rc;
+        if ((rc = device_alloc(ctx, 6ull * n2 * n2 * 4u * sizeof(uint16_t), &d))) return rc;
+        launch_border_skybox(static_cast<const uint16_t *>(plain), v->skybox.faceSize, d, nullptr);
+        PPT_HIP(hipGetLastError());
+        PPT_HIP(hipDeviceSynchronize());
+        device_free(ctx, plain);
         s.skybox = static_cast<const uint16_t *>(d);
         s.skyboxFaceSize = v->skybox.faceSize;
     }

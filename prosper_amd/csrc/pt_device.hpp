@@ -447,9 +447,11 @@ PPT_D f3 cube_face_dir(uint32_t face, float sc, float tc)
     }
 }
 
-PPT_D f3 fetch_cube_rgb(const DeviceScene &s, uint32_t face, int32_t i, int32_t j)
+// Texel (i, j) of a face of the cube as uploaded (6 x n x n RGBA16F), i and j in [-1, n]: outside the face it is the
+// texel the seamless-edge rule finds on the neighbouring face.  Runs once per border texel at upload
+// (border_skybox_kernel); the path's own lookups read the bordered copy.
+PPT_D uint2 cube_texel_seamless(const uint16_t *skybox, int32_t n, uint32_t face, int32_t i, int32_t j)
 {
-    const int32_t n = (int32_t)s.skyboxFaceSize;
     if (i < 0 || j < 0 || i >= n || j >= n)
     {
         // seamless edge: re-project the centre of the out-of-face texel onto the neighbouring face
@@ -467,7 +469,16 @@ PPT_D f3 fetch_cube_rgb(const DeviceScene &s, uint32_t face, int32_t i, int32_t 
         i = i < 0 ? 0 : (i >= n ? n - 1 : i);
         j = j < 0 ? 0 : (j >= n ? n - 1 : j);
     }
-    const uint2 p = *reinterpret_cast<const uint2 *>(s.skybox + 4u * (((size_t)face * n + (size_t)j) * n + (size_t)i));
+    return *reinterpret_cast<const uint2 *>(skybox + 4u * (((size_t)face * n + (size_t)j) * n + (size_t)i));
+}
+
+// DeviceScene::skybox holds every face with a one-texel BORDER, (n + 2) x (n + 2): the border texels are the ones
+// cube_texel_seamless finds for the out-of-face taps of a bilinear footprint, so a lookup is four plain loads - no
+// re-projection branch, which one lane in 250 needs and two waves in five had to walk through.
+PPT_D f3 fetch_cube_rgb(const DeviceScene &s, uint32_t face, int32_t i, int32_t j)
+{
+    const uint32_t n2 = s.skyboxFaceSize + 2u;
+    const uint2 p = *reinterpret_cast<const uint2 *>(s.skybox + 4u * (((size_t)face * n2 + (size_t)(j + 1)) * n2 + (size_t)(i + 1)));
     return f3{half_to_float(p.x & 0xFFFFu), half_to_float(p.x >> 16), half_to_float(p.y & 0xFFFFu)};
 }
 
@@ -488,8 +499,12 @@ PPT_D f3 sample_skybox(const DeviceScene &s, f3 d)
     const float fv = __builtin_floorf(v);
     const float a = u - fu;
     const float b = v - fv;
-    const int32_t i0 = f2i(fu);
-    const int32_t j0 = f2i(fv);
+    // ss, tt in [0, 1] put the footprint's first texel in [-1, n - 1]: the clamp changes nothing for a direction with a
+    // finite, non-zero largest component and keeps the loads of any other inside the bordered face
+    int32_t i0 = f2i(fu);
+    int32_t j0 = f2i(fv);
+    i0 = i0 < -1 ? -1 : (i0 > n - 1 ? n - 1 : i0);
+    j0 = j0 < -1 ? -1 : (j0 > n - 1 ? n - 1 : j0);
     const f3 t00 = fetch_cube_rgb(s, face, i0, j0);
     const f3 t10 = fetch_cube_rgb(s, face, i0 + 1, j0);
     const f3 t01 = fetch_cube_rgb(s, face, i0, j0 + 1);
@@ -546,21 +561,39 @@ PPT_D Material sample_material(const DeviceScene &s, uint32_t index, f2 uv)
     const MaterialPack pack = s.materialPacks[index];
     if (pack.texels != nullptr)
     {
-        // the three textures interleaved per texel (pt_scene.hpp MaterialPack): one footprint, four 12-byte loads
+        // the three textures interleaved per texel (pt_scene.hpp MaterialPack): one footprint, four 12-byte loads - or
+        // four 8-byte ones from the compact pack of an opaque material, which keeps the eight bytes this function reads
         typedef uint32_t u32x3 __attribute__((ext_vector_type(3)));
+        typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
         typedef const __attribute__((address_space(1))) u32x3 *global_u32x3_ptr;
-        const PackTaps k = pack_taps(pack, s.samplers[pack.sampler], uv);
+        typedef const __attribute__((address_space(1))) u32x2 *global_u32x2_ptr;
+        const PackTaps k = pack_taps(pack, s.samplers[pack.sampler & ~kPackCompactBit], uv);
         const global_u32_ptr base = (global_u32_ptr)pack.texels;
-        const u32x3 p00 = *(global_u32x3_ptr)(base + k.o00 * 4u);
-        const u32x3 p10 = *(global_u32x3_ptr)(base + k.o10 * 4u);
-        const u32x3 p01 = *(global_u32x3_ptr)(base + k.o01 * 4u);
-        const u32x3 p11 = *(global_u32x3_ptr)(base + k.o11 * 4u);
         TexelTaps w;
         w.a = k.a;
         w.b = k.b;
-        sBaseT = filter_taps(w, RawTaps{p00.x, p10.x, p01.x, p11.x});
-        sMrT = filter_taps(w, RawTaps{p00.y, p10.y, p01.y, p11.y});
-        sNT = filter_taps(w, RawTaps{p00.z, p10.z, p01.z, p11.z});
+        if (pack.sampler & kPackCompactBit)
+        {
+            const u32x2 p00 = *(global_u32x2_ptr)(base + k.o00 * 2u);
+            const u32x2 p10 = *(global_u32x2_ptr)(base + k.o10 * 2u);
+            const u32x2 p01 = *(global_u32x2_ptr)(base + k.o01 * 2u);
+            const u32x2 p11 = *(global_u32x2_ptr)(base + k.o11 * 2u);
+            const f4 lo = filter_taps(w, RawTaps{p00.x, p10.x, p01.x, p11.x}); // R G B roughness
+            const f4 hi = filter_taps(w, RawTaps{p00.y, p10.y, p01.y, p11.y}); // metallic Nx Ny Nz
+            sBaseT = f4{lo.x, lo.y, lo.z, 1.0f};
+            sMrT = f4{0.0f, lo.w, hi.x, 0.0f};
+            sNT = f4{hi.y, hi.z, hi.w, 0.0f};
+        }
+        else
+        {
+            const u32x3 p00 = *(global_u32x3_ptr)(base + k.o00 * 4u);
+            const u32x3 p10 = *(global_u32x3_ptr)(base + k.o10 * 4u);
+            const u32x3 p01 = *(global_u32x3_ptr)(base + k.o01 * 4u);
+            const u32x3 p11 = *(global_u32x3_ptr)(base + k.o11 * 4u);
+            sBaseT = filter_taps(w, RawTaps{p00.x, p10.x, p01.x, p11.x});
+            sMrT = filter_taps(w, RawTaps{p00.y, p10.y, p01.y, p11.y});
+            sNT = filter_taps(w, RawTaps{p00.z, p10.z, p01.z, p11.z});
+        }
     }
     else if constexpr (!BATCHED)
     {

@@ -1212,8 +1212,27 @@ void launch_srgb_monotonicity(uint32_t firstBits, uint32_t lastBits, uint32_t *o
 
 // Interleaves the three tiled RGBA8 textures of a material into a MaterialPack (pt_scene.hpp): one thread per texel of
 // the padded pack extent (texels outside the image are zero and never addressed).
+// The sky cube with a one-texel border per face (pt_device.hpp fetch_cube_rgb): out[face][j + 1][i + 1] = texel (i, j) of
+// the face, taken from the neighbouring face by the seamless-edge rule where (i, j) is outside.
+__global__ __launch_bounds__(256) void border_skybox_kernel(const uint16_t *__restrict__ cube, uint32_t n, uint2 *__restrict__ out)
+{
+    const uint32_t n2 = n + 2u;
+    const uint32_t x = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t y = blockIdx.y, face = blockIdx.z;
+    if (x >= n2) return;
+    out[((size_t)face * n2 + y) * n2 + x] = cube_texel_seamless(cube, (int32_t)n, face, (int32_t)x - 1, (int32_t)y - 1);
+}
+
+void launch_border_skybox(const uint16_t *cube, uint32_t faceSize, void *bordered, hipStream_t stream)
+{
+    hipLaunchKernelGGL(
+        border_skybox_kernel, dim3((faceSize + 2u + 255u) / 256u, faceSize + 2u, 6u), dim3(256), 0, stream, cube, faceSize,
+        static_cast<uint2 *>(bordered));
+}
+
+template <bool COMPACT>
 __global__ __launch_bounds__(256) void pack_material_textures_kernel(
-    DeviceTexture base, DeviceTexture mr, DeviceTexture normal, MaterialPack pack, uint4 *__restrict__ out, uint32_t paddedW,
+    DeviceTexture base, DeviceTexture mr, DeviceTexture normal, MaterialPack pack, void *__restrict__ out, uint32_t paddedW,
     uint32_t paddedH)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1226,7 +1245,13 @@ __global__ __launch_bounds__(256) void pack_material_textures_kernel(
         t.y = reinterpret_cast<const uint32_t *>(mr.texels)[texel_offset(mr, (int32_t)i, (int32_t)j)];
         t.z = reinterpret_cast<const uint32_t *>(normal.texels)[texel_offset(normal, (int32_t)i, (int32_t)j)];
     }
-    out[pack_texel_offset(pack, (int32_t)i, (int32_t)j)] = t;
+    const uint32_t at = pack_texel_offset(pack, (int32_t)i, (int32_t)j);
+    if constexpr (COMPACT)
+        // {R G B roughness (MR.g)}, {metallic (MR.b) Nx Ny Nz}
+        static_cast<uint2 *>(out)[at] =
+            make_uint2((t.x & 0x00FFFFFFu) | ((t.y << 16) & 0xFF000000u), ((t.y >> 16) & 0xFFu) | (t.z << 8));
+    else
+        static_cast<uint4 *>(out)[at] = t;
 }
 
 void launch_pack_material_textures(
@@ -1234,9 +1259,11 @@ void launch_pack_material_textures(
 {
     const uint32_t paddedW = pack.tilesPerRow * kPackTileW;
     const uint32_t paddedH = ((pack.height + kPackTileH - 1u) / kPackTileH) * kPackTileH;
-    hipLaunchKernelGGL(
-        pack_material_textures_kernel, dim3((paddedW + 255u) / 256u, paddedH), dim3(256), 0, stream, base, mr, normal, pack,
-        const_cast<uint4 *>(pack.texels), paddedW, paddedH);
+    const dim3 grid((paddedW + 255u) / 256u, paddedH);
+    if (pack.sampler & kPackCompactBit)
+        hipLaunchKernelGGL(pack_material_textures_kernel<true>, grid, dim3(256), 0, stream, base, mr, normal, pack, const_cast<void *>(pack.texels), paddedW, paddedH);
+    else
+        hipLaunchKernelGGL(pack_material_textures_kernel<false>, grid, dim3(256), 0, stream, base, mr, normal, pack, const_cast<void *>(pack.texels), paddedW, paddedH);
 }
 
 void launch_eval_fn(

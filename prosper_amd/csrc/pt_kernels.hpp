@@ -133,6 +133,8 @@ void launch_deinterleave_tiles(const float4 *tiles, const TileLayout &layout, fl
 void launch_decode_bc7(
     const void *blocks, uint32_t width, uint32_t height, uint32_t tilesPerRow, void *tiled, hipStream_t stream);
 // fills `pack.texels` (device memory, tilesPerRow * 4 x ceil(height / 2) * 2 uint4s) from the three tiled textures
+// 6 x n x n RGBA16F texels -> 6 x (n + 2) x (n + 2) with the seamless border
+void launch_border_skybox(const uint16_t *cube, uint32_t faceSize, void *bordered, hipStream_t stream);
 void launch_pack_material_textures(
     const DeviceTexture &base, const DeviceTexture &mr, const DeviceTexture &normal, const MaterialPack &pack, hipStream_t stream);
 void launch_eval_fn(

@@ -906,23 +906,26 @@ def test_lds_staged_tables_equal_global_memory_tables(gpu_ctx, oracle, monkeypat
 
 def test_texture_packs_equal_separate_textures(gpu_ctx, oracle, sponza_small, monkeypatch):
     """Materials whose base / MR / normal textures share extent and sampler are sampled from an interleaved copy
-    (pt_scene.hpp MaterialPack: one footprint, four 12-byte loads).  Same texels, same filter arithmetic: the images with
-    and without the packs (PROSPER_PT_DEBUG_NO_TEXTURE_PACKS=1, read at upload) are bit-equal - on S-sponza-class and on
-    a wall of odd-sized textures under every wrap mode and both filters, which also equals the oracle."""
+    (pt_scene.hpp MaterialPack: one footprint, four 8-byte loads for an opaque material - the compact pack - or four
+    12-byte ones).  Same texels, same filter arithmetic: the images with the compact packs, the wide ones
+    (PROSPER_PT_DEBUG_WIDE_PACKS=0 / 1) and without packs (PROSPER_PT_DEBUG_NO_TEXTURE_PACKS=1; both read at upload) are
+    bit-equal - on S-sponza-class and on a wall of odd-sized textures under every wrap mode and both filters, which also
+    equals the oracle with either pack."""
     from prosper_amd.world import World
     w, h = 240, 136
     cam, fl = _camera(oracle, sponza_small, w, h)
     pc = default_pc(S, fl, max_bounces=3, ibl=True)
     images = []
-    for no_packs in (False, True):
-        if no_packs:
-            monkeypatch.setenv("PROSPER_PT_DEBUG_NO_TEXTURE_PACKS", "1")
+    for variant, value in (("PROSPER_PT_DEBUG_WIDE_PACKS", "0"), ("PROSPER_PT_DEBUG_WIDE_PACKS", "1"), ("PROSPER_PT_DEBUG_NO_TEXTURE_PACKS", "1")):
+        # opaque materials: the compact pack (8 bytes per texel; the default of big texture sets), the 12-of-16-byte one,
+        # the textures themselves
+        monkeypatch.setenv(variant, value)
         gpu_ctx.upload_scene(sponza_small)
-        assert bool(gpu_ctx.scene_stats().variantFlags & S.VARIANT_TEXTURE_PACKS) == (not no_packs)
+        assert bool(gpu_ctx.scene_stats().variantFlags & S.VARIANT_TEXTURE_PACKS) == (variant != "PROSPER_PT_DEBUG_NO_TEXTURE_PACKS")
         gpu_ctx.render(pc, cam, w, h, frames=2)
         images.append(gpu_ctx.read_hdr())
-    monkeypatch.delenv("PROSPER_PT_DEBUG_NO_TEXTURE_PACKS")
-    assert same_bits(images[0], images[1]).all()
+        monkeypatch.delenv(variant)
+    assert same_bits(images[0], images[1]).all() and same_bits(images[0], images[2]).all()
 
     rng = np.random.default_rng(7)
     world = World()
@@ -942,15 +945,20 @@ def test_texture_packs_equal_separate_textures(gpu_ctx, oracle, sponza_small, mo
     world.camera = dict(eye=(0.0, 0.0, 6.0), target=(0.0, 0.0, 0.0), up=(0.0, 1.0, 0.0), fov=0.9, zN=0.1, zF=100.0)
     w, h = 384, 192
     cam, fl = _camera(oracle, world, w, h)
-    gpu_ctx.upload_scene(world)
-    assert gpu_ctx.scene_stats().variantFlags & S.VARIANT_TEXTURE_PACKS
     osc = oracle.OracleScene(world, brute_force=True)
-    for draw_type in ("Albedo", "Roughness", "Metallic", "ShadingNormal", "Default"):
-        pc = default_pc(S, fl, draw_type=S.DrawType[draw_type], max_bounces=2)
-        gpu_ctx.render(pc, cam, w, h)
-        want, _ = osc.render(pc, cam, w, h)
-        ok = same_bits(gpu_ctx.read_hdr(), want).all(axis=2)
-        assert ok.all(), "%s: %d of %d pixels differ" % (draw_type, (~ok).sum(), ok.size)
+    wanted = {}
+    for wide in (False, True):
+        monkeypatch.setenv("PROSPER_PT_DEBUG_WIDE_PACKS", "1" if wide else "0")
+        gpu_ctx.upload_scene(world)
+        assert gpu_ctx.scene_stats().variantFlags & S.VARIANT_TEXTURE_PACKS
+        for draw_type in ("Albedo", "Roughness", "Metallic", "ShadingNormal", "Default"):
+            pc = default_pc(S, fl, draw_type=S.DrawType[draw_type], max_bounces=2)
+            gpu_ctx.render(pc, cam, w, h)
+            if draw_type not in wanted:
+                wanted[draw_type], _ = osc.render(pc, cam, w, h)
+            ok = same_bits(gpu_ctx.read_hdr(), wanted[draw_type]).all(axis=2)
+            assert ok.all(), "%s (%s pack): %d of %d pixels differ" % (draw_type, "wide" if wide else "compact", (~ok).sum(), ok.size)
+    monkeypatch.delenv("PROSPER_PT_DEBUG_WIDE_PACKS")
 
 
 def test_moved_instances_refit_equals_fresh_upload(gpu_ctx, oracle, monkeypatch):
