@@ -40,7 +40,7 @@ def main():
         for ranks in ((8, 4, 2, 1) if name == "c2" else (1,)):
             tile = tiling.tile_for_rank(0, ranks) if ranks > 1 else None
             for render_flags, label in ((0, "in order"), (S.RENDER_PIPELINED, "pipelined")):
-                for _ in range(4):
+                for _ in range(int(os.environ.get("WARM", "4"))):
                     ctx.render(pc, cam, width, height, frames=SPP, tile=tile, flags=render_flags)
                 hip.hipDeviceSynchronize()
                 steps = 30 if name == "c2" else 6
