@@ -1391,6 +1391,10 @@ int prosper_pt_render_frames(
     {
         const char *audit = std::getenv("PROSPER_PT_DEBUG_TRACE_DEAD_PATHS");
         p.traceDeadPaths = (audit && std::atoi(audit) != 0) ? 1u : 0u;
+        // sparse segments (pt_wavefront.hip RayMap), an experiment that lost (profiles/r03_sparse_segments.txt):
+        // PROSPER_PT_DEBUG_MERGE_LIMIT = rays up to which a workgroup's four segments are traced by one wave; default never
+        const char *merge = std::getenv("PROSPER_PT_DEBUG_MERGE_LIMIT");
+        p.mergeLimit = merge ? (uint32_t)std::max(0, std::atoi(merge)) : 0u;
     }
 
     if (localWidth == 0) return PROSPER_PT_OK;

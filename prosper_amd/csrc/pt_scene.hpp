@@ -226,6 +226,9 @@ struct RenderParams
     // audit switch (PROSPER_PT_DEBUG_TRACE_DEAD_PATHS=1): keep tracing paths whose throughput is exactly zero, as the
     // GLSL does; the images must not differ (arithmetic contract)
     uint32_t traceDeadPaths;
+    // wf_trace: the four segments of a workgroup are traced by ONE of its waves when together they hold at most this many
+    // shadow rays and at most this many closest-hit rays (pt_wavefront.hip "sparse segments"); 0 = never
+    uint32_t mergeLimit;
 };
 
 // Workspace of the wavefront pipeline (pt_wavefront.hip).  Paths live in fixed-length SEGMENTS of

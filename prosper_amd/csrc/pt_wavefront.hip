@@ -444,19 +444,42 @@ __global__ __launch_bounds__(256, PPT_GEN_WPE) void wf_generate_extend(
 // extend: traceClosest of bounce >= 1
 // ------------------------------------------------------------------------------------------
 
-// One wave's extend work: traces the live rays of its segment (buffer set `cur`), compacts the hits.
+// Sparse segments - an EXPERIMENT (PROSPER_PT_DEBUG_MERGE_LIMIT, default off; profiles/r03_sparse_segments.txt).  A wave
+// owns a segment, and what survives a stage stays in it: on a sparse image (FlightHelmet: one camera ray in ten hits
+// anything) the later stages run waves whose streams hold a few dozen to a few hundred rays (52 % of wf_trace's node steps
+// ran with <= 8 lanes there).  The idea: when the four segments of a workgroup together hold few enough rays, ONE of its
+// waves traces all of them as one stream - RayMap turns a stream position into the record's offset from the first
+// segment's base (the four segments are contiguous), the hits are compacted into the first segment, and from then on the
+// paths of the group live there.  Which wave traces a ray does not change its hit, and a path's shadow ray and next
+// closest-hit ray are still traced by the same wave in that order (both lists are merged, or neither): same pixels
+// (tested).  Measured: fuller waves, and SLOWER the more is merged (FlightHelmet wf_trace 364 -> 445 / 604 us per launch at
+// a limit of 256 / 1024 rays, the step 1.88 -> 1.98 / 2.14 ms; also the 1/8 rank share of C2, 0.32 -> 0.41 ms): with a few
+// hundred rays per wave the kernel is bound by the latency of each wave's own chain of steps, and a quarter of the waves
+// hide a quarter of it.  A sparse stage wants MORE waves, not fuller ones.
+struct RayMap
+{
+    uint32_t c0, c01, c012; // rays in the first one / two / three segments; identity: c0 = ~0
+    uint32_t segLen;
+    __device__ __forceinline__ uint32_t at(uint32_t i) const
+    {
+        return i < c0 ? i : (i < c01 ? segLen + (i - c0) : (i < c012 ? 2u * segLen + (i - c01) : 3u * segLen + (i - c012)));
+    }
+};
+
+// One wave's extend work: traces `n` live rays (buffer set `cur`) of its segment - or of its workgroup's four, through
+// `map` - and compacts the hits into the segment `id`; returns their number.
 template <bool COUNT, class Geom, class Tracer>
-__device__ __forceinline__ void extend_segment(
-    const Geom &g, const DeviceScene &s, const RenderParams &p, const WavefrontBuffers &w, const SegmentId &id, uint32_t bounce,
-    uint32_t cur, const Tracer &tracer, LaneCounters &cnt)
+__device__ __forceinline__ uint32_t extend_segment(
+    const Geom &g, const DeviceScene &s, const RenderParams &p, const WavefrontBuffers &w, const SegmentId &id, uint32_t n,
+    const RayMap &map, uint32_t bounce, uint32_t cur, const Tracer &tracer, LaneCounters &cnt)
 {
     const float4 *__restrict__ rayA = w.rayA[cur];
     const float4 *__restrict__ rayB = w.rayB[cur];
-    const uint32_t n = w.segRays[id.seg];
     uint32_t nHit = 0;
     auto fetch = [&](uint32_t i) {
-        const float4 a = rayA[id.base + i];
-        const float4 b = rayB[id.base + i];
+        const uint32_t k = map.at(i);
+        const float4 a = rayA[id.base + k];
+        const float4 b = rayB[id.base + k];
         if constexpr (COUNT) cnt.closestRays++;
         StreamRay r;
         r.o = xyz(a);
@@ -467,10 +490,11 @@ __device__ __forceinline__ void extend_segment(
         return r;
     };
     auto commit = [&](bool pred, uint32_t i, bool found, const Hit &hit, const f3 &dir) {
+        const uint32_t k = map.at(i);
         if (pred && !found && (p.pc.flags & PROSPER_PC_FLAG_IBL))
         {
             if constexpr (COUNT) cnt.skyLookups++;
-            const float4 t = w.pathT[cur][id.base + i];
+            const float4 t = w.pathT[cur][id.base + k];
             add_to_slot(w.color, asu(t.w) & kSlotMask, p.pc.flags, xyz(t) * sample_skybox(s, dir), bounce);
         }
         const bool isHit = pred && found;
@@ -479,12 +503,12 @@ __device__ __forceinline__ void extend_segment(
         if (isHit)
         {
             w.hit[id.base + pos] = make_uint4(hit.drawInstance, hit.primitive, asu(hit.bary.x), asu(hit.bary.y));
-            w.hitIdx[id.base + pos] = i;
+            w.hitIdx[id.base + pos] = k;
         }
         nHit += total;
     };
     tracer.template run<false, COUNT>(g, s, n, 0.0f, cnt, fetch, commit);
-    if (lane_id() == 0) w.segHits[id.seg] = nHit;
+    return nHit;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -663,15 +687,15 @@ __global__ __launch_bounds__(256, PPT_SHADE_WPE) void wf_shade(
 // shadow
 // ------------------------------------------------------------------------------------------
 
-// One wave's shadow work: shadow() for the shadow rays shade queued in its segment; adds the direct
-// term of bounce `bounce` where the light is visible.
+// One wave's shadow work: shadow() for the `n` shadow rays shade queued in its segment (or in its workgroup's four,
+// through `map`); adds the direct term of bounce `bounce` where the light is visible.
 template <bool COUNT, class Geom, class Tracer>
 __device__ __forceinline__ void shadow_segment(
-    const Geom &g, const DeviceScene &s, const RenderParams &p, const WavefrontBuffers &w, const SegmentId &id, uint32_t bounce,
-    const Tracer &tracer, LaneCounters &cnt)
+    const Geom &g, const DeviceScene &s, const RenderParams &p, const WavefrontBuffers &w, const SegmentId &id, uint32_t n,
+    const RayMap &map, uint32_t bounce, const Tracer &tracer, LaneCounters &cnt)
 {
-    const uint32_t n = w.segShadow[id.seg];
-    auto fetch = [&](uint32_t k) {
+    auto fetch = [&](uint32_t i) {
+        const uint32_t k = map.at(i);
         const float4 a = w.shA[id.base + k];
         const float4 b = w.shB[id.base + k];
         StreamRay r;
@@ -682,10 +706,10 @@ __device__ __forceinline__ void shadow_segment(
         r.seed = asu(a.w);
         return r;
     };
-    auto commit = [&](bool pred, uint32_t k, bool occluded, const Hit &, const f3 &) {
+    auto commit = [&](bool pred, uint32_t i, bool occluded, const Hit &, const f3 &) {
         if (pred)
         {
-            const float4 c = w.shC[id.base + k];
+            const float4 c = w.shC[id.base + map.at(i)];
             const uint32_t packed = asu(c.w);
             const uint32_t nanMask = packed >> 28;
             if (!occluded || nanMask)
@@ -701,6 +725,72 @@ __device__ __forceinline__ void shadow_segment(
         }
     };
     tracer.template run<true, COUNT>(g, s, n, 0.1f, cnt, fetch, commit);
+}
+
+// What a wave of wf_trace traces: its own segment's lists, or - sparse segments, see RayMap - all four of its workgroup's
+// (the leader) or nothing (the other three).
+struct TraceWork
+{
+    SegmentId id;      // where the records are read from (base) and the hits compacted into
+    uint32_t nShadow, nRays;
+    RayMap shadowMap, rayMap;
+    bool merged, leader;
+};
+__device__ __forceinline__ TraceWork trace_work(const RenderParams &p, const WavefrontBuffers &w, const SegmentId &id, bool doExtend)
+{
+    TraceWork t;
+    t.id = id;
+    t.nShadow = w.segShadow[id.seg];
+    t.nRays = doExtend ? w.segRays[id.seg] : 0u;
+    t.shadowMap = t.rayMap = RayMap{~0u, ~0u, ~0u, w.segLen};
+    t.merged = t.leader = false;
+    if (p.mergeLimit == 0u) return t;
+    const uint32_t limit = p.mergeLimit < w.segLen ? p.mergeLimit : w.segLen;
+    const uint32_t seg0 = id.seg & ~3u;
+    uint32_t cs[4], cr[4];
+#pragma unroll
+    for (uint32_t k = 0; k < 4u; ++k)
+    {
+        const bool valid = seg0 + k < w.nSeg;
+        cs[k] = valid ? w.segShadow[seg0 + k] : 0u;
+        cr[k] = (valid && doExtend) ? w.segRays[seg0 + k] : 0u;
+    }
+    const uint32_t totalS = cs[0] + cs[1] + cs[2] + cs[3], totalR = cr[0] + cr[1] + cr[2] + cr[3];
+    if (totalS > limit || totalR > limit) return t;
+    t.merged = true;
+    // the leading wave rotates with the workgroup (the dispatcher deals a workgroup's waves over the SIMDs in order)
+    uint32_t leader = (seg0 >> 2) & 3u;
+    if (seg0 + leader >= w.nSeg) leader = 0u;
+    if ((threadIdx.x >> 6) == leader)
+    {
+        t.leader = true;
+        t.id.seg = seg0;
+        t.id.base = seg0 * w.segLen;
+        t.nShadow = totalS;
+        t.nRays = totalR;
+        t.shadowMap = RayMap{cs[0], cs[0] + cs[1], cs[0] + cs[1] + cs[2], w.segLen};
+        t.rayMap = RayMap{cr[0], cr[0] + cr[1], cr[0] + cr[1] + cr[2], w.segLen};
+    }
+    else
+    {
+        t.nShadow = 0u;
+        t.nRays = 0u;
+    }
+    return t;
+}
+// the hit counts of the segments a wave answers for, after its extend work: its own; merged, the leader's hits are the
+// first segment's and every other segment of the group is empty from here on
+__device__ __forceinline__ void store_hit_counts(const WavefrontBuffers &w, const SegmentId &own, const TraceWork &t, uint32_t nHit)
+{
+    if (lane_id() != 0u) return;
+    if (!t.merged)
+    {
+        w.segHits[own.seg] = nHit;
+        return;
+    }
+    const uint32_t seg0 = own.seg & ~3u;
+    if (t.leader) w.segHits[seg0] = nHit;
+    if (own.seg != seg0) w.segHits[own.seg] = 0u;
 }
 
 // Shadow rays of bounce `bounce` and (unless it was the last bounce) the closest-hit rays of bounce
@@ -725,30 +815,33 @@ __global__ __launch_bounds__(256, PPT_TRACE_WPE(STACK)) void wf_trace(
                                             stackOverflow + blockIdx.x * 256u + threadIdx.x, (uint32_t)STACK,
                                             gridDim.x * 256u, 64u}};
     LaneCounters cnt = {};
+    const TraceWork t = trace_work(p, w, id, doExtend != 0u);
 #ifdef PPT_EXPERIMENT_LDS_SCENE_LOCKSTEP
     const LockstepTracer lockstep{stack.stack};
 #endif
     if constexpr (LDS_SCENE)
 #ifdef PPT_EXPERIMENT_LDS_SCENE_LOCKSTEP
-        shadow_segment<COUNT>(lg, s, p, w, id, bounce, lockstep, cnt);
+        shadow_segment<COUNT>(lg, s, p, w, t.id, t.nShadow, t.shadowMap, bounce, lockstep, cnt);
 #else
-        shadow_segment<COUNT>(lg, s, p, w, id, bounce, stack, cnt);
+        shadow_segment<COUNT>(lg, s, p, w, t.id, t.nShadow, t.shadowMap, bounce, stack, cnt);
 #endif
     else
-        shadow_segment<COUNT>(gg, s, p, w, id, bounce, stack, cnt);
+        shadow_segment<COUNT>(gg, s, p, w, t.id, t.nShadow, t.shadowMap, bounce, stack, cnt);
     if (doExtend)
     {
         // same wave, same CU: a workgroup-scope fence (s_waitcnt vmcnt(0)) orders the shadow phase's
         // radiance stores before the extend phase's loads; the vector L1 is write-through
         __threadfence_block();
+        uint32_t nHit;
         if constexpr (LDS_SCENE)
 #ifdef PPT_EXPERIMENT_LDS_SCENE_LOCKSTEP
-            extend_segment<COUNT>(lg, s, p, w, id, bounce + 1u, nextCur, lockstep, cnt);
+            nHit = extend_segment<COUNT>(lg, s, p, w, t.id, t.nRays, t.rayMap, bounce + 1u, nextCur, lockstep, cnt);
 #else
-            extend_segment<COUNT>(lg, s, p, w, id, bounce + 1u, nextCur, stack, cnt);
+            nHit = extend_segment<COUNT>(lg, s, p, w, t.id, t.nRays, t.rayMap, bounce + 1u, nextCur, stack, cnt);
 #endif
         else
-            extend_segment<COUNT>(gg, s, p, w, id, bounce + 1u, nextCur, stack, cnt);
+            nHit = extend_segment<COUNT>(gg, s, p, w, t.id, t.nRays, t.rayMap, bounce + 1u, nextCur, stack, cnt);
+        store_hit_counts(w, id, t, nHit);
     }
     flush_counters<COUNT>(cnt, counters);
 }
@@ -771,17 +864,22 @@ __global__ __launch_bounds__(256, 3) void wf_trace_pool(
     const PoolTracer<P, S, B> tracer{
         RayPool<P, S>::carve(ldsPool, wave, reinterpret_cast<uint32_t *>(scratch), blockIdx.x * 4u + wave, overflowEntries)};
     LaneCounters cnt = {};
+    RenderParams own = p;
+    own.mergeLimit = 0u; // (the pool experiment keeps every wave on its own segment)
+    const TraceWork t = trace_work(own, w, id, doExtend != 0u);
     if constexpr (LDS_SCENE)
-        shadow_segment<COUNT>(lg, s, p, w, id, bounce, tracer, cnt);
+        shadow_segment<COUNT>(lg, s, p, w, t.id, t.nShadow, t.shadowMap, bounce, tracer, cnt);
     else
-        shadow_segment<COUNT>(gg, s, p, w, id, bounce, tracer, cnt);
+        shadow_segment<COUNT>(gg, s, p, w, t.id, t.nShadow, t.shadowMap, bounce, tracer, cnt);
     if (doExtend)
     {
         __threadfence_block();
+        uint32_t nHit;
         if constexpr (LDS_SCENE)
-            extend_segment<COUNT>(lg, s, p, w, id, bounce + 1u, nextCur, tracer, cnt);
+            nHit = extend_segment<COUNT>(lg, s, p, w, t.id, t.nRays, t.rayMap, bounce + 1u, nextCur, tracer, cnt);
         else
-            extend_segment<COUNT>(gg, s, p, w, id, bounce + 1u, nextCur, tracer, cnt);
+            nHit = extend_segment<COUNT>(gg, s, p, w, t.id, t.nRays, t.rayMap, bounce + 1u, nextCur, tracer, cnt);
+        store_hit_counts(w, id, t, nHit);
     }
     flush_counters<COUNT>(cnt, counters);
 }

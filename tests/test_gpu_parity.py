@@ -1483,3 +1483,33 @@ def test_full_size_flight_helmet_parity(gpu_ctx, oracle):
     from prosper_amd import flight_helmet
     got, _ = _full_size_parity(gpu_ctx, oracle, flight_helmet.load_fixture(), 2, "FlightHelmet")
     assert np.isfinite(got).all() and (got[..., 3] == 2).all()
+
+
+def test_sparse_segments_traced_by_one_wave_give_the_same_pixels(gpu_ctx, oracle, monkeypatch):
+    """PROSPER_PT_DEBUG_MERGE_LIMIT (pt_wavefront.hip RayMap; an experiment, off by default): where the four segments of a
+    workgroup hold few rays, one wave traces them all and the group's paths live in its first segment from then on.  Which
+    wave traces a ray changes no hit: the image of a sparse scene (a small lit object under a sky, most camera rays miss) is
+    the same at every limit, and the oracle's."""
+    world = scenes.sponza_class(lights=(4, 4), foliage=True, texture_size=32, sky_size=16, detail=0.25)
+    # pull the camera far back: the atrium covers a fraction of the image, the rest is sky
+    cam_def = dict(world.camera)
+    eye, target = np.asarray(cam_def["eye"], np.float64), np.asarray(cam_def["target"], np.float64)
+    cam_def["eye"] = tuple(target + (eye - target) * 6.0 + np.array([0.0, 25.0, 0.0]))
+    cam_def["zF"] = 1000.0
+    world.camera = cam_def
+    w, h = 512, 288
+    cam, fl = _camera(oracle, world, w, h)
+    pc = default_pc(S, fl, max_bounces=4, ibl=True)
+    gpu_ctx.upload_scene(world)
+    images = []
+    for limit in ("0", "64", "100000"):
+        monkeypatch.setenv("PROSPER_PT_DEBUG_MERGE_LIMIT", limit)
+        gpu_ctx.render(pc, cam, w, h, frames=4, flags=S.RENDER_PIPELINED)
+        images.append(gpu_ctx.read_hdr())
+    monkeypatch.delenv("PROSPER_PT_DEBUG_MERGE_LIMIT")
+    assert same_bits(images[0], images[1]).all() and same_bits(images[0], images[2]).all()
+    osc = oracle.OracleScene(world)
+    want = None
+    for frame in range(1, 5):
+        want, _ = osc.render(default_pc(S, fl, frame_index=frame, max_bounces=4, ibl=True, skip_history=(frame == 1)), cam, w, h, history=want)
+    assert same_bits(images[0], want).all()
