@@ -224,9 +224,12 @@ typedef struct prosper_pt_scene_stats
     uint32_t maxDepth;
     uint32_t variantFlags;  /* PROSPER_PT_VARIANT_*: the kernel variants the next render of this scene takes */
     uint64_t deviceBytes;   /* HBM resident bytes for the scene */
-    double buildSeconds;    /* acceleration structure: flatten kernel + host BVH build + node/triangle upload */
+    double buildSeconds;    /* acceleration structure: from the first flatten kernel to the uploaded nodes (since round 3
+                             * the host BVH build runs on the host's threads WHILE the calling thread uploads textures,
+                             * sky, lights and alpha tables: this span contains those too) */
     /* (ABI 2) where prosper_pt_upload_scene spent its time: the whole call, the host-side BVH construction alone
-     * (the part a moved instance would pay again), and the texture re-tiling / BC7 decode + copies */
+     * (the part a host-side rebuild would pay again), and the texture re-tiling / BC7 decode + copies - the last two
+     * overlap, so they no longer add up to the first */
     double uploadSeconds;
     double bvhBuildSeconds;
     double textureSeconds;

@@ -10,6 +10,7 @@
 
 #include <algorithm>
 #include <chrono>
+#include <future>
 #include <cmath>
 #include <cstdlib>
 #include <cstdio>
@@ -330,6 +331,103 @@ int upload_scene_impl(prosper_pt_ctx *ctx, const prosper_pt_scene_view *v)
     if ((rc = upload(ctx, v->samplers, sizeof(prosper_pt_sampler_desc) * v->samplerCount, &d))) return rc;
     s.samplers = static_cast<const prosper_pt_sampler_desc *>(d);
 
+    const auto t0 = std::chrono::steady_clock::now();
+    AccelState *acc = new (std::nothrow) AccelState();
+    if (!acc) return fail(PROSPER_PT_ERR_INVALID_ARGUMENT, "out of host memory");
+    ctx->accel = acc;
+    acc->triOffsets.assign(v->drawInstanceCount + 1, 0);
+    std::vector<uint32_t> diFlags(v->drawInstanceCount ? v->drawInstanceCount : 1, 0);
+    uint64_t total = 0;
+    for (uint32_t i = 0; i < v->drawInstanceCount; ++i)
+    {
+        const prosper_pt_mesh_info &info = v->meshInfos[v->drawInstances[i].meshIndex];
+        acc->triOffsets[i] = (uint32_t)total;
+        total += info.indexCount / 3;
+        // World.cpp:646-651: eOpaque iff the mesh's material is AlphaMode_Opaque
+        diFlags[i] = v->materials[info.materialIndex].alphaMode == PROSPER_ALPHA_MODE_OPAQUE ? kTriFlagOpaque : 0u;
+        if (v->geometryMetadatas[v->drawInstances[i].meshIndex].usesShortIndices == 1) diFlags[i] |= kTriFlagShortIndices;
+        // one subtree per run of draw instances of the same model instance (World.cpp:480-513 emits them together):
+        // prosper's TLAS instance (World.cpp:878-928)
+        const uint32_t mi = v->drawInstances[i].modelInstanceIndex;
+        if (acc->ranges.empty() || acc->rangeModelInstance.back() != mi)
+        {
+            acc->ranges.push_back(InstancedBvh::Range{acc->triOffsets[i], 0u});
+            acc->rangeModelInstance.push_back(mi);
+        }
+        acc->ranges.back().count += info.indexCount / 3;
+    }
+    acc->triOffsets[v->drawInstanceCount] = (uint32_t)total;
+    if (total >= (1ull << 28)) return fail(PROSPER_PT_ERR_UNSUPPORTED, "more than 2^28 triangles after instancing");
+    acc->total = total;
+    acc->drawInstanceCount = v->drawInstanceCount;
+    acc->transforms.assign(v->modelInstanceTransforms, v->modelInstanceTransforms + v->modelInstanceCount);
+    ctx->dTransforms = const_cast<prosper_ModelInstanceTransforms *>(s.modelInstanceTransforms);
+    acc->dTransformsV[0] = ctx->dTransforms;
+
+    // ---- world triangles first: the host-side hierarchy build - the longest step of an upload - runs on the host's threads
+    //      while this thread goes on with textures, packs, sky, lights and the alpha tables; the flatten kernel runs
+    //      again below for the shading and any-hit records (the same world triangles a second time) ----
+    std::vector<uint32_t> alphaOffsets(v->drawInstanceCount ? v->drawInstanceCount : 1, 0u);
+    uint64_t alphaTotal = 0;
+    for (uint32_t i = 0; i < v->drawInstanceCount; ++i)
+        if (!(diFlags[i] & kTriFlagOpaque))
+        {
+            alphaOffsets[i] = (uint32_t)alphaTotal;
+            alphaTotal += acc->triOffsets[i + 1] - acc->triOffsets[i];
+        }
+    if ((rc = upload(ctx, alphaOffsets.data(), alphaOffsets.size() * 4, &d))) return rc;
+    s.alphaOffsets = static_cast<const uint32_t *>(d);
+    const size_t triBytes = sizeof(WorldTriangle) * (size_t)(total ? total : 1);
+    if ((rc = device_alloc(ctx, triBytes, &d))) return rc;
+    acc->dFlat = static_cast<WorldTriangle *>(d);
+    if ((rc = upload(ctx, acc->triOffsets.data(), acc->triOffsets.size() * 4, &d))) return rc;
+    acc->dOffsets = static_cast<uint32_t *>(d);
+    if ((rc = upload(ctx, diFlags.data(), diFlags.size() * 4, &d))) return rc;
+    acc->dFlags = static_cast<uint32_t *>(d);
+    launch_flatten_triangles(s, acc->dOffsets, v->drawInstanceCount, acc->dFlags, acc->dFlat, nullptr, nullptr, (uint32_t)total, nullptr);
+    PPT_HIP(hipGetLastError());
+    acc->flat.resize((size_t)total);
+    if (total) PPT_HIP(hipMemcpy(acc->flat.data(), acc->dFlat, sizeof(WorldTriangle) * (size_t)total, hipMemcpyDeviceToHost));
+    PPT_HIP(hipDeviceSynchronize());
+    struct BuildOutcome
+    {
+        BvhBuildResult bvh;
+        bool instanced = false;
+        double seconds = 0.0;
+        std::string error;
+    };
+    // (a std::async future joins in its destructor: an early return below waits for the build, which reads `acc`)
+    std::future<BuildOutcome> buildJob = std::async(std::launch::async, [acc, total]() {
+        BuildOutcome out;
+        const auto tBuild = std::chrono::steady_clock::now();
+        try
+        {
+            // PROSPER_PT_DEBUG_FLAT_BVH=1: one SAH tree over all triangles, as round 1 built it (A/B, hierarchy tests)
+            if (std::getenv("PROSPER_PT_DEBUG_FLAT_BVH"))
+                out.bvh = build_bvh(acc->flat.data(), total);
+            else
+            {
+                try
+                {
+                    out.bvh = acc->bvh.build(acc->flat.data(), total, acc->ranges);
+                    out.instanced = true;
+                }
+                catch (const std::exception &)
+                {
+                    // the subtrees are split without knowing how deep the re-braided top level above them gets: a
+                    // spliced tree can pass the traversal's stack bound where one tree over everything does not
+                    out.bvh = build_bvh(acc->flat.data(), total);
+                }
+            }
+        }
+        catch (const std::exception &ex)
+        {
+            out.error = ex.what();
+        }
+        out.seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - tBuild).count();
+        return out;
+    });
+
     // textures: one allocation each (256-B aligned by hipMalloc), re-laid out in 8x4-texel tiles of one
     // cache line each (pt_scene.hpp DeviceTexture), + descriptor table
     const auto tTextures = std::chrono::steady_clock::now();
@@ -490,52 +588,9 @@ int upload_scene_impl(prosper_pt_ctx *ctx, const prosper_pt_scene_view *v)
     }
 
     // ---- acceleration structure (replaces buildNextBlas/buildCurrentTlas, World.cpp:585-802) ----
-    const auto t0 = std::chrono::steady_clock::now();
-    AccelState *acc = new (std::nothrow) AccelState();
-    if (!acc) return fail(PROSPER_PT_ERR_INVALID_ARGUMENT, "out of host memory");
-    ctx->accel = acc;
-    acc->triOffsets.assign(v->drawInstanceCount + 1, 0);
-    std::vector<uint32_t> diFlags(v->drawInstanceCount ? v->drawInstanceCount : 1, 0);
-    uint64_t total = 0;
-    for (uint32_t i = 0; i < v->drawInstanceCount; ++i)
-    {
-        const prosper_pt_mesh_info &info = v->meshInfos[v->drawInstances[i].meshIndex];
-        acc->triOffsets[i] = (uint32_t)total;
-        total += info.indexCount / 3;
-        // World.cpp:646-651: eOpaque iff the mesh's material is AlphaMode_Opaque
-        diFlags[i] = v->materials[info.materialIndex].alphaMode == PROSPER_ALPHA_MODE_OPAQUE ? kTriFlagOpaque : 0u;
-        if (v->geometryMetadatas[v->drawInstances[i].meshIndex].usesShortIndices == 1) diFlags[i] |= kTriFlagShortIndices;
-        // one subtree per run of draw instances of the same model instance (World.cpp:480-513 emits them together):
-        // prosper's TLAS instance (World.cpp:878-928)
-        const uint32_t mi = v->drawInstances[i].modelInstanceIndex;
-        if (acc->ranges.empty() || acc->rangeModelInstance.back() != mi)
-        {
-            acc->ranges.push_back(InstancedBvh::Range{acc->triOffsets[i], 0u});
-            acc->rangeModelInstance.push_back(mi);
-        }
-        acc->ranges.back().count += info.indexCount / 3;
-    }
-    acc->triOffsets[v->drawInstanceCount] = (uint32_t)total;
-    if (total >= (1ull << 28)) return fail(PROSPER_PT_ERR_UNSUPPORTED, "more than 2^28 triangles after instancing");
-    acc->total = total;
-    acc->drawInstanceCount = v->drawInstanceCount;
-    acc->transforms.assign(v->modelInstanceTransforms, v->modelInstanceTransforms + v->modelInstanceCount);
-    ctx->dTransforms = const_cast<prosper_ModelInstanceTransforms *>(s.modelInstanceTransforms);
-    acc->dTransformsV[0] = ctx->dTransforms;
-
     // ---- what the any-hit shader reads: one 32-byte record per non-opaque triangle, one per material, and the
     //      materials' alpha bounds (pt_scene.hpp AlphaTriangle / AlphaMaterial) ----
     {
-        std::vector<uint32_t> alphaOffsets(v->drawInstanceCount ? v->drawInstanceCount : 1, 0u);
-        uint64_t alphaTotal = 0;
-        for (uint32_t i = 0; i < v->drawInstanceCount; ++i)
-            if (!(diFlags[i] & kTriFlagOpaque))
-            {
-                alphaOffsets[i] = (uint32_t)alphaTotal;
-                alphaTotal += acc->triOffsets[i + 1] - acc->triOffsets[i];
-            }
-        if ((rc = upload(ctx, alphaOffsets.data(), alphaOffsets.size() * 4, &d))) return rc;
-        s.alphaOffsets = static_cast<const uint32_t *>(d);
         if ((rc = device_alloc(ctx, sizeof(AlphaTriangle) * (size_t)(alphaTotal ? alphaTotal : 1), &d))) return rc;
         s.alphaTriangles = static_cast<const AlphaTriangle *>(d);
         const bool noBounds = std::getenv("PROSPER_PT_DEBUG_NO_ALPHA_BOUNDS") != nullptr;
@@ -585,13 +640,6 @@ int upload_scene_impl(prosper_pt_ctx *ctx, const prosper_pt_scene_view *v)
         ctx->alphaBoundBytes = boundBytes;
     }
 
-    const size_t triBytes = sizeof(WorldTriangle) * (size_t)(total ? total : 1);
-    if ((rc = device_alloc(ctx, triBytes, &d))) return rc;
-    acc->dFlat = static_cast<WorldTriangle *>(d);
-    if ((rc = upload(ctx, acc->triOffsets.data(), acc->triOffsets.size() * 4, &d))) return rc;
-    acc->dOffsets = static_cast<uint32_t *>(d);
-    if ((rc = upload(ctx, diFlags.data(), diFlags.size() * 4, &d))) return rc;
-    acc->dFlags = static_cast<uint32_t *>(d);
     if ((rc = device_alloc(ctx, (size_t)(total ? total : 1) * 4, &d))) return rc;
     acc->dPerm = static_cast<uint32_t *>(d);
     // persistent (scene-lifetime) arrays the flatten kernel fills: shading records + their per-instance bases
@@ -624,37 +672,14 @@ int upload_scene_impl(prosper_pt_ctx *ctx, const prosper_pt_scene_view *v)
         const_cast<AlphaTriangle *>(s.alphaTriangles), (uint32_t)total, nullptr, nullptr, nullptr,
         static_cast<RawShadeTriangle *>(dRaw));
     PPT_HIP(hipGetLastError());
-    acc->flat.resize((size_t)total);
-    if (total) PPT_HIP(hipMemcpy(acc->flat.data(), acc->dFlat, sizeof(WorldTriangle) * (size_t)total, hipMemcpyDeviceToHost));
     PPT_HIP(hipDeviceSynchronize());
 
-    BvhBuildResult bvh;
-    const auto tBuild = std::chrono::steady_clock::now();
-    try
-    {
-        // PROSPER_PT_DEBUG_FLAT_BVH=1: one SAH tree over all triangles, as round 1 built it (A/B, hierarchy tests)
-        if (std::getenv("PROSPER_PT_DEBUG_FLAT_BVH"))
-            bvh = build_bvh(acc->flat.data(), total);
-        else
-        {
-            try
-            {
-                bvh = acc->bvh.build(acc->flat.data(), total, acc->ranges);
-                acc->instanced = true;
-            }
-            catch (const std::exception &)
-            {
-                // the subtrees are split without knowing how deep the re-braided top level above them gets: a spliced
-                // tree can pass the traversal's stack bound where one tree over everything does not
-                bvh = build_bvh(acc->flat.data(), total);
-            }
-        }
-    }
-    catch (const std::exception &ex)
-    {
-        return fail(PROSPER_PT_ERR_UNSUPPORTED, std::string("BVH build failed: ") + ex.what());
-    }
-    const double bvhBuildSeconds = seconds_since(tBuild);
+    // the hierarchy the host's threads built meanwhile
+    BuildOutcome built = buildJob.get();
+    if (!built.error.empty()) return fail(PROSPER_PT_ERR_UNSUPPORTED, "BVH build failed: " + built.error);
+    acc->instanced = built.instanced;
+    BvhBuildResult &bvh = built.bvh;
+    const double bvhBuildSeconds = built.seconds;
     if ((rc = upload_hierarchy(ctx, bvh))) return rc;
 
     ctx->stats = prosper_pt_scene_stats{};
