@@ -799,7 +799,9 @@ def main():
                 for name in sub_names:
                     w2, b2, ww, hh, s2, mb2, ibl2 = CONFIGS[name]
                     try:
-                        sub = time_config(ctx, alone_ctx, torch, name, b2(), ww, hh, s2, mb2, ibl2, max(6, args.steps // 2), 2, stream, render_flags,
+                        # 30 steps (1 s for C4): a timed region between two synchronisations also holds the pipeline's ramp-up and
+                        # drain - about a third of a step with three frames in flight, i.e. +3 % over 10 steps, +1 % over 30
+                        sub = time_config(ctx, alone_ctx, torch, name, b2(), ww, hh, s2, mb2, ibl2, max(30, args.steps), 2, stream, render_flags,
                                           pmc_by_config.get(name))
                         sub["workload"] = w2
                         result["configs"][name] = sub
