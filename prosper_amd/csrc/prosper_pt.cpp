@@ -940,6 +940,8 @@ void prosper_pt_destroy(prosper_pt_ctx *ctx)
     }
     for (auto &ws : ctx->workStreams)
         if (ws) (void)hipStreamDestroy(ws);
+    for (auto &ws : ctx->extraStreams)
+        if (ws) (void)hipStreamDestroy(ws);
     if (ctx->chainFork) (void)hipEventDestroy(ctx->chainFork);
     delete ctx;
 }
@@ -1489,11 +1491,22 @@ int prosper_pt_render_frames(
         chains.count = (pipelined || (ctx->flags & PROSPER_PT_CREATE_SINGLE_CHAIN)) ? 1u : 2u;
         if (const char *forced = std::getenv("PROSPER_PT_DEBUG_CHAINS")) // tuning hook (in-order mode)
             if (!pipelined && std::atoi(forced) >= 1 && std::atoi(forced) <= (int)kMaxChains) chains.count = (uint32_t)std::atoi(forced);
+        // experiment (profiles/r03_hip_graph.txt, "two chains per frame in flight"): PROSPER_PT_DEBUG_PIPELINED_CHAINS=2 splits a
+        // pipelined frame's segment groups over two chains, the second on a stream of its own
+        bool twoDetached = false;
+        if (pipelined)
+            if (const char *forced = std::getenv("PROSPER_PT_DEBUG_PIPELINED_CHAINS"))
+                if (std::atoi(forced) == 2)
+                {
+                    if (!ctx->extraStreams[slotIndex]) PPT_HIP(hipStreamCreateWithFlags(&ctx->extraStreams[slotIndex], hipStreamNonBlocking));
+                    twoDetached = true;
+                    chains.count = 2u;
+                }
         chains.detached = pipelined;
         chains.fork = ctx->chainFork;
         for (uint32_t i = 0; i < kMaxChains; ++i)
         {
-            chains.streams[i] = ctx->workStreams[pipelined ? slotIndex : i];
+            chains.streams[i] = pipelined ? ((twoDetached && i == 1u) ? ctx->extraStreams[slotIndex] : ctx->workStreams[slotIndex]) : ctx->workStreams[i];
             chains.join[i] = slot.chainJoin[i];
             chainTimers[i].events = slot.chainEvents[i];
             chainTimers[i].stage = slot.chainStage[i];

@@ -234,6 +234,8 @@ struct prosper_pt_ctx
     // share queues and serialise): a pipelined render's chain runs on workStreams[slot], the two chains of an
     // in-order render on workStreams[0] and [1].  All ordering between them goes through events.
     hipStream_t workStreams[kRenderSlots] = {};
+    // experiment (PROSPER_PT_DEBUG_PIPELINED_CHAINS=2): a second chain per frame in flight; created on first use
+    hipStream_t extraStreams[kRenderSlots] = {};
     RenderSlot slots[kRenderSlots];
     uint32_t lastSlot = 0;  // of the last render
     uint32_t timedSlot = 0; // of the last render that ran with kernel timing on (timing readout)

@@ -1093,11 +1093,13 @@ void launch_render_wavefront(
     static_assert(kTraversalStackDepth == 32, "largest LDS stack variant");
     const uint32_t groups = (w.nSeg + 3u) / 4u;
     // Two chains only pay when each still fills the machine a few times over (>= 1024 workgroups each).
-    uint32_t parts = chains.detached ? 1u : (chains.count < kMaxChains ? chains.count : kMaxChains);
+    uint32_t parts = chains.count < kMaxChains ? chains.count : kMaxChains;
     while (parts > 1u && groups < 256u * parts) --parts;
     const bool ownStreams = parts > 1u || chains.detached;
     const uint32_t per = (groups + parts - 1u) / parts;
-    if (parts > 1u) (void)hipEventRecord(chains.fork, stream);
+    // (detached chains - frames in flight - do not fork from the caller's stream: they wait for their slot's previous user)
+    const bool forked = parts > 1u && !chains.detached;
+    if (forked) (void)hipEventRecord(chains.fork, stream);
     uint32_t blocksBefore = 0;
     for (uint32_t i = 0; i < parts; ++i)
     {
@@ -1106,7 +1108,7 @@ void launch_render_wavefront(
         part.groupCount = (part.groupBase + per <= groups) ? per : groups - part.groupBase;
         hipStream_t cs = ownStreams ? chains.streams[i] : stream;
         LaunchTimer *ct = ownStreams ? chains.timers[i] : timer;
-        if (parts > 1u) (void)hipStreamWaitEvent(cs, chains.fork, 0);
+        if (forked) (void)hipStreamWaitEvent(cs, chains.fork, 0);
         if (chains.detached && chains.after) (void)hipStreamWaitEvent(cs, chains.after, 0);
         if (ownStreams && chains.scene) (void)hipStreamWaitEvent(cs, chains.scene, 0);
         if (ownStreams && chains.lights) (void)hipStreamWaitEvent(cs, chains.lights, 0);
