@@ -758,8 +758,8 @@ int ensure_wavefront_workspace(
             ++nSeg;
         }
     const uint64_t padded = nSeg * segLen;
-    // per slot: 8 x 16 B ping-pong state, hit 16 + idx 4, shadow 48, colour 16; + 3 counters per segment
-    const size_t bytes = (size_t)padded * (8u * 16u + 16u + 4u + 48u + 16u) + (size_t)nSeg * 12u + 4096u;
+    // per slot: 2 x (3 x 16 + 8) B ping-pong state, camera slot 4, hit 16 + idx 4, shadow 48, colour 16; + 3 counters per segment
+    const size_t bytes = (size_t)padded * (2u * (3u * 16u + 8u) + 4u + 16u + 4u + 48u + 16u) + (size_t)nSeg * 12u + 4096u;
     if (bytes > slot.wfBytes)
     {
         PPT_HIP(hipDeviceSynchronize()); // the other slot's render may be in flight on its own streams
@@ -781,8 +781,9 @@ int ensure_wavefront_workspace(
         w.rayA[k] = static_cast<float4 *>(carve(padded * 16u));
         w.rayB[k] = static_cast<float4 *>(carve(padded * 16u));
         w.pathT[k] = static_cast<float4 *>(carve(padded * 16u));
-        w.pathR[k] = static_cast<uint4 *>(carve(padded * 16u));
+        w.pathR[k] = static_cast<uint2 *>(carve(padded * 8u));
     }
+    w.cameraSlot = static_cast<uint32_t *>(carve(padded * 4u));
     w.hit = static_cast<uint4 *>(carve(padded * 16u));
     w.hitIdx = static_cast<uint32_t *>(carve(padded * 4u));
     w.shA = static_cast<float4 *>(carve(padded * 16u));

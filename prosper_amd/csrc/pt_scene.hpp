@@ -238,9 +238,12 @@ struct RenderParams
 struct WavefrontBuffers
 {
     float4 *rayA[2];  // (origin.xyz, closest-ray seed)        ping-pong by bounce parity
-    float4 *rayB[2];  // (direction.xyz, -)
-    float4 *pathT[2]; // (throughput.rgb, slot)
-    uint4 *pathR[2];  // (rng state x,y,z, -)
+    float4 *rayB[2];  // (direction.xyz, rng state x)
+    float4 *pathT[2]; // (throughput.rgb, slot); camera paths have no record - their throughput is (1, 1, 1) - only
+    uint32_t *cameraSlot; // their slot (generate writes it, the first shade reads it).  An array of its own, indexed like the
+                          // others: records of different strides must not share memory - the two chains of an in-order
+                          // render are at different bounces at the same time, each in its own segments
+    uint2 *pathR[2];  // (rng state y, z)
     uint4 *hit;       // (drawInstance, primitive, bary.u, bary.v), compacted per segment
     uint32_t *hitIdx; // in-segment index of the ray each compacted hit came from
     float4 *shA;      // shadow rays: (origin.xyz, seed)

@@ -384,10 +384,11 @@ __global__ __launch_bounds__(256, PPT_GEN_WPE) void wf_generate_extend(
             start_path<COUNT>(p, local_to_global_x(p, bl.lx), bl.py, (p.pc.frameIndex + bl.frame) % PROSPER_RT_FRAME_PERIOD,
                               st, cnt);
             if constexpr (COUNT) cnt.closestRays++;
-            // no pathT record for bounce 0: the throughput is (1, 1, 1) and the path's radiance slot rides in the spare
-            // word of its direction record (32 B per camera path that HBM does not carry)
-            w.rayB[0][at] = make_float4(st.d.x, st.d.y, st.d.z, asf(bl.slot));
-            w.pathR[0][at] = make_uint4(st.rng.x, st.rng.y, st.rng.z, 0u);
+            // a path's state between stages: direction + one word of the generator, the other two words, and for
+            // bounce 0 - no throughput record, it is (1, 1, 1) - the radiance slot as one dword (28 B per camera path)
+            w.rayB[0][at] = make_float4(st.d.x, st.d.y, st.d.z, asf(st.rng.x));
+            w.pathR[0][at] = make_uint2(st.rng.y, st.rng.z);
+            w.cameraSlot[at] = bl.slot;
             r.o = st.o;
             r.d = st.d;
             r.tMin = 0.0f;
@@ -600,11 +601,11 @@ __global__ __launch_bounds__(256, PPT_SHADE_WPE) void wf_shade(
             const uint32_t i = w.hitIdx[id.base + j];
             const uint4 h = w.hit[id.base + j];
             const float4 b = w.rayB[cur][id.base + i];
-            // bounce 0: no throughput record - it is (1, 1, 1) - and the slot rides in the direction record's spare word
-            const float4 t = bounce == 0u ? make_float4(1.0f, 1.0f, 1.0f, b.w) : w.pathT[cur][id.base + i];
-            const uint4 r = w.pathR[cur][id.base + i];
+            // bounce 0: no throughput record - it is (1, 1, 1) - and the slot comes from the camera paths' own array
+            const float4 t = bounce == 0u ? make_float4(1.0f, 1.0f, 1.0f, asf(w.cameraSlot[id.base + i])) : w.pathT[cur][id.base + i];
+            const uint2 r = w.pathR[cur][id.base + i];
             slot = asu(t.w) & kSlotMask;
-            rng = Rng{r.x, r.y, r.z};
+            rng = Rng{asu(b.w), r.x, r.y};
             const f3 throughput = xyz(t);
             Hit hit;
             hit.drawInstance = h.x;
@@ -669,9 +670,9 @@ __global__ __launch_bounds__(256, PPT_SHADE_WPE) void wf_shade(
         if (wantNext)
         {
             w.rayA[nxt][id.base + pos] = make_float4(nO.x, nO.y, nO.z, asf(pcg(rng.x ^ rng.z)));
-            w.rayB[nxt][id.base + pos] = make_float4(nD.x, nD.y, nD.z, 0.0f);
+            w.rayB[nxt][id.base + pos] = make_float4(nD.x, nD.y, nD.z, asf(rng.x));
             w.pathT[nxt][id.base + pos] = make_float4(nT.x, nT.y, nT.z, asf(slot));
-            w.pathR[nxt][id.base + pos] = make_uint4(rng.x, rng.y, rng.z, 0u);
+            w.pathR[nxt][id.base + pos] = make_uint2(rng.y, rng.z);
         }
         nNext += total;
     }
