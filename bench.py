@@ -61,12 +61,15 @@ CONFIGS = {
     "c1": ("S-cornell 256x256 1spp maxBounces 1", lambda: scenes.cornell(), 256, 256, 1, 1, False),
     # the reference's one bundled asset (src/main.cpp:32-33), from the packed fixture (tests/golden/flight_helmet.npz)
     "helmet": ("FlightHelmet 1920x1080 8spp maxBounces 4 IBL", lambda: helmet_world(), 1920, 1080, 8, 4, True),
+    # the same with every texture at the 2048 x 2048 texels the asset ships with (replicated fixture texels: the footprint
+    # of prosper's own load, 252 MB at level 0)
+    "helmet2k": ("FlightHelmet, 2048^2 textures, 1920x1080 8spp maxBounces 4 IBL", lambda: helmet_world(2048), 1920, 1080, 8, 4, True),
 }
 
 
-def helmet_world():
+def helmet_world(texture_size=None):
     from prosper_amd import flight_helmet
-    return flight_helmet.load_fixture()
+    return flight_helmet.load_fixture(texture_size=texture_size)
 
 
 def algorithmic_bytes(c, stats):
@@ -516,7 +519,7 @@ def main():
                     "committed profile if it matches the kernel sources, else null)")
     ap.add_argument("--no-subconfigs", action="store_true", help="skip the C3 / C4 / FlightHelmet sub-objects")
     ap.add_argument("--no-extras", action="store_true", help="skip the tone-map and ReSTIR-DI legs")
-    ap.add_argument("--subconfigs", default="c3,c4,helmet")
+    ap.add_argument("--subconfigs", default="c3,c4,helmet,helmet2k")
     ap.add_argument("--megakernel", action="store_true", help="use the one-lane-per-pixel kernel (A/B)")
     ap.add_argument("--persistent", action="store_true", help="use the persistent path-regeneration kernel (A/B)")
     ap.add_argument("--single-chain", action="store_true",
@@ -540,7 +543,7 @@ def main():
     pmc_gave_up = False
     if world_size == 1 and wavefront:
         for name in [args.config] + sub_names:
-            if name not in ("c2", "c3", "c4", "c5", "helmet"):
+            if name not in ("c2", "c3", "c4", "c5", "helmet"):  # (helmet2k: timed, not profiled - the kernels are helmet's)
                 continue
             got = None
             if not args.no_pmc and not pmc_gave_up:

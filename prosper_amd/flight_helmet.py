@@ -15,9 +15,21 @@ from . import world_io
 FIXTURE = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "flight_helmet.npz")
 
 
-def load_fixture(path=FIXTURE, sky_size=64):
+def load_fixture(path=FIXTURE, sky_size=64, texture_size=None):
+    """texture_size: every texture of the fixture (64 x 64 box-filtered images, 1 x 1 stand-ins) blown up to that many texels
+    a side by replication - texture_size=2048 gives the asset the texel FOOTPRINT prosper loads it with (15 x 2048^2 RGBA8 =
+    252 MB at level 0), which is what the texel fetches of the shade kernel see; the values are the fixture's."""
     from . import scenes
     w = world_io.load_world(path)
+    if texture_size:
+        import numpy as np
+        for i, t in enumerate(w.textures):
+            if i == 0:
+                continue  # the default texture stays what it is
+            t = np.asarray(t)
+            fy, fx = max(1, texture_size // t.shape[0]), max(1, texture_size // t.shape[1])
+            w.textures[i] = np.ascontiguousarray(np.repeat(np.repeat(t, fy, axis=0), fx, axis=1))
+        w._frozen = None
     if sky_size:
         w.skybox = scenes.sky_cube(sky_size)
     # a view that fills the frame with the helmet (the asset is ~0.7 units tall around the origin); prosper's default

@@ -23,6 +23,7 @@ CONFIGS = {
     "c3": (lambda: scenes.sponza_class(), True),
     "c4": (lambda: scenes.sponza_class(lights=True, foliage=True), True),
     "helmet": (lambda: __import__("prosper_amd.flight_helmet", fromlist=["x"]).load_fixture(), True),
+    "helmet2k": (lambda: __import__("prosper_amd.flight_helmet", fromlist=["x"]).load_fixture(texture_size=2048), True),
 }
 
 

@@ -38,6 +38,7 @@ def main():
         "c3": (lambda: scenes.sponza_class(texture_size=tex), 1920, 1080, 8, 4, True),
         "c4": (lambda: scenes.sponza_class(lights=True, foliage=True, texture_size=tex), 1920, 1080, 8, 4, True),
         "helmet": (lambda: __import__("prosper_amd.flight_helmet", fromlist=["x"]).load_fixture(), 1920, 1080, 8, 4, True),
+        "helmet2k": (lambda: __import__("prosper_amd.flight_helmet", fromlist=["x"]).load_fixture(texture_size=2048), 1920, 1080, 8, 4, True),
     }[args.config]
     builder, w, h, spp, mb, ibl = cfg
     spp = args.spp or spp
