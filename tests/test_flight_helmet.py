@@ -82,3 +82,26 @@ def test_flight_helmet_bit_exact(gpu_ctx, oracle, helmet, draw_type):
     assert ok.all(), "%s: %d of %d pixels differ" % (draw_type, (~ok).sum(), ok.size)
     if draw_type == "Default":
         assert np.isfinite(got).all() and (got[..., 3] == 3).all()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("draw_type", ["Default", "Albedo", "ShadingNormal", "Roughness"])
+def test_flight_helmet_with_large_textures_bit_exact(gpu_ctx, oracle, draw_type):
+    """The same asset with every texture blown up to 1024 x 1024 (63 MB of texels: past the threshold at which opaque
+    materials get the compact 8-byte texture packs and the shade kernel batches its texel loads; the BLEND lenses keep the
+    16-byte pack): HIP path == oracle, bit for bit, on what the packs feed."""
+    from prosper_amd import flight_helmet
+    world = flight_helmet.load_fixture(texture_size=1024)
+    cam, fl = _camera(oracle, world)
+    gpu_ctx.upload_scene(world)
+    assert gpu_ctx.scene_stats().variantFlags & S.VARIANT_TEXTURE_PACKS
+    osc = oracle.OracleScene(world)
+    frames = (1, 2) if draw_type == "Default" else (1,)
+    want = None
+    for frame in frames:
+        pc = default_pc(S, fl, frame_index=frame, draw_type=S.DrawType[draw_type], max_bounces=4, ibl=True,
+                        skip_history=(frame == 1))
+        gpu_ctx.render(pc, cam, W, H)
+        want, _ = osc.render(pc, cam, W, H, history=want)
+    ok = same_bits(gpu_ctx.read_hdr(), want).all(axis=2)
+    assert ok.all(), "%s: %d of %d pixels differ" % (draw_type, (~ok).sum(), ok.size)
