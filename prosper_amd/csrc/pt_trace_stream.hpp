@@ -80,6 +80,7 @@ PPT_D void trace_stream(
     uint32_t state = kLaneIdle;
     uint32_t ray = 0;
     f3 o = {}, d = {}, invd = {};
+    RaySlabs rs = {};
     float tMin = 0.0f, tMaxIn = 0.0f;
     uint32_t seed = 0;
     int32_t node = 0, sp = 0;
@@ -168,12 +169,12 @@ PPT_D void trace_stream(
                     bool entered;
                     if constexpr (ANY)
                     {
-                        intersect_node4<false>(nd, o, make_ray_slabs(invd), tMin, hit.t, e, ref);
+                        intersect_node4<false>(nd, o, rs, tMin, hit.t, e, ref);
                         entered = descend_any(e, ref, stack, sp, node);
                     }
                     else
                     {
-                        intersect_node4(nd, o, make_ray_slabs(invd), tMin, hit.t, e, ref);
+                        intersect_node4(nd, o, rs, tMin, hit.t, e, ref);
                         if (e[3] < kInf) stack.push(sp, ref[3]);
                         if (e[2] < kInf) stack.push(sp, ref[2]);
                         if (e[1] < kInf) stack.push(sp, ref[1]);
@@ -329,6 +330,7 @@ PPT_D void trace_stream(
                 tMaxIn = r.tMax;
                 seed = r.seed;
                 invd = f3{safe_rcp_dir(d.x), safe_rcp_dir(d.y), safe_rcp_dir(d.z)};
+                rs = make_ray_slabs(invd);
                 hit.drawInstance = kMissIndex;
                 hit.primitive = kMissIndex;
                 hit.bary = f2{0.0f, 0.0f};
