@@ -10,7 +10,11 @@ max-over-ranks of the wall time).  Steps are enqueued back to back with up to th
 (PROSPER_PT_RENDER_PIPELINED, prosper's frames-in-flight idea; --in-order for A/B): every step's kernels, its
 accumulate and its gather complete inside the timed region, which is bracketed by barrier + synchronize.
 
-What the one JSON line carries besides the contract fields:
+The LAST stdout line is ONE JSON object of under 4 KB (tests/test_bench_contract.py): the contract fields, a numbers-only
+`roofline`, `cpu_baseline`, and per sub-configuration (`configs`: C1, C3, C4, FlightHelmet, the C5 rank share) ms/step,
+Mpaths/s, the dominant kernel's fractions and the CPU tracer's rate.  Everything else - per-kernel tables, counters, notes,
+the full roofline objects - goes to bench_detail.json (next to this file, and under gpurun_out/).  What the detail file
+carries besides the contract fields:
   roofline   the roof that binds the dominant kernel: VALU issue.  achieved = wave-instructions/s of that kernel
              (SQ_INSTS_VALU per launch, measured IN THIS RUN by rocprofv3 child passes over the same launch shape, /
              the kernel's exclusive share of the step time); peak = the guide's 1024 SIMDs x 2.4 GHz / 2 cycles, the
@@ -27,6 +31,7 @@ What the one JSON line carries besides the contract fields
     python bench.py --gpus 1 --steps 20 --warmup 3
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N ...        (no launcher: starts the N ranks itself as a child torch.distributed.run)
 """
 import argparse
 import json
@@ -148,17 +153,22 @@ def host_cores():
     return cores
 
 
-def cpu_baseline(world, cam, focal, width, height, spp, max_bounces, ibl, budget_s=15.0):
-    """The oracle (a scalar port) timed on this box's host cores on a bounded sample."""
+def cpu_baseline(world, cam, focal, width, height, spp, max_bounces, ibl, budget_s=15.0, tile=None):
+    """The oracle (a scalar port) timed on this box's host cores on a bounded sample: accumulated frames of the same
+    workload until the budget is spent (at least one).  `tile` = (rank, ranks): only that rank's stripes."""
     from oracle import binding as oracle
+    t_build = time.perf_counter()
     osc = oracle.OracleScene(world, brute_force=False)
+    build_s = time.perf_counter() - t_build
     cores = host_cores()
     img = None
     frames = 0
+    local_w = width if tile is None else tiling.local_width(width, tile[0], tile[1])
+    kw = {} if tile is None else {"tile": tiling.tile_for_rank(tile[0], tile[1])}
     t0 = time.perf_counter()
     while frames < spp:
         pc = make_pc(focal, frames + 1, max_bounces, ibl, frames == 0)
-        img, _ = osc.render(pc, cam, width, height, history=img, threads=cores)
+        img, _ = osc.render(pc, cam, width, height, history=img, threads=cores, **kw)
         frames += 1
         elapsed = time.perf_counter() - t0
         if elapsed + elapsed / frames > budget_s:
@@ -166,13 +176,143 @@ def cpu_baseline(world, cam, focal, width, height, spp, max_bounces, ibl, budget
     elapsed = time.perf_counter() - t0
     osc.close()
     return {
-        "value": width * height * frames / elapsed / 1e6,
+        "value": local_w * height * frames / elapsed / 1e6,
         "unit": "Mpaths/s",
         "cores": cores,
         "kind": "port",
-        "sample": "%d of %d spp of the same %dx%d frame (%.1f s; 16x16-pixel tiles from a shared counter, one worker per "
-                  "hardware thread, -O3 x86-64-v3, fp contraction off, the oracle's own BVH2)" % (frames, spp, width, height, elapsed),
+        "sample_frames": frames,
+        "sample_seconds": elapsed,
+        "hierarchy_build_seconds": build_s,
+        "sample": "%d of %d spp of the same %dx%d frame%s (%.1f s; 16x16-pixel tiles from a shared counter, one worker per "
+                  "hardware thread, -O3 x86-64-v3, fp contraction off, the oracle's own BVH2)" % (
+                      frames, spp, width, height, "" if tile is None else ", the stripes of rank %d of %d" % tile, elapsed),
     }
+
+
+def rounded(x, digits=5):
+    """Floats to `digits` significant digits (the slim line), everything else as it is."""
+    if isinstance(x, float):
+        return float("%.*g" % (digits, x)) if x == x and abs(x) != float("inf") else None
+    if isinstance(x, dict):
+        return {k: rounded(v, digits) for k, v in x.items()}
+    if isinstance(x, (list, tuple)):
+        return [rounded(v, digits) for v in x]
+    return x
+
+
+def slim_roofline(r):
+    """The numbers of a roofline object (roofline_object): no notes, no sources."""
+    if not r:
+        return None
+    hbm = r.get("hbm") or {}
+    wn = r.get("work_normalised") or {}
+    out = {k: r.get(k) for k in ("bound", "kernel", "unit", "peak", "peak_calibrated", "kernel_ms", "kernel_ms_alone",
+                                 "launches_per_step", "share_of_step", "achieved", "issue_frac", "lane_util", "frac", "traffic")}
+    out["efficiency"] = wn.get("efficiency")
+    out["pmc"] = "live" if str(r.get("pmc_source", "")).startswith("rocprofv3") else ("committed" if str(r.get("pmc_source", "")).startswith("profiles/") else "none")
+    out["hbm"] = {k: hbm.get(k) for k in ("peak_GBps", "algorithmic_bytes_per_launch", "algorithmic_frac", "measured_bytes_per_launch",
+                                          "measured_frac", "measured_over_algorithmic", "cache_served")}
+    ws = r.get("whole_step") or {}
+    out["whole_step"] = {k: ws.get(k) for k in ("issue_frac", "useful_frac", "hbm_measured_frac")}
+    return out
+
+
+def slim_config(c):
+    """One sub-configuration of the slim line."""
+    if "error" in c:
+        return {"error": c["error"][:120]}
+    r = c.get("roofline") or {}
+    hbm = r.get("hbm") or {}
+    out = {"ms_per_step": c.get("ms_per_step"), "Mpaths_per_s": c.get("Mpaths_per_s"), "kernel": r.get("kernel"),
+           "kernel_ms": r.get("kernel_ms"), "frac": r.get("frac"), "issue_frac": r.get("issue_frac"), "lane_util": r.get("lane_util"),
+           "efficiency": (r.get("work_normalised") or {}).get("efficiency"),
+           "hbm_measured_frac": hbm.get("measured_frac"), "traffic": r.get("traffic"),
+           "cpu_Mpaths_per_s": (c.get("cpu_baseline") or {}).get("value")}
+    if "nearest_hbm_roof" in c:
+        out["nearest_hbm_roof"] = {"kernel": c["nearest_hbm_roof"]["kernel"], "frac": c["nearest_hbm_roof"]["frac_of_peak"]}
+    if "extrapolated" in c:
+        out["extrapolated"] = c["extrapolated"]
+    return {k: v for k, v in out.items() if v is not None}
+
+
+DETAIL_NAME = "bench_detail.json"
+SLIM_LIMIT = 4096
+
+
+def slim_line(result):
+    """The ONE stdout line (under SLIM_LIMIT bytes): contract fields + numbers; the rest lives in bench_detail.json."""
+    line = {k: result.get(k) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "frames_per_s",
+                                       "higher_is_better", "scaling", "vs_baseline", "dtype", "data")}
+    cfg = result["config"]
+    line["config"] = {k: cfg.get(k) for k in ("workload", "width", "height", "spp", "max_bounces", "triangles", "bvh_nodes",
+                                              "parallelism", "pipeline")}
+    line["roofline"] = slim_roofline(result.get("roofline"))
+    if "cpu_baseline" in result:
+        cb = result["cpu_baseline"]
+        sample = ("%d of %d spp of the same frame, %.1f s" % (cb["sample_frames"], cfg["spp"], cb["sample_seconds"])
+                  if "sample_frames" in cb else str(cb.get("sample", ""))[:60])
+        line["cpu_baseline"] = {"value": cb["value"], "unit": cb["unit"], "cores": cb["cores"], "kind": cb["kind"], "sample": sample}
+        line["gpu_over_cpu"] = result.get("gpu_over_cpu")
+    for k in ("ranks_seen", "gather_ms", "mean_radiance"):
+        if k in result:
+            line[k] = result[k]
+    for k in ("single_sample_frames", "rank_share"):
+        if k in result and "ms_per_frame" in result[k]:
+            line[k] = {"ms": result[k]["ms_per_frame"]}
+        elif k in result and "ms_per_step" in result[k]:
+            line[k] = {"ms": result[k]["ms_per_step"], "bound_on_scaling_efficiency": result[k].get("bound_on_scaling_efficiency")}
+    if result.get("configs"):
+        line["configs"] = {name: slim_config(c) for name, c in result["configs"].items()}
+    line["detail"] = DETAIL_NAME
+    line = rounded(line)
+    text = json.dumps(line, separators=(",", ":"))
+    if len(text) >= SLIM_LIMIT:  # never again a line the driver cannot parse: drop the optional parts, largest first
+        for k in ("configs", "single_sample_frames", "rank_share"):
+            line.pop(k, None)
+            text = json.dumps(line, separators=(",", ":"))
+            if len(text) < SLIM_LIMIT:
+                break
+    return text
+
+
+def write_detail(result):
+    """bench_detail.json next to this file and under gpurun_out/ (the scratch directory a GPU box's run sends back)."""
+    for d in (ROOT, os.path.join(ROOT, "gpurun_out")):
+        try:
+            os.makedirs(d, exist_ok=True)
+            with open(os.path.join(d, DETAIL_NAME), "w") as f:
+                json.dump(result, f, indent=1)
+                f.write("\n")
+        except OSError as e:
+            print("bench: could not write %s (%s)" % (os.path.join(d, DETAIL_NAME), e), file=sys.stderr)
+
+
+def spawn_ranks(n):
+    """`python bench.py --gpus N` without a launcher: this process - which has not touched the GPU and never will -
+    starts `python -m torch.distributed.run --nproc-per-node N bench.py <the same arguments>` as a CHILD, relays its
+    stdout (rank 0's one line) and exits with its code."""
+    import socket
+    import subprocess
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    child = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    last = None
+    for raw in child.stdout:
+        text = raw.strip()
+        if text.startswith("{") and text.endswith("}"):
+            last = text
+        elif text:
+            print(text, file=sys.stderr)  # (launcher chatter must not share stdout with the one line)
+    rc = child.wait()
+    if last is not None:
+        print(last)
+    sys.stdout.flush()
+    raise SystemExit(rc if rc != 0 else (0 if last is not None else 1))
 
 
 def bench_tone_map(ctx, torch, width, height, stream, repeats=50):
@@ -435,7 +575,8 @@ def time_rank_share(ctx, torch, cam, focal, width, height, spp, max_bounces, ibl
     return out
 
 
-def time_config(ctx, alone_ctx, torch, name, world, width, height, spp, max_bounces, ibl, steps, warmup, stream, render_flags, pmc):
+def time_config(ctx, alone_ctx, torch, name, world, width, height, spp, max_bounces, ibl, steps, warmup, stream, render_flags, pmc,
+                cpu_budget_s=0.0):
     """A sub-configuration on one GPU (C3, C4): upload, one counted render, preheat, `steps` timed pipelined steps with
     per-launch events on one of them."""
     t0 = time.perf_counter()
@@ -497,12 +638,23 @@ def time_config(ctx, alone_ctx, torch, name, world, width, height, spp, max_boun
         out["nearest_hbm_roof"] = {"kernel": k, "GBps": hbm[k], "frac_of_peak": hbm[k] / HBM_PEAK_GBS,
                                    "traffic_over_algorithmic": kernels[k].get("traffic_over_algorithmic")}
     ctx.set_output_buffer(0, 0)
+    if cpu_budget_s:
+        # the CPU tracer beside every configuration - a 1-spp sample of the same frame on the host cores
+        try:
+            out["cpu_baseline"] = cpu_baseline(world, cam, focal, width, height, spp, max_bounces, ibl, budget_s=cpu_budget_s)
+            out["gpu_over_cpu"] = out["Mpaths_per_s"] / out["cpu_baseline"]["value"]
+        except Exception as e:
+            out["cpu_baseline_error"] = str(e)[:300]
     if name == "c3":
         # BASELINE C5 (this scene, 3840x2160, 64 spp, 8 GPUs) as one of its ranks sees it
         try:
             w5, h5 = 3840, 2160
             cam5, focal5 = Camera.from_world(world, w5, h5).update_buffer()
-            out["c5_rank_share"] = time_rank_share(ctx, torch, cam5, focal5, w5, h5, 64, max_bounces, ibl, stream, 8, 3, 3)
+            share = time_rank_share(ctx, torch, cam5, focal5, w5, h5, 64, max_bounces, ibl, stream, 8, 3, 3)
+            if cpu_budget_s:
+                # the CPU tracer on the same rank's stripes, 1 of the 64 spp (a 64-spp sample would take minutes)
+                share["cpu_baseline"] = cpu_baseline(world, cam5, focal5, w5, h5, 64, max_bounces, ibl, budget_s=cpu_budget_s, tile=(3, 8))
+            out["c5_rank_share"] = share
         except Exception as e:
             out["c5_rank_share"] = {"error": str(e)[:300]}
     return out
@@ -517,9 +669,11 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pmc", action="store_true", help="skip the rocprofv3 child passes (roofline then quotes the "
                     "committed profile if it matches the kernel sources, else null)")
+    ap.add_argument("--pmc-budget", type=float, default=240.0, help="seconds all rocprofv3 child passes together may take")
+    ap.add_argument("--cpu-budget", type=float, default=12.0, help="seconds of CPU tracing for the headline's cpu_baseline")
     ap.add_argument("--no-subconfigs", action="store_true", help="skip the C3 / C4 / FlightHelmet sub-objects")
     ap.add_argument("--no-extras", action="store_true", help="skip the tone-map and ReSTIR-DI legs")
-    ap.add_argument("--subconfigs", default="c3,c4,helmet,helmet2k")
+    ap.add_argument("--subconfigs", default="c1,c3,c4,helmet,helmet2k")
     ap.add_argument("--megakernel", action="store_true", help="use the one-lane-per-pixel kernel (A/B)")
     ap.add_argument("--persistent", action="store_true", help="use the persistent path-regeneration kernel (A/B)")
     ap.add_argument("--single-chain", action="store_true",
@@ -528,12 +682,17 @@ def main():
                     help="no frames in flight: every step starts after the previous one has finished (A/B)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # plain `python bench.py --gpus N`: start the ranks as a child process.  Nothing above this line has touched the
+        # GPU (the library is loaded lazily, torch is not imported yet), and this process never does.
+        width = CONFIGS[args.config][2]
+        if not tiling.check_divisible(width, args.gpus):
+            raise SystemExit("--gpus %d: %d stripes of %d pixels do not divide over the ranks" % (args.gpus, width // STRIPE_WIDTH, STRIPE_WIDTH))
+        spawn_ranks(args.gpus)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world_size = int(os.environ.get("WORLD_SIZE", "1"))
     if world_size != args.gpus:
-        if world_size == 1 and args.gpus > 1:
-            raise SystemExit("--gpus %d needs torch.distributed.run with --nproc-per-node %d" % (args.gpus, args.gpus))
         raise SystemExit("WORLD_SIZE %d != --gpus %d" % (world_size, args.gpus))
     wavefront = not (args.megakernel or args.persistent)
 
@@ -541,15 +700,17 @@ def main():
     sub_names = [c for c in args.subconfigs.split(",") if c] if (args.config == "c2" and not args.no_subconfigs) else []
     pmc_by_config = {}
     pmc_gave_up = False
+    pmc_deadline = time.perf_counter() + args.pmc_budget  # all profiler passes together: bounded, whatever a pass does
     if world_size == 1 and wavefront:
         for name in [args.config] + sub_names:
             if name not in ("c2", "c3", "c4", "c5", "helmet"):  # (helmet2k: timed, not profiled - the kernels are helmet's)
                 continue
             got = None
-            if not args.no_pmc and not pmc_gave_up:
+            left = pmc_deadline - time.perf_counter()
+            if not args.no_pmc and not pmc_gave_up and left > 20.0:
                 try:
                     t0 = time.perf_counter()
-                    got = pmc_tools.collect(name, timeout=240)
+                    got = pmc_tools.collect(name, timeout=max(20.0, min(120.0, left / 3.0)))
                     got["source"] = "rocprofv3 --pmc child passes of this run (%.0f s; scripts/pmc_tools.py)" % (time.perf_counter() - t0)
                 except Exception as e:  # no profiler, a refused counter, a timeout: the line says so instead of failing
                     print("bench: live PMC passes unavailable for %s (%s)" % (name, str(e)[:300]), file=sys.stderr)
@@ -730,6 +891,13 @@ def main():
     if world_size > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
+    # what the communicator itself says about the job (ncclCommCount) and the device time of the last gather + de-interleave
+    ranks_seen, ranks_seen_by, gather_ms = world_size, "torch.distributed (gloo)", None
+    if world_size > 1 and not rehearse and fallback_group is None:
+        info = ctx.comm_info(stream)
+        ranks_seen, ranks_seen_by, gather_ms = int(info.ranks), "ncclCommCount of the library's communicator", float(info.lastGatherMs)
+    elif world_size > 1:
+        ranks_seen = dist.get_world_size()
 
     alone_ctx = None
     if rank == 0:
@@ -797,6 +965,9 @@ def main():
                 ctx.render(make_pc(focal, 1, max_bounces, ibl, True), cam, width, height, frames=spp, stream=stream)
                 result["tone_map"] = bench_tone_map(ctx, torch, width, height, stream)
                 result["restir_di_trace"] = bench_restir_di(ctx, torch, world, cam, focal, width, height, stream)
+            if not args.no_cpu_baseline:
+                result["cpu_baseline"] = cpu_baseline(world, cam, focal, width, height, spp, max_bounces, ibl, budget_s=args.cpu_budget)
+                result["gpu_over_cpu"] = result["value"] / result["cpu_baseline"]["value"]
             if sub_names:
                 result["configs"] = {}
                 for name in sub_names:
@@ -804,16 +975,33 @@ def main():
                     try:
                         # 30 steps (1 s for C4): a timed region between two synchronisations also holds the pipeline's ramp-up and
                         # drain - about a third of a step with three frames in flight, i.e. +3 % over 10 steps, +1 % over 30
+                        # CPU tracer beside it: ONE accumulated frame of the same workload (4-9 s on 16 cores for the
+                        # S-sponza-class scenes); helmet2k shares helmet's (same geometry, same rays: the texels differ in size only)
+                        cpu_s = 0.0 if (args.no_cpu_baseline or name == "helmet2k") else 0.5
                         sub = time_config(ctx, alone_ctx, torch, name, b2(), ww, hh, s2, mb2, ibl2, max(30, args.steps), 2, stream, render_flags,
-                                          pmc_by_config.get(name))
+                                          pmc_by_config.get(name), cpu_budget_s=cpu_s)
                         sub["workload"] = w2
+                        if name == "helmet2k" and "cpu_baseline" in result["configs"].get("helmet", {}):
+                            sub["cpu_baseline"] = dict(result["configs"]["helmet"]["cpu_baseline"], sample="configs.helmet's sample (same geometry and rays)")
                         result["configs"][name] = sub
+                        share = sub.pop("c5_rank_share", None)
+                        if share is not None:
+                            # BASELINE C5 needs 8 GPUs: what ONE of its ranks does, timed on this GPU, and the job's rate if
+                            # the eight shares ran side by side with a free gather - an extrapolation, labelled as one
+                            c5 = dict(share)
+                            if "ms_per_step" in share:
+                                c5["Mpaths_per_s"] = share["Mpaths_per_s_of_the_share"]
+                                c5["extrapolated"] = "1 of 8 rank shares on 1 GPU; x8 = %.0f Mpaths/s if the ranks scaled perfectly" % (8.0 * share["Mpaths_per_s_of_the_share"])
+                            c5["workload"] = CONFIGS["c5"][0] + ", rank 3 of 8"
+                            result["configs"]["c5_rank_share"] = c5
                     except Exception as e:  # a sub-configuration must never cost the headline line
                         result["configs"][name] = {"error": str(e)[:300]}
-            if not args.no_cpu_baseline:
-                result["cpu_baseline"] = cpu_baseline(world, cam, focal, width, height, spp, max_bounces, ibl)
-                result["gpu_over_cpu"] = result["value"] / result["cpu_baseline"]["value"]
-        print(json.dumps(result))
+        if world_size > 1:
+            result["ranks_seen"] = ranks_seen
+            result["ranks_seen_by"] = ranks_seen_by
+            result["gather_ms"] = gather_ms
+        write_detail(result)
+        print(slim_line(result))
 
     ctx.set_output_buffer(0, 0)
     ctx.close()

@@ -40,7 +40,7 @@
 extern "C" {
 #endif
 
-#define PROSPER_PT_ABI_VERSION 3
+#define PROSPER_PT_ABI_VERSION 4
 
 enum
 {
@@ -243,7 +243,7 @@ enum
     PROSPER_PT_VARIANT_LDS_TABLES = 1u << 1,      /* wf_shade stages instances/transforms/materials/lights in LDS */
     PROSPER_PT_VARIANT_BATCHED_TEXTURES = 1u << 2, /* the twelve texel loads of a hit issued together */
     PROSPER_PT_VARIANT_TEXTURE_PACKS = 1u << 3,  /* some material's base / MR / normal texels are interleaved per texel */
-    PROSPER_PT_VARIANT_RAW_RECORDS = 1u << 4,    /* 64-byte raw shading records decoded per hit (PROSPER_PT_DEBUG_RAW_RECORDS=1: an experiment) */
+    PROSPER_PT_VARIANT_RAW_RECORDS = 1u << 4,    /* 64-byte raw shading records decoded per hit (debug option rawRecords: an experiment) */
     PROSPER_PT_VARIANT_STACK_SHIFT = 8,           /* bits 8..15: LDS traversal-stack entries (16/24/32) */
 };
 
@@ -261,8 +261,64 @@ enum
     PROSPER_PT_RENDER_PIPELINED = 1u << 1,
 };
 
+/* Tuning and test options of a context.  NOTHING in the library reads the process environment while it uploads, updates or
+ * renders: a host application's environment cannot change what this plugin does.  Tests and measurement scripts fill this
+ * struct instead (prosper_pt_debug_options_default, change fields, prosper_pt_set_debug_options); options marked "upload"
+ * take effect at the next prosper_pt_upload_scene, the others at the next render / update.  No option changes a pixel
+ * (every one of them is exercised by a bit-exactness test).  The one concession to shell-driven sweeps: when the variable
+ * PROSPER_PT_DEBUG is "1" at prosper_pt_create - and only then, and only there - PROSPER_PT_DEBUG_OPTIONS
+ * ("name=value,name=value", the field names below) is parsed into the new context's options.
+ * Zero (or -1 where zero is a value) always means "the library's default". */
+typedef struct prosper_pt_debug_options
+{
+    uint32_t struct_size; /* sizeof(prosper_pt_debug_options) */
+    /* ---- scene upload ---- */
+    int32_t batchedTextures;   /* -1: by texel footprint; 0 / 1: a hit's texel loads one by one / issued together */
+    int32_t widePacks;         /* -1: by texel footprint; 1 / 0: 16-byte / compact 8-byte material texture packs */
+    int32_t alphaCellShift;    /* -1: default; s: alpha-bound cells of 2^s texels a side */
+    uint32_t noTexturePacks;   /* every texture sampled by itself */
+    uint32_t noAlphaBounds;    /* every any-hit candidate runs the exact code */
+    uint32_t noUploadRefit;    /* keep the host emitter's node bytes (the test that compares them with the device encoder's) */
+    uint32_t flatBvh;          /* one SAH tree over everything instead of per-instance subtrees */
+    /* ---- hierarchy builder (upload and rebuild) ---- */
+    float sahTraversalCost;    /* 0: 1.0 */
+    float boxPad;              /* 0: 1.6e-5 (also the minimum) */
+    uint32_t leafSize;         /* 0: 4 */
+    uint32_t buildThreads;     /* 0: the host's threads */
+    uint32_t topEntries;       /* 0: one per four triangles */
+    int32_t nodeOrder;         /* -1: 2 (first 4096 nodes breadth-first, then depth-first subtrees); 0 depth-first; 1 breadth-first */
+    int32_t childOrder;        /* -1 / 1: smallest box first; 0: build order */
+    uint32_t buildTiming;      /* the assembly's stage times to stderr */
+    /* ---- render ---- */
+    uint32_t segments;         /* target segment count of the wavefront workspace */
+    uint32_t segmentLength;    /* segment length in slots (a multiple of 64) */
+    uint32_t chains;           /* launch chains of an in-order render (default 2) */
+    uint32_t ldsStackEntries;  /* 16 / 24 / 32: LDS traversal-stack entries (deeper entries spill to global memory) */
+    uint32_t noLdsScene;       /* keep a small scene in global memory */
+    uint32_t noLdsTables;      /* keep the shading tables in global memory */
+    uint32_t traceDeadPaths;   /* keep tracing zero-throughput paths, as the GLSL does (audit of the contract's rule) */
+    /* ---- updates ---- */
+    float rebuildCostRatio;    /* 0: 1.3 - growth of the tree's surface-area measure at which an update also rebuilds */
+    uint32_t alwaysRebuild;    /* rebuild with every update */
+    uint32_t failNextUpdate;   /* the next host-side rebuild fails (the recovery test); cleared by that failure */
+    /* ---- measured-slower experiments: only in a library built with -DPPT_EXPERIMENTS (prosper_pt_has_experiments);
+     *      setting any of them in the default build fails with PROSPER_PT_ERR_UNSUPPORTED ---- */
+    uint32_t poolVariant;      /* wf_trace out of an LDS ray pool (1, 2, 3) */
+    uint32_t rawRecords;       /* 64-byte raw shading records decoded per hit (upload) */
+    uint32_t tileOrder;        /* camera-ray batches take the tiles by the cost of a probe ray */
+    uint32_t hipGraph;         /* a pipelined render's chain of launches through a HIP graph */
+    uint32_t pipelinedChains;  /* 2: a frame in flight runs as two chains */
+    uint32_t mergeLimit;       /* a workgroup's four segments traced by one wave below this many rays */
+} prosper_pt_debug_options;
+
 const char *prosper_pt_last_error(void);
 uint32_t prosper_pt_abi_version(void);
+/* 1 when the library was built with -DPPT_EXPERIMENTS (the measured-slower kernel variants are compiled in), else 0.
+ * In the default build PROSPER_PT_CREATE_PERSISTENT is refused by prosper_pt_create as well. */
+uint32_t prosper_pt_has_experiments(void);
+void prosper_pt_debug_options_default(prosper_pt_debug_options *out);
+int prosper_pt_set_debug_options(prosper_pt_ctx *ctx, const prosper_pt_debug_options *options);
+int prosper_pt_get_debug_options(prosper_pt_ctx *ctx, prosper_pt_debug_options *out);
 
 int prosper_pt_create(const prosper_pt_device_desc *desc, prosper_pt_ctx **out_ctx);
 void prosper_pt_destroy(prosper_pt_ctx *ctx);
@@ -284,14 +340,19 @@ int prosper_pt_update_lights(
  * microseconds; an unchanged table is a no-op); the refit runs at the head of the next render's own chain of launches,
  * into the next of three versions of the transform / triangle / node arrays - like the per-frame TLAS of a Vulkan frame
  * loop - so the frames in flight (PROSPER_PT_RENDER_PIPELINED) go on reading theirs and nothing waits for them.
- * prosper_pt_update_transforms_async with a non-null stream enqueues the refit on that stream right away instead.  Same
+ * prosper_pt_update_transforms_async with PROSPER_PT_UPDATE_NOW enqueues the refit on `stream` right away instead (any
+ * stream, the null stream included); without the flag it stages like prosper_pt_update_transforms and ignores `stream`.  Same
  * pixels as a fresh prosper_pt_upload_scene of the moved scene (hits do not depend on the hierarchy).  A refit cannot keep
  * the tree good when instances travel far: each one leaves the tree's surface-area measure behind, and when that has
- * grown by 30 % (PROSPER_PT_REBUILD_COST_RATIO) over its value at the last build, the next update also rebuilds -
+ * grown by 30 % (debug option rebuildCostRatio) over its value at the last build, the next update also rebuilds -
  * synchronously, like prosper_pt_rebuild_hierarchy. */
 int prosper_pt_update_transforms(prosper_pt_ctx *ctx, const prosper_ModelInstanceTransforms *transforms, uint32_t count);
+enum
+{
+    PROSPER_PT_UPDATE_NOW = 1u << 0, /* enqueue the refit on `stream` inside the call instead of leaving it to the next render */
+};
 int prosper_pt_update_transforms_async(
-    prosper_pt_ctx *ctx, const prosper_ModelInstanceTransforms *transforms, uint32_t count, void *stream);
+    prosper_pt_ctx *ctx, const prosper_ModelInstanceTransforms *transforms, uint32_t count, uint32_t flags, void *stream);
 /* Re-splits the instances that moved since the last build and re-assembles the tree on the host (one subtree per model
  * instance under a re-braided top level); synchronises the device.  prosper_pt_scene_stats.bvhBuildSeconds reports it. */
 int prosper_pt_rebuild_hierarchy(prosper_pt_ctx *ctx);
@@ -404,6 +465,7 @@ int prosper_pt_restir_di_trace(
  *                                  itself; readers of `device_full_rgba32f` call prosper_pt_gather_wait first.
  *                                  PROSPER_PT_GATHER_IN_STREAM runs everything on `stream` instead.
  *   prosper_pt_gather_wait         makes `stream` wait for the last gather (+ de-interleave)
+ *   prosper_pt_comm_query          the communicator's own rank count / rank / device and the last gather's device time
  *   prosper_pt_deinterleave_tiles  the root's kernel alone: `device_tiles` = the ranks' tiles back to back in rank order
  */
 #define PROSPER_PT_COMM_ID_BYTES 128
@@ -418,6 +480,20 @@ int prosper_pt_comm_destroy(prosper_pt_ctx *ctx);
 int prosper_pt_gather_tiles(
     prosper_pt_ctx *ctx, uint32_t root, void *device_full_rgba32f, size_t byte_size, uint32_t flags, void *stream);
 int prosper_pt_gather_wait(prosper_pt_ctx *ctx, void *stream);
+/* What the communicator itself reports (ncclCommCount / ncclCommUserRank / ncclCommCuDevice - not what the caller passed
+ * to prosper_pt_comm_init), the gathers enqueued so far, and the device time of the last one: its collective + on the
+ * root the de-interleave kernel, between two events on the stream it ran on (waits for it; 0 before the first).
+ * Without a communicator: ranks 1, rank 0, the context's device. */
+typedef struct prosper_pt_comm_info
+{
+    uint32_t ranks;
+    uint32_t rank;
+    int32_t device;
+    uint32_t gathers;
+    float lastGatherMs;
+    uint32_t reserved;
+} prosper_pt_comm_info;
+int prosper_pt_comm_query(prosper_pt_ctx *ctx, prosper_pt_comm_info *out);
 /* The root's gathered image: where the last prosper_pt_gather_tiles put it (the caller's buffer, or the context's own
  * when `device_full_rgba32f` was NULL), and a synchronising copy of it to host memory (width*height RGBA32F). */
 int prosper_pt_get_gathered_device_ptr(prosper_pt_ctx *ctx, void **out_ptr, uint32_t *width, uint32_t *height);

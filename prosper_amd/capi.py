@@ -12,7 +12,9 @@ import numpy as np
 from . import structs as S
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libprosper_pt.so")
+# PROSPER_PT_LIB (read by this BINDING, i.e. by tests and measurement scripts - the library itself never looks): another
+# build of the library, e.g. libprosper_pt_experiments.so (make -C prosper_amd/csrc EXPERIMENTS=1)
+LIB_PATH = os.environ.get("PROSPER_PT_LIB") or os.path.join(_HERE, "libprosper_pt.so")
 
 
 class ProsperPtError(RuntimeError):
@@ -44,6 +46,11 @@ def lib():
     vp, u32, i32 = C.c_void_p, C.c_uint32, C.c_int32
     L.prosper_pt_last_error.restype = C.c_char_p
     L.prosper_pt_abi_version.restype = u32
+    L.prosper_pt_has_experiments.restype = u32
+    L.prosper_pt_debug_options_default.argtypes = [C.POINTER(S.DebugOptions)]
+    L.prosper_pt_debug_options_default.restype = None
+    L.prosper_pt_set_debug_options.argtypes = [vp, C.POINTER(S.DebugOptions)]
+    L.prosper_pt_get_debug_options.argtypes = [vp, C.POINTER(S.DebugOptions)]
     L.prosper_pt_create.argtypes = [C.POINTER(S.DeviceDesc), C.POINTER(vp)]
     L.prosper_pt_destroy.argtypes = [vp]
     L.prosper_pt_destroy.restype = None
@@ -52,7 +59,7 @@ def lib():
         vp, C.POINTER(S.DirectionalLightParameters), C.POINTER(S.PointLightsBuffer), C.POINTER(S.SpotLightsBuffer)]
     L.prosper_pt_get_scene_stats.argtypes = [vp, C.POINTER(S.SceneStats)]
     L.prosper_pt_update_transforms.argtypes = [vp, vp, u32]
-    L.prosper_pt_update_transforms_async.argtypes = [vp, vp, u32, vp]
+    L.prosper_pt_update_transforms_async.argtypes = [vp, vp, u32, u32, vp]
     L.prosper_pt_rebuild_hierarchy.argtypes = [vp]
     L.prosper_pt_get_hierarchy_state.argtypes = [vp, C.POINTER(S.HierarchyState)]
     L.prosper_pt_debug_read_nodes.argtypes = [vp, vp, C.c_size_t]
@@ -86,6 +93,7 @@ def lib():
     L.prosper_pt_comm_destroy.argtypes = [vp]
     L.prosper_pt_gather_tiles.argtypes = [vp, u32, vp, C.c_size_t, u32, vp]
     L.prosper_pt_gather_wait.argtypes = [vp, vp]
+    L.prosper_pt_comm_query.argtypes = [vp, C.POINTER(S.CommInfo)]
     L.prosper_pt_get_gathered_device_ptr.argtypes = [vp, C.POINTER(vp), C.POINTER(u32), C.POINTER(u32)]
     L.prosper_pt_read_gathered.argtypes = [vp, vp, C.c_size_t, vp]
     L.prosper_pt_deinterleave_tiles.argtypes = [vp, vp, u32, u32, u32, u32, vp, C.c_size_t, vp]
@@ -156,11 +164,42 @@ def _tile_ref(tile):
     return C.byref(tile) if tile is not None else None
 
 
+def has_experiments():
+    """True when the loaded library was built with -DPPT_EXPERIMENTS (the measured-slower variants are compiled in)."""
+    return bool(lib().prosper_pt_has_experiments())
+
+
+# Process-wide debug options of THIS BINDING (tests, sweeps): every Context applies them - on top of the library's defaults
+# and under its own set_debug() - before its next upload, update or render.  The library keeps options per context and
+# never reads the environment; this dict is what monkeypatch.setenv used to be for the tests.
+_debug_defaults = {}
+_debug_version = 0
+
+
+def debug(**options):
+    """capi.debug(ldsStackEntries=16) sets, capi.debug(ldsStackEntries=None) clears a process-wide option; capi.debug()
+    with no argument clears them all."""
+    global _debug_version
+    if not options:
+        _debug_defaults.clear()
+    for k, v in options.items():
+        if k not in dict(S.DebugOptions._fields_):
+            raise KeyError("unknown debug option %r" % k)
+        if v is None:
+            _debug_defaults.pop(k, None)
+        else:
+            _debug_defaults[k] = v
+    _debug_version += 1
+
+
 class Context:
     """One prosper_pt context = one GPU (prosper_pt_create .. prosper_pt_destroy)."""
 
     def __init__(self, device=0, flags=0, _borrowed=None):
         self._owned = _borrowed is None
+        self._own_debug = {}
+        self._debug_seen = -1
+        self._world = None
         if _borrowed is not None:
             self._h = C.c_void_p(_borrowed)
             return
@@ -168,7 +207,36 @@ class Context:
         h = C.c_void_p()
         _check(lib().prosper_pt_create(C.byref(desc), C.byref(h)))
         self._h = h
-        self._world = None
+
+    def set_debug(self, **options):
+        """This context's debug options (prosper_pt_set_debug_options): ctx.set_debug(segments=2560); None clears one,
+        no argument clears all.  Applied with the process-wide capi.debug() options before the next call."""
+        if not options:
+            self._own_debug = {}
+        for k, v in options.items():
+            if k not in dict(S.DebugOptions._fields_):
+                raise KeyError("unknown debug option %r" % k)
+            if v is None:
+                self._own_debug.pop(k, None)
+            else:
+                self._own_debug[k] = v
+        self._debug_seen = -1
+        self._sync_debug()
+
+    def debug_options(self):
+        o = S.DebugOptions()
+        _check(lib().prosper_pt_get_debug_options(self._h, C.byref(o)))
+        return o
+
+    def _sync_debug(self):
+        if self._debug_seen == _debug_version:
+            return
+        o = S.DebugOptions()
+        lib().prosper_pt_debug_options_default(C.byref(o))
+        for k, v in list(_debug_defaults.items()) + list(self._own_debug.items()):
+            setattr(o, k, v)
+        _check(lib().prosper_pt_set_debug_options(self._h, C.byref(o)))
+        self._debug_seen = _debug_version
 
     def close(self):
         if getattr(self, "_h", None) and self._owned:
@@ -182,6 +250,7 @@ class Context:
             pass
 
     def upload_scene(self, world):
+        self._sync_debug()
         view = world.view()
         _check(lib().prosper_pt_upload_scene(self._h, C.byref(view)))
         self._world = world
@@ -191,17 +260,23 @@ class Context:
         _check(lib().prosper_pt_update_lights(self._h, C.byref(world.directional), C.byref(world.point_lights),
                                               C.byref(world.spot_lights)))
 
-    def update_transforms(self, world, stream=None):
-        """New ModelInstanceTransforms of the uploaded scene from `world` (same scene, moved instances): a refit
-        enqueued on `stream`."""
+    def update_transforms(self, world, stream=None, now=None):
+        """New ModelInstanceTransforms of the uploaded scene from `world` (same scene, moved instances).  The table is
+        staged and the refit runs at the head of the next render's own chain of launches; with `now` (default: whenever a
+        stream is given) it is enqueued on `stream` by this call instead (PROSPER_PT_UPDATE_NOW; stream None / 0 = the
+        null stream)."""
+        self._sync_debug()
         world._frozen = None
         f = world.freeze()
         t = f["transforms"]
+        if now is None:
+            now = stream is not None
         _check(lib().prosper_pt_update_transforms_async(self._h, C.cast(t, C.c_void_p), len(world.model_instances),
-                                                         C.c_void_p(stream)))
+                                                         S.UPDATE_NOW if now else 0, C.c_void_p(stream)))
         self._world = world
 
     def rebuild_hierarchy(self):
+        self._sync_debug()
         _check(lib().prosper_pt_rebuild_hierarchy(self._h))
 
     def hierarchy_state(self):
@@ -217,6 +292,7 @@ class Context:
         return out
 
     def scene_stats(self):
+        self._sync_debug()
         st = S.SceneStats()
         _check(lib().prosper_pt_get_scene_stats(self._h, C.byref(st)))
         return st
@@ -225,6 +301,7 @@ class Context:
         _check(lib().prosper_pt_set_output_buffer(self._h, C.c_void_p(device_ptr), byte_size))
 
     def render(self, pc, camera, width, height, tile=None, frames=1, flags=0, stream=None):
+        self._sync_debug()
         _check(lib().prosper_pt_render_frames(self._h, C.byref(pc), C.byref(camera), width, height, _tile_ref(tile),
                                               frames, flags, C.c_void_p(stream)))
 
@@ -334,6 +411,12 @@ class Context:
 
     def gather_wait(self, stream=None):
         _check(lib().prosper_pt_gather_wait(self._h, C.c_void_p(stream)))
+
+    def comm_info(self, stream=None):
+        """The communicator's own view (ncclCommCount, rank, device) and the last gather's device time (waits for it)."""
+        info = S.CommInfo()
+        _check(lib().prosper_pt_comm_query(self._h, C.byref(info)))
+        return info
 
     def read_gathered(self, stream=None):
         """Root only: the gathered [height, width, 4] float32 image (synchronises)."""

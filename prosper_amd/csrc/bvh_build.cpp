@@ -72,16 +72,11 @@ struct TmpNode
 constexpr int kBins = 16;
 constexpr float kIntersectCost = 1.0f;
 
-// tuning knobs (PROSPER_PT_DEBUG_SAH_TC, PROSPER_PT_DEBUG_LEAF): experiments only
-float traversal_cost()
+// tuning knobs (BvhBuildOptions::sahTraversalCost, leafSize): experiments only
+float traversal_cost(const BvhBuildOptions &opt) { return opt.sahTraversalCost > 0.0f ? opt.sahTraversalCost : 1.0f; }
+uint32_t max_leaf(const BvhBuildOptions &opt)
 {
-    const char *v = std::getenv("PROSPER_PT_DEBUG_SAH_TC");
-    return v ? (float)std::atof(v) : 1.0f;
-}
-uint32_t max_leaf()
-{
-    const char *v = std::getenv("PROSPER_PT_DEBUG_LEAF");
-    const uint32_t n = v ? (uint32_t)std::atoi(v) : kMaxLeafTriangles;
+    const uint32_t n = opt.leafSize ? opt.leafSize : kMaxLeafTriangles;
     return std::min(std::max(n, 1u), 8u);
 }
 
@@ -92,19 +87,19 @@ uint32_t ceil_log2(uint64_t n)
     return l;
 }
 
-unsigned host_threads()
+unsigned host_threads(const BvhBuildOptions &opt)
 {
     unsigned threads = std::thread::hardware_concurrency();
     threads = std::max(1u, std::min(threads ? threads : 1u, 32u));
-    if (const char *forced = std::getenv("PROSPER_PT_DEBUG_BUILD_THREADS")) threads = (unsigned)std::max(1, std::atoi(forced));
+    if (opt.buildThreads) threads = opt.buildThreads;
     return threads;
 }
 
 // Runs job(0) .. job(n - 1) on the host's threads (the caller's included); rethrows the first exception.
 template <class Job>
-void run_parallel(size_t n, Job &&job)
+void run_parallel(const BvhBuildOptions &opt, size_t n, Job &&job)
 {
-    const unsigned threads = (unsigned)std::min<size_t>(host_threads(), n ? n : 1);
+    const unsigned threads = (unsigned)std::min<size_t>(host_threads(opt), n ? n : 1);
     std::atomic<size_t> next{0};
     std::exception_ptr failure;
     std::mutex failureLock;
@@ -132,9 +127,10 @@ void run_parallel(size_t n, Job &&job)
 struct Builder
 {
     std::vector<Prim> &prims;
+    const BvhBuildOptions &opt;
     std::vector<TmpNode> nodes;
-    const float kTraversalCost = traversal_cost();
-    uint32_t kMaxLeaf = max_leaf();
+    const float kTraversalCost = traversal_cost(opt);
+    uint32_t kMaxLeaf = max_leaf(opt);
     // build_parallel(): subranges of at most this many primitives are not split here but queued as jobs
     uint32_t deferBelow = 0;
     struct Deferred
@@ -144,13 +140,13 @@ struct Builder
     };
     std::vector<Deferred> deferred;
 
-    explicit Builder(std::vector<Prim> &p) : prims(p) {}
+    Builder(std::vector<Prim> &p, const BvhBuildOptions &o) : prims(p), opt(o) {}
 
     // The same tree as build(), with the subranges below the first few splits built on the host's threads: every
     // split only permutes its own slice of `prims`, so the slices of different jobs are disjoint.
     int32_t build_parallel(uint32_t first, uint32_t count, uint32_t depth)
     {
-        const unsigned threads = host_threads();
+        const unsigned threads = host_threads(opt);
         if (threads < 2 || count < 8192u) return build(first, count, depth);
         deferBelow = std::max(1024u, count / (4u * threads));
         const int32_t root = build(first, count, depth);
@@ -160,8 +156,8 @@ struct Builder
         std::sort(jobs.begin(), jobs.end(), [](const Deferred &a, const Deferred &b) { return a.count > b.count; });
         std::vector<std::vector<TmpNode>> built(jobs.size());
         std::vector<int32_t> roots(jobs.size());
-        run_parallel(jobs.size(), [&](size_t j) {
-            Builder local(prims);
+        run_parallel(opt, jobs.size(), [&](size_t j) {
+            Builder local(prims, opt);
             local.kMaxLeaf = kMaxLeaf;
             local.nodes.reserve((size_t)jobs[j].count * 2);
             roots[j] = local.build(jobs[j].first, jobs[j].count, jobs[j].depth);
@@ -302,13 +298,9 @@ struct Builder
     }
 };
 
-// PROSPER_PT_DEBUG_PAD (>= 1.6e-5) fattens the boxes (bvh_encode.hpp enc_padded): a different hierarchy for the tests
+// BvhBuildOptions::boxPad (>= 1.6e-5) fattens the boxes (bvh_encode.hpp enc_padded): a different hierarchy for the tests
 // that check that hits do not depend on it
-float pad_coefficient()
-{
-    const char *forced = std::getenv("PROSPER_PT_DEBUG_PAD");
-    return forced ? std::max(1.6e-5f, (float)std::atof(forced)) : 1.6e-5f;
-}
+float pad_coefficient(const BvhBuildOptions &opt) { return opt.boxPad > 0.0f ? std::max(1.6e-5f, opt.boxPad) : 1.6e-5f; }
 
 EncBox enc_box(const Aabb &b)
 {
@@ -329,10 +321,9 @@ EncBox enc_box(const Aabb &b)
 //                                 2   the first kTopNodes nodes breadth-first, the subtrees below them depth-first (default)
 // Measured (profiles/r02_scheduler_experiments.txt): wf_trace on C3 2562 / 2472 / 2480 us, no difference on C4 and
 // FlightHelmet - the traversal is not waiting for its nodes most of the time.
-void relayout_nodes(std::vector<BvhNode> &nodes)
+void relayout_nodes(std::vector<BvhNode> &nodes, const BvhBuildOptions &opt)
 {
-    int mode = 2;
-    if (const char *v = std::getenv("PROSPER_PT_DEBUG_NODE_ORDER")) mode = std::atoi(v);
+    const int mode = opt.nodeOrder >= 0 ? opt.nodeOrder : 2;
     if (mode == 0 || nodes.size() < 3) return;
     const size_t n = nodes.size();
     const size_t kTopNodes = 4096;
@@ -509,12 +500,12 @@ struct Emitter
 };
 
 // Emits the binary tree `tmp` rooted at `root` as 4-wide nodes + leaf-order permutation into `out`.
-void relayout_nodes(std::vector<BvhNode> &nodes);
-void emit_tree(const std::vector<TmpNode> &tmp, int32_t root, const std::vector<Prim> &prims, uint64_t count, BvhBuildResult &out)
+void emit_tree(
+    const std::vector<TmpNode> &tmp, int32_t root, const std::vector<Prim> &prims, uint64_t count, BvhBuildResult &out,
+    const BvhBuildOptions &opt)
 {
     const float slack = enc_slack(enc_box(tmp[(size_t)root].box));
-    const char *order = std::getenv("PROSPER_PT_DEBUG_CHILD_ORDER");
-    Emitter emitter{tmp, prims, out, slack, pad_coefficient(), !order || std::atoi(order) != 0, {}};
+    Emitter emitter{tmp, prims, out, slack, pad_coefficient(opt), opt.childOrder != 0, {}};
     emitter.plans.resize(tmp.size());
     emitter.plan(root);
     const Emitter::Plan &top = emitter.plans[(size_t)root];
@@ -525,17 +516,17 @@ void emit_tree(const std::vector<TmpNode> &tmp, int32_t root, const std::vector<
     out.nodes.assign(top.nodes, BvhNode());
     out.permutation.assign((size_t)count, 0u);
     std::vector<Emitter::Job> jobs;
-    const uint32_t chunk = std::max(256u, top.nodes / (8u * host_threads()));
-    emitter.emit(root, 0u, 0u, chunk, host_threads() > 1 ? &jobs : nullptr);
-    run_parallel(jobs.size(), [&](size_t j) { emitter.emit(jobs[j].t, jobs[j].self, jobs[j].triBase, 0u, nullptr); });
-    relayout_nodes(out.nodes);
+    const uint32_t chunk = std::max(256u, top.nodes / (8u * host_threads(opt)));
+    emitter.emit(root, 0u, 0u, chunk, host_threads(opt) > 1 ? &jobs : nullptr);
+    run_parallel(opt, jobs.size(), [&](size_t j) { emitter.emit(jobs[j].t, jobs[j].self, jobs[j].triBase, 0u, nullptr); });
+    relayout_nodes(out.nodes, opt);
 }
 
 } // namespace
 
-float bvh_pad_coefficient() { return pad_coefficient(); }
+float bvh_pad_coefficient(const BvhBuildOptions &opt) { return pad_coefficient(opt); }
 
-BvhBuildResult build_bvh(const WorldTriangle *triangles, uint64_t count)
+BvhBuildResult build_bvh(const WorldTriangle *triangles, uint64_t count, const BvhBuildOptions &opt)
 {
     BvhBuildResult out;
     // An unused child slot gets the box lo = hi = +inf: the slab tests (pt_device.hpp,
@@ -572,10 +563,10 @@ BvhBuildResult build_bvh(const WorldTriangle *triangles, uint64_t count)
         return out;
     }
 
-    Builder builder(prims);
+    Builder builder(prims, opt);
     builder.nodes.reserve((size_t)count * 2);
     const int32_t rootTmp = builder.build_parallel(0, (uint32_t)count, 0);
-    emit_tree(builder.nodes, rootTmp, prims, count, out);
+    emit_tree(builder.nodes, rootTmp, prims, count, out, opt);
     return out;
 }
 
@@ -592,6 +583,7 @@ struct InstancedBvh::Impl
     };
     std::vector<Subtree> subtrees;
     uint64_t count = 0;
+    BvhBuildOptions opt; // of the build / rebuild in progress
 
     void fill_prims(const WorldTriangle *triangles, const Range &r)
     {
@@ -616,7 +608,7 @@ struct InstancedBvh::Impl
         st.root = -1;
         if (r.count == 0) return;
         fill_prims(triangles, r);
-        Builder b(prims);
+        Builder b(prims, opt);
         b.nodes.reserve((size_t)r.count * 2);
         st.root = b.build(r.first, r.count, depth0);
         st.nodes.swap(b.nodes);
@@ -631,7 +623,7 @@ struct InstancedBvh::Impl
             if (which.empty() || which[i]) todo.push_back(i);
         // largest first, so that the last thread to finish holds a small one
         std::sort(todo.begin(), todo.end(), [&](size_t a, size_t b) { return instances[a].count > instances[b].count; });
-        run_parallel(todo.size(), [&](size_t j) { build_subtree(triangles, todo[j], depth0); });
+        run_parallel(opt, todo.size(), [&](size_t j) { build_subtree(triangles, todo[j], depth0); });
     }
 
     // Top level over the instances, spliced with their subtrees into one binary tree, emitted as 4-wide nodes.
@@ -647,7 +639,7 @@ struct InstancedBvh::Impl
     BvhBuildResult assemble()
     {
         BvhBuildResult out;
-        const bool timing = std::getenv("PROSPER_PT_DEBUG_BUILD_TIMING") != nullptr;
+        const bool timing = opt.buildTiming != 0;
         auto tick = std::chrono::steady_clock::now();
         auto lap = [&](const char *what) {
             const auto now = std::chrono::steady_clock::now();
@@ -681,10 +673,10 @@ struct InstancedBvh::Impl
             }
             heap.push_back(Entry{merged[(size_t)(shift + st.root)].box.half_area(), shift + st.root});
         }
-        if (heap.empty()) return build_bvh(nullptr, 0);
+        if (heap.empty()) return build_bvh(nullptr, 0, opt);
         lap("merge");
         size_t target = std::min(std::max(kMinTopEntries, (size_t)(count / kTrianglesPerTopEntry)), kMaxTopEntries);
-        if (const char *forced = std::getenv("PROSPER_PT_DEBUG_TOP_ENTRIES")) target = (size_t)std::max(1, std::atoi(forced));
+        if (opt.topEntries) target = (size_t)opt.topEntries;
         std::make_heap(heap.begin(), heap.end());
         std::vector<int32_t> entries; // subtree nodes that become top-level leaves
         while (!heap.empty() && heap.size() + entries.size() < target)
@@ -713,7 +705,7 @@ struct InstancedBvh::Impl
             for (int k = 0; k < 3; ++k) top[i].centroid[k] = 0.5f * (top[i].box.lo[k] + top[i].box.hi[k]);
             top[i].index = (uint32_t)i;
         }
-        Builder tb(top);
+        Builder tb(top, opt);
         tb.kMaxLeaf = 1; // a top-level leaf is exactly one entry
         const int32_t topRoot = tb.build_parallel(0, (uint32_t)top.size(), 0);
         lap("top level");
@@ -737,7 +729,7 @@ struct InstancedBvh::Impl
             }
         }
         lap("splice");
-        emit_tree(merged, root, prims, count, out);
+        emit_tree(merged, root, prims, count, out, opt);
         lap("emit");
         return out;
     }
@@ -747,8 +739,10 @@ InstancedBvh::InstancedBvh() : m(new Impl()) {}
 InstancedBvh::~InstancedBvh() { delete m; }
 size_t InstancedBvh::instanceCount() const { return m->instances.size(); }
 
-BvhBuildResult InstancedBvh::build(const WorldTriangle *triangles, uint64_t count, const std::vector<Range> &instances)
+BvhBuildResult InstancedBvh::build(
+    const WorldTriangle *triangles, uint64_t count, const std::vector<Range> &instances, const BvhBuildOptions &opt)
 {
+    m->opt = opt;
     if (count >= (1ull << 28)) throw std::runtime_error("too many triangles for the leaf reference encoding");
     uint64_t covered = 0;
     for (const Range &r : instances)
@@ -765,8 +759,9 @@ BvhBuildResult InstancedBvh::build(const WorldTriangle *triangles, uint64_t coun
     return m->assemble();
 }
 
-BvhBuildResult InstancedBvh::rebuild(const WorldTriangle *triangles, const std::vector<uint8_t> &changed)
+BvhBuildResult InstancedBvh::rebuild(const WorldTriangle *triangles, const std::vector<uint8_t> &changed, const BvhBuildOptions &opt)
 {
+    m->opt = opt;
     if (changed.size() != m->instances.size()) throw std::runtime_error("InstancedBvh::rebuild: one flag per instance");
     m->build_subtrees(triangles, changed);
     return m->assemble();

@@ -21,12 +21,26 @@ struct BvhBuildResult
     uint32_t maxDepth = 0;             // inner nodes on the longest root-to-leaf path
 };
 
-// box padding coefficient of the emitter (1.6e-5, or PROSPER_PT_DEBUG_PAD): the device refit pads with the same value
-float bvh_pad_coefficient();
+// Tuning and test knobs of the builder (prosper_pt_debug_options carries them; zero / negative = the default).  None of
+// them changes a pixel: hits do not depend on the hierarchy (DESIGN.md "hit contract").
+struct BvhBuildOptions
+{
+    float sahTraversalCost = 0.0f; // SAH cost of a node visit relative to a triangle test (default 1)
+    float boxPad = 0.0f;           // box padding coefficient (default and minimum 1.6e-5)
+    uint32_t leafSize = 0;         // most triangles per leaf, 1..8 (default kMaxLeafTriangles)
+    uint32_t buildThreads = 0;     // host threads (default: hardware concurrency, at most 32)
+    uint32_t topEntries = 0;       // entries of the re-braided top level (default: one per four triangles, 1 k .. 64 k)
+    int32_t nodeOrder = -1;        // 0 depth-first as emitted, 1 breadth-first, 2 first 4096 breadth-first (default)
+    int32_t childOrder = -1;       // 0: children in build order instead of smallest box first
+    uint32_t buildTiming = 0;      // stage times of the assembly to stderr
+};
+
+// box padding coefficient of the emitter (1.6e-5, or BvhBuildOptions::boxPad): the device refit pads with the same value
+float bvh_pad_coefficient(const BvhBuildOptions &opt);
 
 // `triangles` are the GPU-flattened world-space triangles in (drawInstance, primitive) order.
 // Throws std::runtime_error if the depth bound of the LDS traversal stack cannot be met.
-BvhBuildResult build_bvh(const WorldTriangle *triangles, uint64_t count);
+BvhBuildResult build_bvh(const WorldTriangle *triangles, uint64_t count, const BvhBuildOptions &opt = BvhBuildOptions());
 
 // The same hierarchy built the way prosper builds its acceleration structures (src/scene/World.cpp:585-802: one BLAS
 // per mesh, a TLAS over the instances rebuilt every frame): one SAH subtree per model INSTANCE over that instance's
@@ -48,10 +62,13 @@ class InstancedBvh
     InstancedBvh(const InstancedBvh &) = delete;
     InstancedBvh &operator=(const InstancedBvh &) = delete;
     // Full build: every instance's subtree, the top level, the emitted nodes.
-    BvhBuildResult build(const WorldTriangle *triangles, uint64_t count, const std::vector<Range> &instances);
+    BvhBuildResult build(
+        const WorldTriangle *triangles, uint64_t count, const std::vector<Range> &instances,
+        const BvhBuildOptions &opt = BvhBuildOptions());
     // `triangles` again holds ALL world triangles; only the subtrees of the instances flagged in `changed`
     // (one flag per entry of the `instances` given to build) are rebuilt.
-    BvhBuildResult rebuild(const WorldTriangle *triangles, const std::vector<uint8_t> &changed);
+    BvhBuildResult rebuild(
+        const WorldTriangle *triangles, const std::vector<uint8_t> &changed, const BvhBuildOptions &opt = BvhBuildOptions());
     [[nodiscard]] size_t instanceCount() const;
 
   private:

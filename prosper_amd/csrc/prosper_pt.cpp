@@ -68,6 +68,33 @@ void device_free(prosper_pt_ctx *ctx, const void *p)
         }
 }
 
+// the context's debug options as the builder and the wavefront launcher take them
+BvhBuildOptions build_options(const prosper_pt_ctx *ctx)
+{
+    const prosper_pt_debug_options &d = ctx->debug;
+    BvhBuildOptions o;
+    o.sahTraversalCost = d.sahTraversalCost;
+    o.boxPad = d.boxPad;
+    o.leafSize = d.leafSize;
+    o.buildThreads = d.buildThreads;
+    o.topEntries = d.topEntries;
+    o.nodeOrder = d.nodeOrder;
+    o.childOrder = d.childOrder;
+    o.buildTiming = d.buildTiming;
+    return o;
+}
+WavefrontOptions wavefront_options(const prosper_pt_ctx *ctx)
+{
+    const prosper_pt_debug_options &d = ctx->debug;
+    WavefrontOptions o;
+    o.ldsStackEntries = d.ldsStackEntries;
+    o.noLdsScene = d.noLdsScene != 0;
+    o.noLdsTables = d.noLdsTables != 0;
+    o.poolVariant = d.poolVariant;
+    o.hipGraph = d.hipGraph != 0;
+    return o;
+}
+
 int upload(prosper_pt_ctx *ctx, const void *src, size_t bytes, void **out)
 {
     const int rc = device_alloc(ctx, bytes, out);
@@ -173,19 +200,40 @@ int validate_scene(const prosper_pt_scene_view *v)
     return PROSPER_PT_OK;
 }
 
-// The refit's GPU work on `stream`: exact bounds level by level, every node re-encoded, the tree's surface-area measure
-// into acc->dCost (read back through acc->hCost / costEvent).
-int enqueue_refit(prosper_pt_ctx *ctx, hipStream_t stream)
+// The refit's GPU work on `stream` for the node / triangle arrays of scene version `version`: exact bounds level by level,
+// every node re-encoded, the tree's surface-area measure into the version's cost slot (read back through hCost / costEvent).
+int enqueue_refit(prosper_pt_ctx *ctx, BvhNode *nodes, const WorldTriangle *tris, uint32_t version, hipStream_t stream)
 {
     AccelState *acc = ctx->accel;
-    PPT_HIP(hipMemsetAsync(acc->dCost, 0, sizeof(float), stream));
+    const uint32_t slot = version % AccelState::kCostSlots;
+    PPT_HIP(hipMemsetAsync(acc->dCost + slot, 0, sizeof(float), stream));
     launch_refit(
-        acc->dNodes, acc->dTris, acc->dNodeBounds, acc->dRefitOrder, acc->levelOffsets.data(),
-        (uint32_t)acc->levelOffsets.size() - 1u, acc->nodeCount, bvh_pad_coefficient(), acc->dCost, stream);
+        nodes, tris, acc->dNodeBounds, acc->dRefitOrder, acc->levelOffsets.data(), (uint32_t)acc->levelOffsets.size() - 1u,
+        acc->nodeCount, bvh_pad_coefficient(build_options(ctx)), acc->dCost + slot, stream);
     PPT_HIP(hipGetLastError());
-    PPT_HIP(hipMemcpyAsync(acc->hCost, acc->dCost, sizeof(float), hipMemcpyDeviceToHost, stream));
-    PPT_HIP(hipEventRecord(acc->costEvent, stream));
-    acc->costPending = true;
+    PPT_HIP(hipMemcpyAsync(acc->hCost + slot, acc->dCost + slot, sizeof(float), hipMemcpyDeviceToHost, stream));
+    PPT_HIP(hipEventRecord(acc->costEvent[slot], stream));
+    acc->costPending[slot] = true;
+    acc->costSequence[slot] = ++acc->refitSequence;
+    return PROSPER_PT_OK;
+}
+
+// Takes the newest measure that has arrived (wait: also waits for the newest refit's) into lastCostRatio.
+int poll_refit_cost(AccelState *acc, bool wait)
+{
+    for (uint32_t i = 0; i < AccelState::kCostSlots; ++i)
+    {
+        if (!acc->costPending[i]) continue;
+        const bool newest = acc->costSequence[i] == acc->refitSequence;
+        if (wait && newest) PPT_HIP(hipEventSynchronize(acc->costEvent[i]));
+        if (hipEventQuery(acc->costEvent[i]) != hipSuccess) continue;
+        acc->costPending[i] = false;
+        if (acc->costSequence[i] > acc->costRead)
+        {
+            acc->costRead = acc->costSequence[i];
+            if (acc->builtCost > 0.0f) acc->lastCostRatio = acc->hCost[i] / acc->builtCost;
+        }
+    }
     return PROSPER_PT_OK;
 }
 
@@ -270,10 +318,10 @@ int upload_hierarchy(prosper_pt_ctx *ctx, const BvhBuildResult &bvh)
         int rc;
         if ((rc = device_alloc(ctx, (size_t)(acc->total ? acc->total : 1) * sizeof(uint32_t), &d))) return rc;
         acc->dLeafPosition = static_cast<uint32_t *>(d);
-        if ((rc = device_alloc(ctx, sizeof(float), &d))) return rc;
+        if ((rc = device_alloc(ctx, sizeof(float) * AccelState::kCostSlots, &d))) return rc;
         acc->dCost = static_cast<float *>(d);
-        PPT_HIP(hipHostMalloc((void **)&acc->hCost, sizeof(float), hipHostMallocDefault));
-        PPT_HIP(hipEventCreateWithFlags(&acc->costEvent, hipEventDisableTiming));
+        PPT_HIP(hipHostMalloc((void **)&acc->hCost, sizeof(float) * AccelState::kCostSlots, hipHostMallocDefault));
+        for (hipEvent_t &e : acc->costEvent) PPT_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
         PPT_HIP(hipEventCreateWithFlags(&acc->sceneEvent, hipEventDisableTiming));
     }
     if (acc->total)
@@ -284,15 +332,23 @@ int upload_hierarchy(prosper_pt_ctx *ctx, const BvhBuildResult &bvh)
     }
     // one refit right away: the device encoder writes the bytes the emitter wrote (tested), and leaves the tree's
     // surface-area measure to compare later refits with
-    // (PROSPER_PT_DEBUG_NO_UPLOAD_REFIT keeps the emitter's own bytes, for the test that compares the two; the bounds array
+    // (debug option noUploadRefit keeps the emitter's own bytes, for the test that compares the two; the bounds array
     // and the measure are still computed)
-    const bool keepEmitted = std::getenv("PROSPER_PT_DEBUG_NO_UPLOAD_REFIT") != nullptr;
-    int rc = enqueue_refit(ctx, nullptr);
-    if (rc != PROSPER_PT_OK) return rc;
-    PPT_HIP(hipDeviceSynchronize());
-    if (keepEmitted) PPT_HIP(hipMemcpy(acc->dNodes, bvh.nodes.data(), nodeBytes, hipMemcpyHostToDevice));
-    acc->costPending = false;
-    acc->builtCost = *acc->hCost;
+    const bool keepEmitted = ctx->debug.noUploadRefit != 0;
+    for (bool &pending : acc->costPending) pending = false;
+    acc->builtCost = 0.0f;
+    if (acc->total)
+    {
+        // (an empty scene keeps the emitter's root - child boxes at +inf - as it is: the encoder has no bounds to write)
+        int rc = enqueue_refit(ctx, acc->dNodes, acc->dTris, acc->cur, nullptr);
+        if (rc != PROSPER_PT_OK) return rc;
+        PPT_HIP(hipDeviceSynchronize());
+        if (keepEmitted) PPT_HIP(hipMemcpy(acc->dNodes, bvh.nodes.data(), nodeBytes, hipMemcpyHostToDevice));
+        const uint32_t slot = acc->cur % AccelState::kCostSlots;
+        acc->costPending[slot] = false;
+        acc->builtCost = acc->hCost[slot];
+    }
+    acc->costRead = acc->refitSequence;
     acc->lastCostRatio = 1.0f;
     acc->movedSinceBuild.assign(acc->ranges.size(), 0);
     acc->flatStale = false;
@@ -397,26 +453,28 @@ int upload_scene_impl(prosper_pt_ctx *ctx, const prosper_pt_scene_view *v)
         std::string error;
     };
     // (a std::async future joins in its destructor: an early return below waits for the build, which reads `acc`)
-    std::future<BuildOutcome> buildJob = std::async(std::launch::async, [acc, total]() {
+    const BvhBuildOptions buildOpt = build_options(ctx);
+    const bool flatBvh = ctx->debug.flatBvh != 0;
+    std::future<BuildOutcome> buildJob = std::async(std::launch::async, [acc, total, buildOpt, flatBvh]() {
         BuildOutcome out;
         const auto tBuild = std::chrono::steady_clock::now();
         try
         {
-            // PROSPER_PT_DEBUG_FLAT_BVH=1: one SAH tree over all triangles, as round 1 built it (A/B, hierarchy tests)
-            if (std::getenv("PROSPER_PT_DEBUG_FLAT_BVH"))
-                out.bvh = build_bvh(acc->flat.data(), total);
+            // debug option flatBvh: one SAH tree over all triangles, as round 1 built it (A/B, hierarchy tests)
+            if (flatBvh)
+                out.bvh = build_bvh(acc->flat.data(), total, buildOpt);
             else
             {
                 try
                 {
-                    out.bvh = acc->bvh.build(acc->flat.data(), total, acc->ranges);
+                    out.bvh = acc->bvh.build(acc->flat.data(), total, acc->ranges, buildOpt);
                     out.instanced = true;
                 }
                 catch (const std::exception &)
                 {
                     // the subtrees are split without knowing how deep the re-braided top level above them gets: a
                     // spliced tree can pass the traversal's stack bound where one tree over everything does not
-                    out.bvh = build_bvh(acc->flat.data(), total);
+                    out.bvh = build_bvh(acc->flat.data(), total, buildOpt);
                 }
             }
         }
@@ -473,19 +531,19 @@ int upload_scene_impl(prosper_pt_ctx *ctx, const prosper_pt_scene_view *v)
         textures[i] = DeviceTexture{static_cast<const uint8_t *>(d), t.width, t.height, tilesX, 0u};
     }
     // beyond the 8 x 4 MB of L2 the texels of a hit come from the Infinity Cache or HBM: overlap their fetches
-    // (PROSPER_PT_DEBUG_BATCHED_TEXTURES = 0 / 1 forces either path: same pixels, tested)
+    // (debug option batchedTextures = 0 / 1 forces either path: same pixels, tested)
     s.batchedTextures = texelBytes > (32ull << 20) ? 1u : 0u;
-    if (const char *forced = std::getenv("PROSPER_PT_DEBUG_BATCHED_TEXTURES")) s.batchedTextures = std::atoi(forced) ? 1u : 0u;
+    if (ctx->debug.batchedTextures >= 0) s.batchedTextures = ctx->debug.batchedTextures ? 1u : 0u;
     // material texture packs (pt_scene.hpp MaterialPack): base / MR / normal interleaved per texel where a material's
-    // three textures share extent and sampler.  PROSPER_PT_DEBUG_NO_TEXTURE_PACKS=1 keeps every material unpacked.
+    // three textures share extent and sampler.  Debug option noTexturePacks keeps every material unpacked.
     std::vector<MaterialPack> packs(v->materialCount);
     uint32_t packedMaterials = 0;
-    const bool noPacks = std::getenv("PROSPER_PT_DEBUG_NO_TEXTURE_PACKS") != nullptr;
+    const bool noPacks = ctx->debug.noTexturePacks != 0;
     // compact packs where the texels outgrow the caches (the threshold of the batched loads above): on a small texture set
     // the bytes are not what the shade kernel waits for, and two kinds of pack in one wave cost a divergent branch
-    // (FlightHelmet fixture: +1 % on the step).  PROSPER_PT_DEBUG_WIDE_PACKS = 1 / 0 forces the 16-byte / the compact pack.
+    // (FlightHelmet fixture: +1 % on the step).  Debug option widePacks = 1 / 0 forces the 16-byte / the compact pack.
     bool widePacks = texelBytes <= (32ull << 20);
-    if (const char *forced = std::getenv("PROSPER_PT_DEBUG_WIDE_PACKS")) widePacks = std::atoi(forced) != 0;
+    if (ctx->debug.widePacks >= 0) widePacks = ctx->debug.widePacks != 0;
     for (uint32_t i = 0; i < v->materialCount; ++i)
     {
         packs[i] = MaterialPack{nullptr, 0u, 0u, 0u, 0u};
@@ -593,8 +651,8 @@ int upload_scene_impl(prosper_pt_ctx *ctx, const prosper_pt_scene_view *v)
     {
         if ((rc = device_alloc(ctx, sizeof(AlphaTriangle) * (size_t)(alphaTotal ? alphaTotal : 1), &d))) return rc;
         s.alphaTriangles = static_cast<const AlphaTriangle *>(d);
-        const bool noBounds = std::getenv("PROSPER_PT_DEBUG_NO_ALPHA_BOUNDS") != nullptr;
-        const char *cellEnv = std::getenv("PROSPER_PT_DEBUG_ALPHA_CELL");
+        const bool noBounds = ctx->debug.noAlphaBounds != 0;
+        const int32_t forcedCell = ctx->debug.alphaCellShift;
         std::vector<AlphaMaterial> alphaMaterials(v->materialCount ? v->materialCount : 1);
         uint64_t boundBytes = 0;
         for (uint32_t i = 0; i < v->materialCount; ++i)
@@ -619,7 +677,7 @@ int upload_scene_impl(prosper_pt_ctx *ctx, const prosper_pt_scene_view *v)
                 // the texels would have been read through); coarser for textures whose table would pass 2 MB
                 uint32_t shift = 1;
                 while (((uint64_t)(t.width >> shift) + 1u) * ((t.height >> shift) + 1u) * 2u > (2ull << 20)) ++shift;
-                if (cellEnv) shift = (uint32_t)std::min(15, std::max(0, std::atoi(cellEnv)));
+                if (forcedCell >= 0) shift = (uint32_t)std::min(15, forcedCell);
                 const bool factorOk = std::isfinite(m.baseColorFactor.w) && m.baseColorFactor.w >= 0.0f;
                 if (!noBounds && factorOk)
                 {
@@ -643,12 +701,11 @@ int upload_scene_impl(prosper_pt_ctx *ctx, const prosper_pt_scene_view *v)
     if ((rc = device_alloc(ctx, (size_t)(total ? total : 1) * 4, &d))) return rc;
     acc->dPerm = static_cast<uint32_t *>(d);
     // persistent (scene-lifetime) arrays the flatten kernel fills: shading records + their per-instance bases
-    // decoded 128-byte records; PROSPER_PT_DEBUG_RAW_RECORDS=1 keeps the raw 64-byte form instead, decoded per hit (same
+    // decoded 128-byte records; debug option rawRecords (an experiment) keeps the raw 64-byte form instead, decoded per hit (same
     // pixels, tested).  Measured and not made a default for any scene size (profiles/r03_raw_records.txt): even on
     // S-sponza-class, whose 33.6 MB of records outgrow the L2 and whose wf_shade runs at 6.7 TB/s, the ~150 instructions of
     // decoding cost more than the 64 bytes save (wf_shade 910 -> 931 us; C4 687 -> 721, C2 220 -> 248, FlightHelmet 97 -> 104)
-    bool rawRecords = false;
-    if (const char *forced = std::getenv("PROSPER_PT_DEBUG_RAW_RECORDS")) rawRecords = std::atoi(forced) != 0;
+    const bool rawRecords = ctx->debug.rawRecords != 0; // (refused by prosper_pt_set_debug_options unless built with -DPPT_EXPERIMENTS)
     void *dShade = nullptr, *dRaw = nullptr;
     if (rawRecords)
     {
@@ -726,11 +783,7 @@ int ensure_wavefront_workspace(
     // (round 3, small batches re-swept - profiles/r03_seglen_sweep.txt: a 1-spp frame of C2 0.326 -> 0.317 ms at 2560 instead of
     // 3700 segments, FlightHelmet 0.524 -> 0.499, a 1/8 rank share 0.330 -> 0.317, C3 1.826 -> 1.867: 3000)
     uint64_t target = pipelined ? 3000u : 11500u;
-    if (const char *forced = std::getenv("PROSPER_PT_DEBUG_SEGMENTS")) // tuning hook
-    {
-        const uint64_t v = (uint64_t)std::atoll(forced);
-        if (v >= 64u && v <= (1u << 20)) target = v;
-    }
+    if (ctx->debug.segments >= 64u && ctx->debug.segments <= (1u << 20)) target = ctx->debug.segments; // tuning hook
     uint64_t batches = (slots / target + 32u) / 64u;
     if (batches < 2u) batches = 2u; // small renders: 128-slot segments
     if (batches > 2u && batches % 2u == 0u) batches += 1u;
@@ -741,9 +794,8 @@ int ensure_wavefront_workspace(
     // FlightHelmet 2.04 -> 1.91 -> 1.87 ms, C4 27.9 -> 27.05 -> 27.15, C2 1.95 -> 1.96 -> 1.94, C3 12.93 -> 13.07 -> 13.14.
     if (batches > 49u) batches = 49u;
     uint64_t segLen = batches * 64u;
-    if (const char *forced = std::getenv("PROSPER_PT_DEBUG_SEGLEN")) // tuning/test hook
     {
-        const uint64_t v = (uint64_t)std::atoll(forced);
+        const uint64_t v = ctx->debug.segmentLength; // tuning / test hook
         if (v >= 64u && v <= 8192u && v % 64u == 0u) segLen = v;
     }
     uint64_t nSeg = (slots + segLen - 1u) / segLen;
@@ -858,12 +910,151 @@ uint32_t compute_local_width(uint32_t width, const prosper_pt_tile_desc *tile)
     return n;
 }
 
+// ---- debug options: validation, and the one opt-in reading of the environment (prosper_pt_create) ----
+
+int check_debug_options(const prosper_pt_debug_options &o)
+{
+#ifndef PPT_EXPERIMENTS
+    if (o.poolVariant || o.rawRecords || o.tileOrder || o.hipGraph || o.pipelinedChains || o.mergeLimit)
+        return fail(PROSPER_PT_ERR_UNSUPPORTED, "debug options: an experiment was requested, but the library was built without -DPPT_EXPERIMENTS");
+#endif
+    if (o.ldsStackEntries != 0u && o.ldsStackEntries != 16u && o.ldsStackEntries != 24u && o.ldsStackEntries != 32u)
+        return fail(PROSPER_PT_ERR_INVALID_ARGUMENT, "debug options: ldsStackEntries is 0, 16, 24 or 32");
+    if (o.segmentLength != 0u && (o.segmentLength < 64u || o.segmentLength > 8192u || o.segmentLength % 64u != 0u))
+        return fail(PROSPER_PT_ERR_INVALID_ARGUMENT, "debug options: segmentLength is a multiple of 64 in [64, 8192]");
+    if (o.chains > kMaxChains) return fail(PROSPER_PT_ERR_INVALID_ARGUMENT, "debug options: at most three launch chains");
+    if (o.leafSize > 8u || o.alphaCellShift > 15 || o.nodeOrder > 2 || o.poolVariant > 3u)
+        return fail(PROSPER_PT_ERR_INVALID_ARGUMENT, "debug options: a value is out of range");
+    if (!(o.sahTraversalCost >= 0.0f) || !(o.boxPad >= 0.0f) || !(o.rebuildCostRatio >= 0.0f))
+        return fail(PROSPER_PT_ERR_INVALID_ARGUMENT, "debug options: a coefficient is negative or NaN");
+    return PROSPER_PT_OK;
+}
+
+// name -> field, for the "name=value,name=value" form of the environment gate
+struct DebugField
+{
+    const char *name;
+    size_t offset;
+    char kind; // 'u' uint32, 'i' int32, 'f' float
+};
+#define PPT_FIELD(member, kind) {#member, offsetof(prosper_pt_debug_options, member), kind}
+const DebugField kDebugFields[] = {
+    PPT_FIELD(batchedTextures, 'i'), PPT_FIELD(widePacks, 'i'), PPT_FIELD(alphaCellShift, 'i'), PPT_FIELD(noTexturePacks, 'u'),
+    PPT_FIELD(noAlphaBounds, 'u'), PPT_FIELD(noUploadRefit, 'u'), PPT_FIELD(flatBvh, 'u'), PPT_FIELD(sahTraversalCost, 'f'),
+    PPT_FIELD(boxPad, 'f'), PPT_FIELD(leafSize, 'u'), PPT_FIELD(buildThreads, 'u'), PPT_FIELD(topEntries, 'u'),
+    PPT_FIELD(nodeOrder, 'i'), PPT_FIELD(childOrder, 'i'), PPT_FIELD(buildTiming, 'u'), PPT_FIELD(segments, 'u'),
+    PPT_FIELD(segmentLength, 'u'), PPT_FIELD(chains, 'u'), PPT_FIELD(ldsStackEntries, 'u'), PPT_FIELD(noLdsScene, 'u'),
+    PPT_FIELD(noLdsTables, 'u'), PPT_FIELD(traceDeadPaths, 'u'), PPT_FIELD(rebuildCostRatio, 'f'), PPT_FIELD(alwaysRebuild, 'u'),
+    PPT_FIELD(failNextUpdate, 'u'), PPT_FIELD(poolVariant, 'u'), PPT_FIELD(rawRecords, 'u'), PPT_FIELD(tileOrder, 'u'),
+    PPT_FIELD(hipGraph, 'u'), PPT_FIELD(pipelinedChains, 'u'), PPT_FIELD(mergeLimit, 'u'),
+};
+#undef PPT_FIELD
+
+bool parse_debug_options(const char *text, prosper_pt_debug_options *out, std::string *err)
+{
+    std::string rest = text ? text : "";
+    while (!rest.empty())
+    {
+        const size_t comma = rest.find(',');
+        const std::string item = rest.substr(0, comma);
+        rest = comma == std::string::npos ? std::string() : rest.substr(comma + 1);
+        if (item.empty()) continue;
+        const size_t eq = item.find('=');
+        const std::string name = item.substr(0, eq), value = eq == std::string::npos ? std::string("1") : item.substr(eq + 1);
+        const DebugField *field = nullptr;
+        for (const DebugField &f : kDebugFields)
+            if (name == f.name) field = &f;
+        if (!field)
+        {
+            *err = "debug options: unknown option '" + name + "'";
+            return false;
+        }
+        char *end = nullptr;
+        uint8_t *at = reinterpret_cast<uint8_t *>(out) + field->offset;
+        if (field->kind == 'f')
+        {
+            const float v = std::strtof(value.c_str(), &end);
+            std::memcpy(at, &v, sizeof(v));
+        }
+        else if (field->kind == 'i')
+        {
+            const int32_t v = (int32_t)std::strtol(value.c_str(), &end, 10);
+            std::memcpy(at, &v, sizeof(v));
+        }
+        else
+        {
+            const uint32_t v = (uint32_t)std::strtoul(value.c_str(), &end, 10);
+            std::memcpy(at, &v, sizeof(v));
+        }
+        if (end == value.c_str() || *end != '\0')
+        {
+            *err = "debug options: '" + value + "' is not a value for '" + name + "'";
+            return false;
+        }
+    }
+    return true;
+}
+
+bool debug_options_from_environment(prosper_pt_debug_options *out, std::string *err)
+{
+    const char *gate = std::getenv("PROSPER_PT_DEBUG");
+    if (!gate || std::strcmp(gate, "1") != 0) return true;
+    const char *text = std::getenv("PROSPER_PT_DEBUG_OPTIONS");
+    if (!text) return true;
+    if (!parse_debug_options(text, out, err)) return false;
+    if (check_debug_options(*out) != PROSPER_PT_OK)
+    {
+        *err = ppt::g_lastErrorStorage;
+        return false;
+    }
+    return true;
+}
+
 } // namespace
 
 extern "C" {
 
 const char *prosper_pt_last_error(void) { return ppt::g_lastErrorStorage.c_str(); }
 uint32_t prosper_pt_abi_version(void) { return PROSPER_PT_ABI_VERSION; }
+
+uint32_t prosper_pt_has_experiments(void)
+{
+#ifdef PPT_EXPERIMENTS
+    return 1u;
+#else
+    return 0u;
+#endif
+}
+
+void prosper_pt_debug_options_default(prosper_pt_debug_options *out)
+{
+    if (!out) return;
+    *out = prosper_pt_debug_options{};
+    out->struct_size = (uint32_t)sizeof(prosper_pt_debug_options);
+    out->batchedTextures = -1;
+    out->widePacks = -1;
+    out->alphaCellShift = -1;
+    out->nodeOrder = -1;
+    out->childOrder = -1;
+}
+
+int prosper_pt_set_debug_options(prosper_pt_ctx *ctx, const prosper_pt_debug_options *options)
+{
+    if (!ctx || !options) return fail(PROSPER_PT_ERR_INVALID_ARGUMENT, "prosper_pt_set_debug_options: null argument");
+    if (options->struct_size != sizeof(prosper_pt_debug_options))
+        return fail(PROSPER_PT_ERR_INVALID_ARGUMENT, "prosper_pt_set_debug_options: struct_size mismatch");
+    const int rc = check_debug_options(*options);
+    if (rc != PROSPER_PT_OK) return rc;
+    ctx->debug = *options;
+    return PROSPER_PT_OK;
+}
+
+int prosper_pt_get_debug_options(prosper_pt_ctx *ctx, prosper_pt_debug_options *out)
+{
+    if (!ctx || !out) return fail(PROSPER_PT_ERR_INVALID_ARGUMENT, "prosper_pt_get_debug_options: null argument");
+    *out = ctx->debug;
+    return PROSPER_PT_OK;
+}
 
 int prosper_pt_create(const prosper_pt_device_desc *desc, prosper_pt_ctx **out_ctx)
 {
@@ -880,10 +1071,24 @@ int prosper_pt_create(const prosper_pt_device_desc *desc, prosper_pt_ctx **out_c
     PPT_HIP(hipGetDeviceProperties(&prop, desc->device_ordinal));
     if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
         return fail(PROSPER_PT_ERR_NO_DEVICE, std::string("device is ") + prop.gcnArchName + ", this library carries gfx950 code only");
+#ifndef PPT_EXPERIMENTS
+    if (desc->flags & PROSPER_PT_CREATE_PERSISTENT)
+        return fail(PROSPER_PT_ERR_UNSUPPORTED, "the persistent pipeline is an experiment: build the library with -DPPT_EXPERIMENTS");
+#endif
     prosper_pt_ctx *ctx = new (std::nothrow) prosper_pt_ctx();
     if (!ctx) return fail(PROSPER_PT_ERR_INVALID_ARGUMENT, "out of host memory");
     ctx->device = desc->device_ordinal;
     ctx->flags = desc->flags;
+    prosper_pt_debug_options_default(&ctx->debug);
+    {
+        // the ONE place the library looks at the environment, and only when asked to (prosper_pt.h, debug options)
+        std::string err;
+        if (!debug_options_from_environment(&ctx->debug, &err))
+        {
+            delete ctx;
+            return fail(PROSPER_PT_ERR_INVALID_ARGUMENT, err);
+        }
+    }
     bool eventsOk = true;
     for (auto &e : ctx->events) eventsOk = eventsOk && hipEventCreate(&e) == hipSuccess;
     for (auto &ws : ctx->workStreams) eventsOk = eventsOk && hipStreamCreateWithFlags(&ws, hipStreamNonBlocking) == hipSuccess;
@@ -1059,8 +1264,13 @@ static int rebuild_hierarchy_impl(prosper_pt_ctx *ctx)
     const auto tBuild = std::chrono::steady_clock::now();
     try
     {
-        if (std::getenv("PROSPER_PT_DEBUG_FAIL_NEXT_UPDATE")) throw std::runtime_error("PROSPER_PT_DEBUG_FAIL_NEXT_UPDATE is set");
-        bvh = acc->instanced ? acc->bvh.rebuild(acc->flat.data(), acc->movedSinceBuild) : build_bvh(acc->flat.data(), acc->total);
+        if (ctx->debug.failNextUpdate)
+        {
+            ctx->debug.failNextUpdate = 0;
+            throw std::runtime_error("debug option failNextUpdate is set");
+        }
+        bvh = acc->instanced ? acc->bvh.rebuild(acc->flat.data(), acc->movedSinceBuild, build_options(ctx))
+                             : build_bvh(acc->flat.data(), acc->total, build_options(ctx));
     }
     catch (const std::exception &ex)
     {
@@ -1080,10 +1290,9 @@ static int rebuild_hierarchy_impl(prosper_pt_ctx *ctx)
     return PROSPER_PT_OK;
 }
 
-static float rebuild_cost_ratio()
+static float rebuild_cost_ratio(const prosper_pt_ctx *ctx)
 {
-    if (const char *v = std::getenv("PROSPER_PT_REBUILD_COST_RATIO")) return std::max(1.0f, (float)std::atof(v));
-    return 1.3f;
+    return ctx->debug.rebuildCostRatio > 0.0f ? std::max(1.0f, ctx->debug.rebuildCostRatio) : 1.3f;
 }
 
 // World::updateScene + the per-frame TLAS rebuild (World.cpp:359-466,749-802,878-928) as a REFIT: the new transforms, the
@@ -1123,8 +1332,9 @@ static int flush_pending_update(prosper_pt_ctx *ctx, hipStream_t stream)
         acc->nodesCurrent[v] = false;
     }
     if (!acc->versionFree[v]) PPT_HIP(hipEventCreateWithFlags(&acc->versionFree[v], hipEventDisableTiming));
-    // from here on the context is in between two scenes until the last step has been enqueued
-    acc->stale = true;
+    // Everything is enqueued for version v through LOCAL names; the context switches to v only after the last call has
+    // succeeded.  On a failure the previous version stays current and the update stays pending (the next consumer of the
+    // scene tries again); what was half-written into v is rewritten by that retry.
     // the version's last readers (three updates ago), and the previous update: it wrote the node array copied below,
     // and it shares the flat triangle array and the bounds scratch with this one
     if (acc->versionUsed[v]) PPT_HIP(hipStreamWaitEvent(stream, acc->versionFree[v], 0));
@@ -1138,27 +1348,29 @@ static int flush_pending_update(prosper_pt_ctx *ctx, hipStream_t stream)
     PPT_HIP(hipMemcpyAsync(acc->dTransformsV[v], acc->staging[k], sizeof(prosper_ModelInstanceTransforms) * acc->pendingCount, hipMemcpyHostToDevice, stream));
     PPT_HIP(hipEventRecord(acc->stagingDone[k], stream));
     acc->stagingUsed[k] = true;
-    // the new version becomes the scene
+    // world-space triangles again, in both orders (the shading and any-hit records hold object-space attributes and stay
+    // as they are), then the boxes.  (Also when only transforms of instances without geometry changed: a version must be
+    // whole.)
+    DeviceScene next = ctx->scene;
+    next.nodes = acc->dNodesV[v];
+    next.triangles = acc->dTrisV[v];
+    next.modelInstanceTransforms = acc->dTransformsV[v];
+    launch_flatten_triangles(
+        next, acc->dOffsets, acc->drawInstanceCount, acc->dFlags, acc->dFlat, nullptr, nullptr, (uint32_t)acc->total, stream,
+        acc->dLeafPosition, acc->dTrisV[v]);
+    PPT_HIP(hipGetLastError());
+    acc->flatStale = true; // (the flat array now holds the new pose whatever happens next)
+    if (acc->total && (rc = enqueue_refit(ctx, acc->dNodesV[v], acc->dTrisV[v], v, stream))) return rc;
+    PPT_HIP(hipEventRecord(acc->sceneEvent, stream));
+    // ---- commit: the new version becomes the scene ----
+    acc->sceneEventRecorded = true;
     acc->cur = v;
     acc->dNodes = acc->dNodesV[v];
     acc->dTris = acc->dTrisV[v];
     ctx->dTransforms = acc->dTransformsV[v];
-    ctx->scene.nodes = acc->dNodes;
-    ctx->scene.triangles = acc->dTris;
-    ctx->scene.modelInstanceTransforms = ctx->dTransforms;
-    // world-space triangles again, in both orders (the shading and any-hit records hold object-space attributes and stay
-    // as they are), then the boxes.  (Also when only transforms of instances without geometry changed: a version must be
-    // whole.)
-    launch_flatten_triangles(
-        ctx->scene, acc->dOffsets, acc->drawInstanceCount, acc->dFlags, acc->dFlat, nullptr, nullptr, (uint32_t)acc->total, stream,
-        acc->dLeafPosition, acc->dTris);
-    PPT_HIP(hipGetLastError());
-    acc->flatStale = true;
-    if ((rc = enqueue_refit(ctx, stream))) return rc;
+    ctx->scene = next;
     acc->refits++;
     ctx->sceneStamp++;
-    PPT_HIP(hipEventRecord(acc->sceneEvent, stream));
-    acc->sceneEventRecorded = true;
     acc->pending = false;
     acc->stale = false;
     return PROSPER_PT_OK;
@@ -1181,11 +1393,10 @@ static int stage_transforms(prosper_pt_ctx *ctx, const prosper_ModelInstanceTran
     }
     if (!any && std::memcmp(transforms, acc->transforms.data(), sizeof(prosper_ModelInstanceTransforms) * count) == 0) return PROSPER_PT_OK;
     PPT_HIP(hipSetDevice(ctx->device));
-    // the measure the previous refit left behind, if it has arrived
-    if (acc->costPending && hipEventQuery(acc->costEvent) == hipSuccess)
+    // the measure of the newest refit that has finished (the newest may still be queued behind frames in flight)
     {
-        acc->costPending = false;
-        if (acc->builtCost > 0.0f) acc->lastCostRatio = *acc->hCost / acc->builtCost;
+        const int prc = poll_refit_cost(acc, false);
+        if (prc != PROSPER_PT_OK) return prc;
     }
     // into pinned staging (a pageable source would make the later copy synchronous).  An update that was never consumed
     // is simply replaced: its staging buffer is reused.
@@ -1205,7 +1416,7 @@ static int stage_transforms(prosper_pt_ctx *ctx, const prosper_ModelInstanceTran
     acc->transforms.assign(transforms, transforms + count);
     ctx->stats.bvhBuildSeconds = 0.0;
     ctx->stats.buildSeconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-    if (any && (acc->lastCostRatio > rebuild_cost_ratio() || std::getenv("PROSPER_PT_DEBUG_ALWAYS_REBUILD")))
+    if (any && (acc->lastCostRatio > rebuild_cost_ratio(ctx) || ctx->debug.alwaysRebuild))
         return rebuild_hierarchy_impl(ctx);
     return PROSPER_PT_OK;
 }
@@ -1233,12 +1444,11 @@ int prosper_pt_update_transforms(prosper_pt_ctx *ctx, const prosper_ModelInstanc
 }
 
 int prosper_pt_update_transforms_async(
-    prosper_pt_ctx *ctx, const prosper_ModelInstanceTransforms *transforms, uint32_t count, void *stream)
+    prosper_pt_ctx *ctx, const prosper_ModelInstanceTransforms *transforms, uint32_t count, uint32_t flags, void *stream)
 {
-    // `stream`: where the refit runs when the caller wants it enqueued NOW (PROSPER_PT_UPDATE_NOW semantics of the header);
-    // a null stream argument defers it to the next render's own chain like prosper_pt_update_transforms
+    if (flags & ~(uint32_t)PROSPER_PT_UPDATE_NOW) return fail(PROSPER_PT_ERR_INVALID_ARGUMENT, "prosper_pt_update_transforms_async: unknown flag");
     const int rc = check_update_arguments(ctx, transforms, count);
-    return rc != PROSPER_PT_OK ? rc : update_transforms_impl(ctx, transforms, count, static_cast<hipStream_t>(stream), stream != nullptr);
+    return rc != PROSPER_PT_OK ? rc : update_transforms_impl(ctx, transforms, count, static_cast<hipStream_t>(stream), (flags & PROSPER_PT_UPDATE_NOW) != 0);
 }
 
 int prosper_pt_rebuild_hierarchy(prosper_pt_ctx *ctx)
@@ -1258,11 +1468,9 @@ int prosper_pt_get_hierarchy_state(prosper_pt_ctx *ctx, prosper_pt_hierarchy_sta
         const int frc = flush_pending_update(ctx, nullptr);
         if (frc != PROSPER_PT_OK) return frc;
     }
-    if (acc->costPending)
     {
-        PPT_HIP(hipEventSynchronize(acc->costEvent));
-        acc->costPending = false;
-        if (acc->builtCost > 0.0f) acc->lastCostRatio = *acc->hCost / acc->builtCost;
+        const int prc = poll_refit_cost(acc, true);
+        if (prc != PROSPER_PT_OK) return prc;
     }
     out->refits = acc->refits;
     out->rebuilds = acc->rebuilds;
@@ -1294,14 +1502,12 @@ int prosper_pt_get_scene_stats(prosper_pt_ctx *ctx, prosper_pt_scene_stats *out)
     if (!ctx || !out) return fail(PROSPER_PT_ERR_INVALID_ARGUMENT, "prosper_pt_get_scene_stats: null argument");
     if (!ctx->haveScene) return fail(PROSPER_PT_ERR_NO_SCENE, "no scene uploaded");
     *out = ctx->stats;
-    // the variants depend on tuning/test hooks read from the environment at launch time: report what a render
-    // started now would take
-    const uint32_t ldsEntries = wavefront_lds_stack_entries(ctx->stats.maxDepth);
+    // the variants depend on the context's debug options at launch time: report what a render started now would take
+    const WavefrontPlan plan = wavefront_plan(
+        ctx->stats.maxDepth, (uint32_t)ctx->stats.nodeCount, (uint32_t)ctx->stats.triangleCount, ctx->scene, wavefront_options(ctx));
+    const uint32_t ldsEntries = plan.ldsStackEntries;
     out->variantFlags =
-        (wavefront_scene_in_lds(ldsEntries, (uint32_t)ctx->stats.nodeCount, (uint32_t)ctx->stats.triangleCount)
-             ? PROSPER_PT_VARIANT_LDS_SCENE
-             : 0u) |
-        (wavefront_shade_tables_in_lds(ctx->scene) ? PROSPER_PT_VARIANT_LDS_TABLES : 0u) |
+        (plan.sceneInLds ? PROSPER_PT_VARIANT_LDS_SCENE : 0u) | (plan.tablesInLds ? PROSPER_PT_VARIANT_LDS_TABLES : 0u) |
         (ctx->scene.batchedTextures ? PROSPER_PT_VARIANT_BATCHED_TEXTURES : 0u) |
         (ctx->packedMaterials ? PROSPER_PT_VARIANT_TEXTURE_PACKS : 0u) | (ctx->rawRecords ? PROSPER_PT_VARIANT_RAW_RECORDS : 0u) |
         (ldsEntries << PROSPER_PT_VARIANT_STACK_SHIFT);
@@ -1416,14 +1622,10 @@ int prosper_pt_render_frames(
     p.stripeCount = tiled ? tile->stripeCount : 1;
     p.localWidth = localWidth;
     p.frameCount = frame_count;
-    {
-        const char *audit = std::getenv("PROSPER_PT_DEBUG_TRACE_DEAD_PATHS");
-        p.traceDeadPaths = (audit && std::atoi(audit) != 0) ? 1u : 0u;
-        // sparse segments (pt_wavefront.hip RayMap), an experiment that lost (profiles/r03_sparse_segments.txt):
-        // PROSPER_PT_DEBUG_MERGE_LIMIT = rays up to which a workgroup's four segments are traced by one wave; default never
-        const char *merge = std::getenv("PROSPER_PT_DEBUG_MERGE_LIMIT");
-        p.mergeLimit = merge ? (uint32_t)std::max(0, std::atoi(merge)) : 0u;
-    }
+    p.traceDeadPaths = ctx->debug.traceDeadPaths ? 1u : 0u;
+    // sparse segments (pt_wavefront.hip RayMap), an experiment that lost (profiles/r03_sparse_segments.txt): debug option
+    // mergeLimit = rays up to which a workgroup's four segments are traced by one wave; default never
+    p.mergeLimit = ctx->debug.mergeLimit;
 
     if (localWidth == 0) return PROSPER_PT_OK;
     const bool countWork = (render_flags & PROSPER_PT_RENDER_COUNT_WORK) != 0;
@@ -1457,6 +1659,7 @@ int prosper_pt_render_frames(
         launch_render_megakernel(ctx->scene, p, ctx->hdr, ctx->dCounters, ovf, countWork, s);
         release_slot(ctx->slots[0], s);
     }
+#ifdef PPT_EXPERIMENTS
     else if (ctx->flags & PROSPER_PT_CREATE_PERSISTENT)
     {
         int32_t *ovf = nullptr;
@@ -1467,6 +1670,7 @@ int prosper_pt_render_frames(
         launch_render_persistent(ctx->scene, p, ctx->hdr, ctx->dCounters, ctx->dWorkCounter, ovf, countWork, s);
         release_slot(ctx->slots[0], s);
     }
+#endif
     else
     {
         // wavefront: all frames of the batch are in flight together, in chunks that keep the
@@ -1490,19 +1694,18 @@ int prosper_pt_render_frames(
         WavefrontChains chains;
         LaunchTimer chainTimers[kMaxChains];
         chains.count = (pipelined || (ctx->flags & PROSPER_PT_CREATE_SINGLE_CHAIN)) ? 1u : 2u;
-        if (const char *forced = std::getenv("PROSPER_PT_DEBUG_CHAINS")) // tuning hook (in-order mode)
-            if (!pipelined && std::atoi(forced) >= 1 && std::atoi(forced) <= (int)kMaxChains) chains.count = (uint32_t)std::atoi(forced);
-        // experiment (profiles/r03_hip_graph.txt, "two chains per frame in flight"): PROSPER_PT_DEBUG_PIPELINED_CHAINS=2 splits a
+        if (!pipelined && ctx->debug.chains >= 1u && ctx->debug.chains <= kMaxChains) chains.count = ctx->debug.chains; // tuning hook (in-order mode)
+        // experiment (profiles/r03_hip_graph.txt, "two chains per frame in flight"): debug option pipelinedChains = 2 splits a
         // pipelined frame's segment groups over two chains, the second on a stream of its own
         bool twoDetached = false;
-        if (pipelined)
-            if (const char *forced = std::getenv("PROSPER_PT_DEBUG_PIPELINED_CHAINS"))
-                if (std::atoi(forced) == 2)
-                {
-                    if (!ctx->extraStreams[slotIndex]) PPT_HIP(hipStreamCreateWithFlags(&ctx->extraStreams[slotIndex], hipStreamNonBlocking));
-                    twoDetached = true;
-                    chains.count = 2u;
-                }
+#ifdef PPT_EXPERIMENTS
+        if (pipelined && ctx->debug.pipelinedChains == 2u)
+        {
+            if (!ctx->extraStreams[slotIndex]) PPT_HIP(hipStreamCreateWithFlags(&ctx->extraStreams[slotIndex], hipStreamNonBlocking));
+            twoDetached = true;
+            chains.count = 2u;
+        }
+#endif
         chains.detached = pipelined;
         chains.fork = ctx->chainFork;
         for (uint32_t i = 0; i < kMaxChains; ++i)
@@ -1526,15 +1729,16 @@ int prosper_pt_render_frames(
             pp.pc.frameIndex = (p.pc.frameIndex + f0) % PROSPER_RT_FRAME_PERIOD;
             if (f0 > 0) pp.pc.flags &= ~(uint32_t)PROSPER_PC_FLAG_SKIP_HISTORY;
             const WavefrontPlan plan = wavefront_plan(
-                ctx->stats.maxDepth, (uint32_t)ctx->stats.nodeCount, (uint32_t)ctx->stats.triangleCount);
+                ctx->stats.maxDepth, (uint32_t)ctx->stats.nodeCount, (uint32_t)ctx->stats.triangleCount, ctx->scene, wavefront_options(ctx));
             int32_t *ovf = nullptr;
             const int orc = ensure_scratch_dwords(ctx, slot, plan.scratchDwordsPerBlock, wavefront_grid_blocks(w), s, &ovf);
             if (orc != PROSPER_PT_OK) return orc;
-            // EXPERIMENT (PROSPER_PT_DEBUG_TILE_ORDER=1; measured slower, profiles/r03_tile_order.txt): the camera-ray batches
+            w.tileOrder = nullptr;
+#ifdef PPT_EXPERIMENTS
+            // EXPERIMENT (debug option tileOrder; measured slower, profiles/r03_tile_order.txt): the camera-ray batches
             // take the tiles by cost, heaviest first, so that every segment's stride through the sequence gets the same mix;
             // recomputed when the view or the geometry changed since this slot's last order
-            const bool tileOrderExperiment = std::getenv("PROSPER_PT_DEBUG_TILE_ORDER") != nullptr;
-            w.tileOrder = nullptr;
+            const bool tileOrderExperiment = ctx->debug.tileOrder != 0;
             if (frames >= 4u && tileOrderExperiment)
             {
                 const size_t tiles = (size_t)tilesX * tilesY;
@@ -1574,6 +1778,7 @@ int prosper_pt_render_frames(
                 }
                 w.tileOrder = slot.tileOrder;
             }
+#endif
             // the slot's previous user (a render of two calls ago, or the previous chunk of this one) must be done
             // with the workspace: detached chains wait for that on their own stream, the others on the caller's
             chains.after = slot.freeRecorded ? slot.free : nullptr;

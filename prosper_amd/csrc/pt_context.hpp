@@ -93,10 +93,16 @@ struct AccelState
     size_t refitCapacityNodes = 0;
     std::vector<uint32_t> levelOffsets; // [levels + 1] into dRefitOrder
     uint32_t nodeCount = 0;
-    float *dCost = nullptr;             // surface-area measure of the refitted tree (encode_nodes_kernel)
-    float *hCost = nullptr;             // pinned; valid once costEvent has passed
-    hipEvent_t costEvent = nullptr;
-    bool costPending = false;
+    // Surface-area measure of the refitted tree (encode_nodes_kernel), one slot per scene version: a refit writes the
+    // slot of the version it produces, so a measure can be read as soon as ITS refit has finished - in a pipelined loop
+    // that updates every frame the newest refit has only just been enqueued, but the one of two updates ago is done.
+    float *dCost = nullptr;             // [kCostSlots] device
+    float *hCost = nullptr;             // [kCostSlots] pinned; slot i valid once costEvent[i] has passed
+    static constexpr uint32_t kCostSlots = 3;
+    hipEvent_t costEvent[kCostSlots] = {};
+    bool costPending[kCostSlots] = {};
+    uint64_t costSequence[kCostSlots] = {}; // which refit (a running number) the slot's measure belongs to
+    uint64_t refitSequence = 0, costRead = 0; // refits enqueued so far / the newest one whose measure has been taken
     float builtCost = 0.0f;             // the same measure right after the last build
     float lastCostRatio = 1.0f;
     std::vector<uint8_t> movedSinceBuild; // per range: its subtree is out of date in `bvh` and `flat`
@@ -137,7 +143,8 @@ struct AccelState
             if (stagingDone[i]) (void)hipEventDestroy(stagingDone[i]);
         }
         if (hCost) (void)hipHostFree(hCost);
-        if (costEvent) (void)hipEventDestroy(costEvent);
+        for (hipEvent_t e : costEvent)
+            if (e) (void)hipEventDestroy(e);
         if (sceneEvent) (void)hipEventDestroy(sceneEvent);
         for (hipEvent_t e : versionFree)
             if (e) (void)hipEventDestroy(e);
@@ -161,6 +168,7 @@ struct prosper_pt_ctx
 {
     int device = 0;
     uint32_t flags = 0;
+    prosper_pt_debug_options debug = {}; // tuning / test options (prosper_pt_set_debug_options); never the environment
     std::vector<ppt::DeviceAllocation> sceneAllocations;
     uint64_t sceneBytes = 0;
     bool haveScene = false;
@@ -234,7 +242,7 @@ struct prosper_pt_ctx
     // share queues and serialise): a pipelined render's chain runs on workStreams[slot], the two chains of an
     // in-order render on workStreams[0] and [1].  All ordering between them goes through events.
     hipStream_t workStreams[kRenderSlots] = {};
-    // experiment (PROSPER_PT_DEBUG_PIPELINED_CHAINS=2): a second chain per frame in flight; created on first use
+    // experiment (debug option pipelinedChains = 2): a second chain per frame in flight; created on first use
     hipStream_t extraStreams[kRenderSlots] = {};
     RenderSlot slots[kRenderSlots];
     uint32_t lastSlot = 0;  // of the last render

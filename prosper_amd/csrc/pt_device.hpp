@@ -9,6 +9,13 @@ namespace ppt
 {
 
 #define PPT_D __device__ __forceinline__
+// 64-byte raw shading records (pt_scene.hpp RawShadeTriangle): an experiment that lost (profiles/r03_raw_records.txt),
+// compiled in only with -DPPT_EXPERIMENTS
+#ifdef PPT_EXPERIMENTS
+#define PPT_RAW_RECORDS(s) ((s).rawShadeTriangles != nullptr)
+#else
+#define PPT_RAW_RECORDS(s) false
+#endif
 
 constexpr uint32_t kMissIndex = 0xFFFFFFFFu; // rt/reference/main.rgen:47
 
@@ -1162,7 +1169,7 @@ PPT_D uint32_t any_hit_settle(
         cnt.anyHitCalls++;
         const uint32_t di = s.alphaTriangles[alphaIndex].drawInstance, prim = s.alphaTriangles[alphaIndex].primitive;
         const uint32_t record = s.triangleOffsets[di] + prim;
-        const uint32_t recordFlags = s.rawShadeTriangles ? s.rawShadeTriangles[record].flags : s.shadeTriangles[record].flags;
+        const uint32_t recordFlags = PPT_RAW_RECORDS(s) ? s.rawShadeTriangles[record].flags : s.shadeTriangles[record].flags;
         cnt.shortIndexHits += (recordFlags & kTriFlagShortIndices) ? 1u : 0u;
     }
     if (texelBits == 0ull) return alpha_verdict(fp.mode, 1.0f, fp.factorA, fp.cutoff, fp.u) ? kAlphaAccept : kAlphaReject;
@@ -1597,7 +1604,7 @@ PPT_D Surface evaluate_surface(const DeviceScene &s, f3 rayDir, const Hit &hit, 
     const uint32_t record = s.triangleOffsets[hit.drawInstance] + hit.primitive;
     Vertex v0, v1, v2;
     uint32_t recordFlags;
-    if (s.rawShadeTriangles != nullptr)
+    if (PPT_RAW_RECORDS(s))
     {
         const uint4 *rec = reinterpret_cast<const uint4 *>(s.rawShadeTriangles + record);
         const uint4 q0 = rec[0], q1 = rec[1], q2 = rec[2], q3 = rec[3];

@@ -68,6 +68,7 @@ __global__ void flatten_triangles_kernel(
     uint32_t uvBits[3];
     for (int c = 0; c < 3; ++c)
         uvBits[c] = m.texCoord0sOffset == PROSPER_PT_ABSENT ? 0u : geo_u32(s, m.bufferIndex)[m.texCoord0sOffset + vi[c]];
+#ifdef PPT_EXPERIMENTS
     if (rawOut != nullptr)
     {
         RawShadeTriangle raw;
@@ -89,6 +90,7 @@ __global__ void flatten_triangles_kernel(
                     (m.tangentsOffset == PROSPER_PT_ABSENT ? kRawNoTangents : 0u);
         rawOut[g] = raw;
     }
+#endif
     if (shadeOut != nullptr)
     {
         ShadeTriangle sh;
@@ -440,6 +442,7 @@ void launch_render_megakernel(
         hipLaunchKernelGGL(render_megakernel<false>, grid, block, 0, stream, s, p, hdr, counters, stackOverflow);
 }
 
+#ifdef PPT_EXPERIMENTS // (A/B pipeline, measured no faster than the megakernel: profiles/r01_*)
 // ------------------------------------------------------------------------------------------
 // Persistent waves with path regeneration.
 //
@@ -642,6 +645,8 @@ void launch_render_persistent(
     else
         hipLaunchKernelGGL(render_persistent<false>, grid, block, 0, stream, s, p, hdr, counters, workCounter, stackOverflow);
 }
+
+#endif // PPT_EXPERIMENTS
 
 // ------------------------------------------------------------------------------------------
 // RGBA32F -> RGBA16F

@@ -64,21 +64,27 @@ void launch_tone_map(
     const float4 *hdr, const uint32_t *lut, uint32_t dim, float exposure, float contrast, void *outRgba8, uint32_t count,
     hipStream_t stream);
 uint32_t megakernel_grid_blocks(const RenderParams &p);
+#ifdef PPT_EXPERIMENTS
 uint32_t persistent_grid_blocks();
+#endif
 uint32_t wavefront_grid_blocks(const WavefrontBuffers &w);
 // tiles ordered by the cost of a probe ray (heaviest first) into order[tilesX * tilesY]; `scratch` holds
 // tilesX * tilesY + 512 more uint32s; `stackOverflow` as for the render's traversal kernels (the probe's grid is smaller)
+#ifdef PPT_EXPERIMENTS
 void launch_tile_order(
     const DeviceScene &s, const RenderParams &p, uint32_t tilesX, uint32_t tilesY, uint32_t ldsStackEntries, int32_t *stackOverflow,
     uint32_t *order, uint32_t *scratch, hipStream_t stream);
+#endif
 // `stackOverflow`: global array of (stack bound - LDS entries) x (grid lanes) ints, or nullptr when the
 // BVH's stack bound fits the kernel's LDS stack
 void launch_render_megakernel(
     const DeviceScene &s, const RenderParams &p, float4 *hdr, unsigned long long *counters, int32_t *stackOverflow,
     bool countWork, hipStream_t stream);
+#ifdef PPT_EXPERIMENTS
 void launch_render_persistent(
     const DeviceScene &s, const RenderParams &p, float4 *hdr, unsigned long long *counters, uint32_t *workCounter,
     int32_t *stackOverflow, bool countWork, hipStream_t stream);
+#endif
 // The wavefront pipeline runs its segment groups as `count` independent chains of launches (generate,
 // shade/trace per bounce), chain i on streams[i] with its own launch timer, forked from and joined back
 // into the caller's stream around them; the accumulate kernel follows on the caller's stream.  With
@@ -103,21 +109,33 @@ struct WavefrontPlan
 {
     uint32_t ldsStackEntries;       // 16 / 24 / 32: LDS stack entries per lane of the lane-owned traversal kernels
     uint32_t overflowEntries;       // their stack entries per lane in global memory (stack bound - LDS entries)
+    bool sceneInLds;                // a scene of a few KB is traversed out of an LDS copy
+    bool tablesInLds;               // wf_shade stages the scene tables in LDS
+    bool hipGraph;                  // experiment: a detached chain's launches through a HIP graph
     uint32_t poolVariant;           // 0: wf_trace walks its rays lane-owned (trace_stream); else index + 1 of the ray-pool variant
     uint32_t poolOverflowEntries;   // stack entries per pool slot in global memory
     uint32_t scratchDwordsPerBlock; // ints of `scratch` per workgroup: the larger of the two kernels' needs
 };
-WavefrontPlan wavefront_plan(uint32_t stackBound, uint32_t nodeCount, uint32_t triCount);
+// what a context's debug options (prosper_pt_debug_options) say about the kernel variants; all zero = the defaults
+struct WavefrontOptions
+{
+    uint32_t ldsStackEntries = 0; // 16 / 24 / 32 forces the LDS stack size
+    bool noLdsScene = false, noLdsTables = false;
+    uint32_t poolVariant = 0;     // experiments (-DPPT_EXPERIMENTS): ray-pool wf_trace, HIP graph
+    bool hipGraph = false;
+};
+WavefrontPlan wavefront_plan(
+    uint32_t stackBound, uint32_t nodeCount, uint32_t triCount, const DeviceScene &s, const WavefrontOptions &opt);
 // `scratch`: plan.scratchDwordsPerBlock ints per workgroup of the launch grid (nullptr when that is 0)
 void launch_render_wavefront(
     const DeviceScene &s, const RenderParams &p, float4 *hdr, unsigned long long *counters, const WavefrontBuffers &w,
     const WavefrontPlan &plan, int32_t *scratch, uint32_t nodeCount, uint32_t triCount, bool countWork, LaunchTimer *timer,
     const WavefrontChains &chains, hipStream_t stream);
 // LDS stack entries (16/24/32) the wavefront traversal kernels use for a tree with this stack bound
-uint32_t wavefront_lds_stack_entries(uint32_t stackBound);
+uint32_t wavefront_lds_stack_entries(uint32_t stackBound, uint32_t forced);
 // kernel variants a render takes: wf_shade with the scene tables staged in LDS; traversal out of an LDS copy of the scene
-bool wavefront_shade_tables_in_lds(const DeviceScene &s);
-bool wavefront_scene_in_lds(uint32_t ldsStackEntries, uint32_t nodeCount, uint32_t triCount);
+bool wavefront_shade_tables_in_lds(const DeviceScene &s, bool disabled);
+bool wavefront_scene_in_lds(uint32_t ldsStackEntries, uint32_t nodeCount, uint32_t triCount, bool disabled);
 void launch_blit_rgba16f(const float4 *in, void *out, uint32_t count, hipStream_t stream);
 // Where each rank's tile sits in the gathered buffer (texel offsets) and how wide its rows are
 constexpr uint32_t kMaxRanks = 64;

@@ -29,6 +29,9 @@ struct Rccl
     decltype(&ncclSend) send = nullptr;
     decltype(&ncclRecv) recv = nullptr;
     decltype(&ncclGetErrorString) getErrorString = nullptr;
+    decltype(&ncclCommCount) commCount = nullptr;
+    decltype(&ncclCommUserRank) commUserRank = nullptr;
+    decltype(&ncclCommCuDevice) commCuDevice = nullptr;
     std::string error;
 };
 
@@ -62,6 +65,9 @@ Rccl &rccl()
         r.send = reinterpret_cast<decltype(r.send)>(sym("ncclSend"));
         r.recv = reinterpret_cast<decltype(r.recv)>(sym("ncclRecv"));
         r.getErrorString = reinterpret_cast<decltype(r.getErrorString)>(sym("ncclGetErrorString"));
+        r.commCount = reinterpret_cast<decltype(r.commCount)>(sym("ncclCommCount"));
+        r.commUserRank = reinterpret_cast<decltype(r.commUserRank)>(sym("ncclCommUserRank"));
+        r.commCuDevice = reinterpret_cast<decltype(r.commCuDevice)>(sym("ncclCommCuDevice"));
     });
     return r;
 }
@@ -90,6 +96,9 @@ struct TilingState
     hipEvent_t tileReady = nullptr;   // recorded on the caller's stream: the tile's accumulate kernel is done
     hipEvent_t gatherDone = nullptr;  // recorded on the comm stream behind gather (+ de-interleave on the root)
     bool gatherPending = false;
+    hipEvent_t gatherT0 = nullptr, gatherT1 = nullptr; // timing events around the last gather (+ de-interleave), on its stream
+    bool gatherTimed = false;
+    uint32_t gathers = 0;
     float4 *staging = nullptr; // root: the ranks' tiles back to back, rank order
     size_t stagingBytes = 0;
     float4 *ownedFull = nullptr; // root: the gathered image when the caller passes no destination
@@ -118,6 +127,8 @@ void destroy_tiling(prosper_pt_ctx *ctx)
     if (t->ownedFull) (void)hipFree(t->ownedFull);
     if (t->tileReady) (void)hipEventDestroy(t->tileReady);
     if (t->gatherDone) (void)hipEventDestroy(t->gatherDone);
+    if (t->gatherT0) (void)hipEventDestroy(t->gatherT0);
+    if (t->gatherT1) (void)hipEventDestroy(t->gatherT1);
     if (t->commStream) (void)hipStreamDestroy(t->commStream);
     delete t;
     ctx->tiling = nullptr;
@@ -146,10 +157,14 @@ int ensure_state(prosper_pt_ctx *ctx)
     hipError_t e = hipStreamCreateWithFlags(&t->commStream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&t->tileReady, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&t->gatherDone, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreate(&t->gatherT0);
+    if (e == hipSuccess) e = hipEventCreate(&t->gatherT1);
     if (e != hipSuccess)
     {
         if (t->tileReady) (void)hipEventDestroy(t->tileReady);
         if (t->gatherDone) (void)hipEventDestroy(t->gatherDone);
+        if (t->gatherT0) (void)hipEventDestroy(t->gatherT0);
+        if (t->gatherT1) (void)hipEventDestroy(t->gatherT1);
         if (t->commStream) (void)hipStreamDestroy(t->commStream);
         delete t;
         return fail(PROSPER_PT_ERR_HIP, std::string("multi-GPU state: ") + hipGetErrorString(e));
@@ -310,6 +325,7 @@ int prosper_pt_gather_tiles(
     rc = fill_layout(width, height, ctx->stripeWidth, ranks, &layout);
     if (rc != PROSPER_PT_OK) return rc;
     const size_t myCount = (size_t)ctx->localWidth * height * 4u; // floats
+    PPT_HIP(hipEventRecord(t->gatherT0, cs));
     if (ranks == 1 && !t->comm)
     {
         if (device_full_rgba32f != ctx->hdr)
@@ -354,10 +370,41 @@ int prosper_pt_gather_tiles(
             PPT_HIP(hipGetLastError());
         }
     }
+    PPT_HIP(hipEventRecord(t->gatherT1, cs));
+    t->gatherTimed = true;
+    t->gathers++;
     if (!inStream)
     {
         PPT_HIP(hipEventRecord(t->gatherDone, cs));
         t->gatherPending = true;
+    }
+    return PROSPER_PT_OK;
+}
+
+int prosper_pt_comm_query(prosper_pt_ctx *ctx, prosper_pt_comm_info *out)
+{
+    if (!ctx || !out) return fail(PROSPER_PT_ERR_INVALID_ARGUMENT, "prosper_pt_comm_query: null argument");
+    *out = prosper_pt_comm_info{1u, 0u, ctx->device, 0u, 0.0f, 0u};
+    TilingState *t = ctx->tiling;
+    if (!t) return PROSPER_PT_OK;
+    PPT_HIP(hipSetDevice(ctx->device));
+    if (t->comm)
+    {
+        int count = 0, rank = 0, device = 0;
+        PPT_NCCL(rccl().commCount(t->comm, &count));
+        PPT_NCCL(rccl().commUserRank(t->comm, &rank));
+        PPT_NCCL(rccl().commCuDevice(t->comm, &device));
+        out->ranks = (uint32_t)count;
+        out->rank = (uint32_t)rank;
+        out->device = device;
+    }
+    out->gathers = t->gathers;
+    if (t->gatherTimed)
+    {
+        PPT_HIP(hipEventSynchronize(t->gatherT1));
+        float ms = 0.0f;
+        PPT_HIP(hipEventElapsedTime(&ms, t->gatherT0, t->gatherT1));
+        out->lastGatherMs = ms;
     }
     return PROSPER_PT_OK;
 }

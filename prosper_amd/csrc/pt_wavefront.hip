@@ -21,11 +21,11 @@
 // (direct of bounce b, then sky of bounce b+1).
 #include "pt_kernels.hpp"
 
-#include <cstdlib>
-
 #include "pt_device.hpp"
 #include "pt_render_common.hpp"
+#ifdef PPT_EXPERIMENTS
 #include "pt_trace_pool.hpp"
+#endif
 #include "pt_trace_stream.hpp"
 
 // Register budgets (measured on C2/C3, profiles/r01_occupancy_ab.txt): the traversal kernels (generate,
@@ -154,7 +154,11 @@ __device__ __forceinline__ BatchLane batch_lane(const WavefrontBuffers &w, const
     }
     // 2^shift batches per tile, each a block of 64 >> shift pixels: 8x8, 8x4, 4x4, 4x2, 2x2, 2x1, 1x1
     const uint32_t rank = rem >> shift, part = rem & ((1u << shift) - 1u);
+#ifdef PPT_EXPERIMENTS
     const uint32_t tile = (w.tileOrder != nullptr && rank < tiles) ? w.tileOrder[rank] : rank; // (wave-uniform: a scalar load)
+#else
+    const uint32_t tile = rank;
+#endif
     const uint32_t wShift = (7u - shift) >> 1, hShift = (6u - shift) >> 1; // log2 of the block's width and height
     const uint32_t pixel = lane & ((64u >> shift) - 1u);
     const uint32_t bx = part & ((8u >> wShift) - 1u), by = part >> (3u - wShift);
@@ -215,6 +219,7 @@ struct LockstepTracer
         }
     }
 };
+#ifdef PPT_EXPERIMENTS
 template <uint32_t P, uint32_t S, uint32_t B>
 struct PoolTracer
 {
@@ -226,6 +231,7 @@ struct PoolTracer
         trace_pool<ANY, COUNT, B>(g, s, n, tMin, pool, cnt, fetch, commit);
     }
 };
+#endif
 
 // Copies the BVH nodes and world triangles into this workgroup's LDS.
 __device__ __forceinline__ LdsGeom stage_scene_in_lds(const DeviceScene &s, float4 *lds, uint32_t nodeCount, uint32_t triCount)
@@ -241,11 +247,12 @@ __device__ __forceinline__ LdsGeom stage_scene_in_lds(const DeviceScene &s, floa
 
 } // namespace
 
+#ifdef PPT_EXPERIMENTS
 // ------------------------------------------------------------------------------------------
 // tile order: which tiles are expensive?
 // ------------------------------------------------------------------------------------------
 //
-// EXPERIMENT (PROSPER_PT_DEBUG_TILE_ORDER=1), measured and NOT the default (profiles/r03_tile_order.txt).
+// EXPERIMENT (debug option tileOrder, -DPPT_EXPERIMENTS builds only), measured and NOT the default (profiles/r03_tile_order.txt).
 // A segment takes every nSeg-th batch of the render's batch sequence.  In raster order its share of expensive tiles
 // (FlightHelmet: a fifth of the tiles see the mesh and cost 15-20x a sky tile) varies from segment to segment like any
 // systematic sample of a patchy image - the slowest wave sets the launch's tail (cu_busy 0.78).  Sorted by cost, the
@@ -324,6 +331,8 @@ void launch_tile_order(
     hipLaunchKernelGGL(tile_order_scan_kernel, dim3(1), dim3(256), 0, stream, histogram, cursor);
     hipLaunchKernelGGL(tile_order_scatter_kernel, grid, block, 0, stream, bins, cursor, order, tiles);
 }
+
+#endif // PPT_EXPERIMENTS
 
 // ------------------------------------------------------------------------------------------
 // generate + first extend
@@ -445,7 +454,7 @@ __global__ __launch_bounds__(256, PPT_GEN_WPE) void wf_generate_extend(
 // extend: traceClosest of bounce >= 1
 // ------------------------------------------------------------------------------------------
 
-// Sparse segments - an EXPERIMENT (PROSPER_PT_DEBUG_MERGE_LIMIT, default off; profiles/r03_sparse_segments.txt).  A wave
+// Sparse segments - an EXPERIMENT (debug option mergeLimit, -DPPT_EXPERIMENTS builds only; profiles/r03_sparse_segments.txt).  A wave
 // owns a segment, and what survives a stage stays in it: on a sparse image (FlightHelmet: one camera ray in ten hits
 // anything) the later stages run waves whose streams hold a few dozen to a few hundred rays (52 % of wf_trace's node steps
 // ran with <= 8 lanes there).  The idea: when the four segments of a workgroup together hold few enough rays, ONE of its
@@ -745,6 +754,7 @@ __device__ __forceinline__ TraceWork trace_work(const RenderParams &p, const Wav
     t.nRays = doExtend ? w.segRays[id.seg] : 0u;
     t.shadowMap = t.rayMap = RayMap{~0u, ~0u, ~0u, w.segLen};
     t.merged = t.leader = false;
+#ifdef PPT_EXPERIMENTS
     if (p.mergeLimit == 0u) return t;
     const uint32_t limit = p.mergeLimit < w.segLen ? p.mergeLimit : w.segLen;
     const uint32_t seg0 = id.seg & ~3u;
@@ -777,6 +787,7 @@ __device__ __forceinline__ TraceWork trace_work(const RenderParams &p, const Wav
         t.nShadow = 0u;
         t.nRays = 0u;
     }
+#endif
     return t;
 }
 // the hit counts of the segments a wave answers for, after its extend work: its own; merged, the leader's hits are the
@@ -847,6 +858,7 @@ __global__ __launch_bounds__(256, PPT_TRACE_WPE(STACK)) void wf_trace(
     flush_counters<COUNT>(cnt, counters);
 }
 
+#ifdef PPT_EXPERIMENTS
 // wf_trace with the wave's rays in an LDS pool of P slots (pt_trace_pool.hpp) instead of one per lane.
 template <bool COUNT, uint32_t P, uint32_t S, uint32_t B, bool LDS_SCENE>
 __global__ __launch_bounds__(256, 3) void wf_trace_pool(
@@ -884,6 +896,8 @@ __global__ __launch_bounds__(256, 3) void wf_trace_pool(
     }
     flush_counters<COUNT>(cnt, counters);
 }
+
+#endif // PPT_EXPERIMENTS
 
 // ------------------------------------------------------------------------------------------
 // accumulate: main.rgen:285-298 over the frames of the batch, in order
@@ -931,7 +945,8 @@ __global__ __launch_bounds__(256) void wf_accumulate(
 // host-side sequencing
 // ------------------------------------------------------------------------------------------
 
-// ray-pool variants of wf_trace (PROSPER_PT_DEBUG_POOL = index): slots per wave, LDS stack entries per slot, batches per
+#ifdef PPT_EXPERIMENTS
+// ray-pool variants of wf_trace (debug option poolVariant = index): slots per wave, LDS stack entries per slot, batches per
 // step.  An experiment kept for its measurements (profiles/r02_pool_experiment.txt): fewer, fuller instructions, but slower.
 #define PPT_POOL_VARIANTS(X) X(1, 128, 8, 1) X(2, 96, 10, 1) X(3, 128, 8, 2)
 
@@ -955,6 +970,8 @@ static void launch_trace_pool(
         break;
     }
 }
+
+#endif // PPT_EXPERIMENTS
 
 template <bool COUNT, int STACK, bool LDS_SCENE>
 static void enqueue_wavefront(
@@ -982,7 +999,7 @@ static void enqueue_wavefront(
         const uint32_t cur = b & 1u;
         const uint32_t last = (b + 1u == bounces) ? 1u : 0u;
         mark(kStageShade);
-        const int ldsTables = !wavefront_shade_tables_in_lds(s) ? 0 : (shade_table_bytes(s, true) <= kLdsTableBytes ? 1 : 2);
+        const int ldsTables = !plan.tablesInLds ? 0 : (shade_table_bytes(s, true) <= kLdsTableBytes ? 1 : 2);
         auto shade = [&](auto kernel) { hipLaunchKernelGGL(kernel, grid, block, 0, stream, s, p, w, b, cur, last, cShade); };
         if (s.batchedTextures)
             ldsTables == 1 ? shade(wf_shade<COUNT, 1, true>) : (ldsTables == 2 ? shade(wf_shade<COUNT, 2, true>) : shade(wf_shade<COUNT, 0, true>));
@@ -991,11 +1008,13 @@ static void enqueue_wavefront(
         if (!debugDraw)
         {
             mark(kStageTrace);
+#ifdef PPT_EXPERIMENTS
             if (plan.poolVariant)
                 launch_trace_pool<COUNT, LDS_SCENE>(
                     plan.poolVariant, grid, block, stream, s, p, w, b, cur ^ 1u, last ? 0u : 1u, nodeCount, triCount,
                     stackOverflow, plan.poolOverflowEntries, cTrace);
             else
+#endif
                 hipLaunchKernelGGL(
                     (wf_trace<COUNT, STACK, LDS_SCENE>), grid, block, 0, stream, s, p, w, b, cur ^ 1u, last ? 0u : 1u,
                     nodeCount, triCount, stackOverflow, cTrace);
@@ -1009,15 +1028,11 @@ uint32_t wavefront_grid_blocks(const WavefrontBuffers &w)
     return ((groups + 7u) / 8u) * 8u + 8u * kMaxChains; // + the per-chain rounding of a split launch
 }
 
-uint32_t wavefront_lds_stack_entries(uint32_t stackBound)
+uint32_t wavefront_lds_stack_entries(uint32_t stackBound, uint32_t forced)
 {
-    // test/tuning hook: PROSPER_PT_DEBUG_STACK=16|24|32 forces a variant (deeper entries then live in
+    // test/tuning hook (debug option ldsStackEntries = 16 | 24 | 32): forces a variant (deeper entries then live in
     // the global overflow array, which is always safe, only slower)
-    if (const char *forced = std::getenv("PROSPER_PT_DEBUG_STACK"))
-    {
-        const uint32_t v = (uint32_t)std::atoi(forced);
-        if (v == 16u || v == 24u || v == 32u) return v;
-    }
+    if (forced == 16u || forced == 24u || forced == 32u) return forced;
     // Deeper trees keep 24 entries in LDS and spill the rest to the global overflow array: the 4-wide
     // tree rarely has more than ~2 entries per level in flight, and a 32-entry LDS stack (32 KB per
     // workgroup) costs more in occupancy than the rare overflow access does (C3: 4.41 vs 3.89 ms/launch).
@@ -1026,29 +1041,29 @@ uint32_t wavefront_lds_stack_entries(uint32_t stackBound)
 
 // Which kernel variants a render of this scene takes (also reported by prosper_pt_get_scene_stats, so that a
 // test of a variant can assert it is the one that ran).
-bool wavefront_shade_tables_in_lds(const DeviceScene &s)
+bool wavefront_shade_tables_in_lds(const DeviceScene &s, bool disabled)
 {
-    return shade_table_bytes(s, false) <= kLdsTableBytes && !std::getenv("PROSPER_PT_DEBUG_NO_LDS_TABLES");
+    return shade_table_bytes(s, false) <= kLdsTableBytes && !disabled;
 }
-bool wavefront_scene_in_lds(uint32_t ldsStackEntries, uint32_t nodeCount, uint32_t triCount)
+bool wavefront_scene_in_lds(uint32_t ldsStackEntries, uint32_t nodeCount, uint32_t triCount, bool disabled)
 {
-    return ldsStackEntries == 16u && nodeCount * kLdsNodeStride + triCount * 3u <= kLdsSceneFloat4s &&
-           !std::getenv("PROSPER_PT_DEBUG_NO_LDS_SCENE");
+    return ldsStackEntries == 16u && nodeCount * kLdsNodeStride + triCount * 3u <= kLdsSceneFloat4s && !disabled;
 }
 
 // The traversal kernels of a render and the global scratch they index: the lane-owned kernels keep `overflowEntries`
 // stack entries per lane there, a ray-pool wf_trace its slots' hit / candidate records and deeper stack entries.
-WavefrontPlan wavefront_plan(uint32_t stackBound, uint32_t nodeCount, uint32_t triCount)
+WavefrontPlan wavefront_plan(
+    uint32_t stackBound, uint32_t nodeCount, uint32_t triCount, const DeviceScene &s, const WavefrontOptions &opt)
 {
-    (void)nodeCount;
-    (void)triCount;
     WavefrontPlan plan = {};
-    plan.ldsStackEntries = wavefront_lds_stack_entries(stackBound);
+    plan.ldsStackEntries = wavefront_lds_stack_entries(stackBound, opt.ldsStackEntries);
     plan.overflowEntries = stackBound > plan.ldsStackEntries ? stackBound - plan.ldsStackEntries : 0u;
-    uint32_t variant = 0;
-    if (const char *forced = std::getenv("PROSPER_PT_DEBUG_POOL")) variant = (uint32_t)std::atoi(forced);
+    plan.sceneInLds = wavefront_scene_in_lds(plan.ldsStackEntries, nodeCount, triCount, opt.noLdsScene);
+    plan.tablesInLds = wavefront_shade_tables_in_lds(s, opt.noLdsTables);
     uint32_t poolDwords = 0;
-    switch (variant)
+#ifdef PPT_EXPERIMENTS
+    plan.hipGraph = opt.hipGraph;
+    switch (opt.poolVariant)
     {
 #define PPT_POOL_CASE(index, P, S, B)                                                                                  \
     case index:                                                                                                        \
@@ -1061,6 +1076,7 @@ WavefrontPlan wavefront_plan(uint32_t stackBound, uint32_t nodeCount, uint32_t t
     default:
         break;
     }
+#endif
     const uint32_t laneDwords = plan.overflowEntries * 256u;
     plan.scratchDwordsPerBlock = laneDwords > poolDwords ? laneDwords : poolDwords;
     return plan;
@@ -1073,8 +1089,7 @@ static void enqueue_for_stack(
     hipStream_t stream)
 {
     // a scene of a few KB is traversed out of LDS
-    const bool ldsScene = wavefront_scene_in_lds(plan.ldsStackEntries, nodeCount, triCount);
-    if (ldsScene)
+    if (plan.sceneInLds)
         enqueue_wavefront<COUNT, 16, true>(s, p, counters, w, plan, nodeCount, triCount, stackOverflow, timer, stream);
     else if (plan.ldsStackEntries == 16u)
         enqueue_wavefront<COUNT, 16, false>(s, p, counters, w, plan, nodeCount, triCount, stackOverflow, timer, stream);
@@ -1090,7 +1105,6 @@ void launch_render_wavefront(
     LaunchTimer *timer, const WavefrontChains &chains, hipStream_t stream)
 {
     if (w.nSeg == 0) return;
-    static const bool graphExperiment = std::getenv("PROSPER_PT_DEBUG_GRAPH") != nullptr;
     static_assert(kTraversalStackDepth == 32, "largest LDS stack variant");
     const uint32_t groups = (w.nSeg + 3u) / 4u;
     // Two chains only pay when each still fills the machine a few times over (>= 1024 workgroups each).
@@ -1118,33 +1132,60 @@ void launch_render_wavefront(
         int32_t *ovf = stackOverflow ? stackOverflow + (size_t)blocksBefore * plan.scratchDwordsPerBlock : nullptr;
         if (countWork)
             enqueue_for_stack<true>(s, p, counters, part, plan, ovf, nodeCount, triCount, ct, cs);
-        else if (graphExperiment && !ct)
+#ifdef PPT_EXPERIMENTS
+        else if (plan.hipGraph && !ct)
         {
-            // EXPERIMENT (PROSPER_PT_DEBUG_GRAPH=1, profiles/r03_hip_graph.txt): the chain's launches captured into a HIP
+            // EXPERIMENT (debug option hipGraph, profiles/r03_hip_graph.txt): the chain's launches captured into a HIP
             // graph and submitted as one; captured and instantiated anew every time (the kernel arguments change with
             // every frame), so only the DEVICE side of the comparison means anything
-            static thread_local hipGraphExec_t previous[8] = {};
+            struct Launched
+            {
+                hipGraphExec_t exec = nullptr;
+                hipEvent_t done = nullptr;
+            };
+            static thread_local Launched previous[8];
             static thread_local uint32_t turn = 0;
+            Launched &mine = previous[turn++ & 7u];
+            // an executable graph goes once ITS launch has finished: the event recorded behind it says so
+            if (mine.exec)
+            {
+                (void)hipEventSynchronize(mine.done);
+                (void)hipGraphExecDestroy(mine.exec);
+                mine.exec = nullptr;
+            }
+            if (!mine.done) (void)hipEventCreateWithFlags(&mine.done, hipEventDisableTiming);
             hipGraph_t graph = nullptr;
             hipGraphExec_t exec = nullptr;
             bool ok = hipStreamBeginCapture(cs, hipStreamCaptureModeRelaxed) == hipSuccess;
             if (ok)
             {
                 enqueue_for_stack<false>(s, p, counters, part, plan, ovf, nodeCount, triCount, nullptr, cs);
+                // (a failed EndCapture still ends the capture: the stream is usable again either way)
                 ok = hipStreamEndCapture(cs, &graph) == hipSuccess && graph != nullptr;
             }
             if (ok) ok = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) == hipSuccess;
             if (ok) ok = hipGraphLaunch(exec, cs) == hipSuccess;
             if (graph) (void)hipGraphDestroy(graph);
-            if (!ok)
+            if (ok)
             {
+                mine.exec = exec;
+                (void)hipEventRecord(mine.done, cs);
+            }
+            else
+            {
+                if (exec) (void)hipGraphExecDestroy(exec);
                 (void)hipGetLastError();
+                hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+                if (hipStreamIsCapturing(cs, &st) == hipSuccess && st != hipStreamCaptureStatusNone)
+                {
+                    hipGraph_t dropped = nullptr;
+                    (void)hipStreamEndCapture(cs, &dropped);
+                    if (dropped) (void)hipGraphDestroy(dropped);
+                }
                 enqueue_for_stack<false>(s, p, counters, part, plan, ovf, nodeCount, triCount, ct, cs);
             }
-            // an executable graph may go once its launch has finished: eight launches later it has
-            if (previous[turn & 7u]) (void)hipGraphExecDestroy(previous[turn & 7u]);
-            previous[turn++ & 7u] = ok ? exec : nullptr;
         }
+#endif
         else
             enqueue_for_stack<false>(s, p, counters, part, plan, ovf, nodeCount, triCount, ct, cs);
         blocksBefore += ((part.groupCount + 7u) / 8u) * 8u;

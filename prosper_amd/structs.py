@@ -276,7 +276,28 @@ class HierarchyState(C.Structure):
                 ("nodeCount", C.c_uint32), ("levels", C.c_uint32)]
 
 
+class DebugOptions(C.Structure):
+    """prosper_pt_debug_options (include/prosper_pt/prosper_pt.h): tuning / test options of a context."""
+
+    _fields_ = [("struct_size", C.c_uint32),
+                ("batchedTextures", C.c_int32), ("widePacks", C.c_int32), ("alphaCellShift", C.c_int32),
+                ("noTexturePacks", C.c_uint32), ("noAlphaBounds", C.c_uint32), ("noUploadRefit", C.c_uint32), ("flatBvh", C.c_uint32),
+                ("sahTraversalCost", C.c_float), ("boxPad", C.c_float), ("leafSize", C.c_uint32), ("buildThreads", C.c_uint32),
+                ("topEntries", C.c_uint32), ("nodeOrder", C.c_int32), ("childOrder", C.c_int32), ("buildTiming", C.c_uint32),
+                ("segments", C.c_uint32), ("segmentLength", C.c_uint32), ("chains", C.c_uint32), ("ldsStackEntries", C.c_uint32),
+                ("noLdsScene", C.c_uint32), ("noLdsTables", C.c_uint32), ("traceDeadPaths", C.c_uint32),
+                ("rebuildCostRatio", C.c_float), ("alwaysRebuild", C.c_uint32), ("failNextUpdate", C.c_uint32),
+                ("poolVariant", C.c_uint32), ("rawRecords", C.c_uint32), ("tileOrder", C.c_uint32), ("hipGraph", C.c_uint32),
+                ("pipelinedChains", C.c_uint32), ("mergeLimit", C.c_uint32)]
+
+
+class CommInfo(C.Structure):
+    _fields_ = [("ranks", C.c_uint32), ("rank", C.c_uint32), ("device", C.c_int32), ("gathers", C.c_uint32),
+                ("lastGatherMs", C.c_float), ("reserved", C.c_uint32)]
+
+
 GATHER_IN_STREAM = 1
+UPDATE_NOW = 1
 VARIANT_LDS_SCENE = 1
 VARIANT_LDS_TABLES = 2
 VARIANT_BATCHED_TEXTURES = 4

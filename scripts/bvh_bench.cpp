@@ -21,6 +21,8 @@ static float rnd()
 int main(int argc, char **argv)
 {
     const int instances = 43, side = argc > 1 ? atoi(argv[1]) : 55;
+    BvhBuildOptions opt;
+    if (argc > 2) opt.buildThreads = (uint32_t)atoi(argv[2]); // host threads of the builder (default: all)
     std::vector<WorldTriangle> tris;
     std::vector<InstancedBvh::Range> ranges;
     for (int i = 0; i < instances; ++i)
@@ -63,7 +65,7 @@ int main(int argc, char **argv)
     auto ms = [](auto a, auto b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
     InstancedBvh bvh;
     auto t0 = now();
-    BvhBuildResult res = bvh.build(tris.data(), tris.size(), ranges);
+    BvhBuildResult res = bvh.build(tris.data(), tris.size(), ranges, opt);
     auto t1 = now();
     auto digest = [](const BvhBuildResult &r) {
         unsigned long long h = 1469598103934665603ull;
@@ -84,12 +86,12 @@ int main(int argc, char **argv)
         for (uint32_t i = r.first; i < r.first + r.count; ++i)
             for (float *v : {tris[i].v0, tris[i].v1, tris[i].v2}) v[0] += 0.1f;
         t0 = now();
-        res = bvh.rebuild(tris.data(), changed);
+        res = bvh.rebuild(tris.data(), changed, opt);
         t1 = now();
         printf("rebuild after moving 1 instance: %.1f ms, %zu nodes, digest %016llx\n", ms(t0, t1), res.nodes.size(), digest(res));
     }
     t0 = now();
-    res = build_bvh(tris.data(), tris.size());
+    res = build_bvh(tris.data(), tris.size(), opt);
     t1 = now();
     printf("flat build: %.1f ms, %zu nodes, digest %016llx\n", ms(t0, t1), res.nodes.size(), digest(res));
     return 0;

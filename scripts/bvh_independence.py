@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Renders one configuration and prints a SHA-256 of the HDR image plus the schedule-independent counters.
 
-Run it under different hierarchies (PROSPER_PT_DEBUG_PAD=<coefficient >= 1.6e-5>, PROSPER_PT_DEBUG_STACK, ...):
+Run it under different hierarchies (PROSPER_PT_DEBUG=1 PROSPER_PT_DEBUG_OPTIONS="boxPad=<coefficient >= 1.6e-5>,ldsStackEntries=16,..."):
 the hit contract says the digest must not change.
 """
 import argparse
@@ -35,7 +35,7 @@ def main():
     c = ctx.counters()
     st = ctx.scene_stats()
     print("%s pad=%s nodes=%d sha256=%s closestHits=%d shadowRays=%d anyHitCalls=%d nodeVisits=%d triangleTests=%d" % (
-        args.config, os.environ.get("PROSPER_PT_DEBUG_PAD", "default"), st.nodeCount,
+        args.config, ("%g" % ctx.debug_options().boxPad) if ctx.debug_options().boxPad else "default", st.nodeCount,
         hashlib.sha256(img.tobytes()).hexdigest()[:16], c.closestHits, c.shadowRays, c.anyHitCalls, c.nodeVisits,
         c.triangleTests))
 

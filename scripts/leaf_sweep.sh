@@ -4,7 +4,8 @@
 mkdir -p gpurun_out
 out=gpurun_out/r03_leaf_sweep.txt
 : > $out
-for v in "" "PROSPER_PT_DEBUG_LEAF=2" "PROSPER_PT_DEBUG_LEAF=1" "PROSPER_PT_DEBUG_SAH_TC=0.5" "PROSPER_PT_DEBUG_SAH_TC=2" "PROSPER_PT_DEBUG_LEAF=2 PROSPER_PT_DEBUG_SAH_TC=0.5"; do
+# (the library reads PROSPER_PT_DEBUG_OPTIONS at prosper_pt_create only while PROSPER_PT_DEBUG=1: prosper_pt.h, debug options)
+for v in "" "leafSize=2" "leafSize=1" "sahTraversalCost=0.5" "sahTraversalCost=2" "leafSize=2,sahTraversalCost=0.5"; do
   echo "== ${v:-default}" >> $out
-  env $v python scripts/pipelined_bench.py c4 helmet c3 2>&1 | grep pipelined >> $out || exit 1
+  env PROSPER_PT_DEBUG=1 PROSPER_PT_DEBUG_OPTIONS="$v" python scripts/pipelined_bench.py c4 helmet c3 2>&1 | grep pipelined >> $out || exit 1
 done

@@ -13,4 +13,4 @@ for cfg in sys.argv[2:]:
     pmc_tools.run_pass(cfg, counters, d)
     for k, v in sorted(pmc_tools.summarise(d).items()):
         if "trace" in k:
-            print(cfg, "pool=%s" % os.environ.get("PROSPER_PT_DEBUG_POOL"), k, " ".join("%s=%.3e" % (c, v.get(c, 0.0)) for c in counters), "us=%.0f" % v["us_per_launch"], flush=True)
+            print(cfg, "options=%s" % os.environ.get("PROSPER_PT_DEBUG_OPTIONS"), k, " ".join("%s=%.3e" % (c, v.get(c, 0.0)) for c in counters), "us=%.0f" % v["us_per_launch"], flush=True)

@@ -47,7 +47,7 @@ def main():
             hip.hipDeviceSynchronize()
             hip.hipEventRecord(start, stream)
             t0 = time.perf_counter()
-            capi._check(capi.lib().prosper_pt_update_transforms_async(ctx._h, ctypes.cast(f["transforms"], ctypes.c_void_p), n, stream))
+            capi._check(capi.lib().prosper_pt_update_transforms_async(ctx._h, ctypes.cast(f["transforms"], ctypes.c_void_p), n, 1, stream))
             host.append((time.perf_counter() - t0) * 1e3)
             hip.hipEventRecord(stop, stream)
             hip.hipEventSynchronize(stop)

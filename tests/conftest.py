@@ -13,6 +13,24 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def _has_experiments():
+    from prosper_amd import capi
+    return os.path.exists(capi.LIB_PATH) and capi.has_experiments()
+
+
+# tests of the measured-slower variants: they exist only in libprosper_pt_experiments.so (make EXPERIMENTS=1; run the suite
+# with PROSPER_PT_LIB=prosper_amd/libprosper_pt_experiments.so)
+needs_experiments = pytest.mark.skipif(not _has_experiments(), reason="library built without -DPPT_EXPERIMENTS")
+
+
+@pytest.fixture(autouse=True)
+def _no_debug_options_leak():
+    """Process-wide debug options (capi.debug) never outlive the test that set them."""
+    yield
+    from prosper_amd import capi
+    capi.debug()
+
+
 @pytest.fixture(scope="session")
 def oracle():
     from oracle import binding

@@ -5,7 +5,7 @@ import numpy as np
 import pytest
 
 from conftest import default_pc, same_bits
-from prosper_amd import scenes, structs as S
+from prosper_amd import capi, scenes, structs as S
 
 
 def _camera(oracle, world, w, h):
@@ -39,7 +39,7 @@ def test_srgb_to_linear_is_monotone_over_every_input(gpu_ctx):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("cell", ["default", "0", "1", "2", "3", "5", "off"])
-def test_alpha_wall_bit_exact(gpu_ctx, oracle, monkeypatch, cell):
+def test_alpha_wall_bit_exact(gpu_ctx, oracle, cell):
     """Every wrap mode x filter x MASK / BLEND x factor x cutoff, odd texture sizes, UVs over several periods: three
     accumulated frames with shadows and bounces through the quads == the oracle, bit for bit, for every cell size of
     the bounds (1, 2, 4, 8, 32 texels) and without them."""
@@ -47,9 +47,9 @@ def test_alpha_wall_bit_exact(gpu_ctx, oracle, monkeypatch, cell):
     w, h = 400, 256
     cam, fl = _camera(oracle, world, w, h)
     if cell == "off":
-        monkeypatch.setenv("PROSPER_PT_DEBUG_NO_ALPHA_BOUNDS", "1")
+        capi.debug(noAlphaBounds=1)
     elif cell != "default":
-        monkeypatch.setenv("PROSPER_PT_DEBUG_ALPHA_CELL", cell)
+        capi.debug(alphaCellShift=int(cell))
     gpu_ctx.upload_scene(world)
     st = gpu_ctx.scene_stats()
     assert st.alphaTriangleCount == 80 and (st.alphaBoundBytes == 0) == (cell == "off")
@@ -81,7 +81,7 @@ def test_alpha_wall_bit_exact(gpu_ctx, oracle, monkeypatch, cell):
 
 
 @pytest.mark.gpu
-def test_foliage_candidates_settled_without_texels(gpu_ctx, oracle, monkeypatch):
+def test_foliage_candidates_settled_without_texels(gpu_ctx, oracle):
     """C4's foliage (leaf-shaped MASK and BLEND quads, 128^2 alpha textures): the bounds settle most candidates - fewer
     than 30 % still fetch texels - the any-hit count itself (a property of the rays, equal with and without the table)
     and the image do not change."""
@@ -92,7 +92,7 @@ def test_foliage_candidates_settled_without_texels(gpu_ctx, oracle, monkeypatch)
     images, counters = [], []
     for off in (False, True):
         if off:
-            monkeypatch.setenv("PROSPER_PT_DEBUG_NO_ALPHA_BOUNDS", "1")
+            capi.debug(noAlphaBounds=1)
         gpu_ctx.upload_scene(world)
         gpu_ctx.reset_counters()
         gpu_ctx.render(pc, cam, w, h, frames=2, flags=S.RENDER_COUNT_WORK)

@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol():
     assert len(syms) >= 30
     for name in syms:
         assert hasattr(lib, name), name
-    assert lib.prosper_pt_abi_version() == 3
+    assert lib.prosper_pt_abi_version() == 4
 
 
 def test_create_fails_loudly_without_gpu():
@@ -55,3 +55,41 @@ def test_product_does_not_reference_the_oracle():
             if f.endswith((".py", ".cpp", ".hpp", ".hip", ".h", "Makefile")):
                 text = open(os.path.join(dirpath, f), errors="ignore").read()
                 assert "oracle" not in text.replace("the oracle", "").replace("CPU oracle", ""), os.path.join(dirpath, f)
+
+
+def test_debug_options_struct_matches_the_binding():
+    """prosper_pt_debug_options <-> structs.DebugOptions: same size, and the defaults the header documents."""
+    o = S.DebugOptions()
+    capi.lib().prosper_pt_debug_options_default(C.byref(o))
+    assert o.struct_size == C.sizeof(S.DebugOptions)
+    assert (o.batchedTextures, o.widePacks, o.alphaCellShift, o.nodeOrder, o.childOrder) == (-1, -1, -1, -1, -1)
+    others = [n for n, _ in S.DebugOptions._fields_ if n not in ("struct_size", "batchedTextures", "widePacks", "alphaCellShift", "nodeOrder", "childOrder")]
+    assert all(getattr(o, n) == 0 for n in others)
+    # every field of the header's struct, in order
+    text = open(os.path.join(ROOT, "include", "prosper_pt", "prosper_pt.h")).read()
+    body = text[text.index("typedef struct prosper_pt_debug_options"):text.index("} prosper_pt_debug_options;")]
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    names = re.findall(r"\b(?:uint32_t|int32_t|float)\s+([A-Za-z_]+);", body)
+    assert names == [n for n, _ in S.DebugOptions._fields_]
+
+
+def test_the_library_does_not_read_the_environment_outside_create():
+    """A plugin in someone else's process: no ambient variable may change what it does.  The one opt-in gate
+    (PROSPER_PT_DEBUG=1 -> PROSPER_PT_DEBUG_OPTIONS, read by prosper_pt_create) is all the binary knows of."""
+    import subprocess
+    names = subprocess.run(["strings", capi.LIB_PATH], capture_output=True, text=True, check=True).stdout.splitlines()
+    hits = [n for n in names if "PROSPER_PT_DEBUG" in n or "PROSPER_PT_REBUILD" in n]
+    assert sorted(hits) == ["PROSPER_PT_DEBUG", "PROSPER_PT_DEBUG_OPTIONS"], hits
+    calls = {}
+    base = os.path.join(ROOT, "prosper_amd", "csrc")
+    for dirpath, _, files in os.walk(base):
+        for f in files:
+            if f.endswith((".cpp", ".hpp", ".hip")):
+                n = open(os.path.join(dirpath, f)).read().count("getenv(")
+                if n:
+                    calls[os.path.relpath(os.path.join(dirpath, f), base)] = n
+    assert calls == {"prosper_pt.cpp": 2}, calls
+    src = open(os.path.join(base, "prosper_pt.cpp")).read()
+    gate = src[src.index("bool debug_options_from_environment"):]
+    assert gate[:gate.index("\n}\n")].count("getenv(") == 2  # both inside the gate that only prosper_pt_create calls
+    assert src.count("debug_options_from_environment(") == 2  # its definition and that one call

@@ -7,8 +7,8 @@ import os
 import numpy as np
 import pytest
 
-from conftest import default_pc, same_bits
-from prosper_amd import scenes, structs as S
+from conftest import default_pc, needs_experiments, same_bits
+from prosper_amd import capi, scenes, structs as S
 
 pytestmark = pytest.mark.gpu
 
@@ -620,7 +620,7 @@ def test_c5_own_workload_rank_tile(gpu_ctx, oracle, sponza_full):
     assert same_bits(gpu_ctx.read_hdr(), a).all()
 
 
-def test_two_launch_chains_equal_one_chain(gpu_ctx, oracle, sponza_small, monkeypatch):
+def test_two_launch_chains_equal_one_chain(gpu_ctx, oracle, sponza_small):
     """The default pipeline runs the segment groups as two chains of launches on two internal streams
     (tails of one overlap the other); PROSPER_PT_CREATE_SINGLE_CHAIN runs one chain on the caller's stream.
     Same pixels, same counters - also when the traversal stacks spill to the (per-chain) global overflow
@@ -633,7 +633,7 @@ def test_two_launch_chains_equal_one_chain(gpu_ctx, oracle, sponza_small, monkey
     try:
         for forced in (None, "16"):
             if forced:
-                monkeypatch.setenv("PROSPER_PT_DEBUG_STACK", forced)
+                capi.debug(ldsStackEntries=int(forced))
             out = []
             for ctx in (gpu_ctx, single):
                 ctx.upload_scene(sponza_small)
@@ -648,11 +648,11 @@ def test_two_launch_chains_equal_one_chain(gpu_ctx, oracle, sponza_small, monkey
                 assert out[0][1][k] == out[1][1][k], (forced, k)
             assert out[0][2]["wf_trace"][1] == 2 * out[1][2]["wf_trace"][1]  # twice the launches, half the size
     finally:
-        monkeypatch.delenv("PROSPER_PT_DEBUG_STACK", raising=False)
+        capi.debug(ldsStackEntries=None)
         single.close()
 
 
-def test_pipelined_renders_equal_in_order_renders(gpu_ctx, oracle, sponza_small, monkeypatch):
+def test_pipelined_renders_equal_in_order_renders(gpu_ctx, oracle, sponza_small):
     """PROSPER_PT_RENDER_PIPELINED (up to three frames in flight: the path stages of a render overlap the previous
     renders, taking the context's three workspaces in turn): an accumulation sequence - every frame reads the previous frame's image
     as history - and a sequence of independent frames into alternating output buffers give the same bits as the
@@ -675,7 +675,7 @@ def test_pipelined_renders_equal_in_order_renders(gpu_ctx, oracle, sponza_small,
         return out
     for forced in (None, "16"):
         if forced:
-            monkeypatch.setenv("PROSPER_PT_DEBUG_STACK", forced)
+            capi.debug(ldsStackEntries=int(forced))
         results = []
         for flags in (0, S.RENDER_PIPELINED):
             gpu_ctx.set_kernel_timing(flags != 0)
@@ -698,7 +698,7 @@ def test_pipelined_renders_equal_in_order_renders(gpu_ctx, oracle, sponza_small,
         for a, b in zip(*results):
             assert same_bits(a, b).all(), forced
         assert (results[0][0][..., 3] == 9.0).all()  # 2+1+2+1+2+1 accumulated samples
-    monkeypatch.delenv("PROSPER_PT_DEBUG_STACK", raising=False)
+    capi.debug(ldsStackEntries=None)
     for ptr in bufs:
         hip.hipFree(ptr)
     # and the last pipelined frame equals the oracle's
@@ -729,9 +729,10 @@ def test_gltf_scene_bit_exact(gpu_ctx, oracle, draw_type):
     assert ok.all(), "%s: %d of %d pixels differ" % (draw_type, (~ok).sum(), ok.size)
 
 
-def test_raw_shading_records_equal_decoded_ones(gpu_ctx, oracle, sponza_small, monkeypatch):
+@needs_experiments
+def test_raw_shading_records_equal_decoded_ones(gpu_ctx, oracle, sponza_small):
     """Big scenes keep a triangle's three corners as the vertex streams hold them (64 B, RawShadeTriangle) and decode them
-    per hit; small ones keep the decoded 128-byte record.  PROSPER_PT_DEBUG_RAW_RECORDS forces either: the same bits, on
+    per hit; small ones keep the decoded 128-byte record.  debug option rawRecords forces either: the same bits, on
     scenes with normal maps and instancing, on meshes without tangents or normals (a hand-made one), through every
     pipeline and the counting kernels - and the oracle's."""
     import os
@@ -751,7 +752,7 @@ def test_raw_shading_records_equal_decoded_ones(gpu_ctx, oracle, sponza_small, m
         cam, fl = _camera(oracle, world, w, h)
         images = {}
         for raw in ("0", "1"):
-            monkeypatch.setenv("PROSPER_PT_DEBUG_RAW_RECORDS", raw)
+            capi.debug(rawRecords=int(raw))
             gpu_ctx.upload_scene(world)
             assert bool(gpu_ctx.scene_stats().variantFlags & S.VARIANT_RAW_RECORDS) == (raw == "1")
             out = []
@@ -760,7 +761,7 @@ def test_raw_shading_records_equal_decoded_ones(gpu_ctx, oracle, sponza_small, m
                 gpu_ctx.render(pc, cam, w, h, frames=2, flags=S.RENDER_COUNT_WORK if name == "Default" else 0)
                 out.append(gpu_ctx.read_hdr())
             images[raw] = out
-        monkeypatch.delenv("PROSPER_PT_DEBUG_RAW_RECORDS")
+        capi.debug(rawRecords=None)
         for a, b in zip(images["0"], images["1"]):
             assert same_bits(a, b).all()
         osc = oracle.OracleScene(world, brute_force=brute)
@@ -771,8 +772,9 @@ def test_raw_shading_records_equal_decoded_ones(gpu_ctx, oracle, sponza_small, m
         assert same_bits(images["1"][0], want).all()
 
 
-def test_tiles_dealt_by_cost_give_the_same_pixels(gpu_ctx, oracle, monkeypatch):
-    """PROSPER_PT_DEBUG_TILE_ORDER=1 (an experiment, profiles/r03_tile_order.txt): the camera-ray batches take the tiles by
+@needs_experiments
+def test_tiles_dealt_by_cost_give_the_same_pixels(gpu_ctx, oracle):
+    """debug option tileOrder (an experiment, profiles/r03_tile_order.txt): the camera-ray batches take the tiles by
     the cost of a probe ray instead of in raster order.  Which wave traces which tile never decides a pixel: the same
     bits on the FlightHelmet fixture (mostly sky) and on a rank's stripes of S-sponza-class, in order and with frames in
     flight, after the view changed and after an instance moved."""
@@ -787,7 +789,7 @@ def test_tiles_dealt_by_cost_give_the_same_pixels(gpu_ctx, oracle, monkeypatch):
         images = {}
         for on in (False, True):
             if on:
-                monkeypatch.setenv("PROSPER_PT_DEBUG_TILE_ORDER", "1")
+                capi.debug(tileOrder=1)
             gpu_ctx.upload_scene(world)
             out = []
             for flags in (0, S.RENDER_PIPELINED, S.RENDER_PIPELINED):
@@ -805,7 +807,7 @@ def test_tiles_dealt_by_cost_give_the_same_pixels(gpu_ctx, oracle, monkeypatch):
                 gpu_ctx.render(pc, cam, w, h, tile=tile, frames=8, flags=S.RENDER_PIPELINED)
                 out.append(gpu_ctx.read_hdr())
             images[on] = out
-        monkeypatch.delenv("PROSPER_PT_DEBUG_TILE_ORDER")
+        capi.debug(tileOrder=None)
         assert same_bits(images[False][0], images[False][1]).all()
         for a, b in zip(images[False], images[True]):
             assert same_bits(a, b).all()
@@ -817,7 +819,13 @@ def test_all_pipelines_produce_identical_pixels(gpu_ctx, oracle, cornell_world):
     from prosper_amd import capi
     w, h = 200, 120  # not a multiple of the 8x8 / 16x16 tiles: exercises partial tiles
     cam, fl = _camera(oracle, cornell_world, w, h)
-    others = [capi.Context(device=0, flags=S.CREATE_MEGAKERNEL), capi.Context(device=0, flags=S.CREATE_PERSISTENT)]
+    others = [capi.Context(device=0, flags=S.CREATE_MEGAKERNEL)]
+    if capi.has_experiments():  # (the persistent pipeline is compiled in only with -DPPT_EXPERIMENTS)
+        others.append(capi.Context(device=0, flags=S.CREATE_PERSISTENT))
+    else:
+        with pytest.raises(capi.ProsperPtError) as refused:
+            capi.Context(device=0, flags=S.CREATE_PERSISTENT)
+        assert refused.value.code == -6  # PROSPER_PT_ERR_UNSUPPORTED
     images, counts = [], []
     for ctx in [gpu_ctx] + others:
         ctx.upload_scene(cornell_world)
@@ -827,7 +835,7 @@ def test_all_pipelines_produce_identical_pixels(gpu_ctx, oracle, cornell_world):
         counts.append(ctx.counters().as_dict())
     for ctx in others:
         ctx.close()
-    assert same_bits(images[0], images[1]).all() and same_bits(images[0], images[2]).all()
+    assert all(same_bits(images[0], other).all() for other in images[1:])
     # schedule-independent counters are identical; node visits / triangle tests / any-hit calls depend on
     # the order candidates are found in (slab test form, traversal scheduler) and only need to be close
     stable = [k for k in counts[0] if k not in ("nodeVisits", "triangleTests", "anyHitCalls", "shortIndexHits", "shortIndexTriangleTests",
@@ -847,7 +855,7 @@ def test_all_pipelines_produce_identical_pixels(gpu_ctx, oracle, cornell_world):
     assert (z[..., :3] == 0).all() and (z[..., 3] == 1).all()
 
 
-def test_lds_stack_variants_agree(gpu_ctx, oracle, sponza_small, monkeypatch):
+def test_lds_stack_variants_agree(gpu_ctx, oracle, sponza_small):
     """The traversal kernels are instantiated for 16/24/32-entry LDS stacks and picked by BVH depth;
     forcing the deeper variants must not change a pixel."""
     w, h = 160, 96
@@ -858,17 +866,17 @@ def test_lds_stack_variants_agree(gpu_ctx, oracle, sponza_small, monkeypatch):
     gpu_ctx.render(pc, cam, w, h, frames=2)
     base = gpu_ctx.read_hdr()
     for forced in ("16", "24", "32"):  # 16 pushes the deeper entries of this tree into the global overflow array
-        monkeypatch.setenv("PROSPER_PT_DEBUG_STACK", forced)
+        capi.debug(ldsStackEntries=int(forced))
         gpu_ctx.render(pc, cam, w, h, frames=2)
         assert same_bits(gpu_ctx.read_hdr(), base).all(), forced
-    monkeypatch.delenv("PROSPER_PT_DEBUG_STACK")
+    capi.debug(ldsStackEntries=None)
 
 
-def test_lds_staged_tables_equal_global_memory_tables(gpu_ctx, oracle, monkeypatch):
+def test_lds_staged_tables_equal_global_memory_tables(gpu_ctx, oracle):
     """wf_shade stages draw instances, transforms, materials and lights in LDS when they fit in 16 KB.  The scene
     here is S-sponza-class with the first 24 + 24 lights of C4's sequences (about 8 KB of tables: the LDS variant
     is the one that runs - asserted through prosper_pt_scene_stats.variantFlags);
-    PROSPER_PT_DEBUG_NO_LDS_TABLES reads the tables from global memory.  Same bits, and the oracle's."""
+    debug option noLdsTables reads the tables from global memory.  Same bits, and the oracle's."""
     world = scenes.sponza_class(lights=(24, 24), foliage=True, texture_size=64, sky_size=32, detail=0.25)
     assert world.point_lights.count == 24 and world.spot_lights.count == 24
     w, h = 200, 120
@@ -878,10 +886,10 @@ def test_lds_staged_tables_equal_global_memory_tables(gpu_ctx, oracle, monkeypat
     assert gpu_ctx.scene_stats().variantFlags & S.VARIANT_LDS_TABLES
     gpu_ctx.render(pc, cam, w, h, frames=2)
     base = gpu_ctx.read_hdr()
-    monkeypatch.setenv("PROSPER_PT_DEBUG_NO_LDS_TABLES", "1")
+    capi.debug(noLdsTables=1)
     assert not (gpu_ctx.scene_stats().variantFlags & S.VARIANT_LDS_TABLES)
     gpu_ctx.render(pc, cam, w, h, frames=2)
-    monkeypatch.delenv("PROSPER_PT_DEBUG_NO_LDS_TABLES")
+    capi.debug(noLdsTables=None)
     assert same_bits(gpu_ctx.read_hdr(), base).all()
     osc = oracle.OracleScene(world)
     want = None
@@ -898,17 +906,17 @@ def test_lds_staged_tables_equal_global_memory_tables(gpu_ctx, oracle, monkeypat
     assert gpu_ctx.scene_stats().variantFlags & S.VARIANT_LDS_TABLES
     gpu_ctx.render(pc, cam, w, h, frames=2)
     staged = gpu_ctx.read_hdr()
-    monkeypatch.setenv("PROSPER_PT_DEBUG_NO_LDS_TABLES", "1")
+    capi.debug(noLdsTables=1)
     gpu_ctx.render(pc, cam, w, h, frames=2)
-    monkeypatch.delenv("PROSPER_PT_DEBUG_NO_LDS_TABLES")
+    capi.debug(noLdsTables=None)
     assert same_bits(gpu_ctx.read_hdr(), staged).all()
 
 
-def test_texture_packs_equal_separate_textures(gpu_ctx, oracle, sponza_small, monkeypatch):
+def test_texture_packs_equal_separate_textures(gpu_ctx, oracle, sponza_small):
     """Materials whose base / MR / normal textures share extent and sampler are sampled from an interleaved copy
     (pt_scene.hpp MaterialPack: one footprint, four 8-byte loads for an opaque material - the compact pack - or four
     12-byte ones).  Same texels, same filter arithmetic: the images with the compact packs, the wide ones
-    (PROSPER_PT_DEBUG_WIDE_PACKS=0 / 1) and without packs (PROSPER_PT_DEBUG_NO_TEXTURE_PACKS=1; both read at upload) are
+    (debug option widePacks = 0 / 1) and without packs (noTexturePacks = 1; both read at upload) are
     bit-equal - on S-sponza-class and on a wall of odd-sized textures under every wrap mode and both filters, which also
     equals the oracle with either pack."""
     from prosper_amd.world import World
@@ -916,15 +924,15 @@ def test_texture_packs_equal_separate_textures(gpu_ctx, oracle, sponza_small, mo
     cam, fl = _camera(oracle, sponza_small, w, h)
     pc = default_pc(S, fl, max_bounces=3, ibl=True)
     images = []
-    for variant, value in (("PROSPER_PT_DEBUG_WIDE_PACKS", "0"), ("PROSPER_PT_DEBUG_WIDE_PACKS", "1"), ("PROSPER_PT_DEBUG_NO_TEXTURE_PACKS", "1")):
+    for variant, value in (("widePacks", 0), ("widePacks", 1), ("noTexturePacks", 1)):
         # opaque materials: the compact pack (8 bytes per texel; the default of big texture sets), the 12-of-16-byte one,
         # the textures themselves
-        monkeypatch.setenv(variant, value)
+        capi.debug(**{variant: value})
         gpu_ctx.upload_scene(sponza_small)
-        assert bool(gpu_ctx.scene_stats().variantFlags & S.VARIANT_TEXTURE_PACKS) == (variant != "PROSPER_PT_DEBUG_NO_TEXTURE_PACKS")
+        assert bool(gpu_ctx.scene_stats().variantFlags & S.VARIANT_TEXTURE_PACKS) == (variant != "noTexturePacks")
         gpu_ctx.render(pc, cam, w, h, frames=2)
         images.append(gpu_ctx.read_hdr())
-        monkeypatch.delenv(variant)
+        capi.debug(**{variant: None})
     assert same_bits(images[0], images[1]).all() and same_bits(images[0], images[2]).all()
 
     rng = np.random.default_rng(7)
@@ -948,7 +956,7 @@ def test_texture_packs_equal_separate_textures(gpu_ctx, oracle, sponza_small, mo
     osc = oracle.OracleScene(world, brute_force=True)
     wanted = {}
     for wide in (False, True):
-        monkeypatch.setenv("PROSPER_PT_DEBUG_WIDE_PACKS", "1" if wide else "0")
+        capi.debug(widePacks=1 if wide else 0)
         gpu_ctx.upload_scene(world)
         assert gpu_ctx.scene_stats().variantFlags & S.VARIANT_TEXTURE_PACKS
         for draw_type in ("Albedo", "Roughness", "Metallic", "ShadingNormal", "Default"):
@@ -958,10 +966,10 @@ def test_texture_packs_equal_separate_textures(gpu_ctx, oracle, sponza_small, mo
                 wanted[draw_type], _ = osc.render(pc, cam, w, h)
             ok = same_bits(gpu_ctx.read_hdr(), wanted[draw_type]).all(axis=2)
             assert ok.all(), "%s (%s pack): %d of %d pixels differ" % (draw_type, "wide" if wide else "compact", (~ok).sum(), ok.size)
-    monkeypatch.delenv("PROSPER_PT_DEBUG_WIDE_PACKS")
+    capi.debug(widePacks=None)
 
 
-def test_moved_instances_refit_equals_fresh_upload(gpu_ctx, oracle, monkeypatch):
+def test_moved_instances_refit_equals_fresh_upload(gpu_ctx, oracle):
     """prosper_pt_update_transforms (prosper: World::updateScene + the per-frame TLAS rebuild, World.cpp:359-466,749-802):
     a refit on the GPU - new world triangles and new boxes for the unchanged tree, no host build.  After moving two
     instances the image equals a fresh upload of the moved scene, the flat (round-1) hierarchy's image and the
@@ -998,11 +1006,11 @@ def test_moved_instances_refit_equals_fresh_upload(gpu_ctx, oracle, monkeypatch)
         images = []
         for flat in (False, True):
             if flat:
-                monkeypatch.setenv("PROSPER_PT_DEBUG_FLAT_BVH", "1")
+                capi.debug(flatBvh=1)
             fresh.upload_scene(moved)
             fresh.render(pc, cam, w, h, frames=2)
             images.append(fresh.read_hdr())
-        monkeypatch.delenv("PROSPER_PT_DEBUG_FLAT_BVH")
+        capi.debug(flatBvh=None)
     finally:
         fresh.close()
     assert same_bits(refit, images[0]).all() and same_bits(refit, images[1]).all()
@@ -1030,12 +1038,12 @@ def test_moved_instances_refit_equals_fresh_upload(gpu_ctx, oracle, monkeypatch)
         capi._check(capi.lib().prosper_pt_update_transforms(gpu_ctx._h, None, 3))
     # a rebuild that fails half way (forced) must not be mistaken for done: renders are refused until an update has gone
     # through, and then show the moved scene
-    monkeypatch.setenv("PROSPER_PT_DEBUG_FAIL_NEXT_UPDATE", "1")
-    monkeypatch.setenv("PROSPER_PT_DEBUG_ALWAYS_REBUILD", "1")
+    capi.debug(failNextUpdate=1)
+    capi.debug(alwaysRebuild=1)
     with pytest.raises(capi.ProsperPtError):
         gpu_ctx.update_transforms(moved)
-    monkeypatch.delenv("PROSPER_PT_DEBUG_FAIL_NEXT_UPDATE")
-    monkeypatch.delenv("PROSPER_PT_DEBUG_ALWAYS_REBUILD")
+    capi.debug(failNextUpdate=None)
+    capi.debug(alwaysRebuild=None)
     with pytest.raises(capi.ProsperPtError):
         gpu_ctx.render(pc, cam, w, h, frames=2)
     gpu_ctx.update_transforms(moved)
@@ -1046,19 +1054,26 @@ def test_moved_instances_refit_equals_fresh_upload(gpu_ctx, oracle, monkeypatch)
     assert np.array_equal(gpu_ctx.read_nodes(), nodes_at_upload)
 
 
-def test_refit_writes_the_emitters_bytes(gpu_ctx, monkeypatch):
+def test_refit_writes_the_emitters_bytes(gpu_ctx):
     """The device encoder of a node's child boxes (bvh_encode.hpp through encode_nodes_kernel) and the host emitter are
-    the same code: with the refit at upload switched off (PROSPER_PT_DEBUG_NO_UPLOAD_REFIT) the node array is the
+    the same code: with the refit at upload switched off (debug option noUploadRefit) the node array is the
     emitter's own, and it equals the refitted one byte for byte - on a scene with instancing, scaling and a skewed
     transform, and on the big one."""
-    for world in (scenes.transform_zoo(), scenes.sponza_class(foliage=True, texture_size=64, sky_size=32, detail=0.5)):
-        monkeypatch.setenv("PROSPER_PT_DEBUG_NO_UPLOAD_REFIT", "1")
+    from prosper_amd.world import World
+    empty = World()  # no geometry at all: the root the emitter writes (origin 0, child boxes at +inf) must survive the upload
+    empty.add_material(base_color=(1.0, 1.0, 1.0, 1.0))
+    empty.camera = dict(eye=(0.0, 0.0, 3.0), target=(0.0, 0.0, 0.0), up=(0.0, 1.0, 0.0), fov=0.9, zN=0.1, zF=100.0)
+    for world in (scenes.transform_zoo(), scenes.sponza_class(foliage=True, texture_size=64, sky_size=32, detail=0.5), empty):
+        capi.debug(noUploadRefit=1)
         gpu_ctx.upload_scene(world)
         emitted = gpu_ctx.read_nodes()
-        monkeypatch.delenv("PROSPER_PT_DEBUG_NO_UPLOAD_REFIT")
+        capi.debug(noUploadRefit=None)
         gpu_ctx.upload_scene(world)
         refitted = gpu_ctx.read_nodes()
-        assert emitted.shape == refitted.shape and emitted.shape[0] > 8
+        assert emitted.shape == refitted.shape and (emitted.shape[0] > 8 or world is empty)
+        if world is empty:
+            assert emitted.shape[0] == 1 and (emitted[0, :3] == 0).all() and np.isfinite(emitted[0, :3].view(np.float32)).all()
+            assert gpu_ctx.hierarchy_state().builtCost == 0.0
         differing = np.argwhere(emitted != refitted)
         assert differing.size == 0, "node %d word %d: emitter %08x, refit %08x" % (
             differing[0][0], differing[0][1], emitted[tuple(differing[0])], refitted[tuple(differing[0])])
@@ -1135,12 +1150,12 @@ def test_far_moves_trigger_the_host_side_rebuild(gpu_ctx, oracle):
         assert same_bits(got, want).all()
 
 
-def test_refit_of_a_flat_tree_and_of_alpha_geometry(gpu_ctx, oracle, monkeypatch):
-    """The refit does not care how the tree was built: on the one-tree-over-everything hierarchy (PROSPER_PT_DEBUG_FLAT_BVH)
+def test_refit_of_a_flat_tree_and_of_alpha_geometry(gpu_ctx, oracle):
+    """The refit does not care how the tree was built: on the one-tree-over-everything hierarchy (debug option flatBvh)
     moved instances give the oracle's image of the moved scene too - here on the instance-transform zoo (mirrors, shears,
     non-uniform scales) and with MASK / BLEND quads among the movers (their any-hit records are object-space and stay)."""
     from prosper_amd.world import rotate_z, translate
-    monkeypatch.setenv("PROSPER_PT_DEBUG_FLAT_BVH", "1")
+    capi.debug(flatBvh=1)
     for builder, picks in ((scenes.transform_zoo, (1, 4, 6)), (scenes.alpha_wall, (0, 3, 17, 30))):
         still, moved = builder(), builder()
         for k in picks:
@@ -1204,6 +1219,42 @@ def test_moving_instances_between_frames_in_flight(gpu_ctx, oracle):
             fresh.upload_scene(world)
             fresh.render(pc, cam, w, h, frames=2)
             assert same_bits(images[k], fresh.read_hdr()).all(), "pose %d" % k
+    finally:
+        fresh.close()
+
+
+def test_drifting_instances_trigger_the_rebuild_with_frames_in_flight(gpu_ctx, oracle):
+    """A GPU-bound frame loop that moves instances EVERY frame, three frames in flight, no host synchronisation: the refit
+    whose measure says "the tree has degraded" is never the newest one - that has only just been enqueued when the next
+    update arrives - so the measure is kept per scene version and the newest FINISHED one is read.  Instances carried far
+    out of the hall must make an update rebuild by itself (prosper_pt_hierarchy_state.rebuilds), and every frame still
+    shows its own pose."""
+    from prosper_amd.world import translate
+
+    def pose(k):
+        world = scenes.sponza_class(lights=(4, 4), texture_size=64, sky_size=32, detail=0.25)
+        for i in (3, 5, 7):
+            model, m = world.model_instances[i]
+            world.model_instances[i] = (model, translate((1.5 * k, 0.2 * k, 0.4 * k)) @ m)
+        return world
+    poses = [pose(k) for k in range(14)]  # 21 units in the end: far past the 30 % growth of the measure
+    w, h = 192, 108
+    cam, fl = _camera(oracle, poses[0], w, h)
+    pc = default_pc(S, fl, max_bounces=2, ibl=True)
+    gpu_ctx.upload_scene(poses[0])
+    before = gpu_ctx.hierarchy_state()
+    for world in poses[1:]:
+        gpu_ctx.update_transforms(world)  # staged; the refit runs at the head of the render's own chain
+        gpu_ctx.render(pc, cam, w, h, frames=8, flags=S.RENDER_PIPELINED)
+    last = gpu_ctx.read_hdr()
+    after = gpu_ctx.hierarchy_state()
+    assert after.rebuilds > before.rebuilds, "refits %d, rebuilds %d, measure x%.3f" % (after.refits, after.rebuilds, after.costRatio)
+    assert after.costRatio < 1.3  # the tree is good again
+    fresh = capi.Context(device=0)
+    try:
+        fresh.upload_scene(poses[-1])
+        fresh.render(pc, cam, w, h, frames=8)
+        assert same_bits(last, fresh.read_hdr()).all()
     finally:
         fresh.close()
 
@@ -1283,8 +1334,8 @@ def test_pipelined_renders_survive_changing_extents(gpu_ctx, oracle, cornell_wor
         assert same_bits(a, b).all()
 
 
-def test_zero_throughput_rule_does_not_change_the_image(gpu_ctx, oracle, sponza_small, monkeypatch):
-    """Arithmetic contract: a path whose throughput is exactly (0, 0, 0) ends.  With PROSPER_PT_DEBUG_TRACE_DEAD_PATHS=1
+def test_zero_throughput_rule_does_not_change_the_image(gpu_ctx, oracle, sponza_small):
+    """Arithmetic contract: a path whose throughput is exactly (0, 0, 0) ends.  With debug option traceDeadPaths
     the kernels keep tracing such paths like the GLSL does: more rays (the counters say how many), the same bits in
     every pixel with clampIndirect on, the reference's default (without it the traced paths' NaN sky terms survive:
     DESIGN.md section 3) - on the small S-sponza-class scene with lights, foliage and IBL and on S-cornell, all three pipelines."""
@@ -1300,11 +1351,11 @@ def test_zero_throughput_rule_does_not_change_the_image(gpu_ctx, oracle, sponza_
                 ctx.upload_scene(world)
                 out = []
                 for audit in ("0", "1"):
-                    monkeypatch.setenv("PROSPER_PT_DEBUG_TRACE_DEAD_PATHS", audit)
+                    capi.debug(traceDeadPaths=int(audit))
                     ctx.reset_counters()
                     ctx.render(pc, cam, w, h, frames=2, flags=S.RENDER_COUNT_WORK)
                     out.append((ctx.read_hdr(), ctx.counters().as_dict()))
-                monkeypatch.delenv("PROSPER_PT_DEBUG_TRACE_DEAD_PATHS")
+                capi.debug(traceDeadPaths=None)
             finally:
                 ctx.close()
             assert same_bits(out[0][0], out[1][0]).all(), create
@@ -1312,7 +1363,7 @@ def test_zero_throughput_rule_does_not_change_the_image(gpu_ctx, oracle, sponza_
             assert out[1][1]["paths"] == out[0][1]["paths"]
 
 
-def test_batched_texture_fetches_equal_sequential_ones(gpu_ctx, oracle, sponza_small, monkeypatch):
+def test_batched_texture_fetches_equal_sequential_ones(gpu_ctx, oracle, sponza_small):
     """sample_material<true> (big texture sets: the twelve texel loads of a hit's three textures in flight together)
     against the one-texture-after-the-other path, forced either way on the texture-addressing wall (every wrap mode
     and filter, odd sizes) and on the small S-sponza-class scene: same bits, and the wall equals the oracle."""
@@ -1323,11 +1374,11 @@ def test_batched_texture_fetches_equal_sequential_ones(gpu_ctx, oracle, sponza_s
         pc = default_pc(S, fl, **kw)
         images = []
         for forced in ("0", "1"):
-            monkeypatch.setenv("PROSPER_PT_DEBUG_BATCHED_TEXTURES", forced)
+            capi.debug(batchedTextures=int(forced))
             gpu_ctx.upload_scene(world)
             gpu_ctx.render(pc, cam, w, h, frames=2)
             images.append(gpu_ctx.read_hdr())
-        monkeypatch.delenv("PROSPER_PT_DEBUG_BATCHED_TEXTURES")
+        capi.debug(batchedTextures=None)
         assert same_bits(images[0], images[1]).all()
         if world is not sponza_small:
             want = None
@@ -1338,7 +1389,7 @@ def test_batched_texture_fetches_equal_sequential_ones(gpu_ctx, oracle, sponza_s
             assert same_bits(images[1], want).all()
 
 
-def test_hits_do_not_depend_on_the_hierarchy(gpu_ctx, oracle, sponza_small, monkeypatch):
+def test_hits_do_not_depend_on_the_hierarchy(gpu_ctx, oracle, sponza_small):
     """Hit contract: the box guard bounds where a triangle can be hit, so fatter BVH boxes (a different
     tree: other culling, other traversal order) must give the same bits."""
     w, h = 160, 96
@@ -1347,20 +1398,20 @@ def test_hits_do_not_depend_on_the_hierarchy(gpu_ctx, oracle, sponza_small, monk
     images, nodes = [], []
     for pad in (None, "1e-4", "3e-3"):
         if pad is None:
-            monkeypatch.delenv("PROSPER_PT_DEBUG_PAD", raising=False)
+            capi.debug(boxPad=None)
         else:
-            monkeypatch.setenv("PROSPER_PT_DEBUG_PAD", pad)
+            capi.debug(boxPad=float(pad))
         gpu_ctx.upload_scene(sponza_small)
         gpu_ctx.reset_counters()
         gpu_ctx.render(pc, cam, w, h, frames=2, flags=S.RENDER_COUNT_WORK)
         images.append(gpu_ctx.read_hdr())
         nodes.append(gpu_ctx.counters().nodeVisits)
-    monkeypatch.delenv("PROSPER_PT_DEBUG_PAD", raising=False)
+    capi.debug(boxPad=None)
     assert nodes[0] < nodes[1] < nodes[2]  # the hierarchies really differ
     assert same_bits(images[0], images[1]).all() and same_bits(images[0], images[2]).all()
 
 
-def test_lds_resident_scene_equals_global_memory_traversal(gpu_ctx, oracle, cornell_world, monkeypatch):
+def test_lds_resident_scene_equals_global_memory_traversal(gpu_ctx, oracle, cornell_world):
     """Scenes of a few KB are traversed out of LDS (LdsGeom); same pixels as the HBM path."""
     w, h = 224, 128
     cam, fl = _camera(oracle, cornell_world, w, h)
@@ -1368,15 +1419,16 @@ def test_lds_resident_scene_equals_global_memory_traversal(gpu_ctx, oracle, corn
     gpu_ctx.upload_scene(cornell_world)
     gpu_ctx.render(pc, cam, w, h, frames=2)
     lds = gpu_ctx.read_hdr()
-    monkeypatch.setenv("PROSPER_PT_DEBUG_NO_LDS_SCENE", "1")
+    capi.debug(noLdsScene=1)
     gpu_ctx.render(pc, cam, w, h, frames=2)
     assert same_bits(gpu_ctx.read_hdr(), lds).all()
-    monkeypatch.delenv("PROSPER_PT_DEBUG_NO_LDS_SCENE")
+    capi.debug(noLdsScene=None)
 
 
+@needs_experiments
 @pytest.mark.parametrize("variant", ["1", "2", "3"])
-def test_ray_pool_trace_variants_equal_the_lane_owned_traversal(gpu_ctx, oracle, monkeypatch, variant):
-    """wf_trace_pool (pt_trace_pool.hpp: the wave's rays in an LDS pool, PROSPER_PT_DEBUG_POOL) is an experiment kept
+def test_ray_pool_trace_variants_equal_the_lane_owned_traversal(gpu_ctx, oracle, variant):
+    """wf_trace_pool (pt_trace_pool.hpp: the wave's rays in an LDS pool, debug option poolVariant) is an experiment kept
     for its measurements; it must still produce the oracle's pixels - opaque and alpha-tested geometry, lights, sky."""
     from prosper_amd import scenes
     world = scenes.sponza_class(detail=0.25, lights=(24, 24), foliage=True, texture_size=64, sky_size=64)
@@ -1385,10 +1437,10 @@ def test_ray_pool_trace_variants_equal_the_lane_owned_traversal(gpu_ctx, oracle,
     pc = default_pc(S, fl, max_bounces=4, ibl=True)
     gpu_ctx.upload_scene(world)
     want, _ = oracle.OracleScene(world).render(pc, cam, w, h)
-    monkeypatch.setenv("PROSPER_PT_DEBUG_POOL", variant)
+    capi.debug(poolVariant=int(variant))
     gpu_ctx.render(pc, cam, w, h)
     got = gpu_ctx.read_hdr()
-    monkeypatch.delenv("PROSPER_PT_DEBUG_POOL")
+    capi.debug(poolVariant=None)
     ok = same_bits(got, want).all(axis=2)
     assert ok.all(), "%d of %d pixels differ" % ((~ok).sum(), ok.size)
 
@@ -1485,8 +1537,9 @@ def test_full_size_flight_helmet_parity(gpu_ctx, oracle):
     assert np.isfinite(got).all() and (got[..., 3] == 2).all()
 
 
-def test_sparse_segments_traced_by_one_wave_give_the_same_pixels(gpu_ctx, oracle, monkeypatch):
-    """PROSPER_PT_DEBUG_MERGE_LIMIT (pt_wavefront.hip RayMap; an experiment, off by default): where the four segments of a
+@needs_experiments
+def test_sparse_segments_traced_by_one_wave_give_the_same_pixels(gpu_ctx, oracle):
+    """debug option mergeLimit (pt_wavefront.hip RayMap; an experiment, off by default): where the four segments of a
     workgroup hold few rays, one wave traces them all and the group's paths live in its first segment from then on.  Which
     wave traces a ray changes no hit: the image of a sparse scene (a small lit object under a sky, most camera rays miss) is
     the same at every limit, and the oracle's."""
@@ -1503,10 +1556,10 @@ def test_sparse_segments_traced_by_one_wave_give_the_same_pixels(gpu_ctx, oracle
     gpu_ctx.upload_scene(world)
     images = []
     for limit in ("0", "64", "100000"):
-        monkeypatch.setenv("PROSPER_PT_DEBUG_MERGE_LIMIT", limit)
+        capi.debug(mergeLimit=int(limit))
         gpu_ctx.render(pc, cam, w, h, frames=4, flags=S.RENDER_PIPELINED)
         images.append(gpu_ctx.read_hdr())
-    monkeypatch.delenv("PROSPER_PT_DEBUG_MERGE_LIMIT")
+    capi.debug(mergeLimit=None)
     assert same_bits(images[0], images[1]).all() and same_bits(images[0], images[2]).all()
     osc = oracle.OracleScene(world)
     want = None

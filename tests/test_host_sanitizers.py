@@ -23,8 +23,7 @@ def test_bvh_builder_under_sanitizers(tmp_path, sanitizer):
     subprocess.check_call(cmd)
     env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0", TSAN_OPTIONS="halt_on_error=1")
     for threads in ("1", "4"):
-        env["PROSPER_PT_DEBUG_BUILD_THREADS"] = threads
-        out = subprocess.run([exe, "12"], env=env, capture_output=True, text=True, timeout=600)
+        out = subprocess.run([exe, "12", threads], env=env, capture_output=True, text=True, timeout=600)
         text = out.stdout + out.stderr
         assert out.returncode == 0, text[-2000:]
         assert "runtime error" not in text and "Sanitizer" not in text, text[-2000:]
