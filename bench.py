@@ -239,7 +239,7 @@ DETAIL_NAME = "bench_detail.json"
 SLIM_LIMIT = 4096
 
 
-def slim_line(result):
+def slim_line(result, detail_path=None):
     """The ONE stdout line (under SLIM_LIMIT bytes): contract fields + numbers; the rest lives in bench_detail.json."""
     line = {k: result.get(k) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "frames_per_s",
                                        "higher_is_better", "scaling", "vs_baseline", "dtype", "data")}
@@ -263,7 +263,7 @@ def slim_line(result):
             line[k] = {"ms": result[k]["ms_per_step"], "bound_on_scaling_efficiency": result[k].get("bound_on_scaling_efficiency")}
     if result.get("configs"):
         line["configs"] = {name: slim_config(c) for name, c in result["configs"].items()}
-    line["detail"] = DETAIL_NAME
+    line["detail"] = detail_path or DETAIL_NAME
     line = rounded(line)
     text = json.dumps(line, separators=(",", ":"))
     if len(text) >= SLIM_LIMIT:  # never again a line the driver cannot parse: drop the optional parts, largest first
@@ -275,16 +275,18 @@ def slim_line(result):
     return text
 
 
-def write_detail(result):
-    """bench_detail.json next to this file and under gpurun_out/ (the scratch directory a GPU box's run sends back)."""
-    for d in (ROOT, os.path.join(ROOT, "gpurun_out")):
+def write_detail(result, path=None):
+    """The full result: to `path` when given (tests), else bench_detail.json next to this file and a copy under gpurun_out/
+    (the scratch directory a GPU box's run sends back)."""
+    targets = [path] if path else [os.path.join(ROOT, DETAIL_NAME), os.path.join(ROOT, "gpurun_out", DETAIL_NAME)]
+    for t in targets:
         try:
-            os.makedirs(d, exist_ok=True)
-            with open(os.path.join(d, DETAIL_NAME), "w") as f:
+            os.makedirs(os.path.dirname(os.path.abspath(t)), exist_ok=True)
+            with open(t, "w") as f:
                 json.dump(result, f, indent=1)
                 f.write("\n")
         except OSError as e:
-            print("bench: could not write %s (%s)" % (os.path.join(d, DETAIL_NAME), e), file=sys.stderr)
+            print("bench: could not write %s (%s)" % (t, e), file=sys.stderr)
 
 
 def spawn_ranks(n):
@@ -671,6 +673,7 @@ def main():
                     "committed profile if it matches the kernel sources, else null)")
     ap.add_argument("--pmc-budget", type=float, default=240.0, help="seconds all rocprofv3 child passes together may take")
     ap.add_argument("--cpu-budget", type=float, default=12.0, help="seconds of CPU tracing for the headline's cpu_baseline")
+    ap.add_argument("--detail", default=None, help="where the full result goes (default: bench_detail.json here and under gpurun_out/)")
     ap.add_argument("--no-subconfigs", action="store_true", help="skip the C3 / C4 / FlightHelmet sub-objects")
     ap.add_argument("--no-extras", action="store_true", help="skip the tone-map and ReSTIR-DI legs")
     ap.add_argument("--subconfigs", default="c1,c3,c4,helmet,helmet2k")
@@ -1000,8 +1003,8 @@ def main():
             result["ranks_seen"] = ranks_seen
             result["ranks_seen_by"] = ranks_seen_by
             result["gather_ms"] = gather_ms
-        write_detail(result)
-        print(slim_line(result))
+        write_detail(result, args.detail)
+        print(slim_line(result, args.detail))
 
     ctx.set_output_buffer(0, 0)
     ctx.close()

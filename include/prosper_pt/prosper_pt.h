@@ -297,6 +297,8 @@ typedef struct prosper_pt_debug_options
     uint32_t noLdsScene;       /* keep a small scene in global memory */
     uint32_t noLdsTables;      /* keep the shading tables in global memory */
     uint32_t traceDeadPaths;   /* keep tracing zero-throughput paths, as the GLSL does (audit of the contract's rule) */
+    int32_t bandedBatches;     /* 1: every XCD's segments take the camera-ray batches of ONE band of the image instead of batches
+                                * strided over all of it (measured slower: profiles/r04_banded_batches.txt); -1 / 0: strided */
     /* ---- updates ---- */
     float rebuildCostRatio;    /* 0: 1.3 - growth of the tree's surface-area measure at which an update also rebuilds */
     uint32_t alwaysRebuild;    /* rebuild with every update */

@@ -198,6 +198,7 @@ class Context:
     def __init__(self, device=0, flags=0, _borrowed=None):
         self._owned = _borrowed is None
         self._own_debug = {}
+        self._base_debug = None
         self._debug_seen = -1
         self._world = None
         if _borrowed is not None:
@@ -231,8 +232,10 @@ class Context:
     def _sync_debug(self):
         if self._debug_seen == _debug_version:
             return
-        o = S.DebugOptions()
-        lib().prosper_pt_debug_options_default(C.byref(o))
+        if self._base_debug is None:
+            # what the context was created with: the library's defaults, or PROSPER_PT_DEBUG_OPTIONS under PROSPER_PT_DEBUG=1
+            self._base_debug = self.debug_options()
+        o = S.DebugOptions.from_buffer_copy(bytes(self._base_debug))
         for k, v in list(_debug_defaults.items()) + list(self._own_debug.items()):
             setattr(o, k, v)
         _check(lib().prosper_pt_set_debug_options(self._h, C.byref(o)))

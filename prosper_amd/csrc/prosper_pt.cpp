@@ -769,7 +769,7 @@ void release_slot(RenderSlot &slot, hipStream_t stream)
 
 // Sizes and carves the wavefront workspace for `frames` x (tilesX*tilesY*64) path slots.
 int ensure_wavefront_workspace(
-    prosper_pt_ctx *ctx, RenderSlot &slot, uint32_t tilesX, uint32_t tilesY, uint32_t frames, bool pipelined,
+    prosper_pt_ctx *ctx, RenderSlot &slot, uint32_t tilesX, uint32_t tilesY, uint32_t frames, bool pipelined, bool banded,
     WavefrontBuffers *out)
 {
     const uint64_t pixelsPadded = (uint64_t)tilesX * tilesY * 64u;
@@ -809,6 +809,36 @@ int ensure_wavefront_workspace(
             if (cols >= tilesX / 8u && tilesX - cols >= tilesX / 8u) break;
             ++nSeg;
         }
+    // Banded batches: with a launch that covers all segment groups, XCD x runs the groups [x * perXcd, (x + 1) * perXcd)
+    // (pt_wavefront.hip my_segment), i.e. the segments [x * bandSegments, ...).  Each band of segments takes the batches of
+    // its own band of tiles - as many tiles as its segments have room for (batches per segment / batches per tile); when
+    // rounding leaves a tile without a place, one more round of segments makes room.
+    uint32_t bandSegments = 0, bandTile[9] = {};
+    if (banded)
+    {
+        const uint64_t tiles = (uint64_t)tilesX * tilesY, perSegment = segLen / 64u; // batches a segment holds
+        for (uint32_t tries = 0; tries < 64u; ++tries)
+        {
+            const uint64_t groups = (nSeg + 3u) / 4u, perXcd = (groups + 7u) / 8u;
+            bandSegments = (uint32_t)(perXcd * 4u);
+            uint64_t placed = 0;
+            for (uint32_t x = 0; x < 8u; ++x)
+            {
+                const uint64_t first = (uint64_t)x * bandSegments;
+                const uint64_t segs = first >= nSeg ? 0u : std::min<uint64_t>(bandSegments, nSeg - first);
+                const uint64_t room = segs * perSegment / frames; // tiles: `frames` batches each
+                // what is left, spread evenly over the bands that remain
+                const uint64_t want = (tiles - placed + (8u - x) - 1u) / (8u - x);
+                bandTile[x] = (uint32_t)placed;
+                placed += std::min(room, want);
+            }
+            bandTile[8] = (uint32_t)placed;
+            if (placed >= tiles) break;
+            nSeg += 8u;
+            bandSegments = 0;
+        }
+        if (bandSegments == 0) return fail(PROSPER_PT_ERR_UNSUPPORTED, "banded batches: no segment layout covers the image");
+    }
     const uint64_t padded = nSeg * segLen;
     // per slot: 2 x (3 x 16 + 8) B ping-pong state, camera slot 4, hit 16 + idx 4, shadow 48, colour 16; + 3 counters per segment
     const size_t bytes = (size_t)padded * (2u * (3u * 16u + 8u) + 4u + 16u + 4u + 48u + 16u) + (size_t)nSeg * 12u + 4096u;
@@ -850,6 +880,8 @@ int ensure_wavefront_workspace(
     w.pixelsPadded = (uint32_t)pixelsPadded;
     w.tilesX = tilesX;
     w.tilesY = tilesY;
+    w.bandSegments = bandSegments;
+    for (uint32_t x = 0; x < 9u; ++x) w.bandTile[x] = bandTile[x];
     if ((size_t)(cursor - static_cast<uint8_t *>(slot.wfBlock)) > slot.wfBytes + 0u)
     {
         // carve() rounds every array up to 256 B: re-allocate with the exact carved size
@@ -860,7 +892,7 @@ int ensure_wavefront_workspace(
         slot.wfBytes = 0;
         PPT_HIP(hipMalloc(&slot.wfBlock, need));
         slot.wfBytes = need;
-        return ensure_wavefront_workspace(ctx, slot, tilesX, tilesY, frames, pipelined, out);
+        return ensure_wavefront_workspace(ctx, slot, tilesX, tilesY, frames, pipelined, banded, out);
     }
     *out = w;
     return PROSPER_PT_OK;
@@ -944,7 +976,7 @@ const DebugField kDebugFields[] = {
     PPT_FIELD(boxPad, 'f'), PPT_FIELD(leafSize, 'u'), PPT_FIELD(buildThreads, 'u'), PPT_FIELD(topEntries, 'u'),
     PPT_FIELD(nodeOrder, 'i'), PPT_FIELD(childOrder, 'i'), PPT_FIELD(buildTiming, 'u'), PPT_FIELD(segments, 'u'),
     PPT_FIELD(segmentLength, 'u'), PPT_FIELD(chains, 'u'), PPT_FIELD(ldsStackEntries, 'u'), PPT_FIELD(noLdsScene, 'u'),
-    PPT_FIELD(noLdsTables, 'u'), PPT_FIELD(traceDeadPaths, 'u'), PPT_FIELD(rebuildCostRatio, 'f'), PPT_FIELD(alwaysRebuild, 'u'),
+    PPT_FIELD(noLdsTables, 'u'), PPT_FIELD(traceDeadPaths, 'u'), PPT_FIELD(bandedBatches, 'i'), PPT_FIELD(rebuildCostRatio, 'f'), PPT_FIELD(alwaysRebuild, 'u'),
     PPT_FIELD(failNextUpdate, 'u'), PPT_FIELD(poolVariant, 'u'), PPT_FIELD(rawRecords, 'u'), PPT_FIELD(tileOrder, 'u'),
     PPT_FIELD(hipGraph, 'u'), PPT_FIELD(pipelinedChains, 'u'), PPT_FIELD(mergeLimit, 'u'),
 };
@@ -1036,6 +1068,7 @@ void prosper_pt_debug_options_default(prosper_pt_debug_options *out)
     out->alphaCellShift = -1;
     out->nodeOrder = -1;
     out->childOrder = -1;
+    out->bandedBatches = -1;
 }
 
 int prosper_pt_set_debug_options(prosper_pt_ctx *ctx, const prosper_pt_debug_options *options)
@@ -1722,7 +1755,14 @@ int prosper_pt_render_frames(
         {
             const uint32_t frames = (frame_count - f0 < framesPerChunk) ? frame_count - f0 : framesPerChunk;
             WavefrontBuffers w = {};
-            const int rc = ensure_wavefront_workspace(ctx, slot, tilesX, tilesY, frames, pipelined, &w);
+            // Banded batches (debug option bandedBatches = 1; round 4, profiles/r04_banded_batches.txt): every XCD's segments take
+            // the camera-ray batches of one band of the image, so that the paths an XCD traces START in one part of the scene.
+            // Measured and NOT a default: on S-sponza-class wf_trace's FETCH_SIZE moves by 3 % (2.249 -> 2.184 GB per launch) -
+            // three of its four launches trace bounce rays and sun shadows that cross the whole hall wherever they start -
+            // while the bands' unequal costs bind the step to the slowest XCD: C3 13.0 -> 13.6 ms, C4 27.2 -> 30.7,
+            // FlightHelmet (a band of sky is nearly free) 1.88 -> 2.48.
+            const bool banded = ctx->debug.bandedBatches > 0;
+            const int rc = ensure_wavefront_workspace(ctx, slot, tilesX, tilesY, frames, pipelined, banded, &w);
             if (rc != PROSPER_PT_OK) return rc;
             RenderParams pp = p;
             pp.frameCount = frames;

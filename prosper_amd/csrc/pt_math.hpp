@@ -104,6 +104,13 @@ PPT_HD float max3(f3 v) { return fmax_(fmax_(v.x, v.y), v.z); }
 // sin and cos of x, |x| < 2^15: three-step Cody-Waite reduction by pi/2, Cephes sinf/cosf kernels.
 PPT_HD void sincos_(float x, float &s, float &c)
 {
+#if defined(PPT_EXPERIMENT_NATIVE_TRANSCENDENTALS) && defined(__HIP_DEVICE_COMPILE__)
+    // TIMING ONLY (scripts/build_variant.sh native "-DPPT_EXPERIMENT_NATIVE_TRANSCENDENTALS"; profiles/r04_transcendentals.txt):
+    // v_sin_f32 / v_cos_f32 - what the contract's polynomial kernels cost against the hardware's; breaks bit parity
+    s = __builtin_amdgcn_sinf(x * 0.15915494309189532f);
+    c = __builtin_amdgcn_cosf(x * 0.15915494309189532f);
+    return;
+#endif
     const float k = __builtin_rintf(x * 0.636619772f);
     float r = __builtin_fmaf(-k, 1.57079625f, x);
     r = __builtin_fmaf(-k, 7.54978942e-08f, r);
@@ -125,6 +132,9 @@ PPT_HD void sincos_(float x, float &s, float &c)
 // log2 of a normal x > 0: mantissa folded to [sqrt(.5), sqrt(2)), atanh series in (m-1)/(m+1)
 PPT_HD float log2_(float x)
 {
+#if defined(PPT_EXPERIMENT_NATIVE_TRANSCENDENTALS) && defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_logf(x); // v_log_f32 (timing only)
+#endif
     const uint32_t bits = f2u(x);
     int32_t e = (int32_t)(bits >> 23) - 127;
     float m = u2f((bits & 0x007FFFFFu) | 0x3F800000u);
@@ -146,6 +156,9 @@ PPT_HD float log2_(float x)
 // exp2 on [-126, 127]: integer part by exponent bits, degree-7 Taylor in ln2 on [-.5, .5]
 PPT_HD float exp2_(float x)
 {
+#if defined(PPT_EXPERIMENT_NATIVE_TRANSCENDENTALS) && defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_exp2f(x); // v_exp_f32 (timing only)
+#endif
     x = clamp_(x, -126.0f, 127.0f);
     const float n = __builtin_rintf(x);
     const float f = x - n;

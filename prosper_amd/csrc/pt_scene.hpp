@@ -261,6 +261,12 @@ struct WavefrontBuffers
     // tiles in the order the camera-ray batches take them: heaviest first, by the cost of a probe ray through the tile's
     // centre (pt_wavefront.hip tile order); nullptr = raster order
     const uint32_t *tileOrder;
+    // Banded batches (pt_wavefront.hip batch dealing): the segments [x * bandSegments, (x + 1) * bandSegments) - the ones XCD x
+    // runs when a launch covers all groups - take the camera-ray batches of the tiles [bandTile[x], bandTile[x + 1]) only, so
+    // that the paths an XCD traces start in one band of the image and the part of the scene they see stays in its L2.
+    // bandSegments == 0: batches strided over the whole image.
+    uint32_t bandSegments;
+    uint32_t bandTile[9];
     uint32_t groupBase;  // this launch covers segment groups [groupBase, groupBase + groupCount)
     uint32_t groupCount; // (a group = the 4 segments of one workgroup)
 };

@@ -167,7 +167,13 @@ PPT_D void trace_stream(
                     float e[4];
                     int32_t ref[4];
                     bool entered;
+#ifdef PPT_EXPERIMENT_UNSORTED_CLOSEST
+                    // measurement only (profiles/r04_child_order.txt): closest-hit rays take the children in storage order
+                    // like the any-hit rays - what the five-comparator sort buys in node visits against what it costs
+                    if constexpr (true)
+#else
                     if constexpr (ANY)
+#endif
                     {
                         intersect_node4<false>(nd, o, rs, tMin, hit.t, e, ref);
                         entered = descend_any(e, ref, stack, sp, node);

@@ -118,11 +118,12 @@ struct BatchLane
 #ifndef PPT_BATCH_MAX_FRAMES
 #define PPT_BATCH_MAX_FRAMES 64u
 #endif
-__device__ __forceinline__ BatchLane batch_lane(const WavefrontBuffers &w, const RenderParams &p, uint32_t q, uint32_t lane)
+// `q` counts the batches of the tiles [tileBase, tileBase + tiles) only (the whole image: 0, pixelsPadded >> 6).
+__device__ __forceinline__ BatchLane batch_lane(
+    const WavefrontBuffers &w, const RenderParams &p, uint32_t q, uint32_t lane, uint32_t tileBase, uint32_t tiles)
 {
     constexpr uint32_t kMax = PPT_BATCH_MAX_FRAMES, kMaxShift = kMax == 64u ? 6u : (kMax == 32u ? 5u : (kMax == 16u ? 4u : (kMax == 8u ? 3u : 0u)));
     static_assert(kMaxShift != 0u || kMax == 1u, "PPT_BATCH_MAX_FRAMES is 1, 8, 16, 32 or 64");
-    const uint32_t tiles = w.pixelsPadded >> 6;
     const uint32_t frames = p.frameCount;
     uint32_t shift = kMaxShift, firstFrame = 0u, rem = q;
     const uint32_t fullGroups = frames >> kMaxShift;
@@ -155,9 +156,9 @@ __device__ __forceinline__ BatchLane batch_lane(const WavefrontBuffers &w, const
     // 2^shift batches per tile, each a block of 64 >> shift pixels: 8x8, 8x4, 4x4, 4x2, 2x2, 2x1, 1x1
     const uint32_t rank = rem >> shift, part = rem & ((1u << shift) - 1u);
 #ifdef PPT_EXPERIMENTS
-    const uint32_t tile = (w.tileOrder != nullptr && rank < tiles) ? w.tileOrder[rank] : rank; // (wave-uniform: a scalar load)
+    const uint32_t tile = (w.tileOrder != nullptr && tileBase + rank < (w.pixelsPadded >> 6)) ? w.tileOrder[tileBase + rank] : tileBase + rank; // (wave-uniform: a scalar load)
 #else
-    const uint32_t tile = rank;
+    const uint32_t tile = tileBase + rank;
 #endif
     const uint32_t wShift = (7u - shift) >> 1, hShift = (6u - shift) >> 1; // log2 of the block's width and height
     const uint32_t pixel = lane & ((64u >> shift) - 1u);
@@ -169,7 +170,7 @@ __device__ __forceinline__ BatchLane batch_lane(const WavefrontBuffers &w, const
     r.lx = (tile - ty * w.tilesX) * 8u + ix;
     r.py = ty * 8u + iy;
     r.slot = r.frame * w.pixelsPadded + tile * 64u + iy * 8u + ix;
-    r.valid = inRange && r.frame < frames && r.lx < p.localWidth && r.py < p.height;
+    r.valid = inRange && rank < tiles && r.frame < frames && r.lx < p.localWidth && r.py < p.height;
     return r;
 }
 
@@ -432,10 +433,22 @@ __global__ __launch_bounds__(256, PPT_GEN_WPE) void wf_generate_extend(
         // stream scheduler and its bookkeeping.  Running them through trace_stream() instead was measured slower on
         // every configuration (profiles/r02_scheduler_experiments.txt: C2 365 -> 572 us, C3 1551 -> 1922, C4 7119 ->
         // 9805, FlightHelmet 1438 -> 1562).
+        // ... or, banded (WavefrontBuffers::bandSegments): batch number b * S + j of the batches of ONE band of tiles, S the
+        // segments that share the band and j this segment's place among them - the same striding inside the band.
+        uint32_t dealStride = w.nSeg, dealFirst = id.seg, tileBase = 0u, tileCount = w.pixelsPadded >> 6;
+        if (w.bandSegments != 0u)
+        {
+            const uint32_t band = id.seg / w.bandSegments;
+            const uint32_t firstSeg = band * w.bandSegments;
+            dealStride = w.nSeg - firstSeg < w.bandSegments ? w.nSeg - firstSeg : w.bandSegments;
+            dealFirst = id.seg - firstSeg;
+            tileBase = w.bandTile[band];
+            tileCount = w.bandTile[band + 1u] - tileBase;
+        }
         for (uint32_t k0 = 0; k0 < w.segLen; k0 += 64u)
         {
             const uint32_t k = k0 + lane;
-            bl = batch_lane(w, p, (k0 >> 6) * w.nSeg + id.seg, lane);
+            bl = batch_lane(w, p, (k0 >> 6) * dealStride + dealFirst, lane, tileBase, tileCount);
             const StreamRay r = fetch(k);
             Hit hit;
             bool found;

@@ -285,7 +285,7 @@ class DebugOptions(C.Structure):
                 ("sahTraversalCost", C.c_float), ("boxPad", C.c_float), ("leafSize", C.c_uint32), ("buildThreads", C.c_uint32),
                 ("topEntries", C.c_uint32), ("nodeOrder", C.c_int32), ("childOrder", C.c_int32), ("buildTiming", C.c_uint32),
                 ("segments", C.c_uint32), ("segmentLength", C.c_uint32), ("chains", C.c_uint32), ("ldsStackEntries", C.c_uint32),
-                ("noLdsScene", C.c_uint32), ("noLdsTables", C.c_uint32), ("traceDeadPaths", C.c_uint32),
+                ("noLdsScene", C.c_uint32), ("noLdsTables", C.c_uint32), ("traceDeadPaths", C.c_uint32), ("bandedBatches", C.c_int32),
                 ("rebuildCostRatio", C.c_float), ("alwaysRebuild", C.c_uint32), ("failNextUpdate", C.c_uint32),
                 ("poolVariant", C.c_uint32), ("rawRecords", C.c_uint32), ("tileOrder", C.c_uint32), ("hipGraph", C.c_uint32),
                 ("pipelinedChains", C.c_uint32), ("mergeLimit", C.c_uint32)]

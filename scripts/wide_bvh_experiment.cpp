@@ -19,6 +19,7 @@
 #include <cstdlib>
 #include <limits>
 #include <numeric>
+#include <string>
 #include <vector>
 
 namespace
@@ -168,6 +169,37 @@ struct WideNode
     uint8_t octantOrder[8][8]; // per ray octant: the children, nearest first along the octant's diagonal
 };
 
+// WIDE_ORDER=axis: what a traversal kernel can afford without a sort or a per-octant table - the children kept sorted by
+// box centre along ONE axis per node (the one their centres spread most along), walked in storage order by a ray that
+// travels in + along it and in reverse by the others (one compare + four selects instead of a five-comparator sort)
+bool gAxisOrder = false;
+void axis_order(WideNode &w)
+{
+    int axis = 0;
+    float bestSpread = -1.0f;
+    for (int a = 0; a < 3; ++a)
+    {
+        float lo = 1e30f, hi = -1e30f;
+        for (int i = 0; i < w.n; ++i)
+        {
+            const float c = 0.5f * (w.box[i].lo[a] + w.box[i].hi[a]);
+            lo = std::min(lo, c);
+            hi = std::max(hi, c);
+        }
+        if (hi - lo > bestSpread)
+        {
+            bestSpread = hi - lo;
+            axis = a;
+        }
+    }
+    uint8_t idx[8] = {0, 1, 2, 3, 4, 5, 6, 7};
+    std::sort(idx, idx + w.n, [&](uint8_t p, uint8_t q) {
+        return w.box[p].lo[axis] + w.box[p].hi[axis] < w.box[q].lo[axis] + w.box[q].hi[axis];
+    });
+    for (int oct = 0; oct < 8; ++oct)
+        for (int i = 0; i < w.n; ++i) w.octantOrder[oct][i] = ((oct >> axis) & 1) ? idx[w.n - 1 - i] : idx[i];
+}
+
 int collapse(int k, int root2, std::vector<WideNode> &out)
 {
     const int self = (int)out.size();
@@ -207,6 +239,7 @@ int collapse(int k, int root2, std::vector<WideNode> &out)
         std::sort(idx, idx + w.n, [&](uint8_t p, uint8_t q) { return key[p] < key[q]; });
         for (int i = 0; i < 8; ++i) w.octantOrder[oct][i] = idx[i];
     }
+    if (gAxisOrder) axis_order(w);
     out[self] = w;
     for (int i = 0; i < (int)kids.size(); ++i)
     {
@@ -329,6 +362,7 @@ int dp_collapse(int k, int n, std::vector<WideNode> &out)
         std::sort(idx, idx + w.n, [&](uint8_t p, uint8_t q) { return key[p] < key[q]; });
         for (int i = 0; i < 8; ++i) w.octantOrder[oct][i] = idx[i];
     }
+    if (gAxisOrder) axis_order(w);
     out[self] = w;
     for (int i = 0; i < (int)kids.size(); ++i)
     {
@@ -541,6 +575,7 @@ int main(int argc, char **argv)
     }
 
     if (const char *v = std::getenv("WIDE_TRI_COST")) gTriCost = std::atof(v);
+    if (const char *v = std::getenv("WIDE_ORDER")) gAxisOrder = std::string(v) == "axis";
     for (int optimal = 0; optimal < 2; ++optimal)
     {
         gFullDepth = optimal != 0 && !std::getenv("WIDE_KEEP_LEAVES"); // WIDE_KEEP_LEAVES: the optimal collapse over the SAH-terminated tree

@@ -13,14 +13,18 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
-def _has_experiments():
+@pytest.fixture
+def _experiments_only():
+    """Tests of the measured-slower variants: they exist only in libprosper_pt_experiments.so (make EXPERIMENTS=1; run the
+    suite with PROSPER_PT_LIB=prosper_amd/libprosper_pt_experiments.so).  Decided when the test runs, not at import: the
+    library must not be loaded before the test modules are collected (one of them imports torch, which brings its own
+    copy of the HIP runtime; whichever loads first is the one the process uses)."""
     from prosper_amd import capi
-    return os.path.exists(capi.LIB_PATH) and capi.has_experiments()
+    if not capi.has_experiments():
+        pytest.skip("library built without -DPPT_EXPERIMENTS")
 
 
-# tests of the measured-slower variants: they exist only in libprosper_pt_experiments.so (make EXPERIMENTS=1; run the suite
-# with PROSPER_PT_LIB=prosper_amd/libprosper_pt_experiments.so)
-needs_experiments = pytest.mark.skipif(not _has_experiments(), reason="library built without -DPPT_EXPERIMENTS")
+needs_experiments = pytest.mark.usefixtures("_experiments_only")
 
 
 @pytest.fixture(autouse=True)

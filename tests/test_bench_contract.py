@@ -39,15 +39,15 @@ def test_slim_line_of_a_full_result_stays_under_4_kb():
 
 
 @pytest.mark.gpu
-def test_bench_json_line_has_the_contract_fields():
-    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--config", "c1", "--steps", "5", "--warmup", "2"],
-                         capture_output=True, text=True, timeout=600, cwd=ROOT)
+def test_bench_json_line_has_the_contract_fields(tmp_path):
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--config", "c1", "--steps", "5", "--warmup", "2",
+                          "--detail", str(tmp_path / "detail.json")], capture_output=True, text=True, timeout=600, cwd=ROOT)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [l for l in out.stdout.splitlines() if l.strip()]
     assert len(lines) == 1, "exactly one line on stdout"
     assert len(lines[0]) < 4096, "the line must fit every tail the driver keeps"
     d = json.loads(lines[0])
-    detail = json.load(open(os.path.join(ROOT, d["detail"])))
+    detail = json.load(open(d["detail"]))
     assert detail["value"] == pytest.approx(d["value"], rel=1e-4) and "kernels" in detail and "counters" in detail
     for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
                 "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
@@ -88,7 +88,7 @@ def test_bench_json_line_has_the_contract_fields():
 
 
 @pytest.mark.gpu
-def test_plain_invocation_with_several_gpus_starts_its_own_ranks():
+def test_plain_invocation_with_several_gpus_starts_its_own_ranks(tmp_path):
     """`python bench.py --gpus 2` with no launcher and no WORLD_SIZE: the parent starts torch.distributed.run as a child
     process before anything touches the GPU and relays rank 0's line.  On a one-GPU box the two ranks share GPU 0
     (PROSPER_BENCH_REHEARSE=1: tiles through host memory over gloo, the product's de-interleave kernel on the root) -
@@ -96,7 +96,8 @@ def test_plain_invocation_with_several_gpus_starts_its_own_ranks():
     env = dict(os.environ, PROSPER_BENCH_REHEARSE="1")
     for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
-    common = ["--config", "c1", "--steps", "3", "--warmup", "1", "--no-pmc", "--no-cpu-baseline", "--no-subconfigs", "--no-extras"]
+    common = ["--config", "c1", "--steps", "3", "--warmup", "1", "--no-pmc", "--no-cpu-baseline", "--no-subconfigs", "--no-extras",
+              "--detail", str(tmp_path / "detail.json")]
     one = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + common, capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
     assert one.returncode == 0, one.stderr[-2000:]
     two = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"] + common, capture_output=True, text=True,

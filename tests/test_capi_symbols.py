@@ -62,8 +62,9 @@ def test_debug_options_struct_matches_the_binding():
     o = S.DebugOptions()
     capi.lib().prosper_pt_debug_options_default(C.byref(o))
     assert o.struct_size == C.sizeof(S.DebugOptions)
-    assert (o.batchedTextures, o.widePacks, o.alphaCellShift, o.nodeOrder, o.childOrder) == (-1, -1, -1, -1, -1)
-    others = [n for n, _ in S.DebugOptions._fields_ if n not in ("struct_size", "batchedTextures", "widePacks", "alphaCellShift", "nodeOrder", "childOrder")]
+    signed = ("batchedTextures", "widePacks", "alphaCellShift", "nodeOrder", "childOrder", "bandedBatches")
+    assert all(getattr(o, n) == -1 for n in signed)
+    others = [n for n, _ in S.DebugOptions._fields_ if n not in ("struct_size",) + signed]
     assert all(getattr(o, n) == 0 for n in others)
     # every field of the header's struct, in order
     text = open(os.path.join(ROOT, "include", "prosper_pt", "prosper_pt.h")).read()

@@ -772,6 +772,38 @@ def test_raw_shading_records_equal_decoded_ones(gpu_ctx, oracle, sponza_small):
         assert same_bits(images["1"][0], want).all()
 
 
+def test_banded_batches_give_the_same_pixels(gpu_ctx, oracle, sponza_small):
+    """Debug option bandedBatches (default: by scene size): every XCD's segments take the camera-ray batches of one band of
+    the image instead of batches strided over all of it (pt_wavefront.hip, WavefrontBuffers::bandSegments).  Which segment
+    a path lives in never decides a pixel: the same bits with and without, in order and with frames in flight, for frame
+    counts that are not powers of two, for a rank's stripes, for an image smaller than a band, and equal to the oracle."""
+    from prosper_amd import tiling
+    cases = ((640, 360, 8, None), (200, 120, 5, None), (256, 144, 3, tiling.tile_for_rank(1, 2)), (72, 40, 70, None), (1920, 1080, 2, None))
+    gpu_ctx.upload_scene(sponza_small)
+    for w, h, frames, tile in cases:
+        cam, fl = _camera(oracle, sponza_small, w, h)
+        pc = default_pc(S, fl, max_bounces=3, ibl=True)
+        images = []
+        for banded in (0, 1):
+            capi.debug(bandedBatches=banded)
+            for flags in (0, S.RENDER_PIPELINED, S.RENDER_PIPELINED):
+                gpu_ctx.render(pc, cam, w, h, tile=tile, frames=frames, flags=flags)
+                images.append(gpu_ctx.read_hdr())
+        capi.debug(bandedBatches=None)
+        for other in images[1:]:
+            assert same_bits(images[0], other).all(), (w, h, frames)
+        assert (images[0][..., 3] == frames).all()
+    w, h, frames, tile = cases[1]
+    cam, fl = _camera(oracle, sponza_small, w, h)
+    osc = oracle.OracleScene(sponza_small)
+    want = None
+    for f in range(frames):
+        want, _ = osc.render(default_pc(S, fl, frame_index=1 + f, max_bounces=3, ibl=True, skip_history=(f == 0)), cam, w, h, history=want)
+    capi.debug(bandedBatches=1)
+    gpu_ctx.render(default_pc(S, fl, max_bounces=3, ibl=True), cam, w, h, frames=frames, flags=S.RENDER_PIPELINED)
+    assert same_bits(gpu_ctx.read_hdr(), want).all()
+
+
 @needs_experiments
 def test_tiles_dealt_by_cost_give_the_same_pixels(gpu_ctx, oracle):
     """debug option tileOrder (an experiment, profiles/r03_tile_order.txt): the camera-ray batches take the tiles by
@@ -1345,7 +1377,7 @@ def test_zero_throughput_rule_does_not_change_the_image(gpu_ctx, oracle, sponza_
         w, h = 480, 270
         cam, fl = _camera(oracle, world, w, h)
         pc = default_pc(S, fl, **kw)
-        for create in (0, S.CREATE_MEGAKERNEL, S.CREATE_PERSISTENT):
+        for create in (0, S.CREATE_MEGAKERNEL) + ((S.CREATE_PERSISTENT,) if capi.has_experiments() else ()):
             ctx = capi.Context(device=0, flags=create)
             try:
                 ctx.upload_scene(world)
