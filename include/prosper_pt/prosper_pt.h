@@ -13,6 +13,8 @@
  *                                     and the descriptor sets the pass binds       RtReference.cpp:238-274
  *   prosper_pt_update_lights          lights ring write                            World.cpp:531-535
  *   prosper_pt_update_transforms      instance transforms + TLAS rebuild           World.cpp:359-466,749-802,878-928
+ *   prosper_pt_update_textures /      adoption of streamed-in images / materials   src/scene/WorldData.cpp:568-647,2182-2239
+ *   prosper_pt_update_materials
  *   prosper_pt_render                 pushConstants + traceRaysKHR                 RtReference.cpp:278-330
  *                                     + the previous/illumination ping-pong        RtReference.cpp:178-219,332-334
  *   prosper_pt_read_hdr               the RGBA32F "rtIllumination" image           RtReference.cpp:178-187
@@ -355,6 +357,25 @@ enum
 };
 int prosper_pt_update_transforms_async(
     prosper_pt_ctx *ctx, const prosper_ModelInstanceTransforms *transforms, uint32_t count, uint32_t flags, void *stream);
+/* ---- incremental adoption: streamed-in textures and materials ----
+ * prosper loads a scene in the background and adopts what has arrived a few items per frame: new images get their slot in
+ * materialTextures[] (src/scene/WorldData.cpp:2182-2206), a material switches from its placeholder - the default material
+ * with the real alpha mode (WorldData.cpp:817-826) - to the real one once its three images are there (:2208-2239), and the
+ * next frame's material buffer is rewritten when that happened (:568-586; App.cpp:526-529, 601).  No acceleration structure
+ * is touched.  Upload the scene with placeholder textures (1 x 1 texels will do) and placeholder materials, then:
+ *   prosper_pt_update_textures   replaces the texels of materialTextures[first .. first + count) (any extent / format);
+ *                                the caller's memory is borrowed for the call only.  Materials that sample a replaced
+ *                                texture get their texture pack and alpha bounds rebuilt.
+ *   prosper_pt_update_materials  replaces MaterialData[first .. first + count); an unchanged entry costs a memcmp (prosper
+ *                                rewrites the whole table).  A material's alpha mode must be the one it was uploaded with:
+ *                                it decides the opaque flag of the geometry (World.cpp:646-651).
+ * Both only stage: the copies, re-tiling / BC7 decode, packs and alpha bounds run on a stream the context owns, and the next
+ * render switches to a new version of the material / texture tables at the head of its own chain of launches, like
+ * prosper_pt_update_transforms - the frames in flight (PROSPER_PT_RENDER_PIPELINED) keep reading theirs.  (One exception: a
+ * changed MASK / BLEND material rewrites the any-hit records in place, behind the frames in flight.)  Every frame shows the
+ * scene a fresh prosper_pt_upload_scene of that state would show, bit for bit. */
+int prosper_pt_update_textures(prosper_pt_ctx *ctx, const prosper_pt_texture_desc *textures, uint32_t first, uint32_t count);
+int prosper_pt_update_materials(prosper_pt_ctx *ctx, const prosper_MaterialData *materials, uint32_t first, uint32_t count);
 /* Re-splits the instances that moved since the last build and re-assembles the tree on the host (one subtree per model
  * instance under a re-braided top level); synchronises the device.  prosper_pt_scene_stats.bvhBuildSeconds reports it. */
 int prosper_pt_rebuild_hierarchy(prosper_pt_ctx *ctx);

@@ -58,6 +58,8 @@ def lib():
     L.prosper_pt_update_lights.argtypes = [
         vp, C.POINTER(S.DirectionalLightParameters), C.POINTER(S.PointLightsBuffer), C.POINTER(S.SpotLightsBuffer)]
     L.prosper_pt_get_scene_stats.argtypes = [vp, C.POINTER(S.SceneStats)]
+    L.prosper_pt_update_textures.argtypes = [vp, vp, u32, u32]
+    L.prosper_pt_update_materials.argtypes = [vp, vp, u32, u32]
     L.prosper_pt_update_transforms.argtypes = [vp, vp, u32]
     L.prosper_pt_update_transforms_async.argtypes = [vp, vp, u32, u32, vp]
     L.prosper_pt_rebuild_hierarchy.argtypes = [vp]
@@ -277,6 +279,26 @@ class Context:
         _check(lib().prosper_pt_update_transforms_async(self._h, C.cast(t, C.c_void_p), len(world.model_instances),
                                                          S.UPDATE_NOW if now else 0, C.c_void_p(stream)))
         self._world = world
+
+    def update_textures(self, textures, first):
+        """Replaces materialTextures[first .. first + len(textures)): numpy [h, w, 4] uint8 arrays or world.Bc7Texture."""
+        self._sync_debug()
+        descs = (S.TextureDesc * len(textures))()
+        keep = []
+        for i, t in enumerate(textures):
+            if hasattr(t, "blocks"):
+                descs[i].texels, descs[i].width, descs[i].height, descs[i].format = t.blocks.ctypes.data, t.width, t.height, S.FORMAT_BC7_UNORM
+                continue
+            a = np.ascontiguousarray(t, np.uint8)
+            keep.append(a)
+            descs[i].texels, descs[i].width, descs[i].height, descs[i].format = a.ctypes.data, a.shape[1], a.shape[0], S.FORMAT_RGBA8_UNORM
+        _check(lib().prosper_pt_update_textures(self._h, C.cast(descs, C.c_void_p), first, len(textures)))
+
+    def update_materials(self, materials, first):
+        """Replaces MaterialData[first .. first + len(materials)) (structs.MaterialData)."""
+        self._sync_debug()
+        arr = (S.MaterialData * len(materials))(*materials)
+        _check(lib().prosper_pt_update_materials(self._h, C.cast(arr, C.c_void_p), first, len(materials)))
 
     def rebuild_hierarchy(self):
         self._sync_debug()

@@ -23,6 +23,7 @@
 #include "bvh_build.hpp"
 #include "pt_context.hpp"
 #include "pt_kernels.hpp"
+#include "pt_materials.hpp"
 #include "pt_scene.hpp"
 #include "pt_tiling.hpp"
 
@@ -41,7 +42,7 @@ int fail(int code, const std::string &msg)
 using RenderSlot = prosper_pt_ctx::RenderSlot;
 constexpr uint32_t kStageChains = 4; // unnamed interval of the caller's stream: fork .. join of the chains
 
-namespace
+namespace ppt
 {
 
 int device_alloc(prosper_pt_ctx *ctx, size_t bytes, void **out)
@@ -67,6 +68,19 @@ void device_free(prosper_pt_ctx *ctx, const void *p)
             return;
         }
 }
+
+int upload(prosper_pt_ctx *ctx, const void *src, size_t bytes, void **out)
+{
+    const int rc = device_alloc(ctx, bytes, out);
+    if (rc != PROSPER_PT_OK) return rc;
+    if (bytes) PPT_HIP(hipMemcpy(*out, src, bytes, hipMemcpyHostToDevice));
+    return PROSPER_PT_OK;
+}
+
+} // namespace ppt
+
+namespace
+{
 
 // the context's debug options as the builder and the wavefront launcher take them
 BvhBuildOptions build_options(const prosper_pt_ctx *ctx)
@@ -95,14 +109,6 @@ WavefrontOptions wavefront_options(const prosper_pt_ctx *ctx)
     return o;
 }
 
-int upload(prosper_pt_ctx *ctx, const void *src, size_t bytes, void **out)
-{
-    const int rc = device_alloc(ctx, bytes, out);
-    if (rc != PROSPER_PT_OK) return rc;
-    if (bytes) PPT_HIP(hipMemcpy(*out, src, bytes, hipMemcpyHostToDevice));
-    return PROSPER_PT_OK;
-}
-
 void free_scene(prosper_pt_ctx *ctx)
 {
     for (auto &a : ctx->sceneAllocations) (void)hipFree(a.ptr);
@@ -111,6 +117,8 @@ void free_scene(prosper_pt_ctx *ctx)
     ctx->accel = nullptr;
     delete ctx->lights;
     ctx->lights = nullptr;
+    delete ctx->materialState;
+    ctx->materialState = nullptr;
     ctx->dTransforms = nullptr;
     ctx->sceneBytes = 0;
     ctx->haveScene = false;
@@ -358,7 +366,7 @@ int upload_hierarchy(prosper_pt_ctx *ctx, const BvhBuildResult &bvh)
 int upload_scene_impl(prosper_pt_ctx *ctx, const prosper_pt_scene_view *v)
 {
     DeviceScene &s = ctx->scene;
-    int rc;
+    int rc = PROSPER_PT_OK;
     const auto tUpload = std::chrono::steady_clock::now();
     auto seconds_since = [](std::chrono::steady_clock::time_point t) {
         return std::chrono::duration<double>(std::chrono::steady_clock::now() - t).count();
@@ -486,95 +494,61 @@ int upload_scene_impl(prosper_pt_ctx *ctx, const prosper_pt_scene_view *v)
         return out;
     });
 
-    // textures: one allocation each (256-B aligned by hipMalloc), re-laid out in 8x4-texel tiles of one
-    // cache line each (pt_scene.hpp DeviceTexture), + descriptor table
+    // textures: one allocation each (256-B aligned by hipMalloc), re-laid out in 8x4-texel tiles of one cache line each
+    // (pt_scene.hpp DeviceTexture) by a kernel - until round 4 the host did that a texel at a time, 40 ms for
+    // S-sponza-class - + descriptor table.  The tables a later prosper_pt_update_textures / _materials changes are mirrored
+    // in ctx->materialState (pt_materials.cpp).
     const auto tTextures = std::chrono::steady_clock::now();
-    std::vector<DeviceTexture> textures(v->textureCount ? v->textureCount : 1);
-    std::vector<uint32_t> tiled;
+    MaterialState *ms = new (std::nothrow) MaterialState();
+    if (!ms) return fail(PROSPER_PT_ERR_INVALID_ARGUMENT, "out of host memory");
+    ctx->materialState = ms;
+    ms->materials.assign(v->materials, v->materials + v->materialCount);
+    ms->samplers.assign(v->samplers, v->samplers + v->samplerCount);
+    std::vector<DeviceTexture> &textures = ms->textures;
+    textures.assign(v->textureCount ? v->textureCount : 1, DeviceTexture{nullptr, 0u, 0u, 0u, 0u});
     uint64_t texelBytes = 0;
-    for (uint32_t i = 0; i < v->textureCount; ++i)
     {
-        const prosper_pt_texture_desc &t = v->textures[i];
-        const uint32_t tilesX = (t.width + kTexTileW - 1u) / kTexTileW, tilesY = (t.height + kTexTileH - 1u) / kTexTileH;
-        texelBytes += (uint64_t)t.width * t.height * 4u;
-        if (t.format == PROSPER_PT_FORMAT_BC7_UNORM)
+        size_t stagingBytes = 0;
+        for (uint32_t i = 0; i < v->textureCount; ++i) stagingBytes = std::max(stagingBytes, texture_staging_bytes(v->textures[i]));
+        void *staging = nullptr;
+        if (stagingBytes) PPT_HIP(hipMalloc(&staging, stagingBytes));
+        for (uint32_t i = 0; i < v->textureCount && rc == PROSPER_PT_OK; ++i)
         {
-            // the blocks go up as they are and a kernel decodes them into the tiles (pt_bc7.hpp)
-            const size_t blockBytes = (size_t)(t.width / 4u) * (t.height / 4u) * 16u;
-            void *dBlocks = nullptr;
-            PPT_HIP(hipMalloc(&dBlocks, blockBytes));
-            hipError_t e = hipMemcpy(dBlocks, t.texels, blockBytes, hipMemcpyHostToDevice);
-            if (e == hipSuccess && (rc = device_alloc(ctx, (size_t)tilesX * tilesY * (kTexTileW * kTexTileH) * 4u, &d)) == PROSPER_PT_OK)
-            {
-                e = hipMemset(d, 0, (size_t)tilesX * tilesY * (kTexTileW * kTexTileH) * 4u);
-                if (e == hipSuccess)
-                {
-                    launch_decode_bc7(dBlocks, t.width, t.height, tilesX, d, nullptr);
-                    e = hipDeviceSynchronize();
-                }
-            }
-            (void)hipFree(dBlocks);
-            if (rc != PROSPER_PT_OK) return rc;
-            PPT_HIP(e);
-            textures[i] = DeviceTexture{static_cast<const uint8_t *>(d), t.width, t.height, tilesX, 0u};
-            continue;
+            texelBytes += (uint64_t)v->textures[i].width * v->textures[i].height * 4u;
+            // (one staging area, one stream: the copy of texture i + 1 queues behind the kernel that reads texture i)
+            rc = create_device_texture(ctx, v->textures[i], staging, nullptr, &textures[i]);
         }
-        tiled.assign((size_t)tilesX * tilesY * (kTexTileW * kTexTileH), 0u);
-        const uint32_t *src = static_cast<const uint32_t *>(t.texels);
-        for (uint32_t y = 0; y < t.height; ++y)
-        {
-            const uint32_t *row = src + (size_t)y * t.width;
-            uint32_t *dstRow = tiled.data() + (size_t)(y >> 2) * tilesX * 32u + ((y & 3u) << 3);
-            for (uint32_t x = 0; x < t.width; ++x) dstRow[(size_t)(x >> 3) * 32u + (x & 7u)] = row[x];
-        }
-        if ((rc = upload(ctx, tiled.data(), tiled.size() * 4u, &d))) return rc;
-        textures[i] = DeviceTexture{static_cast<const uint8_t *>(d), t.width, t.height, tilesX, 0u};
+        const hipError_t e = hipDeviceSynchronize();
+        if (staging) (void)hipFree(staging);
+        if (rc != PROSPER_PT_OK) return rc;
+        PPT_HIP(e);
     }
+    ms->texelBytes = texelBytes;
     // beyond the 8 x 4 MB of L2 the texels of a hit come from the Infinity Cache or HBM: overlap their fetches
     // (debug option batchedTextures = 0 / 1 forces either path: same pixels, tested)
-    s.batchedTextures = texelBytes > (32ull << 20) ? 1u : 0u;
+    s.batchedTextures = texel_set_is_big(texelBytes) ? 1u : 0u;
     if (ctx->debug.batchedTextures >= 0) s.batchedTextures = ctx->debug.batchedTextures ? 1u : 0u;
     // material texture packs (pt_scene.hpp MaterialPack): base / MR / normal interleaved per texel where a material's
     // three textures share extent and sampler.  Debug option noTexturePacks keeps every material unpacked.
-    std::vector<MaterialPack> packs(v->materialCount);
-    uint32_t packedMaterials = 0;
-    const bool noPacks = ctx->debug.noTexturePacks != 0;
-    // compact packs where the texels outgrow the caches (the threshold of the batched loads above): on a small texture set
+    // Compact packs where the texels outgrow the caches (the threshold of the batched loads above): on a small texture set
     // the bytes are not what the shade kernel waits for, and two kinds of pack in one wave cost a divergent branch
     // (FlightHelmet fixture: +1 % on the step).  Debug option widePacks = 1 / 0 forces the 16-byte / the compact pack.
-    bool widePacks = texelBytes <= (32ull << 20);
+    std::vector<MaterialPack> &packs = ms->packs;
+    packs.assign(v->materialCount, MaterialPack{nullptr, 0u, 0u, 0u, 0u});
+    uint32_t packedMaterials = 0;
+    bool widePacks = !texel_set_is_big(texelBytes);
     if (ctx->debug.widePacks >= 0) widePacks = ctx->debug.widePacks != 0;
     for (uint32_t i = 0; i < v->materialCount; ++i)
     {
-        packs[i] = MaterialPack{nullptr, 0u, 0u, 0u, 0u};
-        const prosper_MaterialData &m = v->materials[i];
-        const uint32_t tb = m.baseColorTextureSampler & 0xFFFFFFu, tm = m.metallicRoughnessTextureSampler & 0xFFFFFFu,
-                       tn = m.normalTextureSampler & 0xFFFFFFu;
-        const uint32_t sb = m.baseColorTextureSampler >> 24, sm = m.metallicRoughnessTextureSampler >> 24,
-                       sn = m.normalTextureSampler >> 24;
-        if (noPacks || tb == 0 || tm == 0 || tn == 0 || sb != sm || sb != sn) continue;
-        const DeviceTexture &b = textures[tb], &r = textures[tm], &n = textures[tn];
-        if (b.width != r.width || b.width != n.width || b.height != r.height || b.height != n.height) continue;
-        if (b.width < 8u || b.height < 8u) continue; // tiny placeholder textures: nothing to gain
-        MaterialPack pk;
-        pk.width = b.width;
-        pk.height = b.height;
-        pk.tilesPerRow = (b.width + kPackTileW - 1u) / kPackTileW;
-        // an OPAQUE material never reads base.a: the 8-byte texel
-        const bool compact = m.alphaMode == PROSPER_ALPHA_MODE_OPAQUE && !widePacks;
-        pk.sampler = sb | (compact ? kPackCompactBit : 0u);
-        const size_t texelCount = (size_t)pk.tilesPerRow * kPackTileW * (((size_t)b.height + kPackTileH - 1u) / kPackTileH) * kPackTileH;
-        if ((rc = device_alloc(ctx, texelCount * (compact ? sizeof(uint2) : sizeof(uint4)), &d))) return rc;
-        pk.texels = d;
-        launch_pack_material_textures(b, r, n, pk, nullptr);
-        packs[i] = pk;
-        ++packedMaterials;
+        if ((rc = build_material_pack(ctx, v->materials[i], textures, ctx->debug.noTexturePacks != 0, widePacks, nullptr, &packs[i]))) return rc;
+        packedMaterials += packs[i].texels ? 1u : 0u;
     }
     PPT_HIP(hipGetLastError());
     PPT_HIP(hipDeviceSynchronize());
     if ((rc = upload(ctx, packs.data(), packs.size() * sizeof(MaterialPack), &d))) return rc;
     s.materialPacks = static_cast<const MaterialPack *>(d);
     ctx->packedMaterials = packedMaterials;
+    ms->packedMaterials = packedMaterials;
     // A texture that only packed materials use is never sampled by itself again (sample_material takes the pack): its
     // own copy goes - half of a packed scene's texel memory.  What keeps a texture: an unpacked material, or the any-hit
     // of a MASK / BLEND material, which reads the base colour's alpha out of the texture itself.
@@ -590,8 +564,16 @@ int upload_scene_impl(prosper_pt_ctx *ctx, const prosper_pt_scene_view *v)
                 for (uint32_t t : t3) needed[t] = 1;
             if (m.alphaMode != PROSPER_ALPHA_MODE_OPAQUE) needed[t3[0]] = 1;
         }
+        // (a texture no material samples yet stays: it is what a streamed-in material will point at)
+        std::vector<uint8_t> sampled(textures.size(), 0);
+        for (uint32_t i = 0; i < v->materialCount; ++i)
+        {
+            const prosper_MaterialData &m = v->materials[i];
+            sampled[m.baseColorTextureSampler & 0xFFFFFFu] = sampled[m.metallicRoughnessTextureSampler & 0xFFFFFFu] =
+                sampled[m.normalTextureSampler & 0xFFFFFFu] = 1;
+        }
         for (uint32_t i = 1; i < v->textureCount; ++i)
-            if (!needed[i] && textures[i].texels)
+            if (!needed[i] && sampled[i] && textures[i].texels)
             {
                 device_free(ctx, textures[i].texels);
                 textures[i].texels = nullptr;
@@ -651,51 +633,27 @@ int upload_scene_impl(prosper_pt_ctx *ctx, const prosper_pt_scene_view *v)
     {
         if ((rc = device_alloc(ctx, sizeof(AlphaTriangle) * (size_t)(alphaTotal ? alphaTotal : 1), &d))) return rc;
         s.alphaTriangles = static_cast<const AlphaTriangle *>(d);
-        const bool noBounds = ctx->debug.noAlphaBounds != 0;
-        const int32_t forcedCell = ctx->debug.alphaCellShift;
-        std::vector<AlphaMaterial> alphaMaterials(v->materialCount ? v->materialCount : 1);
+        std::vector<AlphaMaterial> &alphaMaterials = ms->alphaMaterials;
+        alphaMaterials.assign(v->materialCount ? v->materialCount : 1, AlphaMaterial{});
         uint64_t boundBytes = 0;
         for (uint32_t i = 0; i < v->materialCount; ++i)
         {
-            const prosper_MaterialData &m = v->materials[i];
-            AlphaMaterial am{};
-            am.factorA = m.baseColorFactor.w;
-            am.cutoff = m.alphaCutoff;
-            am.bits = m.alphaMode & 3u;
-            const uint32_t tex = m.baseColorTextureSampler & 0xFFFFFFu;
-            if (m.alphaMode != PROSPER_ALPHA_MODE_OPAQUE && tex != 0)
-            {
-                const DeviceTexture &t = textures[tex];
-                const prosper_pt_sampler_desc &sd = v->samplers[m.baseColorTextureSampler >> 24];
-                if (t.width > 0xFFFFu || t.height > 0xFFFFu)
-                    return fail(PROSPER_PT_ERR_UNSUPPORTED, "base-colour texture of a MASK / BLEND material exceeds 65535 texels a side");
-                am.texels = t.texels;
-                am.width = (uint16_t)t.width;
-                am.height = (uint16_t)t.height;
-                am.bits |= (sd.wrapS & 3u) << 2 | (sd.wrapT & 3u) << 4 | (sd.magFilter == PROSPER_PT_FILTER_NEAREST ? 64u : 0u);
-                // cells of 2 x 2 texels: the table is an eighth of the texture (8 KB for 128^2: it lives in the L1 / L2
-                // the texels would have been read through); coarser for textures whose table would pass 2 MB
-                uint32_t shift = 1;
-                while (((uint64_t)(t.width >> shift) + 1u) * ((t.height >> shift) + 1u) * 2u > (2ull << 20)) ++shift;
-                if (forcedCell >= 0) shift = (uint32_t)std::min(15, forcedCell);
-                const bool factorOk = std::isfinite(m.baseColorFactor.w) && m.baseColorFactor.w >= 0.0f;
-                if (!noBounds && factorOk)
-                {
-                    const uint32_t cellsX = (t.width + (1u << shift) - 1u) >> shift, cellsY = (t.height + (1u << shift) - 1u) >> shift;
-                    if ((rc = device_alloc(ctx, (size_t)cellsX * cellsY * 2u, &d))) return rc;
-                    launch_build_alpha_bounds(t, sd.wrapS, sd.wrapT, m.baseColorFactor.w, shift, static_cast<uint16_t *>(d), nullptr);
-                    am.bounds = static_cast<const uint16_t *>(d);
-                    am.bits |= shift << 8;
-                    boundBytes += (uint64_t)cellsX * cellsY * 2u;
-                }
-            }
-            alphaMaterials[i] = am;
+            uint64_t bytes = 0;
+            if ((rc = build_alpha_material(ctx, v->materials[i], textures, ms->samplers, nullptr, &alphaMaterials[i], &bytes))) return rc;
+            boundBytes += bytes;
         }
         PPT_HIP(hipGetLastError());
         if ((rc = upload(ctx, alphaMaterials.data(), alphaMaterials.size() * sizeof(AlphaMaterial), &d))) return rc;
         s.alphaMaterials = static_cast<const AlphaMaterial *>(d);
         ctx->alphaTriangleCount = alphaTotal;
         ctx->alphaBoundBytes = boundBytes;
+        ms->alphaBoundBytes = boundBytes;
+        // layout of the table block of a later version (pt_materials.cpp flush_pending_materials)
+        auto align16 = [](size_t n) { return (n + 15u) & ~(size_t)15u; };
+        ms->packsOffset = align16(ms->materials.size() * sizeof(prosper_MaterialData));
+        ms->alphaOffset = ms->packsOffset + align16(ms->packs.size() * sizeof(MaterialPack));
+        ms->texturesOffset = ms->alphaOffset + align16(ms->alphaMaterials.size() * sizeof(AlphaMaterial));
+        ms->blockBytes = ms->texturesOffset + align16(ms->textures.size() * sizeof(DeviceTexture));
     }
 
     if ((rc = device_alloc(ctx, (size_t)(total ? total : 1) * 4, &d))) return rc;
@@ -1580,6 +1538,11 @@ static int mark_versions_read(prosper_pt_ctx *ctx, hipStream_t s)
         const int rc = mark(ls->versionFree[ls->cur], ls->versionUsed[ls->cur], ls->versionStream[ls->cur]);
         if (rc != PROSPER_PT_OK) return rc;
     }
+    if (MaterialState *ms = ctx->materialState)
+    {
+        const int rc = mark(ms->versionFree[ms->cur], ms->versionUsed[ms->cur], ms->versionStream[ms->cur]);
+        if (rc != PROSPER_PT_OK) return rc;
+    }
     return PROSPER_PT_OK;
 }
 
@@ -1676,8 +1639,10 @@ int prosper_pt_render_frames(
         hipStream_t us = wavefrontPipelined ? ctx->workStreams[nextSlot] : s;
         int frc = flush_pending_update(ctx, us);
         if (frc == PROSPER_PT_OK) frc = flush_pending_lights(ctx, us);
+        if (frc == PROSPER_PT_OK) frc = flush_pending_materials(ctx, us);
         if (frc != PROSPER_PT_OK) return frc;
         if (ctx->lights && ctx->lights->readyRecorded) PPT_HIP(hipStreamWaitEvent(s, ctx->lights->ready, 0));
+        if (ctx->materialState && ctx->materialState->readyRecorded) PPT_HIP(hipStreamWaitEvent(s, ctx->materialState->ready, 0));
         // a refit enqueued on another stream (another render's chain, or prosper_pt_update_transforms_async) must be
         // done before anything on the caller's stream reads the scene
         if (ctx->accel && ctx->accel->sceneEventRecorded) PPT_HIP(hipStreamWaitEvent(s, ctx->accel->sceneEvent, 0));
@@ -1824,6 +1789,7 @@ int prosper_pt_render_frames(
             chains.after = slot.freeRecorded ? slot.free : nullptr;
             chains.scene = (ctx->accel && ctx->accel->sceneEventRecorded) ? ctx->accel->sceneEvent : nullptr;
             chains.lights = (ctx->lights && ctx->lights->readyRecorded) ? ctx->lights->ready : nullptr;
+            chains.materials = (ctx->materialState && ctx->materialState->readyRecorded) ? ctx->materialState->ready : nullptr;
             if (!pipelined) wait_for_slot(slot, s);
             if (tp) tp->mark(kStageChains, s);
             launch_render_wavefront(
@@ -1920,7 +1886,9 @@ int prosper_pt_restir_di_trace(
     {
         int frc = flush_pending_update(ctx, s);
         if (frc == PROSPER_PT_OK) frc = flush_pending_lights(ctx, s);
+        if (frc == PROSPER_PT_OK) frc = flush_pending_materials(ctx, s);
         if (frc != PROSPER_PT_OK) return frc;
+        if (ctx->materialState && ctx->materialState->readyRecorded) PPT_HIP(hipStreamWaitEvent(s, ctx->materialState->ready, 0));
         if (ctx->accel && ctx->accel->sceneEventRecorded) PPT_HIP(hipStreamWaitEvent(s, ctx->accel->sceneEvent, 0));
         if (ctx->lights && ctx->lights->readyRecorded) PPT_HIP(hipStreamWaitEvent(s, ctx->lights->ready, 0));
     }

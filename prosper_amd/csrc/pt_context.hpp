@@ -151,8 +151,69 @@ struct AccelState
     }
 };
 
+// The tables a streamed-in texture or material changes (prosper adopts loaded textures and materials a few per frame:
+// src/scene/WorldData.cpp:588-647, 2182-2239; the material buffer is re-uploaded when materialsGeneration moves, :568-586):
+// MaterialData[], MaterialPack[], AlphaMaterial[], DeviceTexture[] as ONE device block per version.  Version 0 is what
+// prosper_pt_upload_scene made (four allocations of their own, never rewritten); prosper_pt_update_textures / _materials
+// change the host mirrors, build the new texel arrays / packs / alpha bounds on `uploadStream`, and the next render copies
+// the tables into the next of three rotating blocks at the head of its own chain of launches - the frames in flight keep
+// reading theirs (pt_materials.cpp).  Replaced texel arrays stay allocated until the scene goes: a frame in flight may
+// still read them, and a streamed scene replaces each placeholder once.
+struct MaterialState
+{
+    static constexpr uint32_t kVersions = 4; // 0: the upload's tables; 1..3: rotating blocks
+    std::vector<prosper_MaterialData> materials;
+    std::vector<MaterialPack> packs;
+    std::vector<AlphaMaterial> alphaMaterials;
+    std::vector<DeviceTexture> textures;
+    std::vector<prosper_pt_sampler_desc> samplers;
+    uint64_t texelBytes = 0;       // level-0 texel footprint of the textures as the caller gave them (4 B per texel)
+    uint64_t alphaBoundBytes = 0;
+    uint32_t packedMaterials = 0;
+    // device side
+    uint8_t *dBlocks[kVersions] = {};
+    size_t blockBytes = 0, packsOffset = 0, alphaOffset = 0, texturesOffset = 0;
+    hipEvent_t versionFree[kVersions] = {};
+    bool versionUsed[kVersions] = {};
+    hipStream_t versionStream[kVersions] = {};
+    uint32_t cur = 0;
+    uint8_t *staging[2] = {nullptr, nullptr}; // pinned images of the block
+    hipEvent_t stagingDone[2] = {nullptr, nullptr};
+    bool stagingUsed[2] = {false, false};
+    uint32_t stagingNext = 0;
+    bool pending = false;          // the mirrors differ from version `cur`
+    bool pendingAlphaPatch = false; // ... in a MASK / BLEND material: the any-hit records' copies must follow
+    hipStream_t uploadStream = nullptr; // texel copies, re-tiling / BC7 decode, packs, alpha bounds of an update
+    hipEvent_t uploaded = nullptr;      // behind the last of them
+    bool uploadedRecorded = false;
+    hipEvent_t ready = nullptr;         // behind the last flush: every later render's chains wait for it
+    bool readyRecorded = false;
+    void *linearStaging = nullptr;      // device: the texels of an update as the caller holds them, before re-tiling
+    size_t linearStagingBytes = 0;
+    uint32_t updates = 0;
+    ~MaterialState()
+    {
+        for (int i = 0; i < 2; ++i)
+        {
+            if (staging[i]) (void)hipHostFree(staging[i]);
+            if (stagingDone[i]) (void)hipEventDestroy(stagingDone[i]);
+        }
+        for (hipEvent_t e : versionFree)
+            if (e) (void)hipEventDestroy(e);
+        if (uploaded) (void)hipEventDestroy(uploaded);
+        if (ready) (void)hipEventDestroy(ready);
+        if (uploadStream) (void)hipStreamDestroy(uploadStream);
+        if (linearStaging) (void)hipFree(linearStaging);
+    }
+};
+
 // multi-GPU state of a context (pt_tiling.cpp): the communicator, its stream and the root's staging buffer
 struct TilingState;
+
+// scene-lifetime device memory of a context (prosper_pt.cpp): freed by the next upload / destroy
+int device_alloc(prosper_pt_ctx *ctx, size_t bytes, void **out);
+void device_free(prosper_pt_ctx *ctx, const void *p);
+int upload(prosper_pt_ctx *ctx, const void *src, size_t bytes, void **out);
 
 } // namespace ppt
 
@@ -180,6 +241,7 @@ struct prosper_pt_ctx
     uint64_t alphaTriangleCount = 0, alphaBoundBytes = 0; // any-hit records and bytes of alpha bounds (AlphaMaterial)
     // light buffers are re-uploaded every frame in prosper; keep their device addresses mutable
     ppt::LightState *lights = nullptr; // the scene's light buffers (device copies in the scene's allocation list)
+    ppt::MaterialState *materialState = nullptr; // mirrors + versions of the material / texture tables (pt_materials.cpp)
 
     float4 *hdr = nullptr; // current HDR buffer (internal or caller-owned)
     float4 *ownedHdr = nullptr;

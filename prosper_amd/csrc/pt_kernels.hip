@@ -1113,6 +1113,44 @@ void launch_decode_bc7(
         tilesPerRow, static_cast<uint32_t *>(tiled));
 }
 
+// Row-major RGBA8 texels -> the 8 x 4-texel tiles of DeviceTexture (one thread per texel of the padded extent; texels outside
+// the image are zero and never addressed): what prosper_pt_upload_scene did on the host, a texel at a time, before round 4.
+__global__ __launch_bounds__(256) void retile_rgba8_kernel(
+    const uint32_t *__restrict__ linear, uint32_t width, uint32_t height, uint32_t tilesPerRow, uint32_t tilesY, uint32_t *__restrict__ tiled)
+{
+    const uint32_t x = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t y = blockIdx.y;
+    if (x >= tilesPerRow * kTexTileW || y >= tilesY * kTexTileH) return;
+    const uint32_t v = (x < width && y < height) ? linear[(size_t)y * width + x] : 0u;
+    tiled[((size_t)(y >> 2) * tilesPerRow + (x >> 3)) * (kTexTileW * kTexTileH) + ((y & 3u) << 3) + (x & 7u)] = v;
+}
+
+void launch_retile_rgba8(const void *linear, uint32_t width, uint32_t height, uint32_t tilesPerRow, void *tiled, hipStream_t stream)
+{
+    const uint32_t tilesY = (height + kTexTileH - 1u) / kTexTileH;
+    if (width == 0 || height == 0) return;
+    hipLaunchKernelGGL(
+        retile_rgba8_kernel, dim3((tilesPerRow * kTexTileW + 255u) / 256u, tilesY * kTexTileH), dim3(256), 0, stream,
+        static_cast<const uint32_t *>(linear), width, height, tilesPerRow, tilesY, static_cast<uint32_t *>(tiled));
+}
+
+// After prosper_pt_update_materials / _textures touched a MASK / BLEND material: every any-hit record's copy of its
+// material's AlphaMaterial again from the (new) table.
+__global__ __launch_bounds__(256) void patch_alpha_records_kernel(
+    AlphaTriangle *__restrict__ records, uint32_t count, const AlphaMaterial *__restrict__ table, uint32_t materialCount)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    const uint32_t m = records[i].materialIndex;
+    if (m < materialCount) records[i].material = table[m];
+}
+
+void launch_patch_alpha_records(AlphaTriangle *records, uint32_t count, const AlphaMaterial *table, uint32_t materialCount, hipStream_t stream)
+{
+    if (count == 0) return;
+    hipLaunchKernelGGL(patch_alpha_records_kernel, dim3((count + 255u) / 256u), dim3(256), 0, stream, records, count, table, materialCount);
+}
+
 // Alpha bounds of a non-opaque material (pt_scene.hpp AlphaMaterial): one thread per cell of 2^shift x 2^shift texels.
 // A sample whose footprint STARTS in the cell (i0, j0 of texel_taps / any_hit_record) reads texels (i0, j0), (i1, j0),
 // (i0, j1), (i1, j1) with i1 = the wrapped neighbour of i0: one of i0 - 1, i0, i0 + 1 (mirrored repeat can step back),

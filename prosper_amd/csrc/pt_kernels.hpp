@@ -99,6 +99,7 @@ struct WavefrontChains
     hipEvent_t after = nullptr;
     hipEvent_t scene = nullptr; // the last prosper_pt_update_transforms: every chain waits for it
     hipEvent_t lights = nullptr; // the last prosper_pt_update_lights
+    hipEvent_t materials = nullptr; // the last prosper_pt_update_textures / _materials
     hipStream_t streams[kMaxChains] = {};
     hipEvent_t fork = nullptr;
     hipEvent_t join[kMaxChains] = {};
@@ -150,6 +151,10 @@ void launch_deinterleave_tiles(const float4 *tiles, const TileLayout &layout, fl
 // layout of DeviceTexture
 void launch_decode_bc7(
     const void *blocks, uint32_t width, uint32_t height, uint32_t tilesPerRow, void *tiled, hipStream_t stream);
+// width x height row-major RGBA8 texels (device memory) -> the tiled layout of DeviceTexture, padding zeroed
+void launch_retile_rgba8(const void *linear, uint32_t width, uint32_t height, uint32_t tilesPerRow, void *tiled, hipStream_t stream);
+// every any-hit record's copy of its material's AlphaMaterial from `table` again
+void launch_patch_alpha_records(AlphaTriangle *records, uint32_t count, const AlphaMaterial *table, uint32_t materialCount, hipStream_t stream);
 // fills `pack.texels` (device memory, tilesPerRow * 4 x ceil(height / 2) * 2 uint4s) from the three tiled textures
 // 6 x n x n RGBA16F texels -> 6 x (n + 2) x (n + 2) with the seamless border
 void launch_border_skybox(const uint16_t *cube, uint32_t faceSize, void *bordered, hipStream_t stream);

@@ -1140,6 +1140,7 @@ void launch_render_wavefront(
         if (chains.detached && chains.after) (void)hipStreamWaitEvent(cs, chains.after, 0);
         if (ownStreams && chains.scene) (void)hipStreamWaitEvent(cs, chains.scene, 0);
         if (ownStreams && chains.lights) (void)hipStreamWaitEvent(cs, chains.lights, 0);
+        if (ownStreams && chains.materials) (void)hipStreamWaitEvent(cs, chains.materials, 0);
         // every chain gets its own region of the stack-overflow array: its kernels index it by their own
         // blockIdx / gridDim (TraversalStack), and the chains run concurrently
         int32_t *ovf = stackOverflow ? stackOverflow + (size_t)blocksBefore * plan.scratchDwordsPerBlock : nullptr;

@@ -10,5 +10,5 @@ for f in pt_kernels pt_wavefront; do
   /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC -ffp-contract=off -Wno-unused-function -fno-slp-vectorize --offload-arch=gfx950 "$@" -c $f.hip -o /tmp/variant_$name/$f.o &
 done
 wait
-/opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 -o ../../build/variants/lib_$name.so prosper_pt.o pt_tiling.o bvh_build.o host/camera.o host/rt_reference.o host/tiled_rt_reference.o host/tone_map.o /tmp/variant_$name/pt_kernels.o /tmp/variant_$name/pt_wavefront.o -ldl
+/opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 -o ../../build/variants/lib_$name.so prosper_pt.o pt_materials.o pt_tiling.o bvh_build.o host/camera.o host/rt_reference.o host/tiled_rt_reference.o host/tone_map.o /tmp/variant_$name/pt_kernels.o /tmp/variant_$name/pt_wavefront.o -ldl
 echo built build/variants/lib_$name.so
