@@ -21,7 +21,7 @@ carries besides the contract fields:
              chip's measured v_fma_f32 rate (profiles/r02_valu_calibration.json) beside it; frac = the USEFUL fraction =
              achieved / peak x lane utilisation; hbm = measured (PMC) and algorithmic bytes over that time
              against 8 TB/s, with cache_served where the byte model prices bytes the caches serve; work_normalised =
-             issue slots per node visit / triangle test / any-hit call against their static cost (profiles/r03_unit_costs.json)
+             issue slots per node visit / triangle test / any-hit call against their static cost (profiles/r04_unit_costs.json)
   single_sample_frames, rank_share   one render per 1-spp frame as RtReference::record makes them; one rank's stripes of
              the frame of an 8-rank job, alone on this GPU
   configs    C3 (+ the C5 rank share), C4 and the reference's bundled FlightHelmet, each with ms/step, Mpaths/s, the same
@@ -108,13 +108,13 @@ def valu_peak_calibrated():
 
 def unit_costs():
     """Static VALU instructions per unit of work (scripts/unit_costs.py over scripts/unit_costs.hip ->
-    profiles/r03_unit_costs.json): the yardstick of the work-normalised figures."""
+    profiles/r04_unit_costs.json): the yardstick of the work-normalised figures."""
     try:
-        with open(os.path.join(ROOT, "profiles", "r03_unit_costs.json")) as f:
+        with open(os.path.join(ROOT, "profiles", "r04_unit_costs.json")) as f:
             d = json.load(f)
-        return {k: v["valu"] for k, v in d["units"].items()}, "profiles/r03_unit_costs.json (kernel sources sha16 %s)" % d.get("kernel_source_sha16")
+        return {k: v["valu"] for k, v in d["units"].items()}, "profiles/r04_unit_costs.json (kernel sources sha16 %s)" % d.get("kernel_source_sha16")
     except (OSError, KeyError, ValueError):
-        return None, "profiles/r03_unit_costs.json is missing"
+        return None, "profiles/r04_unit_costs.json is missing"
 
 
 def priced_work(c, unit):

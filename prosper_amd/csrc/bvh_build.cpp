@@ -69,7 +69,10 @@ struct TmpNode
     uint32_t first = 0, count = 0;
 };
 
-constexpr int kBins = 16;
+#ifndef PPT_SAH_BINS
+#define PPT_SAH_BINS 16
+#endif
+constexpr int kBins = PPT_SAH_BINS; // (32 and 64 bins measured in round 4: profiles/r04_sah_bins.txt)
 constexpr float kIntersectCost = 1.0f;
 
 // tuning knobs (BvhBuildOptions::sahTraversalCost, leafSize): experiments only

@@ -581,10 +581,18 @@ PPT_D Material sample_material(const DeviceScene &s, uint32_t index, f2 uv)
         w.b = k.b;
         if (pack.sampler & kPackCompactBit)
         {
+            // (the compact pack is the one of texture sets that outgrow the caches: PPT_TEXEL_NT reads it past them)
+#if defined(PPT_TEXEL_NT) && PPT_TEXEL_NT
+            const u32x2 p00 = __builtin_nontemporal_load((global_u32x2_ptr)(base + k.o00 * 2u));
+            const u32x2 p10 = __builtin_nontemporal_load((global_u32x2_ptr)(base + k.o10 * 2u));
+            const u32x2 p01 = __builtin_nontemporal_load((global_u32x2_ptr)(base + k.o01 * 2u));
+            const u32x2 p11 = __builtin_nontemporal_load((global_u32x2_ptr)(base + k.o11 * 2u));
+#else
             const u32x2 p00 = *(global_u32x2_ptr)(base + k.o00 * 2u);
             const u32x2 p10 = *(global_u32x2_ptr)(base + k.o10 * 2u);
             const u32x2 p01 = *(global_u32x2_ptr)(base + k.o01 * 2u);
             const u32x2 p11 = *(global_u32x2_ptr)(base + k.o11 * 2u);
+#endif
             const f4 lo = filter_taps(w, RawTaps{p00.x, p10.x, p01.x, p11.x}); // R G B roughness
             const f4 hi = filter_taps(w, RawTaps{p00.y, p10.y, p01.y, p11.y}); // metallic Nx Ny Nz
             sBaseT = f4{lo.x, lo.y, lo.z, 1.0f};

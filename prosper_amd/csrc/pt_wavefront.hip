@@ -84,6 +84,84 @@ __device__ __forceinline__ f3 xyz(float4 v) { return f3{v.x, v.y, v.z}; }
 __device__ __forceinline__ uint32_t asu(float f) { return __builtin_bit_cast(uint32_t, f); }
 __device__ __forceinline__ float asf(uint32_t u) { return __builtin_bit_cast(float, u); }
 
+// The path state between stages (ray, throughput, generator, hit and shadow records) is written by one stage and read by
+// the next one or two: 3.3 GB per 8-spp step that passes through the L2 and the Infinity Cache once.  PPT_STREAM_NT marks
+// those accesses non-temporal (global_load / global_store ... nt), so that they do not push the scene - nodes, triangles,
+// shading records, texels: what IS re-read - out of the caches.  (profiles/r04_stream_nt.txt)
+#ifndef PPT_STREAM_NT
+#define PPT_STREAM_NT 7 // bit 0: loads, bit 1: stores, bit 2: the radiance slots too (round 4: C3 12.95 -> 12.50 ms, others -0 .. 1 %)
+#endif
+typedef float ppt_f4v __attribute__((ext_vector_type(4)));
+typedef uint32_t ppt_u4v __attribute__((ext_vector_type(4)));
+typedef uint32_t ppt_u2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float4 sld(const float4 *p)
+{
+#if PPT_STREAM_NT & 1
+    const ppt_f4v v = __builtin_nontemporal_load(reinterpret_cast<const ppt_f4v *>(p));
+    return make_float4(v.x, v.y, v.z, v.w);
+#else
+    return *p;
+#endif
+}
+__device__ __forceinline__ uint4 sld(const uint4 *p)
+{
+#if PPT_STREAM_NT & 1
+    const ppt_u4v v = __builtin_nontemporal_load(reinterpret_cast<const ppt_u4v *>(p));
+    return make_uint4(v.x, v.y, v.z, v.w);
+#else
+    return *p;
+#endif
+}
+__device__ __forceinline__ uint2 sld(const uint2 *p)
+{
+#if PPT_STREAM_NT & 1
+    const ppt_u2v v = __builtin_nontemporal_load(reinterpret_cast<const ppt_u2v *>(p));
+    return make_uint2(v.x, v.y);
+#else
+    return *p;
+#endif
+}
+__device__ __forceinline__ uint32_t sld(const uint32_t *p)
+{
+#if PPT_STREAM_NT & 1
+    return __builtin_nontemporal_load(p);
+#else
+    return *p;
+#endif
+}
+__device__ __forceinline__ void sst(float4 *p, float4 v)
+{
+#if PPT_STREAM_NT & 2
+    __builtin_nontemporal_store(ppt_f4v{v.x, v.y, v.z, v.w}, reinterpret_cast<ppt_f4v *>(p));
+#else
+    *p = v;
+#endif
+}
+__device__ __forceinline__ void sst(uint4 *p, uint4 v)
+{
+#if PPT_STREAM_NT & 2
+    __builtin_nontemporal_store(ppt_u4v{v.x, v.y, v.z, v.w}, reinterpret_cast<ppt_u4v *>(p));
+#else
+    *p = v;
+#endif
+}
+__device__ __forceinline__ void sst(uint2 *p, uint2 v)
+{
+#if PPT_STREAM_NT & 2
+    __builtin_nontemporal_store(ppt_u2v{v.x, v.y}, reinterpret_cast<ppt_u2v *>(p));
+#else
+    *p = v;
+#endif
+}
+__device__ __forceinline__ void sst(uint32_t *p, uint32_t v)
+{
+#if PPT_STREAM_NT & 2
+    __builtin_nontemporal_store(v, p);
+#else
+    *p = v;
+#endif
+}
+
 struct SlotPixel
 {
     uint32_t lx, py, frame;
@@ -177,10 +255,19 @@ __device__ __forceinline__ BatchLane batch_lane(
 // addBounce (main.rgen:83-88) into the path's radiance slot
 __device__ __forceinline__ void add_to_slot(float4 *color, uint32_t slot, uint32_t flags, f3 value, uint32_t bounce)
 {
+#if PPT_STREAM_NT & 4
+    const ppt_f4v cv = __builtin_nontemporal_load(reinterpret_cast<const ppt_f4v *>(color + slot));
+    float4 c = make_float4(cv.x, cv.y, cv.z, cv.w);
+#else
     float4 c = color[slot];
+#endif
     f3 acc = f3{c.x, c.y, c.z};
     add_bounce(flags, acc, value, bounce);
+#if PPT_STREAM_NT & 4
+    __builtin_nontemporal_store(ppt_f4v{acc.x, acc.y, acc.z, 0.0f}, reinterpret_cast<ppt_f4v *>(color + slot));
+#else
     color[slot] = make_float4(acc.x, acc.y, acc.z, 0.0f);
+#endif
 }
 
 // How a wave walks a stream of rays: lane-owned (trace_stream) or out of its LDS ray pool (trace_pool)
@@ -396,9 +483,9 @@ __global__ __launch_bounds__(256, PPT_GEN_WPE) void wf_generate_extend(
             if constexpr (COUNT) cnt.closestRays++;
             // a path's state between stages: direction + one word of the generator, the other two words, and for
             // bounce 0 - no throughput record, it is (1, 1, 1) - the radiance slot as one dword (28 B per camera path)
-            w.rayB[0][at] = make_float4(st.d.x, st.d.y, st.d.z, asf(st.rng.x));
-            w.pathR[0][at] = make_uint2(st.rng.y, st.rng.z);
-            w.cameraSlot[at] = bl.slot;
+            sst(&w.rayB[0][at], make_float4(st.d.x, st.d.y, st.d.z, asf(st.rng.x)));
+            sst(&w.pathR[0][at], make_uint2(st.rng.y, st.rng.z));
+            sst(&w.cameraSlot[at], bl.slot);
             r.o = st.o;
             r.d = st.d;
             r.tMin = 0.0f;
@@ -416,16 +503,19 @@ __global__ __launch_bounds__(256, PPT_GEN_WPE) void wf_generate_extend(
                     if constexpr (COUNT) cnt.skyLookups++;
                     add_bounce(p.pc.flags, color, sample_skybox(s, dir), 0u); // throughput is (1,1,1)
                 }
+#if PPT_STREAM_NT & 4
+                __builtin_nontemporal_store(ppt_f4v{color.x, color.y, color.z, 0.0f}, reinterpret_cast<ppt_f4v *>(w.color + bl.slot));
+#else
                 w.color[bl.slot] = make_float4(color.x, color.y, color.z, 0.0f);
+#endif
             }
             const bool isHit = valid && found;
             uint32_t total;
             const uint32_t pos = nHit + wave_rank(isHit, total);
             if (isHit)
             {
-                w.hit[id.base + pos] =
-                    make_uint4(hit.drawInstance, hit.primitive, asu(hit.bary.x), asu(hit.bary.y));
-                w.hitIdx[id.base + pos] = k;
+                sst(&w.hit[id.base + pos], make_uint4(hit.drawInstance, hit.primitive, asu(hit.bary.x), asu(hit.bary.y)));
+                sst(&w.hitIdx[id.base + pos], k);
             }
             nHit += total;
         };
@@ -501,8 +591,8 @@ __device__ __forceinline__ uint32_t extend_segment(
     uint32_t nHit = 0;
     auto fetch = [&](uint32_t i) {
         const uint32_t k = map.at(i);
-        const float4 a = rayA[id.base + k];
-        const float4 b = rayB[id.base + k];
+        const float4 a = sld(&rayA[id.base + k]);
+        const float4 b = sld(&rayB[id.base + k]);
         if constexpr (COUNT) cnt.closestRays++;
         StreamRay r;
         r.o = xyz(a);
@@ -517,7 +607,7 @@ __device__ __forceinline__ uint32_t extend_segment(
         if (pred && !found && (p.pc.flags & PROSPER_PC_FLAG_IBL))
         {
             if constexpr (COUNT) cnt.skyLookups++;
-            const float4 t = w.pathT[cur][id.base + k];
+            const float4 t = sld(&w.pathT[cur][id.base + k]);
             add_to_slot(w.color, asu(t.w) & kSlotMask, p.pc.flags, xyz(t) * sample_skybox(s, dir), bounce);
         }
         const bool isHit = pred && found;
@@ -525,8 +615,8 @@ __device__ __forceinline__ uint32_t extend_segment(
         const uint32_t pos = nHit + wave_rank(isHit, total);
         if (isHit)
         {
-            w.hit[id.base + pos] = make_uint4(hit.drawInstance, hit.primitive, asu(hit.bary.x), asu(hit.bary.y));
-            w.hitIdx[id.base + pos] = k;
+            sst(&w.hit[id.base + pos], make_uint4(hit.drawInstance, hit.primitive, asu(hit.bary.x), asu(hit.bary.y)));
+            sst(&w.hitIdx[id.base + pos], k);
         }
         nHit += total;
     };
@@ -620,12 +710,12 @@ __global__ __launch_bounds__(256, PPT_SHADE_WPE) void wf_shade(
         uint32_t slot = 0;
         if (j < n)
         {
-            const uint32_t i = w.hitIdx[id.base + j];
-            const uint4 h = w.hit[id.base + j];
-            const float4 b = w.rayB[cur][id.base + i];
+            const uint32_t i = sld(&w.hitIdx[id.base + j]);
+            const uint4 h = sld(&w.hit[id.base + j]);
+            const float4 b = sld(&w.rayB[cur][id.base + i]);
             // bounce 0: no throughput record - it is (1, 1, 1) - and the slot comes from the camera paths' own array
-            const float4 t = bounce == 0u ? make_float4(1.0f, 1.0f, 1.0f, asf(w.cameraSlot[id.base + i])) : w.pathT[cur][id.base + i];
-            const uint2 r = w.pathR[cur][id.base + i];
+            const float4 t = bounce == 0u ? make_float4(1.0f, 1.0f, 1.0f, asf(sld(&w.cameraSlot[id.base + i]))) : sld(&w.pathT[cur][id.base + i]);
+            const uint2 r = sld(&w.pathR[cur][id.base + i]);
             slot = asu(t.w) & kSlotMask;
             rng = Rng{asu(b.w), r.x, r.y};
             const f3 throughput = xyz(t);
@@ -683,18 +773,18 @@ __global__ __launch_bounds__(256, PPT_SHADE_WPE) void wf_shade(
         uint32_t pos = nShadow + wave_rank(wantShadow, total);
         if (wantShadow)
         {
-            w.shA[id.base + pos] = make_float4(shP.x, shP.y, shP.z, asf(shSeed));
-            w.shB[id.base + pos] = make_float4(shL.x, shL.y, shL.z, shDist);
-            w.shC[id.base + pos] = make_float4(shC1.x, shC1.y, shC1.z, asf(slot | (nanMask << 28)));
+            sst(&w.shA[id.base + pos], make_float4(shP.x, shP.y, shP.z, asf(shSeed)));
+            sst(&w.shB[id.base + pos], make_float4(shL.x, shL.y, shL.z, shDist));
+            sst(&w.shC[id.base + pos], make_float4(shC1.x, shC1.y, shC1.z, asf(slot | (nanMask << 28))));
         }
         nShadow += total;
         pos = nNext + wave_rank(wantNext, total);
         if (wantNext)
         {
-            w.rayA[nxt][id.base + pos] = make_float4(nO.x, nO.y, nO.z, asf(pcg(rng.x ^ rng.z)));
-            w.rayB[nxt][id.base + pos] = make_float4(nD.x, nD.y, nD.z, asf(rng.x));
-            w.pathT[nxt][id.base + pos] = make_float4(nT.x, nT.y, nT.z, asf(slot));
-            w.pathR[nxt][id.base + pos] = make_uint2(rng.y, rng.z);
+            sst(&w.rayA[nxt][id.base + pos], make_float4(nO.x, nO.y, nO.z, asf(pcg(rng.x ^ rng.z))));
+            sst(&w.rayB[nxt][id.base + pos], make_float4(nD.x, nD.y, nD.z, asf(rng.x)));
+            sst(&w.pathT[nxt][id.base + pos], make_float4(nT.x, nT.y, nT.z, asf(slot)));
+            sst(&w.pathR[nxt][id.base + pos], make_uint2(rng.y, rng.z));
         }
         nNext += total;
     }
@@ -719,8 +809,8 @@ __device__ __forceinline__ void shadow_segment(
 {
     auto fetch = [&](uint32_t i) {
         const uint32_t k = map.at(i);
-        const float4 a = w.shA[id.base + k];
-        const float4 b = w.shB[id.base + k];
+        const float4 a = sld(&w.shA[id.base + k]);
+        const float4 b = sld(&w.shB[id.base + k]);
         StreamRay r;
         r.o = xyz(a);
         r.d = xyz(b);
@@ -732,7 +822,7 @@ __device__ __forceinline__ void shadow_segment(
     auto commit = [&](bool pred, uint32_t i, bool occluded, const Hit &, const f3 &) {
         if (pred)
         {
-            const float4 c = w.shC[id.base + map.at(i)];
+            const float4 c = sld(&w.shC[id.base + map.at(i)]);
             const uint32_t packed = asu(c.w);
             const uint32_t nanMask = packed >> 28;
             if (!occluded || nanMask)
@@ -931,7 +1021,12 @@ __global__ __launch_bounds__(256) void wf_accumulate(
             float4 history = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
             for (uint32_t f = 0; f < p.frameCount; ++f)
             {
+#if PPT_STREAM_NT & 4
+                const ppt_f4v cv = __builtin_nontemporal_load(reinterpret_cast<const ppt_f4v *>(w.color + (size_t)f * w.pixelsPadded + rem)); // (its last use)
+                const float4 c = make_float4(cv.x, cv.y, cv.z, cv.w);
+#else
                 const float4 c = w.color[(size_t)f * w.pixelsPadded + rem];
+#endif
                 const bool skip = (f == 0 && (p.pc.flags & PROSPER_PC_FLAG_SKIP_HISTORY)) ||
                                   !(p.pc.flags & PROSPER_PC_FLAG_ACCUMULATE);
                 if (skip)

@@ -13,7 +13,7 @@ the dispatches, so every launch runs alone):
 HBM bytes per launch = 2 x FETCH_SIZE + WRITE_SIZE (KB): the guide's gfx950 correction (FETCH_SIZE tallies a 128-B
 request of a 16 B/lane stream at 64 B).  lane_util = SQ_THREAD_CYCLES_VALU / (64 x SQ_INSTS_VALU).
 
-    python scripts/pmc_tools.py c2 [c3 c4 ...]      -> profiles/r03_<config>_pmc.json  (run on the GPU box)
+    python scripts/pmc_tools.py c2 [c3 c4 ...]      -> profiles/r04_<config>_pmc.json  (run on the GPU box)
 bench.py calls collect() itself for the headline configuration, so the figures in its line are measured in that run.
 """
 import collections
@@ -175,8 +175,8 @@ def collect(config, work_dir=None, extra_args=(), keep=False, timeout=600, with_
 
 
 def load_committed(config):
-    """profiles/r03_<config>_pmc.json if it was taken on the current kernel sources, else None."""
-    path = os.path.join(ROOT, "profiles", "r03_%s_pmc.json" % config)
+    """profiles/r04_<config>_pmc.json if it was taken on the current kernel sources, else None."""
+    path = os.path.join(ROOT, "profiles", "r04_%s_pmc.json" % config)
     try:
         with open(path) as f:
             d = json.load(f)
@@ -184,7 +184,7 @@ def load_committed(config):
         return None
     if d.get("kernel_source_sha16") != kernel_source_hash():
         return None
-    d["source"] = "profiles/r03_%s_pmc.json (taken on these kernel sources: sha16 %s)" % (config, d["kernel_source_sha16"])
+    d["source"] = "profiles/r04_%s_pmc.json (taken on these kernel sources: sha16 %s)" % (config, d["kernel_source_sha16"])
     return d
 
 
@@ -192,7 +192,7 @@ def main():
     for config in sys.argv[1:]:
         extra = []
         out = collect(config, extra_args=extra, with_mix=True)
-        path = os.path.join(ROOT, "profiles", "r03_%s_pmc.json" % config)
+        path = os.path.join(ROOT, "profiles", "r04_%s_pmc.json" % config)
         with open(path, "w") as f:
             json.dump(out, f, indent=1)
             f.write("\n")

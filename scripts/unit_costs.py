@@ -2,7 +2,7 @@
 """Static VALU instruction counts of one unit of path-tracing work each, from the gfx950 ISA of scripts/unit_costs.hip
 (the product's device functions, the product's compiler flags): the yardstick bench.py prices the work counters with.
 
-    python scripts/unit_costs.py [--out profiles/r03_unit_costs.json]
+    python scripts/unit_costs.py [--out profiles/r04_unit_costs.json]
 
 A unit's cost = VALU instructions of its kernel minus those of unit_baseline_ray (the same ray load and result store
 without the work).  Both sides of every branch are counted."""
