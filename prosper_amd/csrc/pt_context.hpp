@@ -157,8 +157,8 @@ struct AccelState
 // prosper_pt_upload_scene made (four allocations of their own, never rewritten); prosper_pt_update_textures / _materials
 // change the host mirrors, build the new texel arrays / packs / alpha bounds on `uploadStream`, and the next render copies
 // the tables into the next of three rotating blocks at the head of its own chain of launches - the frames in flight keep
-// reading theirs (pt_materials.cpp).  Replaced texel arrays stay allocated until the scene goes: a frame in flight may
-// still read them, and a streamed scene replaces each placeholder once.
+// reading theirs (pt_materials.cpp).  Replaced texel arrays / packs / bounds are retired, not freed: a frame in flight may
+// still read them (a streamed scene replaces each placeholder once; 256 MB of retired memory buy one synchronisation).
 struct MaterialState
 {
     static constexpr uint32_t kVersions = 4; // 0: the upload's tables; 1..3: rotating blocks
@@ -191,6 +191,11 @@ struct MaterialState
     void *linearStaging = nullptr;      // device: the texels of an update as the caller holds them, before re-tiling
     size_t linearStagingBytes = 0;
     uint32_t updates = 0;
+    // texel arrays, packs and alpha bounds an update replaced: a frame in flight may still read them, so they stay until
+    // enough has piled up to be worth ONE device synchronisation (kRetireBytes), or the scene goes
+    std::vector<const void *> retired;
+    uint64_t retiredBytes = 0;
+    static constexpr uint64_t kRetireBytes = 256ull << 20;
     ~MaterialState()
     {
         for (int i = 0; i < 2; ++i)

@@ -155,22 +155,81 @@ bool wide_packs(const prosper_pt_ctx *ctx)
     return !texel_set_is_big(ctx->materialState->texelBytes);
 }
 
-// the pack and the alpha material of material `i` again, from the mirrors, on the upload stream
-int rebuild_material(prosper_pt_ctx *ctx, uint32_t i)
+size_t allocation_bytes(const prosper_pt_ctx *ctx, const void *p)
+{
+    for (const DeviceAllocation &a : ctx->sceneAllocations)
+        if (a.ptr == p) return a.bytes;
+    return 0;
+}
+
+// `p` was replaced by an update: nothing new will read it, a frame in flight still may
+void retire(prosper_pt_ctx *ctx, const void *p)
+{
+    if (!p) return;
+    MaterialState *ms = ctx->materialState;
+    ms->retired.push_back(p);
+    ms->retiredBytes += allocation_bytes(ctx, p);
+}
+
+// Frees what has been retired once it is worth a device synchronisation (a material slider dragged for a thousand frames
+// must not grow the scene without bound; a streamed scene never gets here: it retires a few placeholder texels).
+int collect_retired(prosper_pt_ctx *ctx)
+{
+    MaterialState *ms = ctx->materialState;
+    if (ms->retiredBytes < MaterialState::kRetireBytes) return PROSPER_PT_OK;
+    PPT_HIP(hipDeviceSynchronize());
+    for (const void *p : ms->retired) device_free(ctx, p);
+    ms->retired.clear();
+    ms->retiredBytes = 0;
+    return PROSPER_PT_OK;
+}
+
+bool same_pack_inputs(const prosper_MaterialData &a, const prosper_MaterialData &b)
+{
+    return a.baseColorTextureSampler == b.baseColorTextureSampler && a.metallicRoughnessTextureSampler == b.metallicRoughnessTextureSampler &&
+           a.normalTextureSampler == b.normalTextureSampler && a.alphaMode == b.alphaMode;
+}
+
+// The pack and the alpha material of material `i` again, from the mirrors, on the upload stream.  `previous`: the
+// material's entry before this update (nullptr: its textures' TEXELS changed) - what does not depend on what changed is
+// kept: the pack on a material's textures and samplers, the alpha bounds on the base-colour texture, its sampler and
+// baseColorFactor.a.
+int rebuild_material(prosper_pt_ctx *ctx, uint32_t i, const prosper_MaterialData *previous)
 {
     MaterialState *ms = ctx->materialState;
     const prosper_MaterialData &m = ms->materials[i];
-    MaterialPack pk;
-    int rc = build_material_pack(ctx, m, ms->textures, ctx->debug.noTexturePacks != 0, wide_packs(ctx), ms->uploadStream, &pk);
-    if (rc != PROSPER_PT_OK) return rc;
-    if ((pk.texels != nullptr) != (ms->packs[i].texels != nullptr)) ms->packedMaterials += pk.texels ? 1u : ~0u;
-    ms->packs[i] = pk; // (the previous pack stays allocated: a frame in flight may read it)
-    AlphaMaterial am;
-    uint64_t bytes = 0;
-    if ((rc = build_alpha_material(ctx, m, ms->textures, ms->samplers, ms->uploadStream, &am, &bytes))) return rc;
-    ms->alphaBoundBytes += bytes;
-    if (m.alphaMode != PROSPER_ALPHA_MODE_OPAQUE) ms->pendingAlphaPatch = true;
-    ms->alphaMaterials[i] = am;
+    int rc;
+    const bool wide = wide_packs(ctx);
+    const bool packKindKept = ms->packs[i].texels == nullptr || (((ms->packs[i].sampler & kPackCompactBit) == 0u) == (wide || m.alphaMode != PROSPER_ALPHA_MODE_OPAQUE));
+    if (!(previous && same_pack_inputs(*previous, m) && packKindKept))
+    {
+        MaterialPack pk;
+        if ((rc = build_material_pack(ctx, m, ms->textures, ctx->debug.noTexturePacks != 0, wide, ms->uploadStream, &pk))) return rc;
+        if ((pk.texels != nullptr) != (ms->packs[i].texels != nullptr)) ms->packedMaterials += pk.texels ? 1u : ~0u;
+        retire(ctx, ms->packs[i].texels);
+        ms->packs[i] = pk;
+    }
+    const AlphaMaterial old = ms->alphaMaterials[i];
+    const bool boundsKept = previous && previous->baseColorTextureSampler == m.baseColorTextureSampler && previous->alphaMode == m.alphaMode &&
+                            std::memcmp(&previous->baseColorFactor.w, &m.baseColorFactor.w, sizeof(float)) == 0;
+    if (boundsKept)
+    {
+        AlphaMaterial am = old; // same texels, same bounds; the cutoff may have moved
+        am.cutoff = m.alphaCutoff;
+        ms->alphaMaterials[i] = am;
+    }
+    else
+    {
+        AlphaMaterial am;
+        uint64_t bytes = 0;
+        if ((rc = build_alpha_material(ctx, m, ms->textures, ms->samplers, ms->uploadStream, &am, &bytes))) return rc;
+        ms->alphaBoundBytes += bytes;
+        ms->alphaBoundBytes -= std::min<uint64_t>(ms->alphaBoundBytes, allocation_bytes(ctx, old.bounds));
+        retire(ctx, old.bounds);
+        ms->alphaMaterials[i] = am;
+    }
+    if (m.alphaMode != PROSPER_ALPHA_MODE_OPAQUE && std::memcmp(&old, &ms->alphaMaterials[i], sizeof(AlphaMaterial)) != 0)
+        ms->pendingAlphaPatch = true;
     return PROSPER_PT_OK;
 }
 
@@ -284,6 +343,7 @@ int prosper_pt_update_textures(prosper_pt_ctx *ctx, const prosper_pt_texture_des
     }
     PPT_HIP(hipSetDevice(ctx->device));
     int rc = ensure_update_state(ctx);
+    if (rc == PROSPER_PT_OK) rc = collect_retired(ctx);
     if (rc != PROSPER_PT_OK) return rc;
     if (stagingBytes > ms->linearStagingBytes)
     {
@@ -308,7 +368,8 @@ int prosper_pt_update_textures(prosper_pt_ctx *ctx, const prosper_pt_texture_des
         const DeviceTexture &old = ms->textures[first + i];
         ms->texelBytes += (uint64_t)dt.width * dt.height * 4u;
         ms->texelBytes -= std::min<uint64_t>(ms->texelBytes, (uint64_t)old.width * old.height * 4u);
-        ms->textures[first + i] = dt; // (the previous texel array stays allocated: a frame in flight may read it)
+        retire(ctx, old.texels); // (a frame in flight may still read the previous texel array)
+        ms->textures[first + i] = dt;
         changed[first + i] = 1;
     }
     // the caller's memory is only borrowed: every copy out of it must be done before the call returns
@@ -320,7 +381,7 @@ int prosper_pt_update_textures(prosper_pt_ctx *ctx, const prosper_pt_texture_des
         const uint32_t t3[3] = {md.baseColorTextureSampler & 0xFFFFFFu, md.metallicRoughnessTextureSampler & 0xFFFFFFu,
                                 md.normalTextureSampler & 0xFFFFFFu};
         if ((t3[0] && changed[t3[0]]) || (t3[1] && changed[t3[1]]) || (t3[2] && changed[t3[2]]))
-            if ((rc = rebuild_material(ctx, m))) return rc;
+            if ((rc = rebuild_material(ctx, m, nullptr))) return rc;
     }
     PPT_HIP(hipEventRecord(ms->uploaded, ms->uploadStream));
     ms->uploadedRecorded = true;
@@ -348,12 +409,14 @@ int prosper_pt_update_materials(prosper_pt_ctx *ctx, const prosper_MaterialData 
         if (!any)
         {
             PPT_HIP(hipSetDevice(ctx->device));
-            const int rc = ensure_update_state(ctx);
+            int rc = ensure_update_state(ctx);
+            if (rc == PROSPER_PT_OK) rc = collect_retired(ctx);
             if (rc != PROSPER_PT_OK) return rc;
         }
         any = true;
+        const prosper_MaterialData previous = ms->materials[first + i];
         ms->materials[first + i] = materials[i];
-        const int rc = rebuild_material(ctx, first + i);
+        const int rc = rebuild_material(ctx, first + i, &previous);
         if (rc != PROSPER_PT_OK) return rc;
     }
     if (!any) return PROSPER_PT_OK;

@@ -212,3 +212,44 @@ def test_an_unchanged_material_table_costs_nothing(gpu_ctx, oracle, cornell_worl
         gpu_ctx.render(pc, cam, w, h)
     assert same_bits(before, gpu_ctx.read_hdr()).all()
     assert gpu_ctx.scene_stats().deviceBytes == bytes_before
+
+
+def test_a_material_slider_does_not_grow_the_scene(gpu_ctx, oracle):
+    """A factor dragged for many frames (RtReference's UI keeps rewriting the table): texture packs and alpha bounds are
+    rebuilt only for what they depend on - a material's textures and samplers; the base-colour texture, its sampler and
+    baseColorFactor.a - so roughness, metallic, colour and cutoff changes allocate nothing, and every frame still equals a
+    fresh upload."""
+    full = scenes.alpha_wall()
+    w, h = 160, 100
+    cam, fl = _camera(oracle, full, w, h)
+    pc = default_pc(S, fl, max_bounces=2)
+    gpu_ctx.upload_scene(full)
+    gpu_ctx.render(pc, cam, w, h)
+    grown = None
+    state = full
+    for k in range(12):
+        state = copy.copy(state)
+        state._frozen = None
+        state.materials = list(state.materials)
+        for i in (1, 4, 9):
+            m = copy.copy(state.materials[i])
+            m.roughnessFactor = 0.2 + 0.05 * k
+            m.metallicFactor = 0.1 * (k % 3)
+            m.alphaCutoff = 0.1 + 0.07 * (k % 5)
+            m.baseColorFactor = S.Vec4(0.3 + 0.05 * k, 0.5, 0.7, m.baseColorFactor.w)
+            state.materials[i] = m
+        gpu_ctx.update_materials(state.materials, 0)
+        gpu_ctx.render(pc, cam, w, h, flags=S.RENDER_PIPELINED)
+        size = gpu_ctx.scene_stats().deviceBytes
+        if k == 3:
+            grown = size  # (the first three updates allocate the three table versions and their pinned staging)
+        if k > 3:
+            assert size == grown, "update %d grew the scene from %d to %d bytes" % (k, grown, size)
+    got = gpu_ctx.read_hdr()
+    fresh = capi.Context(device=0)
+    try:
+        fresh.upload_scene(state)
+        fresh.render(pc, cam, w, h)
+        assert same_bits(got, fresh.read_hdr()).all()
+    finally:
+        fresh.close()
