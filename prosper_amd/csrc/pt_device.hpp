@@ -1355,9 +1355,12 @@ struct TraversalStack
     uint32_t cap;
     uint32_t ovfStride;
     uint32_t ldsStride; // 64: one column per lane of the wave
+    // the tree's stack bound fits the LDS part (a compile-time constant where it is set: the kernels of LDS-resident scenes):
+    // no capacity test, no global path - 1 vector + 5 scalar instructions and two branches less per push and pop
+    bool ldsOnly;
     PPT_D void push(int32_t &sp, int32_t v) const
     {
-        if ((uint32_t)sp < cap)
+        if (ldsOnly || (uint32_t)sp < cap)
             lds[(uint32_t)sp * ldsStride] = v;
         else
             ovf[(size_t)((uint32_t)sp - cap) * ovfStride] = v;
@@ -1366,8 +1369,25 @@ struct TraversalStack
     PPT_D int32_t pop(int32_t &sp) const
     {
         --sp;
-        if ((uint32_t)sp < cap) return lds[(uint32_t)sp * ldsStride];
+        if (ldsOnly || (uint32_t)sp < cap) return lds[(uint32_t)sp * ldsStride];
         return ovf[(size_t)((uint32_t)sp - cap) * ovfStride];
+    }
+    // up to three pushes of one node visit (the far children of a closest-hit ray, farthest first): ONE capacity test for
+    // all three - the LDS part nearly always has room for three more - instead of one per push
+    PPT_D void push_hit_children(int32_t &sp, const float e[4], const int32_t ref[4]) const
+    {
+#ifndef PPT_EXPERIMENT_PUSH_EACH
+        if (ldsOnly || (uint32_t)sp + 3u <= cap)
+        {
+            if (e[3] < kInf) lds[(uint32_t)(sp++) * ldsStride] = ref[3];
+            if (e[2] < kInf) lds[(uint32_t)(sp++) * ldsStride] = ref[2];
+            if (e[1] < kInf) lds[(uint32_t)(sp++) * ldsStride] = ref[1];
+            return;
+        }
+#endif
+        if (e[3] < kInf) push(sp, ref[3]);
+        if (e[2] < kInf) push(sp, ref[2]);
+        if (e[1] < kInf) push(sp, ref[1]);
     }
 };
 
@@ -1477,6 +1497,24 @@ PPT_D void intersect_node4(const NodeData &n, f3 o, const RaySlabs &rs, float tM
 PPT_D bool descend_any(const float e[4], const int32_t ref[4], const TraversalStack &stack, int32_t &sp, int32_t &node)
 {
     bool found = false;
+#ifndef PPT_EXPERIMENT_PUSH_EACH
+    if (stack.ldsOnly || (uint32_t)sp + 3u <= stack.cap) // one capacity test for the (at most three) pushes of this visit
+    {
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (e[k] < kInf)
+            {
+                if (found)
+                    stack.lds[(uint32_t)(sp++) * stack.ldsStride] = ref[k];
+                else
+                {
+                    node = ref[k];
+                    found = true;
+                }
+            }
+        return found;
+    }
+#endif
 #pragma unroll
     for (int k = 0; k < 4; ++k)
         if (e[k] < kInf)
@@ -1530,9 +1568,7 @@ PPT_D bool trace_in(
             else
             {
                 intersect_node4(nd, o, rs, tMin, hit.t, e, ref);
-                if (e[3] < kInf) stack.push(sp, ref[3]);
-                if (e[2] < kInf) stack.push(sp, ref[2]);
-                if (e[1] < kInf) stack.push(sp, ref[1]);
+                stack.push_hit_children(sp, e, ref);
                 entered = e[0] < kInf;
                 if (entered) node = ref[0];
             }

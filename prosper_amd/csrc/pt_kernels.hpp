@@ -136,7 +136,7 @@ void launch_render_wavefront(
 uint32_t wavefront_lds_stack_entries(uint32_t stackBound, uint32_t forced);
 // kernel variants a render takes: wf_shade with the scene tables staged in LDS; traversal out of an LDS copy of the scene
 bool wavefront_shade_tables_in_lds(const DeviceScene &s, bool disabled);
-bool wavefront_scene_in_lds(uint32_t ldsStackEntries, uint32_t nodeCount, uint32_t triCount, bool disabled);
+bool wavefront_scene_in_lds(uint32_t ldsStackEntries, uint32_t stackBound, uint32_t nodeCount, uint32_t triCount, bool disabled);
 void launch_blit_rgba16f(const float4 *in, void *out, uint32_t count, hipStream_t stream);
 // Where each rank's tile sits in the gathered buffer (texel offsets) and how wide its rows are
 constexpr uint32_t kMaxRanks = 64;

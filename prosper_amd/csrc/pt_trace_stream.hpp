@@ -181,9 +181,7 @@ PPT_D void trace_stream(
                     else
                     {
                         intersect_node4(nd, o, rs, tMin, hit.t, e, ref);
-                        if (e[3] < kInf) stack.push(sp, ref[3]);
-                        if (e[2] < kInf) stack.push(sp, ref[2]);
-                        if (e[1] < kInf) stack.push(sp, ref[1]);
+                        stack.push_hit_children(sp, e, ref);
                         entered = e[0] < kInf;
                         if (entered) node = ref[0];
                     }

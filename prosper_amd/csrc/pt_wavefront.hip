@@ -440,7 +440,7 @@ __global__ __launch_bounds__(256, PPT_GEN_WPE) void wf_generate_extend(
     if (!id.valid) return;
     const uint32_t lane = lane_id();
     const TraversalStack stack{(lds_int32 *)ldsStack + (threadIdx.x >> 6) * (STACK * 64u) + lane,
-                               stackOverflow + blockIdx.x * 256u + threadIdx.x, (uint32_t)STACK, gridDim.x * 256u, 64u};
+                               stackOverflow + blockIdx.x * 256u + threadIdx.x, (uint32_t)STACK, gridDim.x * 256u, 64u, LDS_SCENE};
     const bool traceRays = p.pc.maxBounces > 0;
 
     LaneCounters cnt = {};
@@ -928,7 +928,7 @@ __global__ __launch_bounds__(256, PPT_TRACE_WPE(STACK)) void wf_trace(
     if (!id.valid) return;
     const StreamTracer stack{TraversalStack{(lds_int32 *)ldsStack + (threadIdx.x >> 6) * (STACK * 64u) + lane_id(),
                                             stackOverflow + blockIdx.x * 256u + threadIdx.x, (uint32_t)STACK,
-                                            gridDim.x * 256u, 64u}};
+                                            gridDim.x * 256u, 64u, LDS_SCENE}};
     LaneCounters cnt = {};
     const TraceWork t = trace_work(p, w, id, doExtend != 0u);
 #ifdef PPT_EXPERIMENT_LDS_SCENE_LOCKSTEP
@@ -1153,9 +1153,10 @@ bool wavefront_shade_tables_in_lds(const DeviceScene &s, bool disabled)
 {
     return shade_table_bytes(s, false) <= kLdsTableBytes && !disabled;
 }
-bool wavefront_scene_in_lds(uint32_t ldsStackEntries, uint32_t nodeCount, uint32_t triCount, bool disabled)
+bool wavefront_scene_in_lds(uint32_t ldsStackEntries, uint32_t stackBound, uint32_t nodeCount, uint32_t triCount, bool disabled)
 {
-    return ldsStackEntries == 16u && nodeCount * kLdsNodeStride + triCount * 3u <= kLdsSceneFloat4s && !disabled;
+    // (stackBound <= 16: the LDS-scene kernels have no global stack path at all - TraversalStack::ldsOnly)
+    return ldsStackEntries == 16u && stackBound <= 16u && nodeCount * kLdsNodeStride + triCount * 3u <= kLdsSceneFloat4s && !disabled;
 }
 
 // The traversal kernels of a render and the global scratch they index: the lane-owned kernels keep `overflowEntries`
@@ -1166,7 +1167,7 @@ WavefrontPlan wavefront_plan(
     WavefrontPlan plan = {};
     plan.ldsStackEntries = wavefront_lds_stack_entries(stackBound, opt.ldsStackEntries);
     plan.overflowEntries = stackBound > plan.ldsStackEntries ? stackBound - plan.ldsStackEntries : 0u;
-    plan.sceneInLds = wavefront_scene_in_lds(plan.ldsStackEntries, nodeCount, triCount, opt.noLdsScene);
+    plan.sceneInLds = wavefront_scene_in_lds(plan.ldsStackEntries, stackBound, nodeCount, triCount, opt.noLdsScene);
     plan.tablesInLds = wavefront_shade_tables_in_lds(s, opt.noLdsTables);
     uint32_t poolDwords = 0;
 #ifdef PPT_EXPERIMENTS

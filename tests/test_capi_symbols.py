@@ -94,3 +94,42 @@ def test_the_library_does_not_read_the_environment_outside_create():
     gate = src[src.index("bool debug_options_from_environment"):]
     assert gate[:gate.index("\n}\n")].count("getenv(") == 2  # both inside the gate that only prosper_pt_create calls
     assert src.count("debug_options_from_environment(") == 2  # its definition and that one call
+
+
+@pytest.mark.gpu
+def test_the_environment_gate_is_read_once_at_create_and_only_when_asked():
+    """PROSPER_PT_DEBUG=1 + PROSPER_PT_DEBUG_OPTIONS="name=value,...": parsed into a new context's options by prosper_pt_create;
+    without the gate variable the options string is ignored; an unknown name or a bad value fails the create; changing the
+    environment afterwards changes nothing (no other call looks at it)."""
+    import subprocess
+    import sys
+    script = r"""
+import os, sys
+sys.path.insert(0, %r)
+from prosper_amd import capi
+try:
+    ctx = capi.Context(device=0)
+except capi.ProsperPtError as e:
+    print("create failed:", e)
+    sys.exit(0)
+o = ctx.debug_options()
+print("options", o.ldsStackEntries, "%%.1e" %% o.boxPad, o.widePacks, o.noLdsTables)
+os.environ["PROSPER_PT_DEBUG_OPTIONS"] = "ldsStackEntries=32"
+from prosper_amd import scenes
+ctx.upload_scene(scenes.cornell())
+print("after upload", ctx.debug_options().ldsStackEntries)
+""" % ROOT
+
+    def run(env_extra):
+        env = {k: v for k, v in os.environ.items() if not k.startswith("PROSPER_PT_DEBUG")}
+        env.update(env_extra)
+        out = subprocess.run([sys.executable, "-c", script], capture_output=True, text=True, timeout=300, env=env)
+        assert out.returncode == 0, out.stderr[-1500:]
+        return out.stdout
+    text = run({"PROSPER_PT_DEBUG": "1", "PROSPER_PT_DEBUG_OPTIONS": "ldsStackEntries=16,boxPad=3e-5,widePacks=0,noLdsTables"})
+    assert "options 16 3.0e-05 0 1" in text and "after upload 16" in text, text
+    text = run({"PROSPER_PT_DEBUG_OPTIONS": "ldsStackEntries=16"})  # no gate: ignored
+    assert "options 0 0.0e+00 -1 0" in text, text
+    assert "unknown option 'stack'" in run({"PROSPER_PT_DEBUG": "1", "PROSPER_PT_DEBUG_OPTIONS": "stack=16"})
+    assert "is not a value" in run({"PROSPER_PT_DEBUG": "1", "PROSPER_PT_DEBUG_OPTIONS": "ldsStackEntries=sixteen"})
+    assert "ldsStackEntries is 0, 16, 24 or 32" in run({"PROSPER_PT_DEBUG": "1", "PROSPER_PT_DEBUG_OPTIONS": "ldsStackEntries=20"})
