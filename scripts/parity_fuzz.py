@@ -48,7 +48,28 @@ def run(cases, seed, scene_names, log=print):
             worlds[name] = builders[name]()
             oracles[name] = O.OracleScene(worlds[name], brute_force=name in ("cornell", "wall", "zoo", "alpha"))
         world = worlds[name]
-        ctx.upload_scene(world)
+        # a quarter of the textured cases: the scene is uploaded with placeholder texels and placeholder materials
+        # (tests/test_adoption.py streamed_state: what prosper shows while it loads) and the images / materials are ADOPTED
+        # in two or three steps (prosper_pt_update_textures / _materials, round 4), a render in flight between the steps
+        streamed_note = ""
+        if len(world.textures) > 2 and rng.random() < 0.25:
+            from test_adoption import streamed_state
+            images = len(world.textures) - 1
+            cuts = sorted(set(int(x) for x in rng.integers(0, images + 1, size=int(rng.integers(1, 3))))) + [images]
+            ctx.upload_scene(streamed_state(world, 0))
+            warm_cam, warm_fl = O.camera_uniforms(world.camera["eye"], world.camera["target"], world.camera["up"], world.camera["fov"],
+                                                  world.camera["zN"], world.camera["zF"], 64, 48)
+            done = 0
+            for cut in cuts:
+                if cut > done:
+                    ctx.update_textures(world.textures[done + 1:cut + 1], done + 1)
+                    done = cut
+                ctx.update_materials(streamed_state(world, done).materials, 0)
+                if cut != images:  # a frame of the half-loaded scene stays in flight while the next images arrive
+                    ctx.render(S.ReferencePC(0, S.PC_FLAG_SKIP_HISTORY, 1, 1e-5, 1.0, warm_fl, 3, 2), warm_cam, 64, 48, flags=S.RENDER_PIPELINED)
+            streamed_note = " streamed %s" % "+".join(str(c) for c in cuts)
+        else:
+            ctx.upload_scene(world)
         # a third of the cases on instanced scenes: some instances moved by prosper_pt_update_transforms (the GPU refit)
         # after the upload, against the oracle's own scene built at the moved pose
         oracle_scene = oracles[name]
@@ -125,7 +146,7 @@ def run(cases, seed, scene_names, log=print):
         total_px += ok.size
         nan = int(np.isnan(got[..., :3]).any(axis=2).sum())
         log("case %3d %-8s %3dx%-3d draw %2d flags %02x bounces %d rr %d frames %d%s%s  eye-dist %.2g fov %3.0f  -> %s (%d NaN px)" % (
-            case, name, w, h, draw, flags, bounces, roulette, frames, (" batched" if batched else "") + (" pipelined" if pipelined else "") + moved_note,
+            case, name, w, h, draw, flags, bounces, roulette, frames, (" batched" if batched else "") + (" pipelined" if pipelined else "") + moved_note + streamed_note,
             " tile %d/%d" % (tile.stripeIndex, tile.stripeCount) if tile is not None else "", r, math.degrees(fov),
             "ok" if nbad == 0 else "%d PIXELS DIFFER" % nbad, nan))
     ctx.close()
@@ -138,9 +159,21 @@ def main():
     ap.add_argument("--cases", type=int, default=60)
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--scenes", default="cornell,sponza,foliage,wall,zoo,alpha,helmet")
+    ap.add_argument("--quiet", action="store_true", help="print only the cases that are not a plain ok, a progress line every 100 cases, and the summary")
     args = ap.parse_args()
-    bad, _ = run(args.cases, args.seed, [n for n in args.scenes.split(",") if n],
-                 log=lambda *a: print(*a, flush=True))
+    seen = [0]
+
+    def log(*a):
+        text = " ".join(str(x) for x in a)
+        if args.quiet and text.startswith("case "):
+            seen[0] += 1
+            if text.rstrip().endswith("-> ok (0 NaN px)"):
+                if seen[0] % 100 == 0:
+                    print("... %d cases" % seen[0], flush=True)
+                return
+        print(text, flush=True)
+    print("# scripts/parity_fuzz.py --cases %d --seed %d --scenes %s" % (args.cases, args.seed, args.scenes), flush=True)
+    bad, _ = run(args.cases, args.seed, [n for n in args.scenes.split(",") if n], log=log)
     sys.exit(1 if bad else 0)
 
 
