@@ -153,6 +153,10 @@ PPT_D void trace_stream(
             do
             {
                 if constexpr (COUNT) cnt.nodePhaseSteps += lane == 0 ? 1u : 0u;
+#ifdef PPT_EXPERIMENT_COUNT_DRAIN_STEPS
+                // measurement only (profiles/r04_stream_tails.txt): node steps taken after the stream ran out of rays to hand out
+                if constexpr (COUNT) cnt.historyReads += (lane == 0 && next >= n) ? 1u : 0u;
+#endif
 #ifdef PPT_EXPERIMENT_COUNT_NARROW_STEPS
                 if constexpr (COUNT) // measurement only (profiles/r02_exec_mask_microbench.txt): node steps with <= 8 lanes
                 {
@@ -209,6 +213,9 @@ PPT_D void trace_stream(
             do
             {
                 if constexpr (COUNT) cnt.trianglePhaseSteps += lane == 0 ? 1u : 0u;
+#ifdef PPT_EXPERIMENT_COUNT_DRAIN_STEPS
+                if constexpr (COUNT) cnt.pixelsWritten += (lane == 0 && next >= n) ? 1u : 0u; // triangle steps after the stream ran out
+#endif
 #ifdef PPT_EXPERIMENT_COUNT_NARROW_STEPS
                 if constexpr (COUNT) // triangle steps with <= 8 lanes
                 {
