@@ -341,6 +341,21 @@ int prosper_pt_update_textures(prosper_pt_ctx *ctx, const prosper_pt_texture_des
         if (rc != PROSPER_PT_OK) return rc;
         stagingBytes += texture_staging_bytes(textures[i]);
     }
+    // A material that samples a replaced texture gets its pack rebuilt from its three textures' own texels: a texture whose
+    // own copy was released at upload (only packed materials sampled it) must arrive in the same call.
+    for (uint32_t m = 0; m < ms->materials.size(); ++m)
+    {
+        const prosper_MaterialData &md = ms->materials[m];
+        const uint32_t t3[3] = {md.baseColorTextureSampler & 0xFFFFFFu, md.metallicRoughnessTextureSampler & 0xFFFFFFu,
+                                md.normalTextureSampler & 0xFFFFFFu};
+        auto replaced = [&](uint32_t t) { return t >= first && t < first + count; };
+        if (!((t3[0] && replaced(t3[0])) || (t3[1] && replaced(t3[1])) || (t3[2] && replaced(t3[2])))) continue;
+        for (uint32_t t : t3)
+            if (t && !replaced(t) && !ms->textures[t].texels)
+                return fail(
+                    PROSPER_PT_ERR_UNSUPPORTED, "prosper_pt_update_textures: material " + std::to_string(m) + " also samples texture " + std::to_string(t) +
+                                                    ", which kept no texels of its own at upload (only packed materials sampled it): update it in the same call");
+    }
     PPT_HIP(hipSetDevice(ctx->device));
     int rc = ensure_update_state(ctx);
     if (rc == PROSPER_PT_OK) rc = collect_retired(ctx);

@@ -253,3 +253,38 @@ def test_a_material_slider_does_not_grow_the_scene(gpu_ctx, oracle):
         assert same_bits(got, fresh.read_hdr()).all()
     finally:
         fresh.close()
+
+
+def test_a_texture_of_a_packed_material_replaced_after_a_full_upload(gpu_ctx, oracle):
+    """After a FULL upload the textures only packed materials sample keep no texels of their own (the pack holds them): one
+    of a material's three images replaced alone is refused with a message that says so; all three in one call rebuild the
+    pack, and the frame equals a fresh upload."""
+    world = scenes.sponza_class(texture_size=64, sky_size=32, detail=0.25)
+    w, h = 240, 136
+    cam, fl = _camera(oracle, world, w, h)
+    pc = default_pc(S, fl, max_bounces=3, ibl=True)
+    gpu_ctx.upload_scene(world)
+    assert gpu_ctx.scene_stats().variantFlags & S.VARIANT_TEXTURE_PACKS
+    m = next(m for m in world.materials[1:] if all(_texture_indices(m)))
+    tb, tm, tn = _texture_indices(m)
+    assert tm == tb + 1 and tn == tb + 2  # (scenes.sponza_class adds a material's three images in a row)
+    rng = np.random.default_rng(11)
+    fresh_texels = [rng.integers(0, 256, size=np.asarray(world.textures[t]).shape, dtype=np.uint8) for t in (tb, tm, tn)]
+    with pytest.raises(capi.ProsperPtError) as e:
+        gpu_ctx.update_textures(fresh_texels[:1], tb)
+    assert e.value.code == -6 and "update it in the same call" in str(e.value)
+    gpu_ctx.update_textures(fresh_texels, tb)
+    gpu_ctx.render(pc, cam, w, h, frames=2, flags=S.RENDER_PIPELINED)
+    got = gpu_ctx.read_hdr()
+    state = copy.copy(world)
+    state._frozen = None
+    state.textures = list(world.textures)
+    for t, texels in zip((tb, tm, tn), fresh_texels):
+        state.textures[t] = texels
+    fresh = capi.Context(device=0)
+    try:
+        fresh.upload_scene(state)
+        fresh.render(pc, cam, w, h, frames=2)
+        assert same_bits(got, fresh.read_hdr()).all()
+    finally:
+        fresh.close()
