@@ -1290,60 +1290,6 @@ struct NodeData
 {
     uint4 q0, q1, q2, q3, q4;
 };
-struct GlobalGeom
-{
-    const BvhNode *nodes;
-    const WorldTriangle *triangles;
-    PPT_D NodeData node(int32_t i) const
-    {
-        const uint4 *np = reinterpret_cast<const uint4 *>(nodes + i);
-#ifdef PPT_EXPERIMENT_SPLIT_NODE_LOADS
-        // measurement only (scripts/build_variant.sh split -DPPT_EXPERIMENT_SPLIT_NODE_LOADS): the same 80 bytes as ten
-        // 8-byte loads - twice the cache accesses, same lines (profiles/r02_gather_microbench.txt)
-        typedef uint32_t u32x2v __attribute__((ext_vector_type(2)));
-        u32x2v h[10];
-        asm volatile("global_load_dwordx2 %0, %10, off\n\tglobal_load_dwordx2 %1, %10, off offset:8\n\t"
-                     "global_load_dwordx2 %2, %10, off offset:16\n\tglobal_load_dwordx2 %3, %10, off offset:24\n\t"
-                     "global_load_dwordx2 %4, %10, off offset:32\n\tglobal_load_dwordx2 %5, %10, off offset:40\n\t"
-                     "global_load_dwordx2 %6, %10, off offset:48\n\tglobal_load_dwordx2 %7, %10, off offset:56\n\t"
-                     "global_load_dwordx2 %8, %10, off offset:64\n\tglobal_load_dwordx2 %9, %10, off offset:72\n\t"
-                     "s_waitcnt vmcnt(0)"
-                     : "=&v"(h[0]), "=&v"(h[1]), "=&v"(h[2]), "=&v"(h[3]), "=&v"(h[4]), "=&v"(h[5]), "=&v"(h[6]),
-                       "=&v"(h[7]), "=&v"(h[8]), "=&v"(h[9])
-                     : "v"(np)
-                     : "memory");
-        return NodeData{uint4{h[0].x, h[0].y, h[1].x, h[1].y}, uint4{h[2].x, h[2].y, h[3].x, h[3].y},
-                        uint4{h[4].x, h[4].y, h[5].x, h[5].y}, uint4{h[6].x, h[6].y, h[7].x, h[7].y},
-                        uint4{h[8].x, h[8].y, h[9].x, h[9].y}};
-#else
-        return NodeData{np[0], np[1], np[2], np[3], np[4]};
-#endif
-    }
-    PPT_D TriangleData tri(uint32_t i) const
-    {
-        const float4 *tp = reinterpret_cast<const float4 *>(triangles + i);
-        return TriangleData{tp[0], tp[1], tp[2]};
-    }
-};
-constexpr uint32_t kLdsNodeStride = 5; // float4s per node in LDS (80 B)
-struct LdsGeom
-{
-    const float4 *nodes;     // LDS
-    const float4 *triangles; // LDS
-    PPT_D NodeData node(int32_t i) const
-    {
-        const uint4 *np = reinterpret_cast<const uint4 *>(nodes + (uint32_t)i * kLdsNodeStride);
-        return NodeData{np[0], np[1], np[2], np[3], np[4]};
-    }
-    PPT_D TriangleData tri(uint32_t i) const
-    {
-        const float4 *tp = triangles + i * 3u;
-        return TriangleData{tp[0], tp[1], tp[2]};
-    }
-};
-// LDS budget of a staged scene (float4s): nodes * 5 + triangles * 3 must fit
-constexpr uint32_t kLdsSceneFloat4s = 768; // 12 KB
-
 // The traversal stack of one lane: `cap` entries in LDS (entry e at lds[e * 64], conflict-free for
 // b32 accesses), anything deeper in a global overflow column (entry e at ovf[e * ovfStride]).  The
 // builder bounds the worst case (kMaxStackBound); the LDS part is sized for the common case.
@@ -1439,6 +1385,43 @@ PPT_D RaySlabs make_ray_slabs(f3 invd)
 // 24 products; 24 v_fma_mix_f32 + 12 v_pk_mul_f32 then produce the distances.
 // SORTED = false leaves the four (entry, child) pairs in storage order: enough for an any-hit ray, whose answer
 // does not depend on the order its candidates are met in (descend_any below).
+// the common second half of the node test: slab tests of the four children from their twelve near and twelve far
+// distances (pairs: children 0|1 and 2|3), then the sort
+template <bool SORTED>
+PPT_D void finish_node4(
+    v2f tnx01, v2f tnx23, v2f tny01, v2f tny23, v2f tnz01, v2f tnz23, v2f tfx01, v2f tfx23, v2f tfy01, v2f tfy23, v2f tfz01,
+    v2f tfz23, uint4 children, float tMin, float tMax, float e[4], int32_t ref[4])
+{
+    const float tMaxK = tMax * kSlabTol;
+    e[0] = slab_entry(tnx01.x, tny01.x, tnz01.x, tfx01.x, tfy01.x, tfz01.x, tMin, tMaxK);
+    e[1] = slab_entry(tnx01.y, tny01.y, tnz01.y, tfx01.y, tfy01.y, tfz01.y, tMin, tMaxK);
+    e[2] = slab_entry(tnx23.x, tny23.x, tnz23.x, tfx23.x, tfy23.x, tfz23.x, tMin, tMaxK);
+    e[3] = slab_entry(tnx23.y, tny23.y, tnz23.y, tfx23.y, tfy23.y, tfz23.y, tMin, tMaxK);
+    ref[0] = (int32_t)children.x;
+    ref[1] = (int32_t)children.y;
+    ref[2] = (int32_t)children.z;
+    ref[3] = (int32_t)children.w;
+#define PPT_CSWAP(i, j)                                                                                                \
+    {                                                                                                                  \
+        const bool sw = e[j] < e[i];                                                                                   \
+        const float te = sw ? e[j] : e[i];                                                                             \
+        e[j] = sw ? e[i] : e[j];                                                                                       \
+        e[i] = te;                                                                                                     \
+        const int32_t tr = sw ? ref[j] : ref[i];                                                                       \
+        ref[j] = sw ? ref[i] : ref[j];                                                                                 \
+        ref[i] = tr;                                                                                                   \
+    }
+    if constexpr (SORTED)
+    {
+        PPT_CSWAP(0, 1)
+        PPT_CSWAP(2, 3)
+        PPT_CSWAP(0, 2)
+        PPT_CSWAP(1, 3)
+        PPT_CSWAP(1, 2)
+    }
+#undef PPT_CSWAP
+}
+
 template <bool SORTED = true>
 PPT_D void intersect_node4(const NodeData &n, f3 o, const RaySlabs &rs, float tMin, float tMax, float e[4], int32_t ref[4])
 {
@@ -1460,35 +1443,121 @@ PPT_D void intersect_node4(const NodeData &n, f3 o, const RaySlabs &rs, float tM
     const v2f tfx01 = plane_offsets(fx01, ox) * rs.invdK.x, tfx23 = plane_offsets(fx23, ox) * rs.invdK.x;
     const v2f tfy01 = plane_offsets(fy01, oy) * rs.invdK.y, tfy23 = plane_offsets(fy23, oy) * rs.invdK.y;
     const v2f tfz01 = plane_offsets(fz01, oz) * rs.invdK.z, tfz23 = plane_offsets(fz23, oz) * rs.invdK.z;
-    const float tMaxK = tMax * kSlabTol;
-    e[0] = slab_entry(tnx01.x, tny01.x, tnz01.x, tfx01.x, tfy01.x, tfz01.x, tMin, tMaxK);
-    e[1] = slab_entry(tnx01.y, tny01.y, tnz01.y, tfx01.y, tfy01.y, tfz01.y, tMin, tMaxK);
-    e[2] = slab_entry(tnx23.x, tny23.x, tnz23.x, tfx23.x, tfy23.x, tfz23.x, tMin, tMaxK);
-    e[3] = slab_entry(tnx23.y, tny23.y, tnz23.y, tfx23.y, tfy23.y, tfz23.y, tMin, tMaxK);
-    ref[0] = (int32_t)n.q4.x;
-    ref[1] = (int32_t)n.q4.y;
-    ref[2] = (int32_t)n.q4.z;
-    ref[3] = (int32_t)n.q4.w;
-#define PPT_CSWAP(i, j)                                                                                                \
-    {                                                                                                                  \
-        const bool sw = e[j] < e[i];                                                                                   \
-        const float te = sw ? e[j] : e[i];                                                                             \
-        e[j] = sw ? e[i] : e[j];                                                                                       \
-        e[i] = te;                                                                                                     \
-        const int32_t tr = sw ? ref[j] : ref[i];                                                                       \
-        ref[j] = sw ? ref[i] : ref[j];                                                                                 \
-        ref[i] = tr;                                                                                                   \
-    }
-    if constexpr (SORTED)
-    {
-        PPT_CSWAP(0, 1)
-        PPT_CSWAP(2, 3)
-        PPT_CSWAP(0, 2)
-        PPT_CSWAP(1, 3)
-        PPT_CSWAP(1, 2)
-    }
-#undef PPT_CSWAP
+    finish_node4<SORTED>(tnx01, tnx23, tny01, tny23, tnz01, tnz23, tfx01, tfx23, tfy01, tfy23, tfz01, tfz23, n.q4, tMin, tMax, e, ref);
 }
+
+struct GlobalGeom
+{
+    const BvhNode *nodes;
+    const WorldTriangle *triangles;
+    PPT_D NodeData node(int32_t i) const
+    {
+        const uint4 *np = reinterpret_cast<const uint4 *>(nodes + i);
+#ifdef PPT_EXPERIMENT_SPLIT_NODE_LOADS
+        // measurement only (scripts/build_variant.sh split -DPPT_EXPERIMENT_SPLIT_NODE_LOADS): the same 80 bytes as ten
+        // 8-byte loads - twice the cache accesses, same lines (profiles/r02_gather_microbench.txt)
+        typedef uint32_t u32x2v __attribute__((ext_vector_type(2)));
+        u32x2v h[10];
+        asm volatile("global_load_dwordx2 %0, %10, off\n\tglobal_load_dwordx2 %1, %10, off offset:8\n\t"
+                     "global_load_dwordx2 %2, %10, off offset:16\n\tglobal_load_dwordx2 %3, %10, off offset:24\n\t"
+                     "global_load_dwordx2 %4, %10, off offset:32\n\tglobal_load_dwordx2 %5, %10, off offset:40\n\t"
+                     "global_load_dwordx2 %6, %10, off offset:48\n\tglobal_load_dwordx2 %7, %10, off offset:56\n\t"
+                     "global_load_dwordx2 %8, %10, off offset:64\n\tglobal_load_dwordx2 %9, %10, off offset:72\n\t"
+                     "s_waitcnt vmcnt(0)"
+                     : "=&v"(h[0]), "=&v"(h[1]), "=&v"(h[2]), "=&v"(h[3]), "=&v"(h[4]), "=&v"(h[5]), "=&v"(h[6]),
+                       "=&v"(h[7]), "=&v"(h[8]), "=&v"(h[9])
+                     : "v"(np)
+                     : "memory");
+        return NodeData{uint4{h[0].x, h[0].y, h[1].x, h[1].y}, uint4{h[2].x, h[2].y, h[3].x, h[3].y},
+                        uint4{h[4].x, h[4].y, h[5].x, h[5].y}, uint4{h[6].x, h[6].y, h[7].x, h[7].y},
+                        uint4{h[8].x, h[8].y, h[9].x, h[9].y}};
+#else
+        return NodeData{np[0], np[1], np[2], np[3], np[4]};
+#endif
+    }
+    template <bool SORTED>
+    PPT_D void test_node(int32_t i, f3 o, const RaySlabs &rs, float tMin, float tMax, float e[4], int32_t ref[4]) const
+    {
+        intersect_node4<SORTED>(node(i), o, rs, tMin, tMax, e, ref);
+    }
+    PPT_D TriangleData tri(uint32_t i) const
+    {
+        const float4 *tp = reinterpret_cast<const float4 *>(triangles + i);
+        return TriangleData{tp[0], tp[1], tp[2]};
+    }
+};
+// A node as the kernels of LDS-resident scenes keep it (stage_scene_in_lds converts): the planes as fp32 - exactly the values
+// the binary16 ones decode to - one float4 (four children) per plane set, the near / far sets of an axis 64 bytes apart:
+//   f4[0] origin.xyz   f4[1] lo.x  f4[2] lo.y  f4[3] lo.z   f4[4] child[0..3]   f4[5] hi.x  f4[6] hi.y  f4[7] hi.z   f4[8] padding
+// A ray reads its near planes at  16 (a + 1) + 64 s_a  and its far planes at  16 (a + 5) - 64 s_a  (s_a = 1 where it travels
+// in -a): the choice of planes is part of the ADDRESS (two integer instructions per axis) instead of twelve v_cndmask, and
+// (plane - o) is a plain v_sub_f32 instead of a v_fma_mix_f32 - same values, same rounding: 9 x 16 B per visit out of LDS
+// (256 B/clk per CU) instead of 5 x 16 B, ~15 % fewer issue cycles per node visit.  The 144-byte stride spreads the same
+// float4 of neighbouring nodes over different banks.
+constexpr uint32_t kLdsNodeStride = 9; // float4s per node in LDS (144 B)
+struct LdsGeom
+{
+    const float4 *nodes;     // LDS: kLdsNodeStride float4s per node (see above)
+    const float4 *triangles; // LDS
+    template <bool SORTED>
+    PPT_D void test_node(int32_t i, f3 o, const RaySlabs &rs, float tMin, float tMax, float e[4], int32_t ref[4]) const
+    {
+        typedef float f4n __attribute__((ext_vector_type(4)));
+        typedef uint32_t u4n __attribute__((ext_vector_type(4)));
+        typedef __attribute__((address_space(3))) const f4n *lds_f4;
+        typedef __attribute__((address_space(3))) const u4n *lds_u4;
+        // (an LDS address is its low 32 bits; a generic pointer into LDS converts to one by dropping the aperture)
+        const uint32_t base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void *)nodes + (uint32_t)i * (kLdsNodeStride * 16u);
+        // 64 where the ray travels in - along the axis: the sign bit of 1 / d moved to bit 6
+        const uint32_t sx = (__builtin_bit_cast(uint32_t, rs.invd.x) >> 25) & 64u;
+        const uint32_t sy = (__builtin_bit_cast(uint32_t, rs.invd.y) >> 25) & 64u;
+        const uint32_t sz = (__builtin_bit_cast(uint32_t, rs.invd.z) >> 25) & 64u;
+        const f4n origin = *(lds_f4)(uintptr_t)(base);
+        const f4n nx = *(lds_f4)(uintptr_t)(base + 16u + sx), fx = *(lds_f4)(uintptr_t)(base + 80u - sx);
+        const f4n ny = *(lds_f4)(uintptr_t)(base + 32u + sy), fy = *(lds_f4)(uintptr_t)(base + 96u - sy);
+        const f4n nz = *(lds_f4)(uintptr_t)(base + 48u + sz), fz = *(lds_f4)(uintptr_t)(base + 112u - sz);
+        const u4n ch = *(lds_u4)(uintptr_t)(base + 64u);
+        const uint4 children = make_uint4(ch.x, ch.y, ch.z, ch.w);
+        const float ox = o.x - origin.x, oy = o.y - origin.y, oz = o.z - origin.z;
+        const v2f tnx01 = v2f{nx.x - ox, nx.y - ox} * rs.invd.x, tnx23 = v2f{nx.z - ox, nx.w - ox} * rs.invd.x;
+        const v2f tny01 = v2f{ny.x - oy, ny.y - oy} * rs.invd.y, tny23 = v2f{ny.z - oy, ny.w - oy} * rs.invd.y;
+        const v2f tnz01 = v2f{nz.x - oz, nz.y - oz} * rs.invd.z, tnz23 = v2f{nz.z - oz, nz.w - oz} * rs.invd.z;
+        const v2f tfx01 = v2f{fx.x - ox, fx.y - ox} * rs.invdK.x, tfx23 = v2f{fx.z - ox, fx.w - ox} * rs.invdK.x;
+        const v2f tfy01 = v2f{fy.x - oy, fy.y - oy} * rs.invdK.y, tfy23 = v2f{fy.z - oy, fy.w - oy} * rs.invdK.y;
+        const v2f tfz01 = v2f{fz.x - oz, fz.y - oz} * rs.invdK.z, tfz23 = v2f{fz.z - oz, fz.w - oz} * rs.invdK.z;
+        finish_node4<SORTED>(tnx01, tnx23, tny01, tny23, tnz01, tnz23, tfx01, tfx23, tfy01, tfy23, tfz01, tfz23, children, tMin, tMax, e, ref);
+    }
+    PPT_D TriangleData tri(uint32_t i) const
+    {
+        const float4 *tp = triangles + i * 3u;
+        return TriangleData{tp[0], tp[1], tp[2]};
+    }
+};
+// The nodes as they are in HBM (80 B) in LDS: what the camera-ray kernel uses - its lockstep loop holds a whole node of
+// the fp32 image in registers at once and spills at its 96-VGPR budget with it (9 dwords), the stream scheduler's does not.
+constexpr uint32_t kLdsNodeStrideHalf = 5; // float4s per node (80 B)
+struct LdsGeomHalf
+{
+    const float4 *nodes;     // LDS
+    const float4 *triangles; // LDS
+    PPT_D NodeData node(int32_t i) const
+    {
+        const uint4 *np = reinterpret_cast<const uint4 *>(nodes + (uint32_t)i * kLdsNodeStrideHalf);
+        return NodeData{np[0], np[1], np[2], np[3], np[4]};
+    }
+    template <bool SORTED>
+    PPT_D void test_node(int32_t i, f3 o, const RaySlabs &rs, float tMin, float tMax, float e[4], int32_t ref[4]) const
+    {
+        intersect_node4<SORTED>(node(i), o, rs, tMin, tMax, e, ref);
+    }
+    PPT_D TriangleData tri(uint32_t i) const
+    {
+        const float4 *tp = triangles + i * 3u;
+        return TriangleData{tp[0], tp[1], tp[2]};
+    }
+};
+// LDS budget of a staged scene (float4s): nodes * kLdsNodeStride + triangles * 3 must fit
+constexpr uint32_t kLdsSceneFloat4s = 768; // 12 KB
 
 // Any-hit rays (shadow(): terminate on the first accepted hit) take the children a node test reports in storage
 // order: the first one entered becomes the next node, the others go on the stack.  Whether the ray is occluded does
@@ -1555,19 +1624,18 @@ PPT_D bool trace_in(
     {
         while (alive && node >= 0)
         {
-            const NodeData nd = g.node(node);
             if constexpr (COUNT) cnt.nodeVisits++;
             float e[4];
             int32_t ref[4];
             bool entered;
             if constexpr (ANY)
             {
-                intersect_node4<false>(nd, o, rs, tMin, hit.t, e, ref);
+                g.template test_node<false>(node, o, rs, tMin, hit.t, e, ref);
                 entered = descend_any(e, ref, stack, sp, node);
             }
             else
             {
-                intersect_node4(nd, o, rs, tMin, hit.t, e, ref);
+                g.template test_node<true>(node, o, rs, tMin, hit.t, e, ref);
                 stack.push_hit_children(sp, e, ref);
                 entered = e[0] < kInf;
                 if (entered) node = ref[0];

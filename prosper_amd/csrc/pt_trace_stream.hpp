@@ -166,7 +166,6 @@ PPT_D void trace_stream(
 #endif
                 if (state == kLaneNode)
                 {
-                    const NodeData nd = g.node(node);
                     if constexpr (COUNT) cnt.nodeVisits++;
                     float e[4];
                     int32_t ref[4];
@@ -179,12 +178,12 @@ PPT_D void trace_stream(
                     if constexpr (ANY)
 #endif
                     {
-                        intersect_node4<false>(nd, o, rs, tMin, hit.t, e, ref);
+                        g.template test_node<false>(node, o, rs, tMin, hit.t, e, ref);
                         entered = descend_any(e, ref, stack, sp, node);
                     }
                     else
                     {
-                        intersect_node4(nd, o, rs, tMin, hit.t, e, ref);
+                        g.template test_node<true>(node, o, rs, tMin, hit.t, e, ref);
                         stack.push_hit_children(sp, e, ref);
                         entered = e[0] < kInf;
                         if (entered) node = ref[0];

@@ -321,11 +321,39 @@ struct PoolTracer
 };
 #endif
 
-// Copies the BVH nodes and world triangles into this workgroup's LDS.
-__device__ __forceinline__ LdsGeom stage_scene_in_lds(const DeviceScene &s, float4 *lds, uint32_t nodeCount, uint32_t triCount)
+// Copies the BVH nodes and world triangles into this workgroup's LDS as they are (LdsGeomHalf).
+__device__ __forceinline__ LdsGeomHalf stage_scene_in_lds_half(const DeviceScene &s, float4 *lds, uint32_t nodeCount, uint32_t triCount)
 {
     const float4 *gn = reinterpret_cast<const float4 *>(s.nodes);
-    for (uint32_t i = threadIdx.x; i < nodeCount * kLdsNodeStride; i += blockDim.x) lds[i] = gn[i];
+    for (uint32_t i = threadIdx.x; i < nodeCount * kLdsNodeStrideHalf; i += blockDim.x) lds[i] = gn[i];
+    float4 *lt = lds + nodeCount * kLdsNodeStrideHalf;
+    const float4 *gt = reinterpret_cast<const float4 *>(s.triangles);
+    for (uint32_t i = threadIdx.x; i < triCount * 3u; i += blockDim.x) lt[i] = gt[i];
+    __syncthreads();
+    return LdsGeomHalf{lds, lt};
+}
+
+// The BVH nodes - converted to the fp32 image of LdsGeom (pt_device.hpp) - and the world triangles into this workgroup's LDS.
+__device__ __forceinline__ LdsGeom stage_scene_in_lds(const DeviceScene &s, float4 *lds, uint32_t nodeCount, uint32_t triCount)
+{
+    const BvhNode *gn = s.nodes;
+    float *lf = reinterpret_cast<float *>(lds);
+    // one thread per (node, float of the 36-float image)
+    for (uint32_t i = threadIdx.x; i < nodeCount * (kLdsNodeStride * 4u); i += blockDim.x)
+    {
+        const uint32_t n = i / (kLdsNodeStride * 4u), k = i - n * (kLdsNodeStride * 4u);
+        const uint32_t q = k >> 2, c = k & 3u; // float4 index within the image, component
+        float v = 0.0f;
+        if (q == 0u)
+            v = c < 3u ? gn[n].origin[c] : 0.0f;
+        else if (q >= 1u && q <= 3u)
+            v = half_to_float(gn[n].lo[q - 1u][c]);
+        else if (q == 4u)
+            v = __builtin_bit_cast(float, gn[n].child[c]);
+        else if (q <= 7u)
+            v = half_to_float(gn[n].hi[q - 5u][c]);
+        lf[i] = v;
+    }
     float4 *lt = lds + nodeCount * kLdsNodeStride;
     const float4 *gt = reinterpret_cast<const float4 *>(s.triangles);
     for (uint32_t i = threadIdx.x; i < triCount * 3u; i += blockDim.x) lt[i] = gt[i];
@@ -433,8 +461,13 @@ __global__ __launch_bounds__(256, PPT_GEN_WPE) void wf_generate_extend(
 {
     __shared__ int32_t ldsStack[STACK * 256];
     __shared__ float4 ldsScene[LDS_SCENE ? kLdsSceneFloat4s : 1];
+#ifdef PPT_EXPERIMENT_GEN_LDS_F32
     LdsGeom lg = {};
     if constexpr (LDS_SCENE) lg = stage_scene_in_lds(s, ldsScene, nodeCount, triCount);
+#else
+    LdsGeomHalf lg = {};
+    if constexpr (LDS_SCENE) lg = stage_scene_in_lds_half(s, ldsScene, nodeCount, triCount);
+#endif
     const GlobalGeom gg{s.nodes, s.triangles};
     const SegmentId id = my_segment(w);
     if (!id.valid) return;
@@ -921,8 +954,13 @@ __global__ __launch_bounds__(256, PPT_TRACE_WPE(STACK)) void wf_trace(
 {
     __shared__ int32_t ldsStack[STACK * 256];
     __shared__ float4 ldsScene[LDS_SCENE ? kLdsSceneFloat4s : 1];
+#ifdef PPT_EXPERIMENT_TRACE_LDS_HALF
+    LdsGeomHalf lg = {}; // (A/B: the 80-byte node image, as until round 4)
+    if constexpr (LDS_SCENE) lg = stage_scene_in_lds_half(s, ldsScene, nodeCount, triCount);
+#else
     LdsGeom lg = {};
     if constexpr (LDS_SCENE) lg = stage_scene_in_lds(s, ldsScene, nodeCount, triCount);
+#endif
     const GlobalGeom gg{s.nodes, s.triangles};
     const SegmentId id = my_segment(w);
     if (!id.valid) return;
@@ -971,8 +1009,8 @@ __global__ __launch_bounds__(256, 3) void wf_trace_pool(
 {
     __shared__ uint32_t ldsPool[RayPool<P, S>::kLdsDwords * 4u];
     __shared__ float4 ldsScene[LDS_SCENE ? kLdsSceneFloat4s : 1];
-    LdsGeom lg = {};
-    if constexpr (LDS_SCENE) lg = stage_scene_in_lds(s, ldsScene, nodeCount, triCount);
+    LdsGeomHalf lg = {};
+    if constexpr (LDS_SCENE) lg = stage_scene_in_lds_half(s, ldsScene, nodeCount, triCount);
     const GlobalGeom gg{s.nodes, s.triangles};
     const SegmentId id = my_segment(w);
     if (!id.valid) return;
