@@ -53,6 +53,20 @@ void World::updateBuffers(prosper_pt_ctx *ctx)
         throw std::runtime_error(std::string("World::updateBuffers: ") + prosper_pt_last_error());
 }
 
+void World::adoptTextures(prosper_pt_ctx *ctx, const prosper_pt_texture_desc *textures, uint32_t firstSlot, uint32_t count)
+{
+    PROSPER_ASSERT(uploadedTo(ctx));
+    if (prosper_pt_update_textures(ctx, textures, firstSlot, count) != PROSPER_PT_OK)
+        throw std::runtime_error(std::string("World::adoptTextures: ") + prosper_pt_last_error());
+}
+
+void World::uploadMaterialDatas(prosper_pt_ctx *ctx, const prosper_MaterialData *materials, uint32_t count)
+{
+    PROSPER_ASSERT(uploadedTo(ctx));
+    if (prosper_pt_update_materials(ctx, materials, 0, count) != PROSPER_PT_OK)
+        throw std::runtime_error(std::string("World::uploadMaterialDatas: ") + prosper_pt_last_error());
+}
+
 } // namespace scene
 
 namespace render

@@ -39,6 +39,15 @@ class World
     // World::updateBuffers' light writes (src/scene/World.cpp:468-536, :531-535: the three light buffers, every frame), from
     // the light pointers of the scene view.  An unchanged set is a no-op.
     void updateBuffers(prosper_pt_ctx *ctx);
+    // While the scene streams in (src/scene/WorldData.cpp:588-647 handleDeferredLoading, once per frame from App.cpp:601):
+    // the images the texture worker finished this frame take their slots of materialTextures[] (WorldData.cpp:2182-2206
+    // updateDescriptorsWithNewTextures; image k of the glTF is slot k + 1) ...
+    void adoptTextures(prosper_pt_ctx *ctx, const prosper_pt_texture_desc *textures, uint32_t firstSlot, uint32_t count);
+    // ... and uploadMaterialDatas (WorldData.cpp:568-586, every frame from App.cpp:526-529) hands over the whole material
+    // table: entries that did not change cost a memcmp, the materials updateMaterials() just switched from their
+    // placeholders (WorldData.cpp:2208-2239) get their texture packs and alpha bounds.  Both take effect at the head of the
+    // next record()'s launches; frames in flight keep what they started with.  Throw std::runtime_error on failure.
+    void uploadMaterialDatas(prosper_pt_ctx *ctx, const prosper_MaterialData *materials, uint32_t count);
     [[nodiscard]] bool uploadedTo(const prosper_pt_ctx *ctx) const { return m_ctx == ctx && !m_dirty; }
 
   private:
