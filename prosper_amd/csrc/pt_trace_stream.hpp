@@ -157,6 +157,15 @@ PPT_D void trace_stream(
                 // measurement only (profiles/r04_stream_tails.txt): node steps taken after the stream ran out of rays to hand out
                 if constexpr (COUNT) cnt.historyReads += (lane == 0 && next >= n) ? 1u : 0u;
 #endif
+#ifdef PPT_EXPERIMENT_COUNT_IDLE_LANES
+                // measurement only: lanes WITHOUT A RAY (idle, nothing left to refill from) summed over the node steps of the
+                // shadow stream (historyReads) and of the closest-hit stream (pixelsWritten): what a merged stream could fill
+                if constexpr (COUNT)
+                {
+                    const uint32_t idle = (uint32_t)__builtin_popcountll(__ballot(state == kLaneIdle || state == kLaneFinished));
+                    if (lane == 0 && next >= n) (ANY ? cnt.historyReads : cnt.pixelsWritten) += idle;
+                }
+#endif
 #ifdef PPT_EXPERIMENT_COUNT_NARROW_STEPS
                 if constexpr (COUNT) // measurement only (profiles/r02_exec_mask_microbench.txt): node steps with <= 8 lanes
                 {
