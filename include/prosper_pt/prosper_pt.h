@@ -15,6 +15,8 @@
  *   prosper_pt_update_transforms      instance transforms + TLAS rebuild           World.cpp:359-466,749-802,878-928
  *   prosper_pt_update_textures /      adoption of streamed-in images / materials   src/scene/WorldData.cpp:568-647,2182-2239
  *   prosper_pt_update_materials
+ *   prosper_pt_update_meshes          adoption of streamed-in meshes, BLAS once    WorldData.cpp:2003-2110, World.cpp:585-606,
+ *                                     a model is complete, inactive until then     909-915
  *   prosper_pt_render                 pushConstants + traceRaysKHR                 RtReference.cpp:278-330
  *                                     + the previous/illumination ping-pong        RtReference.cpp:178-219,332-334
  *   prosper_pt_read_hdr               the RGBA32F "rtIllumination" image           RtReference.cpp:178-187
@@ -151,7 +153,8 @@ typedef struct prosper_pt_scene_view
     const uint64_t *geometryBufferByteSizes;
     uint32_t geometryBufferCount;
     uint32_t meshCount;
-    const prosper_GeometryMetadata *geometryMetadatas; /* [meshCount] */
+    const prosper_GeometryMetadata *geometryMetadatas; /* [meshCount]; bufferIndex == PROSPER_PT_ABSENT: the mesh has not
+                                                          been loaded yet (prosper_pt_update_meshes) */
     const prosper_pt_mesh_info *meshInfos;             /* [meshCount] */
 
     /* SCENE_INSTANCES_SET (instances.glsl:8-34) */
@@ -376,6 +379,38 @@ int prosper_pt_update_transforms_async(
  * scene a fresh prosper_pt_upload_scene of that state would show, bit for bit. */
 int prosper_pt_update_textures(prosper_pt_ctx *ctx, const prosper_pt_texture_desc *textures, uint32_t first, uint32_t count);
 int prosper_pt_update_materials(prosper_pt_ctx *ctx, const prosper_MaterialData *materials, uint32_t first, uint32_t count);
+
+/* ---- incremental adoption: streamed-in meshes ----
+ * prosper's mesh worker fills the geometry buffers in the background; WorldData::pollMeshWorker adopts at most ten finished
+ * meshes per frame - their GeometryMetadata and MeshInfo slots, their byte range of a geometry buffer, a new 64 MB buffer
+ * now and then (src/scene/WorldData.cpp:2003-2110; at most sMaxGeometryBuffersCount = 100 of them, :31).  Until then a mesh's
+ * metadata holds bufferIndex = 0xFFFFFFFF; World::buildNextBlas builds a model's BLAS only once ALL its sub-meshes are there
+ * (World.cpp:598-606) and a TLAS instance without a BLAS is inactive (accelerationStructureReference 0, World.cpp:909-915):
+ * rays pass through model instances that are still loading.
+ * Here: upload the scene with every mesh slot, draw instance and transform it will have; a mesh that has not arrived has
+ * geometryMetadatas[i].bufferIndex == PROSPER_PT_ABSENT (the rest of its metadata and its MeshInfo are ignored), and a model
+ * instance - a run of draw instances with one modelInstanceIndex - contributes triangles only once every mesh it draws is
+ * there.  prosper_pt_update_meshes hands over the meshes that arrived: metadata and MeshInfo as pollMeshWorker stores them,
+ * and the bytes the worker wrote (`bytes`, borrowed for the call) with their place in geometryBuffers[metadata.bufferIndex].
+ * A buffer index the scene has not seen yet creates that buffer, `bufferByteSize` bytes large (ignored otherwise).
+ * The call re-flattens the scene, builds the subtrees of the model instances that became complete (the others are kept),
+ * re-assembles the hierarchy and synchronises the device: textures, material tables, lights and sky stay as they are, and
+ * the next render shows what a fresh prosper_pt_upload_scene of the new state would show, bit for bit.  A mesh can be
+ * handed over once; its material's alpha mode is the one the table holds at the time of the call. */
+#define PROSPER_PT_MAX_GEOMETRY_BUFFERS 100u
+typedef struct prosper_pt_mesh_update
+{
+    uint32_t meshIndex;
+    uint32_t reserved;
+    prosper_GeometryMetadata metadata; /* bufferIndex < PROSPER_PT_MAX_GEOMETRY_BUFFERS */
+    prosper_pt_mesh_info info;
+    const void *bytes;       /* UploadedGeometryData: the mesh's part of the geometry buffer ... */
+    uint64_t byteOffset;     /* ... its place in that buffer (a multiple of 4) ... */
+    uint64_t byteCount;      /* ... and size; every stream `metadata` names must lie inside */
+    uint64_t bufferByteSize; /* size of geometryBuffers[metadata.bufferIndex] if the scene does not have that buffer yet */
+} prosper_pt_mesh_update;
+int prosper_pt_update_meshes(prosper_pt_ctx *ctx, const prosper_pt_mesh_update *meshes, uint32_t count);
+
 /* Re-splits the instances that moved since the last build and re-assembles the tree on the host (one subtree per model
  * instance under a re-braided top level); synchronises the device.  prosper_pt_scene_stats.bvhBuildSeconds reports it. */
 int prosper_pt_rebuild_hierarchy(prosper_pt_ctx *ctx);

@@ -1157,14 +1157,29 @@ ora_scene *ora_scene_create(const prosper_pt_scene_view *view, int brute_force)
     if (!s) return NULL;
     s->view = *view;
     s->bruteForce = brute_force;
+    /* A mesh that is still loading has GeometryMetadata::bufferIndex 0xFFFFFFFF; World::buildNextBlas builds a model's BLAS
+     * only once ALL its sub-meshes are there (World.cpp:598-606) and a TLAS instance without a BLAS is inactive
+     * (accelerationStructureReference 0, World.cpp:909-915): rays pass through it.  A TLAS instance is a run of draw
+     * instances with one modelInstanceIndex (World.cpp:480-513, 878-928). */
+    uint8_t *active = (uint8_t *)calloc(view->drawInstanceCount ? view->drawInstanceCount : 1, 1);
+    for (uint32_t di = 0; di < view->drawInstanceCount;)
+    {
+        const uint32_t mi = view->drawInstances[di].modelInstanceIndex;
+        uint32_t end = di;
+        int complete = 1;
+        for (; end < view->drawInstanceCount && view->drawInstances[end].modelInstanceIndex == mi; ++end)
+            if (view->geometryMetadatas[view->drawInstances[end].meshIndex].bufferIndex == 0xFFFFFFFFu) complete = 0;
+        for (; di < end; ++di) active[di] = (uint8_t)complete;
+    }
     uint64_t total = 0;
     for (uint32_t di = 0; di < view->drawInstanceCount; ++di)
-        total += view->meshInfos[view->drawInstances[di].meshIndex].indexCount / 3;
+        if (active[di]) total += view->meshInfos[view->drawInstances[di].meshIndex].indexCount / 3;
     s->triCount = total;
     s->tris = (ora_tri *)malloc(sizeof(ora_tri) * (total ? total : 1));
     uint64_t w = 0;
     for (uint32_t di = 0; di < view->drawInstanceCount; ++di)
     {
+        if (!active[di]) continue;
         const prosper_DrawInstance *inst = &view->drawInstances[di];
         const prosper_GeometryMetadata *m = &view->geometryMetadatas[inst->meshIndex];
         const prosper_pt_mesh_info *info = &view->meshInfos[inst->meshIndex];
@@ -1186,6 +1201,7 @@ ora_scene *ora_scene_create(const prosper_pt_scene_view *view, int brute_force)
             t->opaque = opaque;
         }
     }
+    free(active);
     if (!brute_force && total > 0)
     {
         s->nodes = (ora_node *)malloc(sizeof(ora_node) * (size_t)(2 * total + 2));

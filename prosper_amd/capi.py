@@ -60,6 +60,7 @@ def lib():
     L.prosper_pt_get_scene_stats.argtypes = [vp, C.POINTER(S.SceneStats)]
     L.prosper_pt_update_textures.argtypes = [vp, vp, u32, u32]
     L.prosper_pt_update_materials.argtypes = [vp, vp, u32, u32]
+    L.prosper_pt_update_meshes.argtypes = [vp, vp, u32]
     L.prosper_pt_update_transforms.argtypes = [vp, vp, u32]
     L.prosper_pt_update_transforms_async.argtypes = [vp, vp, u32, u32, vp]
     L.prosper_pt_rebuild_hierarchy.argtypes = [vp]
@@ -299,6 +300,22 @@ class Context:
         self._sync_debug()
         arr = (S.MaterialData * len(materials))(*materials)
         _check(lib().prosper_pt_update_materials(self._h, C.cast(arr, C.c_void_p), first, len(materials)))
+
+    def update_meshes(self, world, mesh_indices):
+        """Hands over meshes of `world` (a World that holds them) that the uploaded scene marked as not loaded
+        (World.with_meshes_loaded): metadata, MeshInfo and the mesh's bytes of its geometry buffer."""
+        self._sync_debug()
+        f = world.freeze()
+        ups = (S.MeshUpdate * max(1, len(mesh_indices)))()
+        for u, i in zip(ups, mesh_indices):
+            buffer_index, first_word, words = world.mesh_ranges[i]
+            buf = f["geometry_buffers"][buffer_index]
+            u.meshIndex = i
+            u.metadata = world.metadatas[i]
+            u.info = world.mesh_infos[i]
+            u.bytes = buf.ctypes.data + 4 * first_word
+            u.byteOffset, u.byteCount, u.bufferByteSize = 4 * first_word, 4 * words, buf.nbytes
+        _check(lib().prosper_pt_update_meshes(self._h, C.cast(ups, C.c_void_p), len(mesh_indices)))
 
     def rebuild_hierarchy(self):
         self._sync_debug()

@@ -742,23 +742,60 @@ InstancedBvh::InstancedBvh() : m(new Impl()) {}
 InstancedBvh::~InstancedBvh() { delete m; }
 size_t InstancedBvh::instanceCount() const { return m->instances.size(); }
 
-BvhBuildResult InstancedBvh::build(
-    const WorldTriangle *triangles, uint64_t count, const std::vector<Range> &instances, const BvhBuildOptions &opt)
+static void check_ranges_tile(const std::vector<InstancedBvh::Range> &instances, uint64_t count)
 {
-    m->opt = opt;
-    if (count >= (1ull << 28)) throw std::runtime_error("too many triangles for the leaf reference encoding");
     uint64_t covered = 0;
-    for (const Range &r : instances)
+    for (const InstancedBvh::Range &r : instances)
     {
         if ((uint64_t)r.first != covered) throw std::runtime_error("instance triangle ranges must tile the triangle array");
         covered += r.count;
     }
     if (covered != count) throw std::runtime_error("instance triangle ranges must tile the triangle array");
+}
+
+BvhBuildResult InstancedBvh::build(
+    const WorldTriangle *triangles, uint64_t count, const std::vector<Range> &instances, const BvhBuildOptions &opt)
+{
+    m->opt = opt;
+    if (count >= (1ull << 28)) throw std::runtime_error("too many triangles for the leaf reference encoding");
+    check_ranges_tile(instances, count);
     m->count = count;
     m->instances = instances;
     m->prims.assign((size_t)count, Prim());
     m->subtrees.assign(instances.size(), Impl::Subtree());
     m->build_subtrees(triangles, std::vector<uint8_t>());
+    return m->assemble();
+}
+
+BvhBuildResult InstancedBvh::adopt(
+    const WorldTriangle *triangles, uint64_t count, const std::vector<Range> &instances, const std::vector<uint8_t> &changed,
+    const BvhBuildOptions &opt)
+{
+    m->opt = opt;
+    if (count >= (1ull << 28)) throw std::runtime_error("too many triangles for the leaf reference encoding");
+    if (instances.size() != m->instances.size() || changed.size() != instances.size())
+        throw std::runtime_error("InstancedBvh::adopt: one range and one flag per instance of the last build");
+    check_ranges_tile(instances, count);
+    std::vector<Prim> moved((size_t)count);
+    for (size_t i = 0; i < instances.size(); ++i)
+    {
+        if (changed[i]) continue; // build_subtree fills its slice
+        const Range &was = m->instances[i], &now = instances[i];
+        if (was.count != now.count) throw std::runtime_error("InstancedBvh::adopt: an unflagged instance changed its triangle count");
+        const uint32_t delta = now.first - was.first; // (modulo 2^32: ranges may move down as well as up)
+        for (uint32_t k = 0; k < now.count; ++k)
+        {
+            Prim p = m->prims[(size_t)was.first + k];
+            p.index += delta;
+            moved[(size_t)now.first + k] = p;
+        }
+        for (TmpNode &n : m->subtrees[i].nodes)
+            if (n.left < 0) n.first += delta;
+    }
+    m->prims.swap(moved);
+    m->instances = instances;
+    m->count = count;
+    m->build_subtrees(triangles, changed);
     return m->assemble();
 }
 

@@ -69,6 +69,13 @@ class InstancedBvh
     // (one flag per entry of the `instances` given to build) are rebuilt.
     BvhBuildResult rebuild(
         const WorldTriangle *triangles, const std::vector<uint8_t> &changed, const BvhBuildOptions &opt = BvhBuildOptions());
+    // The instances' triangle ranges changed (meshes arrived: prosper_pt_update_meshes): `instances` has one entry per entry
+    // of the last build, `changed` flags those whose triangles are new or different - only they are split again; the other
+    // subtrees are kept, moved to their new place in the triangle array.  An unflagged instance must hold the triangles it
+    // held (same count, same values).
+    BvhBuildResult adopt(
+        const WorldTriangle *triangles, uint64_t count, const std::vector<Range> &instances, const std::vector<uint8_t> &changed,
+        const BvhBuildOptions &opt = BvhBuildOptions());
     [[nodiscard]] size_t instanceCount() const;
 
   private:

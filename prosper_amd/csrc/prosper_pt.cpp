@@ -119,6 +119,8 @@ void free_scene(prosper_pt_ctx *ctx)
     ctx->lights = nullptr;
     delete ctx->materialState;
     ctx->materialState = nullptr;
+    delete ctx->geometry;
+    ctx->geometry = nullptr;
     ctx->dTransforms = nullptr;
     ctx->sceneBytes = 0;
     ctx->haveScene = false;
@@ -133,6 +135,8 @@ int validate_scene(const prosper_pt_scene_view *v)
         return fail(PROSPER_PT_ERR_INVALID_ARGUMENT, "scene view struct_size mismatch");
     if (v->geometryBufferCount && (!v->geometryBuffers || !v->geometryBufferByteSizes))
         return fail(PROSPER_PT_ERR_SCENE, "geometry buffers missing");
+    if (v->geometryBufferCount > PROSPER_PT_MAX_GEOMETRY_BUFFERS)
+        return fail(PROSPER_PT_ERR_SCENE, "more than PROSPER_PT_MAX_GEOMETRY_BUFFERS geometry buffers");
     if (v->meshCount && (!v->geometryMetadatas || !v->meshInfos)) return fail(PROSPER_PT_ERR_SCENE, "mesh tables missing");
     if (v->drawInstanceCount && !v->drawInstances) return fail(PROSPER_PT_ERR_SCENE, "draw instances missing");
     if (v->modelInstanceCount && !v->modelInstanceTransforms) return fail(PROSPER_PT_ERR_SCENE, "transforms missing");
@@ -176,6 +180,7 @@ int validate_scene(const prosper_pt_scene_view *v)
         const prosper_GeometryMetadata &m = v->geometryMetadatas[i];
         const prosper_pt_mesh_info &info = v->meshInfos[i];
         const std::string name = "mesh " + std::to_string(i);
+        if (m.bufferIndex == PROSPER_PT_ABSENT) continue; // not loaded yet (prosper_pt_update_meshes): nothing else of it is read
         if (m.bufferIndex >= v->geometryBufferCount) return fail(PROSPER_PT_ERR_SCENE, name + ": bufferIndex out of range");
         if (info.materialIndex >= v->materialCount) return fail(PROSPER_PT_ERR_SCENE, name + ": materialIndex out of range");
         if (info.indexCount % 3 != 0) return fail(PROSPER_PT_ERR_SCENE, name + ": indexCount is not a multiple of 3");
@@ -320,12 +325,17 @@ int upload_hierarchy(prosper_pt_ctx *ctx, const BvhBuildResult &bvh)
         acc->refitCapacityNodes = capacity;
     }
     PPT_HIP(hipMemcpy(acc->dRefitOrder, order.data(), n * sizeof(uint32_t), hipMemcpyHostToDevice));
-    if (!acc->dLeafPosition)
+    if (!acc->dLeafPosition) // (also after prosper_pt_update_meshes: the array follows the triangle count)
     {
         void *d = nullptr;
         int rc;
         if ((rc = device_alloc(ctx, (size_t)(acc->total ? acc->total : 1) * sizeof(uint32_t), &d))) return rc;
         acc->dLeafPosition = static_cast<uint32_t *>(d);
+    }
+    if (!acc->dCost)
+    {
+        void *d = nullptr;
+        int rc;
         if ((rc = device_alloc(ctx, sizeof(float) * AccelState::kCostSlots, &d))) return rc;
         acc->dCost = static_cast<float *>(d);
         PPT_HIP(hipHostMalloc((void **)&acc->hCost, sizeof(float) * AccelState::kCostSlots, hipHostMallocDefault));
@@ -363,107 +373,149 @@ int upload_hierarchy(prosper_pt_ctx *ctx, const BvhBuildResult &bvh)
     return PROSPER_PT_OK;
 }
 
-int upload_scene_impl(prosper_pt_ctx *ctx, const prosper_pt_scene_view *v)
+// ---- the geometry of the scene: where every draw instance's triangles live, the hierarchy over them, the per-triangle
+//      records.  prosper_pt_upload_scene builds it from the view, prosper_pt_update_meshes again from the mirrors
+//      (GeometryState) once meshes arrived. ----
+struct GeometryLayout
+{
+    std::vector<uint32_t> triOffsets, diFlags, alphaOffsets; // per draw instance (+ 1 for triOffsets)
+    std::vector<InstancedBvh::Range> ranges;                 // one per run of draw instances of a model instance
+    std::vector<uint32_t> rangeModelInstance;
+    std::vector<uint8_t> rangeComplete;                      // every mesh of the run has been loaded
+    uint64_t total = 0, alphaTotal = 0;
+};
+
+bool mesh_loaded(const prosper_GeometryMetadata &m) { return m.bufferIndex != PROSPER_PT_ABSENT; }
+
+int layout_geometry(const GeometryState &gs, const prosper_MaterialData *materials, GeometryLayout &out)
+{
+    const uint32_t n = (uint32_t)gs.drawInstances.size();
+    out.triOffsets.assign((size_t)n + 1, 0u);
+    out.diFlags.assign(n ? n : 1, 0u);
+    out.alphaOffsets.assign(n ? n : 1, 0u);
+    uint64_t total = 0, alphaTotal = 0;
+    for (uint32_t i = 0; i < n;)
+    {
+        // one subtree per run of draw instances of the same model instance (World.cpp:480-513 emits them together):
+        // prosper's TLAS instance (World.cpp:878-928).  It is active once its BLAS exists, and buildNextBlas waits for ALL
+        // sub-meshes of the model (World.cpp:598-606, 909-915): a run with a mesh still loading has no triangles.
+        const uint32_t mi = gs.drawInstances[i].modelInstanceIndex;
+        uint32_t j = i;
+        bool complete = true;
+        for (; j < n && gs.drawInstances[j].modelInstanceIndex == mi; ++j)
+            complete = complete && mesh_loaded(gs.metadatas[gs.drawInstances[j].meshIndex]);
+        out.ranges.push_back(InstancedBvh::Range{(uint32_t)total, 0u});
+        out.rangeModelInstance.push_back(mi);
+        out.rangeComplete.push_back(complete ? 1 : 0);
+        for (uint32_t k = i; k < j; ++k)
+        {
+            const uint32_t mesh = gs.drawInstances[k].meshIndex;
+            out.triOffsets[k] = (uint32_t)total;
+            if (!mesh_loaded(gs.metadatas[mesh])) continue; // (its MeshInfo is not there yet either)
+            const prosper_pt_mesh_info &info = gs.infos[mesh];
+            // World.cpp:646-651: eOpaque iff the mesh's material is AlphaMode_Opaque
+            out.diFlags[k] = materials[info.materialIndex].alphaMode == PROSPER_ALPHA_MODE_OPAQUE ? kTriFlagOpaque : 0u;
+            if (gs.metadatas[mesh].usesShortIndices == 1) out.diFlags[k] |= kTriFlagShortIndices;
+            const uint32_t tris = complete ? info.indexCount / 3 : 0u;
+            if (!(out.diFlags[k] & kTriFlagOpaque))
+            {
+                out.alphaOffsets[k] = (uint32_t)alphaTotal;
+                alphaTotal += tris;
+            }
+            total += tris;
+            out.ranges.back().count += tris;
+        }
+        if (total >= (1ull << 28)) return fail(PROSPER_PT_ERR_UNSUPPORTED, "more than 2^28 triangles after instancing");
+        i = j;
+    }
+    out.triOffsets[n] = (uint32_t)total;
+    out.total = total;
+    out.alphaTotal = alphaTotal;
+    return PROSPER_PT_OK;
+}
+
+struct BuildOutcome
+{
+    BvhBuildResult bvh;
+    bool instanced = false;
+    double seconds = 0.0;
+    std::string error;
+};
+struct GeometryJob
+{
+    // (a std::async future joins in its destructor: an early return of the caller waits for the build, which reads the
+    //  context's AccelState)
+    std::future<BuildOutcome> build;
+    std::chrono::steady_clock::time_point t0;
+    uint64_t alphaTotal = 0;
+};
+
+// The layout into the AccelState, the world triangles (flatten kernel, copied to the host) and the hierarchy build started
+// on the host's threads.  `changed` == nullptr: everything is new (upload).  Otherwise the device is idle, the context holds
+// the arrays of the previous layout, which are released, and only the flagged ranges' subtrees are split again.
+int begin_geometry(prosper_pt_ctx *ctx, GeometryLayout &layout, const std::vector<uint8_t> *changed, GeometryJob &job)
 {
     DeviceScene &s = ctx->scene;
-    int rc = PROSPER_PT_OK;
-    const auto tUpload = std::chrono::steady_clock::now();
-    auto seconds_since = [](std::chrono::steady_clock::time_point t) {
-        return std::chrono::duration<double>(std::chrono::steady_clock::now() - t).count();
-    };
-
-    // bindless geometry buffers + pointer table
-    std::vector<const void *> bufferPtrs(v->geometryBufferCount ? v->geometryBufferCount : 1, nullptr);
-    for (uint32_t i = 0; i < v->geometryBufferCount; ++i)
-    {
-        void *d = nullptr;
-        if ((rc = upload(ctx, v->geometryBuffers[i], (size_t)v->geometryBufferByteSizes[i], &d))) return rc;
-        bufferPtrs[i] = d;
-    }
+    AccelState *acc = ctx->accel;
+    const bool again = changed != nullptr;
+    int rc;
     void *d = nullptr;
-    if ((rc = upload(ctx, bufferPtrs.data(), bufferPtrs.size() * sizeof(void *), &d))) return rc;
-    s.geometryBuffers = static_cast<const void *const *>(d);
-    if ((rc = upload(ctx, v->geometryMetadatas, sizeof(prosper_GeometryMetadata) * v->meshCount, &d))) return rc;
-    s.geometryMetadatas = static_cast<const prosper_GeometryMetadata *>(d);
-    if ((rc = upload(ctx, v->drawInstances, sizeof(prosper_DrawInstance) * v->drawInstanceCount, &d))) return rc;
-    s.drawInstances = static_cast<const prosper_DrawInstance *>(d);
-    if ((rc = upload(ctx, v->modelInstanceTransforms, sizeof(prosper_ModelInstanceTransforms) * v->modelInstanceCount, &d)))
-        return rc;
-    s.modelInstanceTransforms = static_cast<const prosper_ModelInstanceTransforms *>(d);
-    if ((rc = upload(ctx, v->materials, sizeof(prosper_MaterialData) * v->materialCount, &d))) return rc;
-    s.materials = static_cast<const prosper_MaterialData *>(d);
-    if ((rc = upload(ctx, v->samplers, sizeof(prosper_pt_sampler_desc) * v->samplerCount, &d))) return rc;
-    s.samplers = static_cast<const prosper_pt_sampler_desc *>(d);
-
-    const auto t0 = std::chrono::steady_clock::now();
-    AccelState *acc = new (std::nothrow) AccelState();
-    if (!acc) return fail(PROSPER_PT_ERR_INVALID_ARGUMENT, "out of host memory");
-    ctx->accel = acc;
-    acc->triOffsets.assign(v->drawInstanceCount + 1, 0);
-    std::vector<uint32_t> diFlags(v->drawInstanceCount ? v->drawInstanceCount : 1, 0);
-    uint64_t total = 0;
-    for (uint32_t i = 0; i < v->drawInstanceCount; ++i)
+    job.t0 = std::chrono::steady_clock::now();
+    job.alphaTotal = layout.alphaTotal;
+    const uint32_t drawInstanceCount = (uint32_t)ctx->geometry->drawInstances.size();
+    const uint64_t total = layout.total;
+    if (again)
     {
-        const prosper_pt_mesh_info &info = v->meshInfos[v->drawInstances[i].meshIndex];
-        acc->triOffsets[i] = (uint32_t)total;
-        total += info.indexCount / 3;
-        // World.cpp:646-651: eOpaque iff the mesh's material is AlphaMode_Opaque
-        diFlags[i] = v->materials[info.materialIndex].alphaMode == PROSPER_ALPHA_MODE_OPAQUE ? kTriFlagOpaque : 0u;
-        if (v->geometryMetadatas[v->drawInstances[i].meshIndex].usesShortIndices == 1) diFlags[i] |= kTriFlagShortIndices;
-        // one subtree per run of draw instances of the same model instance (World.cpp:480-513 emits them together):
-        // prosper's TLAS instance (World.cpp:878-928)
-        const uint32_t mi = v->drawInstances[i].modelInstanceIndex;
-        if (acc->ranges.empty() || acc->rangeModelInstance.back() != mi)
-        {
-            acc->ranges.push_back(InstancedBvh::Range{acc->triOffsets[i], 0u});
-            acc->rangeModelInstance.push_back(mi);
-        }
-        acc->ranges.back().count += info.indexCount / 3;
+        // everything sized by the triangle count goes; the per-draw-instance tables are rewritten in place
+        const void *gone[] = {acc->dFlat, acc->dPerm, acc->dLeafPosition, s.alphaTriangles, s.shadeTriangles, s.rawShadeTriangles};
+        for (const void *p : gone)
+            if (p) device_free(ctx, p);
+        for (uint32_t ver = 0; ver < AccelState::kVersions; ++ver)
+            if (acc->dTrisV[ver])
+            {
+                device_free(ctx, acc->dTrisV[ver]);
+                acc->dTrisV[ver] = nullptr;
+            }
+        acc->dFlat = acc->dTris = nullptr;
+        acc->dPerm = acc->dLeafPosition = nullptr;
+        s.alphaTriangles = nullptr;
+        s.shadeTriangles = nullptr;
+        s.rawShadeTriangles = nullptr;
+        s.triangles = nullptr;
+        PPT_HIP(hipMemcpy(const_cast<uint32_t *>(s.alphaOffsets), layout.alphaOffsets.data(), layout.alphaOffsets.size() * 4, hipMemcpyHostToDevice));
+        PPT_HIP(hipMemcpy(acc->dOffsets, layout.triOffsets.data(), layout.triOffsets.size() * 4, hipMemcpyHostToDevice));
+        PPT_HIP(hipMemcpy(acc->dFlags, layout.diFlags.data(), layout.diFlags.size() * 4, hipMemcpyHostToDevice));
     }
-    acc->triOffsets[v->drawInstanceCount] = (uint32_t)total;
-    if (total >= (1ull << 28)) return fail(PROSPER_PT_ERR_UNSUPPORTED, "more than 2^28 triangles after instancing");
+    else
+    {
+        if ((rc = upload(ctx, layout.alphaOffsets.data(), layout.alphaOffsets.size() * 4, &d))) return rc;
+        s.alphaOffsets = static_cast<const uint32_t *>(d);
+        if ((rc = upload(ctx, layout.triOffsets.data(), layout.triOffsets.size() * 4, &d))) return rc;
+        acc->dOffsets = static_cast<uint32_t *>(d);
+        if ((rc = upload(ctx, layout.diFlags.data(), layout.diFlags.size() * 4, &d))) return rc;
+        acc->dFlags = static_cast<uint32_t *>(d);
+    }
+    s.triangleOffsets = acc->dOffsets;
+    acc->triOffsets.swap(layout.triOffsets);
+    acc->ranges.swap(layout.ranges);
+    acc->rangeModelInstance.swap(layout.rangeModelInstance);
     acc->total = total;
-    acc->drawInstanceCount = v->drawInstanceCount;
-    acc->transforms.assign(v->modelInstanceTransforms, v->modelInstanceTransforms + v->modelInstanceCount);
-    ctx->dTransforms = const_cast<prosper_ModelInstanceTransforms *>(s.modelInstanceTransforms);
-    acc->dTransformsV[0] = ctx->dTransforms;
+    acc->drawInstanceCount = drawInstanceCount;
 
-    // ---- world triangles first: the host-side hierarchy build - the longest step of an upload - runs on the host's threads
-    //      while this thread goes on with textures, packs, sky, lights and the alpha tables; the flatten kernel runs
-    //      again below for the shading and any-hit records (the same world triangles a second time) ----
-    std::vector<uint32_t> alphaOffsets(v->drawInstanceCount ? v->drawInstanceCount : 1, 0u);
-    uint64_t alphaTotal = 0;
-    for (uint32_t i = 0; i < v->drawInstanceCount; ++i)
-        if (!(diFlags[i] & kTriFlagOpaque))
-        {
-            alphaOffsets[i] = (uint32_t)alphaTotal;
-            alphaTotal += acc->triOffsets[i + 1] - acc->triOffsets[i];
-        }
-    if ((rc = upload(ctx, alphaOffsets.data(), alphaOffsets.size() * 4, &d))) return rc;
-    s.alphaOffsets = static_cast<const uint32_t *>(d);
     const size_t triBytes = sizeof(WorldTriangle) * (size_t)(total ? total : 1);
     if ((rc = device_alloc(ctx, triBytes, &d))) return rc;
     acc->dFlat = static_cast<WorldTriangle *>(d);
-    if ((rc = upload(ctx, acc->triOffsets.data(), acc->triOffsets.size() * 4, &d))) return rc;
-    acc->dOffsets = static_cast<uint32_t *>(d);
-    if ((rc = upload(ctx, diFlags.data(), diFlags.size() * 4, &d))) return rc;
-    acc->dFlags = static_cast<uint32_t *>(d);
-    launch_flatten_triangles(s, acc->dOffsets, v->drawInstanceCount, acc->dFlags, acc->dFlat, nullptr, nullptr, (uint32_t)total, nullptr);
+    launch_flatten_triangles(s, acc->dOffsets, drawInstanceCount, acc->dFlags, acc->dFlat, nullptr, nullptr, (uint32_t)total, nullptr);
     PPT_HIP(hipGetLastError());
     acc->flat.resize((size_t)total);
     if (total) PPT_HIP(hipMemcpy(acc->flat.data(), acc->dFlat, sizeof(WorldTriangle) * (size_t)total, hipMemcpyDeviceToHost));
     PPT_HIP(hipDeviceSynchronize());
-    struct BuildOutcome
-    {
-        BvhBuildResult bvh;
-        bool instanced = false;
-        double seconds = 0.0;
-        std::string error;
-    };
-    // (a std::async future joins in its destructor: an early return below waits for the build, which reads `acc`)
     const BvhBuildOptions buildOpt = build_options(ctx);
     const bool flatBvh = ctx->debug.flatBvh != 0;
-    std::future<BuildOutcome> buildJob = std::async(std::launch::async, [acc, total, buildOpt, flatBvh]() {
+    // the subtrees of the last build can be kept where that build was an instanced one
+    const bool keep = again && acc->instanced && !flatBvh;
+    std::vector<uint8_t> flags = keep ? *changed : std::vector<uint8_t>();
+    job.build = std::async(std::launch::async, [acc, total, buildOpt, flatBvh, keep, flags]() {
         BuildOutcome out;
         const auto tBuild = std::chrono::steady_clock::now();
         try
@@ -475,7 +527,8 @@ int upload_scene_impl(prosper_pt_ctx *ctx, const prosper_pt_scene_view *v)
             {
                 try
                 {
-                    out.bvh = acc->bvh.build(acc->flat.data(), total, acc->ranges, buildOpt);
+                    out.bvh = keep ? acc->bvh.adopt(acc->flat.data(), total, acc->ranges, flags, buildOpt)
+                                   : acc->bvh.build(acc->flat.data(), total, acc->ranges, buildOpt);
                     out.instanced = true;
                 }
                 catch (const std::exception &)
@@ -493,6 +546,131 @@ int upload_scene_impl(prosper_pt_ctx *ctx, const prosper_pt_scene_view *v)
         out.seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - tBuild).count();
         return out;
     });
+    return PROSPER_PT_OK;
+}
+
+// The arrays the flatten kernel fills for shading and any-hit (scene-lifetime, or until the next prosper_pt_update_meshes),
+// the leaf-order triangles, and the hierarchy the host's threads built meanwhile.
+int finish_geometry(prosper_pt_ctx *ctx, GeometryJob &job)
+{
+    DeviceScene &s = ctx->scene;
+    AccelState *acc = ctx->accel;
+    const uint64_t total = acc->total;
+    int rc;
+    void *d = nullptr;
+    if ((rc = device_alloc(ctx, sizeof(AlphaTriangle) * (size_t)(job.alphaTotal ? job.alphaTotal : 1), &d))) return rc;
+    s.alphaTriangles = static_cast<const AlphaTriangle *>(d);
+    ctx->alphaTriangleCount = job.alphaTotal;
+    if ((rc = device_alloc(ctx, (size_t)(total ? total : 1) * 4, &d))) return rc;
+    acc->dPerm = static_cast<uint32_t *>(d);
+    // decoded 128-byte records; debug option rawRecords (an experiment) keeps the raw 64-byte form instead, decoded per hit (same
+    // pixels, tested).  Measured and not made a default for any scene size (profiles/r03_raw_records.txt): even on
+    // S-sponza-class, whose 33.6 MB of records outgrow the L2 and whose wf_shade runs at 6.7 TB/s, the ~150 instructions of
+    // decoding cost more than the 64 bytes save (wf_shade 910 -> 931 us; C4 687 -> 721, C2 220 -> 248, FlightHelmet 97 -> 104)
+    const bool rawRecords = ctx->debug.rawRecords != 0; // (refused by prosper_pt_set_debug_options unless built with -DPPT_EXPERIMENTS)
+    void *dShade = nullptr, *dRaw = nullptr;
+    if (rawRecords)
+    {
+        if ((rc = device_alloc(ctx, sizeof(RawShadeTriangle) * (size_t)(total ? total : 1), &dRaw))) return rc;
+    }
+    else if ((rc = device_alloc(ctx, sizeof(ShadeTriangle) * (size_t)(total ? total : 1), &dShade)))
+        return rc;
+    s.shadeTriangles = static_cast<const ShadeTriangle *>(dShade);
+    s.rawShadeTriangles = static_cast<const RawShadeTriangle *>(dRaw);
+    ctx->rawRecords = rawRecords;
+    const size_t triBytes = sizeof(WorldTriangle) * (size_t)(total ? total : 1);
+    void *dTris = nullptr;
+    if ((rc = device_alloc(ctx, triBytes, &dTris))) return rc;
+    PPT_HIP(hipMemset(dTris, 0, triBytes));
+    acc->dTris = static_cast<WorldTriangle *>(dTris);
+    acc->dTrisV[acc->cur] = acc->dTris;
+    s.triangles = acc->dTris;
+
+    launch_flatten_triangles(
+        s, acc->dOffsets, acc->drawInstanceCount, acc->dFlags, acc->dFlat, static_cast<ShadeTriangle *>(dShade),
+        const_cast<AlphaTriangle *>(s.alphaTriangles), (uint32_t)total, nullptr, nullptr, nullptr,
+        static_cast<RawShadeTriangle *>(dRaw));
+    PPT_HIP(hipGetLastError());
+    PPT_HIP(hipDeviceSynchronize());
+
+    BuildOutcome built = job.build.get();
+    if (!built.error.empty()) return fail(PROSPER_PT_ERR_UNSUPPORTED, "BVH build failed: " + built.error);
+    acc->instanced = built.instanced;
+    if ((rc = upload_hierarchy(ctx, built.bvh))) return rc;
+
+    ctx->stats.triangleCount = total;
+    ctx->stats.nodeCount = built.bvh.nodes.size();
+    ctx->stats.nodeBytes = sizeof(BvhNode);
+    ctx->stats.triangleBytes = sizeof(WorldTriangle);
+    ctx->stats.maxDepth = built.bvh.maxDepth;
+    ctx->stats.deviceBytes = ctx->sceneBytes;
+    ctx->stats.buildSeconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - job.t0).count();
+    ctx->stats.bvhBuildSeconds = built.seconds;
+    ctx->stats.alphaTriangleCount = ctx->alphaTriangleCount;
+    ctx->stats.alphaBoundBytes = ctx->alphaBoundBytes;
+    ctx->sceneStamp++;
+    return PROSPER_PT_OK;
+}
+
+int upload_scene_impl(prosper_pt_ctx *ctx, const prosper_pt_scene_view *v)
+{
+    DeviceScene &s = ctx->scene;
+    int rc = PROSPER_PT_OK;
+    ctx->stats = prosper_pt_scene_stats{};
+    const auto tUpload = std::chrono::steady_clock::now();
+    auto seconds_since = [](std::chrono::steady_clock::time_point t) {
+        return std::chrono::duration<double>(std::chrono::steady_clock::now() - t).count();
+    };
+
+    // bindless geometry buffers + pointer table, with the mirrors a later prosper_pt_update_meshes works from
+    GeometryState *gs = new (std::nothrow) GeometryState();
+    if (!gs) return fail(PROSPER_PT_ERR_INVALID_ARGUMENT, "out of host memory");
+    ctx->geometry = gs;
+    gs->metadatas.assign(v->geometryMetadatas, v->geometryMetadatas + v->meshCount);
+    gs->infos.assign(v->meshInfos, v->meshInfos + v->meshCount);
+    gs->drawInstances.assign(v->drawInstances, v->drawInstances + v->drawInstanceCount);
+    std::vector<const void *> bufferPtrs(std::max<size_t>(v->geometryBufferCount, PROSPER_PT_MAX_GEOMETRY_BUFFERS), nullptr);
+    void *d = nullptr;
+    for (uint32_t i = 0; i < v->geometryBufferCount; ++i)
+    {
+        if ((rc = upload(ctx, v->geometryBuffers[i], (size_t)v->geometryBufferByteSizes[i], &d))) return rc;
+        bufferPtrs[i] = d;
+        gs->buffers.push_back(d);
+        gs->bufferBytes.push_back(v->geometryBufferByteSizes[i]);
+    }
+    if ((rc = upload(ctx, bufferPtrs.data(), bufferPtrs.size() * sizeof(void *), &d))) return rc;
+    gs->dBufferTable = static_cast<const void **>(d);
+    s.geometryBuffers = gs->dBufferTable;
+    if ((rc = upload(ctx, v->geometryMetadatas, sizeof(prosper_GeometryMetadata) * v->meshCount, &d))) return rc;
+    gs->dMetadatas = static_cast<prosper_GeometryMetadata *>(d);
+    s.geometryMetadatas = gs->dMetadatas;
+    if ((rc = upload(ctx, v->drawInstances, sizeof(prosper_DrawInstance) * v->drawInstanceCount, &d))) return rc;
+    s.drawInstances = static_cast<const prosper_DrawInstance *>(d);
+    if ((rc = upload(ctx, v->modelInstanceTransforms, sizeof(prosper_ModelInstanceTransforms) * v->modelInstanceCount, &d)))
+        return rc;
+    s.modelInstanceTransforms = static_cast<const prosper_ModelInstanceTransforms *>(d);
+    if ((rc = upload(ctx, v->materials, sizeof(prosper_MaterialData) * v->materialCount, &d))) return rc;
+    s.materials = static_cast<const prosper_MaterialData *>(d);
+    if ((rc = upload(ctx, v->samplers, sizeof(prosper_pt_sampler_desc) * v->samplerCount, &d))) return rc;
+    s.samplers = static_cast<const prosper_pt_sampler_desc *>(d);
+    s.drawInstanceCount = v->drawInstanceCount;
+    s.modelInstanceCount = v->modelInstanceCount;
+
+    // ---- world triangles first: the host-side hierarchy build - the longest step of an upload - runs on the host's threads
+    //      while this thread goes on with textures, packs, sky, lights and the alpha tables (begin_geometry); the flatten
+    //      kernel runs again in finish_geometry for the shading and any-hit records (the same world triangles a second time) ----
+    AccelState *acc = new (std::nothrow) AccelState();
+    if (!acc) return fail(PROSPER_PT_ERR_INVALID_ARGUMENT, "out of host memory");
+    ctx->accel = acc;
+    acc->transforms.assign(v->modelInstanceTransforms, v->modelInstanceTransforms + v->modelInstanceCount);
+    ctx->dTransforms = const_cast<prosper_ModelInstanceTransforms *>(s.modelInstanceTransforms);
+    acc->dTransformsV[0] = ctx->dTransforms;
+    GeometryJob job;
+    {
+        GeometryLayout layout;
+        if ((rc = layout_geometry(*gs, v->materials, layout))) return rc;
+        if ((rc = begin_geometry(ctx, layout, nullptr, job))) return rc;
+    }
 
     // textures: one allocation each (256-B aligned by hipMalloc), re-laid out in 8x4-texel tiles of one cache line each
     // (pt_scene.hpp DeviceTexture) by a kernel - until round 4 the host did that a texel at a time, 40 ms for
@@ -605,8 +783,6 @@ int upload_scene_impl(prosper_pt_ctx *ctx, const prosper_pt_scene_view *v)
     s.pointLightCount = v->pointLights->count;
     s.spotLightCount = v->spotLights->count;
     s.materialCount = v->materialCount;
-    s.drawInstanceCount = v->drawInstanceCount;
-    s.modelInstanceCount = v->modelInstanceCount;
 
     // skybox
     s.skybox = nullptr;
@@ -631,8 +807,6 @@ int upload_scene_impl(prosper_pt_ctx *ctx, const prosper_pt_scene_view *v)
     // ---- what the any-hit shader reads: one 32-byte record per non-opaque triangle, one per material, and the
     //      materials' alpha bounds (pt_scene.hpp AlphaTriangle / AlphaMaterial) ----
     {
-        if ((rc = device_alloc(ctx, sizeof(AlphaTriangle) * (size_t)(alphaTotal ? alphaTotal : 1), &d))) return rc;
-        s.alphaTriangles = static_cast<const AlphaTriangle *>(d);
         std::vector<AlphaMaterial> &alphaMaterials = ms->alphaMaterials;
         alphaMaterials.assign(v->materialCount ? v->materialCount : 1, AlphaMaterial{});
         uint64_t boundBytes = 0;
@@ -645,7 +819,6 @@ int upload_scene_impl(prosper_pt_ctx *ctx, const prosper_pt_scene_view *v)
         PPT_HIP(hipGetLastError());
         if ((rc = upload(ctx, alphaMaterials.data(), alphaMaterials.size() * sizeof(AlphaMaterial), &d))) return rc;
         s.alphaMaterials = static_cast<const AlphaMaterial *>(d);
-        ctx->alphaTriangleCount = alphaTotal;
         ctx->alphaBoundBytes = boundBytes;
         ms->alphaBoundBytes = boundBytes;
         // layout of the table block of a later version (pt_materials.cpp flush_pending_materials)
@@ -656,61 +829,9 @@ int upload_scene_impl(prosper_pt_ctx *ctx, const prosper_pt_scene_view *v)
         ms->blockBytes = ms->texturesOffset + align16(ms->textures.size() * sizeof(DeviceTexture));
     }
 
-    if ((rc = device_alloc(ctx, (size_t)(total ? total : 1) * 4, &d))) return rc;
-    acc->dPerm = static_cast<uint32_t *>(d);
-    // persistent (scene-lifetime) arrays the flatten kernel fills: shading records + their per-instance bases
-    // decoded 128-byte records; debug option rawRecords (an experiment) keeps the raw 64-byte form instead, decoded per hit (same
-    // pixels, tested).  Measured and not made a default for any scene size (profiles/r03_raw_records.txt): even on
-    // S-sponza-class, whose 33.6 MB of records outgrow the L2 and whose wf_shade runs at 6.7 TB/s, the ~150 instructions of
-    // decoding cost more than the 64 bytes save (wf_shade 910 -> 931 us; C4 687 -> 721, C2 220 -> 248, FlightHelmet 97 -> 104)
-    const bool rawRecords = ctx->debug.rawRecords != 0; // (refused by prosper_pt_set_debug_options unless built with -DPPT_EXPERIMENTS)
-    void *dShade = nullptr, *dRaw = nullptr;
-    if (rawRecords)
-    {
-        if ((rc = device_alloc(ctx, sizeof(RawShadeTriangle) * (size_t)(total ? total : 1), &dRaw))) return rc;
-    }
-    else if ((rc = device_alloc(ctx, sizeof(ShadeTriangle) * (size_t)(total ? total : 1), &dShade)))
-        return rc;
-    s.shadeTriangles = static_cast<const ShadeTriangle *>(dShade);
-    s.rawShadeTriangles = static_cast<const RawShadeTriangle *>(dRaw);
-    ctx->rawRecords = rawRecords;
-    s.triangleOffsets = acc->dOffsets;
-    void *dTris = nullptr;
-    if ((rc = device_alloc(ctx, triBytes, &dTris))) return rc;
-    PPT_HIP(hipMemset(dTris, 0, triBytes));
-    acc->dTris = static_cast<WorldTriangle *>(dTris);
-    acc->dTrisV[0] = acc->dTris;
-    s.triangles = acc->dTris;
-
-    launch_flatten_triangles(
-        s, acc->dOffsets, v->drawInstanceCount, acc->dFlags, acc->dFlat, static_cast<ShadeTriangle *>(dShade),
-        const_cast<AlphaTriangle *>(s.alphaTriangles), (uint32_t)total, nullptr, nullptr, nullptr,
-        static_cast<RawShadeTriangle *>(dRaw));
-    PPT_HIP(hipGetLastError());
-    PPT_HIP(hipDeviceSynchronize());
-
-    // the hierarchy the host's threads built meanwhile
-    BuildOutcome built = buildJob.get();
-    if (!built.error.empty()) return fail(PROSPER_PT_ERR_UNSUPPORTED, "BVH build failed: " + built.error);
-    acc->instanced = built.instanced;
-    BvhBuildResult &bvh = built.bvh;
-    const double bvhBuildSeconds = built.seconds;
-    if ((rc = upload_hierarchy(ctx, bvh))) return rc;
-
-    ctx->stats = prosper_pt_scene_stats{};
-    ctx->stats.triangleCount = total;
-    ctx->stats.nodeCount = bvh.nodes.size();
-    ctx->stats.nodeBytes = sizeof(BvhNode);
-    ctx->stats.triangleBytes = sizeof(WorldTriangle);
-    ctx->stats.maxDepth = bvh.maxDepth;
-    ctx->stats.deviceBytes = ctx->sceneBytes;
-    ctx->stats.buildSeconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-    ctx->stats.bvhBuildSeconds = bvhBuildSeconds;
+    if ((rc = finish_geometry(ctx, job))) return rc;
     ctx->stats.textureSeconds = textureSeconds;
     ctx->stats.uploadSeconds = seconds_since(tUpload);
-    ctx->sceneStamp++;
-    ctx->stats.alphaTriangleCount = ctx->alphaTriangleCount;
-    ctx->stats.alphaBoundBytes = ctx->alphaBoundBytes;
     return PROSPER_PT_OK;
 }
 
@@ -1447,6 +1568,132 @@ int prosper_pt_rebuild_hierarchy(prosper_pt_ctx *ctx)
     if (!ctx) return fail(PROSPER_PT_ERR_INVALID_ARGUMENT, "prosper_pt_rebuild_hierarchy: null argument");
     if (!ctx->haveScene || !ctx->accel) return fail(PROSPER_PT_ERR_NO_SCENE, "no scene uploaded");
     return rebuild_hierarchy_impl(ctx);
+}
+
+// WorldData::pollMeshWorker + World::buildNextBlas for the meshes that arrived (prosper_pt.h "streamed-in meshes").
+int prosper_pt_update_meshes(prosper_pt_ctx *ctx, const prosper_pt_mesh_update *meshes, uint32_t count)
+{
+    if (!ctx || (!meshes && count)) return fail(PROSPER_PT_ERR_INVALID_ARGUMENT, "prosper_pt_update_meshes: null argument");
+    if (!ctx->haveScene || !ctx->accel || !ctx->geometry || !ctx->materialState) return fail(PROSPER_PT_ERR_NO_SCENE, "no scene uploaded");
+    if (count == 0) return PROSPER_PT_OK;
+    GeometryState *gs = ctx->geometry;
+    AccelState *acc = ctx->accel;
+    MaterialState *ms = ctx->materialState;
+    if (acc->stale) return fail(PROSPER_PT_ERR_NO_SCENE, "the last prosper_pt_update_transforms failed: update the transforms again (or upload the scene) first");
+
+    // ---- everything is checked against the mirrors before anything is touched ----
+    std::vector<uint64_t> bufferBytes(PROSPER_PT_MAX_GEOMETRY_BUFFERS, 0);
+    for (size_t b = 0; b < gs->buffers.size(); ++b)
+        if (gs->buffers[b]) bufferBytes[b] = gs->bufferBytes[b];
+    std::vector<uint8_t> arriving(gs->metadatas.size(), 0);
+    for (uint32_t i = 0; i < count; ++i)
+    {
+        const prosper_pt_mesh_update &u = meshes[i];
+        const prosper_GeometryMetadata &m = u.metadata;
+        const std::string name = "prosper_pt_update_meshes: mesh " + std::to_string(u.meshIndex);
+        if (u.meshIndex >= gs->metadatas.size()) return fail(PROSPER_PT_ERR_INVALID_ARGUMENT, name + " exceeds the scene's meshCount");
+        if (mesh_loaded(gs->metadatas[u.meshIndex]) || arriving[u.meshIndex])
+            return fail(PROSPER_PT_ERR_INVALID_ARGUMENT, name + " has been loaded already");
+        arriving[u.meshIndex] = 1;
+        if (m.bufferIndex >= PROSPER_PT_MAX_GEOMETRY_BUFFERS) return fail(PROSPER_PT_ERR_SCENE, name + ": bufferIndex out of range");
+        if (bufferBytes[m.bufferIndex] == 0)
+        {
+            if (u.bufferByteSize == 0 || u.bufferByteSize % 4 != 0)
+                return fail(PROSPER_PT_ERR_SCENE, name + ": a new geometry buffer needs its bufferByteSize (a multiple of 4)");
+            bufferBytes[m.bufferIndex] = u.bufferByteSize;
+        }
+        const uint64_t size = bufferBytes[m.bufferIndex];
+        if (u.byteOffset % 4 != 0 || u.byteCount % 4 != 0 || u.byteOffset > size || u.byteCount > size - u.byteOffset)
+            return fail(PROSPER_PT_ERR_SCENE, name + ": its byte range does not fit the geometry buffer");
+        if (u.byteCount && !u.bytes) return fail(PROSPER_PT_ERR_INVALID_ARGUMENT, name + ": bytes missing");
+        if (u.info.materialIndex >= ms->materials.size()) return fail(PROSPER_PT_ERR_SCENE, name + ": materialIndex out of range");
+        if (u.info.indexCount % 3 != 0) return fail(PROSPER_PT_ERR_SCENE, name + ": indexCount is not a multiple of 3");
+        if (m.indicesOffset == PROSPER_PT_ABSENT || m.positionsOffset == PROSPER_PT_ABSENT)
+            return fail(PROSPER_PT_ERR_SCENE, name + ": indices/positions are required");
+        // every stream inside the bytes that came with the mesh (words of the buffer)
+        const uint64_t w0 = u.byteOffset / 4, w1 = (u.byteOffset + u.byteCount) / 4;
+        auto inside = [&](uint64_t first, uint64_t words) { return first >= w0 && first <= w1 && words <= w1 - first; };
+        const bool shortIdx = m.usesShortIndices == 1;
+        const uint64_t indexFirst = shortIdx ? (uint64_t)m.indicesOffset / 2 : (uint64_t)m.indicesOffset;
+        const uint64_t indexEnd = shortIdx ? ((uint64_t)m.indicesOffset + u.info.indexCount + 1) / 2 : (uint64_t)m.indicesOffset + u.info.indexCount;
+        if (!inside(indexFirst, indexEnd - indexFirst)) return fail(PROSPER_PT_ERR_SCENE, name + ": indices lie outside its bytes");
+        if (!inside(m.positionsOffset, 2ull * u.info.vertexCount)) return fail(PROSPER_PT_ERR_SCENE, name + ": positions lie outside its bytes");
+        const uint32_t attrs[3] = {m.normalsOffset, m.tangentsOffset, m.texCoord0sOffset};
+        for (uint32_t a : attrs)
+            if (a != PROSPER_PT_ABSENT && !inside(a, u.info.vertexCount))
+                return fail(PROSPER_PT_ERR_SCENE, name + ": an attribute stream lies outside its bytes");
+        const uint8_t *indexBytes = static_cast<const uint8_t *>(u.bytes) + ((uint64_t)m.indicesOffset * (shortIdx ? 2u : 4u) - u.byteOffset);
+        for (uint32_t k = 0; k < u.info.indexCount; ++k)
+        {
+            const uint32_t idx = shortIdx ? (uint32_t) reinterpret_cast<const uint16_t *>(indexBytes)[k]
+                                          : reinterpret_cast<const uint32_t *>(indexBytes)[k];
+            if (idx >= u.info.vertexCount) return fail(PROSPER_PT_ERR_SCENE, name + ": vertex index out of range");
+        }
+    }
+
+    // ---- the device comes to rest: staged updates first, so that the tables the flatten kernel reads are the current ones ----
+    PPT_HIP(hipSetDevice(ctx->device));
+    int rc;
+    if ((rc = flush_pending_update(ctx, nullptr))) return rc;
+    if ((rc = flush_pending_materials(ctx, nullptr))) return rc;
+    PPT_HIP(hipDeviceSynchronize());
+    const auto t0 = std::chrono::steady_clock::now();
+
+    // From here on a failure leaves buffers, tables and hierarchy out of step: the scene goes, the caller uploads it again.
+    auto run = [&]() -> int {
+        void *d = nullptr;
+        for (uint32_t i = 0; i < count; ++i)
+        {
+            const prosper_pt_mesh_update &u = meshes[i];
+            const uint32_t b = u.metadata.bufferIndex;
+            if (gs->buffers.size() <= b)
+            {
+                gs->buffers.resize((size_t)b + 1, nullptr);
+                gs->bufferBytes.resize((size_t)b + 1, 0);
+            }
+            if (!gs->buffers[b])
+            {
+                if ((rc = device_alloc(ctx, (size_t)bufferBytes[b], &d))) return rc;
+                PPT_HIP(hipMemset(d, 0, (size_t)bufferBytes[b]));
+                gs->buffers[b] = d;
+                gs->bufferBytes[b] = bufferBytes[b];
+                PPT_HIP(hipMemcpy(gs->dBufferTable + b, &d, sizeof(void *), hipMemcpyHostToDevice));
+            }
+            if (u.byteCount)
+                PPT_HIP(hipMemcpy(static_cast<uint8_t *>(gs->buffers[b]) + u.byteOffset, u.bytes, (size_t)u.byteCount, hipMemcpyHostToDevice));
+            gs->metadatas[u.meshIndex] = u.metadata;
+            gs->infos[u.meshIndex] = u.info;
+            PPT_HIP(hipMemcpy(gs->dMetadatas + u.meshIndex, &u.metadata, sizeof(prosper_GeometryMetadata), hipMemcpyHostToDevice));
+        }
+        GeometryLayout layout;
+        if ((rc = layout_geometry(*gs, ms->materials.data(), layout))) return rc;
+        // the subtrees that are split again: model instances that draw an arrived mesh, and those that moved since the last build
+        std::vector<uint8_t> changed(layout.ranges.size(), 0);
+        {
+            size_t r = 0;
+            const uint32_t n = (uint32_t)gs->drawInstances.size();
+            for (uint32_t i = 0; i < n; ++r)
+            {
+                const uint32_t mi = gs->drawInstances[i].modelInstanceIndex;
+                for (; i < n && gs->drawInstances[i].modelInstanceIndex == mi; ++i)
+                    if (arriving[gs->drawInstances[i].meshIndex]) changed[r] = 1;
+                if (r < acc->movedSinceBuild.size() && acc->movedSinceBuild[r]) changed[r] = 1;
+            }
+        }
+        GeometryJob job;
+        if ((rc = begin_geometry(ctx, layout, &changed, job))) return rc;
+        return finish_geometry(ctx, job);
+    };
+    rc = run();
+    if (rc != PROSPER_PT_OK)
+    {
+        (void)hipDeviceSynchronize();
+        free_scene(ctx);
+        return rc;
+    }
+    gs->meshUpdates++;
+    ctx->stats.uploadSeconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    return PROSPER_PT_OK;
 }
 
 int prosper_pt_get_hierarchy_state(prosper_pt_ctx *ctx, prosper_pt_hierarchy_state *out)

@@ -212,6 +212,22 @@ struct MaterialState
     }
 };
 
+// What the geometry of the scene is made from, as the host gave it: prosper_pt_update_meshes changes these mirrors (and the
+// device copies they describe) and lays the triangles out again.  The device pointer table has room for every geometry
+// buffer prosper can create (sMaxGeometryBuffersCount, WorldData.cpp:31), the metadata table is written in place: a mesh
+// that has not arrived has no triangle anywhere, so nothing in flight reads its slot.
+struct GeometryState
+{
+    std::vector<prosper_GeometryMetadata> metadatas;
+    std::vector<prosper_pt_mesh_info> infos;
+    std::vector<prosper_DrawInstance> drawInstances;
+    std::vector<void *> buffers;        // device copies of the geometry buffers (scene allocations)
+    std::vector<uint64_t> bufferBytes;
+    const void **dBufferTable = nullptr;           // device: [PROSPER_PT_MAX_GEOMETRY_BUFFERS]
+    prosper_GeometryMetadata *dMetadatas = nullptr; // device: [meshCount]
+    uint32_t meshUpdates = 0;
+};
+
 // multi-GPU state of a context (pt_tiling.cpp): the communicator, its stream and the root's staging buffer
 struct TilingState;
 
@@ -247,6 +263,7 @@ struct prosper_pt_ctx
     // light buffers are re-uploaded every frame in prosper; keep their device addresses mutable
     ppt::LightState *lights = nullptr; // the scene's light buffers (device copies in the scene's allocation list)
     ppt::MaterialState *materialState = nullptr; // mirrors + versions of the material / texture tables (pt_materials.cpp)
+    ppt::GeometryState *geometry = nullptr;       // mirrors of the mesh tables and geometry buffers (prosper_pt_update_meshes)
 
     float4 *hdr = nullptr; // current HDR buffer (internal or caller-owned)
     float4 *ownedHdr = nullptr;

@@ -296,6 +296,13 @@ class CommInfo(C.Structure):
                 ("lastGatherMs", C.c_float), ("reserved", C.c_uint32)]
 
 
+class MeshUpdate(C.Structure):
+    """prosper_pt_mesh_update: one streamed-in mesh (WorldData::pollMeshWorker)."""
+    _fields_ = [("meshIndex", C.c_uint32), ("reserved", C.c_uint32), ("metadata", GeometryMetadata), ("info", MeshInfo),
+                ("bytes", C.c_void_p), ("byteOffset", C.c_uint64), ("byteCount", C.c_uint64), ("bufferByteSize", C.c_uint64)]
+
+
+MAX_GEOMETRY_BUFFERS = 100
 GATHER_IN_STREAM = 1
 UPDATE_NOW = 1
 VARIANT_LDS_SCENE = 1

@@ -200,6 +200,49 @@ class World:
         self.mesh_infos.append(S.MeshInfo(vertex_count, int(indices.size), 0, material_index))
         return len(self.metadatas) - 1
 
+    @property
+    def mesh_ranges(self):
+        """Per mesh: (buffer index, first word, words) of the bytes the path reads of it in its geometry buffer - indices,
+        positions and the attribute streams (UploadedGeometryData's range, DeferredLoadingContext.cpp:1192-1269)."""
+        out = []
+        for md, info in zip(self.metadatas, self.mesh_infos):
+            short = md.usesShortIndices == 1
+            lo = md.indicesOffset // 2 if short else md.indicesOffset
+            hi = (md.indicesOffset + info.indexCount + 1) // 2 if short else md.indicesOffset + info.indexCount
+            hi = max(hi, md.positionsOffset + 2 * info.vertexCount)
+            for off in (md.normalsOffset, md.tangentsOffset, md.texCoord0sOffset):
+                if off != S.ABSENT:
+                    hi = max(hi, off + info.vertexCount)
+                    lo = min(lo, off)
+            lo = min(lo, md.positionsOffset)
+            out.append((md.bufferIndex, lo, hi - lo))
+        return out
+
+    def with_meshes_loaded(self, loaded, buffers=None):
+        """The scene while it streams in (WorldData::pollMeshWorker, WorldData.cpp:2003-2110): a copy in which only the
+        meshes in `loaded` have arrived - the others keep a default-constructed GeometryMetadata (bufferIndex 0xFFFFFFFF),
+        an empty MeshInfo and zeros where their bytes will be; buffers, draw instances and everything else are the
+        finished scene's.  `buffers`: only the first so many geometry buffers exist yet (the loader creates the next one
+        when a mesh no longer fits, DeferredLoadingContext.cpp:1192-1269)."""
+        import copy
+        loaded = set(loaded)
+        keep = buffers
+        w = copy.copy(self)
+        w._frozen = None
+        w.metadatas = [m if i in loaded else S.GeometryMetadata(*([S.ABSENT] * 10), 0) for i, m in enumerate(self.metadatas)]
+        w.mesh_infos = [m if i in loaded else S.MeshInfo(0, 0, 0, 0) for i, m in enumerate(self.mesh_infos)]
+        f = self.freeze()
+        buffers = [b.copy() for b in f["geometry_buffers"]]
+        for i, (b, first, words) in enumerate(self.mesh_ranges):
+            if i not in loaded:
+                buffers[b][first:first + words] = 0
+        if keep is not None:
+            assert all(self.mesh_ranges[i][0] < keep for i in loaded)
+            buffers = buffers[:keep]
+        w._buffers = [[b] for b in buffers]
+        w._buffer_words = [int(b.size) for b in buffers]
+        return w
+
     def add_model(self, sub_models):
         """sub_models: list of (meshIndex, materialIndex) — scene::Model::SubModel."""
         self.models.append(list(sub_models))

@@ -1,0 +1,222 @@
+"""Incremental adoption of meshes (prosper_pt_update_meshes): prosper's mesh worker fills the geometry buffers in the
+background, WorldData::pollMeshWorker adopts up to ten finished meshes per frame (src/scene/WorldData.cpp:2003-2110), a model's
+BLAS is built once ALL its sub-meshes are there (World::buildNextBlas, World.cpp:598-606) and a TLAS instance without a BLAS
+is inactive (World.cpp:909-915).  Every frame of such a sequence - frames in flight between the calls - must show what a
+fresh prosper_pt_upload_scene of that frame's state shows, bit for bit, and the oracle's image of that state."""
+import copy
+import ctypes
+
+import numpy as np
+import pytest
+
+from conftest import default_pc, same_bits
+from prosper_amd import capi, scenes, structs as S
+from prosper_amd.world import translate
+
+
+def _camera(oracle, world, w, h):
+    c = world.camera
+    return oracle.camera_uniforms(c["eye"], c["target"], c["up"], c["fov"], c["zN"], c["zF"], w, h)
+
+
+def _oracle_image(oracle, world, cam, fl, w, h, **pc):
+    osc = oracle.OracleScene(world)
+    want = None
+    for f in (1, 2):
+        want, _ = osc.render(default_pc(S, fl, frame_index=f, skip_history=(f == 1), **pc), cam, w, h, history=want)
+    return want
+
+
+def test_oracle_skips_model_instances_that_are_still_loading(oracle, cornell_world):
+    """The oracle's restatement of the rule, pinned on the CPU: a scene in which a model has a mesh still loading renders
+    like the scene without that model's instances (draw instance indices shift, their order does not)."""
+    full = cornell_world
+    # model 0 has three sub-meshes: with one of them missing, none of the three may show
+    missing = full.models[0][1][0]
+    streaming = full.with_meshes_loaded([i for i in range(len(full.metadatas)) if i != missing])
+    without = copy.copy(full)
+    without._frozen = None
+    without.model_instances = [mi for mi in full.model_instances if mi[0] != 0]
+    w, h = 64, 40
+    cam, fl = _camera(oracle, full, w, h)
+    a = _oracle_image(oracle, streaming, cam, fl, w, h, max_bounces=3)
+    b = _oracle_image(oracle, without, cam, fl, w, h, max_bounces=3)
+    c = _oracle_image(oracle, full, cam, fl, w, h, max_bounces=3)
+    assert same_bits(a, b).all()
+    assert not same_bits(a, c).all()
+    assert oracle.OracleScene(streaming).triangle_count == without.triangle_count()
+
+
+def _device_buffers(hip, n, nbytes):
+    out = []
+    for _ in range(n):
+        ptr = ctypes.c_void_p()
+        assert hip.hipMalloc(ctypes.byref(ptr), ctypes.c_size_t(nbytes)) == 0
+        out.append(ptr)
+    return out
+
+
+def _download(hip, ptr, h, w):
+    img = np.zeros((h, w, 4), np.float32)
+    assert hip.hipMemcpy(ctypes.c_void_p(img.ctypes.data), ptr, ctypes.c_size_t(img.nbytes), 2) == 0  # device to host
+    return img
+
+
+def _moved(world, instance, offset):
+    w = copy.copy(world)
+    w._frozen = None
+    w.model_instances = list(world.model_instances)
+    model, m = w.model_instances[instance]
+    w.model_instances[instance] = (model, translate(offset) @ m)
+    return w
+
+
+@pytest.mark.gpu
+def test_meshes_stream_in_over_frames_in_flight(gpu_ctx, oracle):
+    """S-sponza-class (31 meshes in 15 models, 43 instances; models of up to six sub-meshes) arrives a few meshes per frame,
+    an instance moves in between (its subtree is stale when the next meshes come), frames stay in flight: each frame equals
+    a fresh context's render of that frame's state; an early and the last one equal the oracle's."""
+    full = scenes.sponza_class(texture_size=32, sky_size=16, detail=0.25)
+    meshes = len(full.metadatas)
+    # in the order a loader would finish them; the steps cut through models
+    order = list(range(meshes))
+    steps = [0, 4, 9, 10, 18, 27, meshes]
+    w, h = 240, 136
+    cam, fl = _camera(oracle, full, w, h)
+    pc = default_pc(S, fl, max_bounces=3, ibl=True)
+    hip = ctypes.CDLL("libamdhip64.so")
+    outs = _device_buffers(hip, len(steps), w * h * 16)
+    base = full
+    gpu_ctx.upload_scene(base.with_meshes_loaded([]))
+    assert gpu_ctx.scene_stats().triangleCount == 0
+    states = []
+    for k, loaded in enumerate(steps):
+        if k == 3:
+            base = _moved(base, 2, (0.4, 0.1, -0.3))
+            gpu_ctx.update_transforms(base)
+        if k == 5:
+            base = _moved(base, 7, (-0.2, 0.0, 0.5))
+            gpu_ctx.update_transforms(base)
+        if k:
+            gpu_ctx.update_meshes(base, order[steps[k - 1]:loaded])
+        states.append(base.with_meshes_loaded(order[:loaded]))
+        gpu_ctx.set_output_buffer(outs[k].value, w * h * 16)
+        gpu_ctx.render(pc, cam, w, h, frames=2, flags=S.RENDER_PIPELINED)
+    assert hip.hipDeviceSynchronize() == 0
+    gpu_ctx.set_output_buffer(0, 0)
+    got = [_download(hip, p, h, w) for p in outs]
+    for p in outs:
+        hip.hipFree(p)
+    assert gpu_ctx.scene_stats().triangleCount == full.triangle_count()
+    fresh = capi.Context(device=0)
+    try:
+        counts = []
+        for k, state in enumerate(states):
+            fresh.upload_scene(state)
+            counts.append(fresh.scene_stats().triangleCount)
+            fresh.render(pc, cam, w, h, frames=2)
+            assert same_bits(got[k], fresh.read_hdr()).all(), "frame %d (%d meshes)" % (k, steps[k])
+        assert counts[0] == 0 and all(a <= b for a, b in zip(counts, counts[1:])) and counts[1] < counts[-1]
+    finally:
+        fresh.close()
+    assert not same_bits(got[1], got[-1]).all()
+    for k in (2, len(steps) - 1):
+        assert same_bits(got[k], _oracle_image(oracle, states[k], cam, fl, w, h, max_bounces=3, ibl=True)).all(), "frame %d vs oracle" % k
+
+
+@pytest.mark.gpu
+def test_alpha_meshes_and_a_new_geometry_buffer_arrive(gpu_ctx, oracle):
+    """MASK / BLEND quads (their any-hit records are laid out again), a material that changes in the same frame, and meshes
+    that live in a geometry buffer the scene has not seen yet (the loader opens a new 64 MB buffer when a mesh no longer fits)."""
+    full = scenes.alpha_wall()
+    rng = np.random.default_rng(3)
+    extra = []
+    for k in range(3):
+        p, n, t, uv, idx = scenes.quad((-4.0 + k, -2.2, -0.3 - 0.1 * k), (-3.2 + k, -2.2, -0.3), (-3.2 + k, -1.2, -0.3), (-4.0 + k, -1.2, -0.3 - 0.1 * k))
+        mesh = full.add_mesh(p, idx, 1 + k, normals=n, tangents=t, uvs=uv, buffer_index=1 + k // 2)
+        extra.append(mesh)
+        full.add_instance(full.add_model([(mesh, 1 + k)]))
+    meshes = len(full.metadatas)
+    first = [i for i in range(meshes) if i not in extra]
+    w, h = 240, 150
+    cam, fl = _camera(oracle, full, w, h)
+    pc = default_pc(S, fl, max_bounces=3)
+    order = [first[:13], first[13:30], first[30:] + extra[:1], extra[1:]]
+    gpu_ctx.upload_scene(full.with_meshes_loaded([], buffers=1))
+    loaded = []
+    state = full
+    for k, arrivals in enumerate(order):
+        if k == 2:
+            state = copy.copy(full)
+            state._frozen = None
+            state.materials = list(full.materials)
+            m = copy.copy(state.materials[3])
+            m.baseColorFactor = S.Vec4(0.5, 0.9, 0.4, 0.6)
+            m.alphaCutoff = 0.35
+            state.materials[3] = m
+            gpu_ctx.update_materials(state.materials, 0)
+        gpu_ctx.update_meshes(state, arrivals)
+        loaded += arrivals
+        gpu_ctx.render(pc, cam, w, h, frames=2, flags=S.RENDER_PIPELINED)
+        got = gpu_ctx.read_hdr()
+        now = state.with_meshes_loaded(loaded)
+        fresh = capi.Context(device=0)
+        try:
+            fresh.upload_scene(now)
+            fresh.render(pc, cam, w, h, frames=2)
+            assert same_bits(got, fresh.read_hdr()).all(), "step %d" % k
+            assert gpu_ctx.scene_stats().alphaTriangleCount == fresh.scene_stats().alphaTriangleCount
+        finally:
+            fresh.close()
+    assert same_bits(got, _oracle_image(oracle, state, cam, fl, w, h, max_bounces=3)).all()
+
+
+@pytest.mark.gpu
+def test_what_update_meshes_refuses(gpu_ctx, oracle, cornell_world):
+    """A mesh handed over twice, a byte range or an index outside what came with the mesh: refused before anything is
+    touched - the scene renders as before."""
+    full = cornell_world
+    meshes = len(full.metadatas)
+    w, h = 96, 64
+    cam, fl = _camera(oracle, full, w, h)
+    pc = default_pc(S, fl, max_bounces=2)
+    gpu_ctx.upload_scene(full.with_meshes_loaded(range(meshes - 1)))
+    gpu_ctx.render(pc, cam, w, h)
+    before = gpu_ctx.read_hdr()
+    with pytest.raises(capi.ProsperPtError) as e:
+        gpu_ctx.update_meshes(full, [0])
+    assert e.value.code == -1 and "loaded already" in str(e.value)
+    last = meshes - 1
+    buffer_index, first_word, words = full.mesh_ranges[last]
+    f = full.freeze()
+
+    def update(**change):
+        u = S.MeshUpdate()
+        u.meshIndex, u.metadata, u.info = last, full.metadatas[last], full.mesh_infos[last]
+        u.bytes = f["geometry_buffers"][buffer_index].ctypes.data + 4 * first_word
+        u.byteOffset, u.byteCount, u.bufferByteSize = 4 * first_word, 4 * words, f["geometry_buffers"][buffer_index].nbytes
+        for key, value in change.items():
+            setattr(u, key, value)
+        return capi.lib().prosper_pt_update_meshes(gpu_ctx._h, ctypes.byref(u), 1)
+
+    assert update(meshIndex=meshes) == -1               # no such slot
+    assert update(byteCount=4 * words - 4) == -5        # a stream ends outside the bytes
+    assert update(byteOffset=4 * first_word + 4) == -5  # ... or starts before them
+    assert update(byteCount=1 << 40) == -5              # past the geometry buffer
+    info = copy.copy(full.mesh_infos[last])
+    info.vertexCount -= 1
+    assert update(info=info) == -5                      # an index names a vertex the mesh does not have
+    info = copy.copy(full.mesh_infos[last])
+    info.materialIndex = len(full.materials)
+    assert update(info=info) == -5
+    gpu_ctx.render(pc, cam, w, h)
+    assert same_bits(before, gpu_ctx.read_hdr()).all()
+    assert update() == 0
+    gpu_ctx.render(pc, cam, w, h)
+    fresh = capi.Context(device=0)
+    try:
+        fresh.upload_scene(full)
+        fresh.render(pc, cam, w, h)
+        assert same_bits(gpu_ctx.read_hdr(), fresh.read_hdr()).all()
+    finally:
+        fresh.close()

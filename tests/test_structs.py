@@ -18,6 +18,7 @@ NAMES = {
     "prosper_pt_texture_desc": S.TextureDesc, "prosper_pt_sampler_desc": S.SamplerDesc,
     "prosper_pt_mesh_info": S.MeshInfo, "prosper_pt_cube_desc": S.CubeDesc, "prosper_pt_scene_view": S.SceneView,
     "prosper_pt_tile_desc": S.TileDesc, "prosper_pt_counters": S.Counters, "prosper_pt_scene_stats": S.SceneStats,
+    "prosper_pt_mesh_update": S.MeshUpdate, "prosper_pt_debug_options": S.DebugOptions, "prosper_pt_comm_info": S.CommInfo,
 }
 
 
