@@ -393,10 +393,19 @@ int prosper_pt_update_materials(prosper_pt_ctx *ctx, const prosper_MaterialData 
  * there.  prosper_pt_update_meshes hands over the meshes that arrived: metadata and MeshInfo as pollMeshWorker stores them,
  * and the bytes the worker wrote (`bytes`, borrowed for the call) with their place in geometryBuffers[metadata.bufferIndex].
  * A buffer index the scene has not seen yet creates that buffer, `bufferByteSize` bytes large (ignored otherwise).
- * The call re-flattens the scene, builds the subtrees of the model instances that became complete (the others are kept),
- * re-assembles the hierarchy and synchronises the device: textures, material tables, lights and sky stay as they are, and
- * the next render shows what a fresh prosper_pt_upload_scene of the new state would show, bit for bit.  A mesh can be
- * handed over once; its material's alpha mode is the one the table holds at the time of the call. */
+ * The call copies the bytes, notes the tables and returns: a worker thread of the context lays the triangles out again,
+ * builds the subtrees of the model instances that became complete (the others are kept), re-assembles the hierarchy and
+ * writes the per-triangle records - all into arrays of its own, on a stream of its own - while the frame loop goes on
+ * rendering the geometry it has, frames in flight included.  The first render (or prosper_pt_update_meshes, or
+ * prosper_pt_finish_mesh_updates) after the worker is done switches to the new geometry; instances that moved or materials
+ * that changed meanwhile are brought up to date by that switch.  This is prosper's own timing: a BLAS is built on the
+ * GPU while frames are drawn and its instances appear when it exists.  Meshes that arrive while a build is under way are
+ * taken up by the next one, started at the switch.  Textures, material tables, lights and sky are not touched.  Once a state
+ * is switched in, a render shows what a fresh prosper_pt_upload_scene of that state would show, bit for bit.
+ * prosper_pt_finish_mesh_updates waits until everything handed over so far is in the scene (screenshots, tests, the end of
+ * loading).  A mesh can be handed over once; its material's alpha mode is the one the table holds at the time of the call.
+ * A build that fails (out of memory, a hierarchy too deep for the traversal) is reported by the call that would have
+ * switched to it; the scene stays as it was and the meshes wait for the next build. */
 #define PROSPER_PT_MAX_GEOMETRY_BUFFERS 100u
 typedef struct prosper_pt_mesh_update
 {
@@ -410,6 +419,7 @@ typedef struct prosper_pt_mesh_update
     uint64_t bufferByteSize; /* size of geometryBuffers[metadata.bufferIndex] if the scene does not have that buffer yet */
 } prosper_pt_mesh_update;
 int prosper_pt_update_meshes(prosper_pt_ctx *ctx, const prosper_pt_mesh_update *meshes, uint32_t count);
+int prosper_pt_finish_mesh_updates(prosper_pt_ctx *ctx);
 
 /* Re-splits the instances that moved since the last build and re-assembles the tree on the host (one subtree per model
  * instance under a re-braided top level); synchronises the device.  prosper_pt_scene_stats.bvhBuildSeconds reports it. */
@@ -422,6 +432,10 @@ typedef struct prosper_pt_hierarchy_state
     float builtCost;
     uint32_t nodeCount;
     uint32_t levels;    /* kernel launches of a refit = levels + 1 */
+    uint32_t meshUpdates;        /* prosper_pt_update_meshes calls that handed meshes over */
+    uint32_t geometryInstalls;   /* background geometry builds whose result has become the scene */
+    uint32_t geometryBuildRunning; /* 1: a build is under way (or meshes wait for one) */
+    uint32_t reserved;
 } prosper_pt_hierarchy_state;
 /* Waits for the last refit's measure if it is still on its way. */
 int prosper_pt_get_hierarchy_state(prosper_pt_ctx *ctx, prosper_pt_hierarchy_state *out);

@@ -61,6 +61,7 @@ def lib():
     L.prosper_pt_update_textures.argtypes = [vp, vp, u32, u32]
     L.prosper_pt_update_materials.argtypes = [vp, vp, u32, u32]
     L.prosper_pt_update_meshes.argtypes = [vp, vp, u32]
+    L.prosper_pt_finish_mesh_updates.argtypes = [vp]
     L.prosper_pt_update_transforms.argtypes = [vp, vp, u32]
     L.prosper_pt_update_transforms_async.argtypes = [vp, vp, u32, u32, vp]
     L.prosper_pt_rebuild_hierarchy.argtypes = [vp]
@@ -301,9 +302,11 @@ class Context:
         arr = (S.MaterialData * len(materials))(*materials)
         _check(lib().prosper_pt_update_materials(self._h, C.cast(arr, C.c_void_p), first, len(materials)))
 
-    def update_meshes(self, world, mesh_indices):
+    def update_meshes(self, world, mesh_indices, wait=True):
         """Hands over meshes of `world` (a World that holds them) that the uploaded scene marked as not loaded
-        (World.with_meshes_loaded): metadata, MeshInfo and the mesh's bytes of its geometry buffer."""
+        (World.with_meshes_loaded): metadata, MeshInfo and the mesh's bytes of its geometry buffer.  wait: also
+        prosper_pt_finish_mesh_updates - the next render shows them (otherwise the first render after the context's worker
+        thread has built their geometry does)."""
         self._sync_debug()
         f = world.freeze()
         ups = (S.MeshUpdate * max(1, len(mesh_indices)))()
@@ -316,6 +319,11 @@ class Context:
             u.bytes = buf.ctypes.data + 4 * first_word
             u.byteOffset, u.byteCount, u.bufferByteSize = 4 * first_word, 4 * words, buf.nbytes
         _check(lib().prosper_pt_update_meshes(self._h, C.cast(ups, C.c_void_p), len(mesh_indices)))
+        if wait:
+            self.finish_mesh_updates()
+
+    def finish_mesh_updates(self):
+        _check(lib().prosper_pt_finish_mesh_updates(self._h))
 
     def rebuild_hierarchy(self):
         self._sync_debug()

@@ -77,6 +77,12 @@ class InstancedBvh
         const WorldTriangle *triangles, uint64_t count, const std::vector<Range> &instances, const std::vector<uint8_t> &changed,
         const BvhBuildOptions &opt = BvhBuildOptions());
     [[nodiscard]] size_t instanceCount() const;
+    void swap(InstancedBvh &other) noexcept
+    {
+        Impl *t = m;
+        m = other.m;
+        other.m = t;
+    }
 
   private:
     struct Impl;

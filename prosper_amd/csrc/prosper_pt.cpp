@@ -50,6 +50,7 @@ int device_alloc(prosper_pt_ctx *ctx, size_t bytes, void **out)
     if (bytes == 0) bytes = 16;
     void *p = nullptr;
     PPT_HIP(hipMalloc(&p, bytes));
+    const std::lock_guard<std::mutex> lock(ctx->allocMutex);
     ctx->sceneAllocations.push_back({p, bytes});
     ctx->sceneBytes += bytes;
     *out = p;
@@ -59,6 +60,7 @@ int device_alloc(prosper_pt_ctx *ctx, size_t bytes, void **out)
 // returns a scene allocation early (a texture only its material pack still mirrors, a node array that was outgrown)
 void device_free(prosper_pt_ctx *ctx, const void *p)
 {
+    const std::lock_guard<std::mutex> lock(ctx->allocMutex);
     for (size_t i = 0; i < ctx->sceneAllocations.size(); ++i)
         if (ctx->sceneAllocations[i].ptr == p)
         {
@@ -109,8 +111,44 @@ WavefrontOptions wavefront_options(const prosper_pt_ctx *ctx)
     return o;
 }
 
+} // namespace
+
+namespace ppt
+{
+// A geometry generation under construction (prosper_pt_update_meshes): the worker thread writes only what hangs off this
+// object - a private copy of the scene descriptor, a new AccelState, new device arrays - until the main thread installs it.
+struct MeshBuild
+{
+    DeviceScene scene = {};
+    AccelState *acc = nullptr;
+    prosper_pt_scene_stats stats = {};
+    uint64_t alphaTriangleCount = 0;
+    std::future<int> done;    // the worker's return code ...
+    std::string error;        // ... and message (fail() is thread-local)
+    uint64_t materialChanges = 0; // MaterialState::changes when the build took its copy of the alpha-material table
+    void *dAlphaSnapshot = nullptr;
+};
+} // namespace ppt
+
+namespace
+{
+
+// upload / destroy: the worker is waited for, its result dropped (its device arrays are scene allocations)
+void discard_mesh_build(prosper_pt_ctx *ctx)
+{
+    MeshBuild *b = ctx->meshBuild;
+    if (!b) return;
+    if (b->done.valid()) (void)b->done.get();
+    delete b->acc;
+    delete b;
+    ctx->meshBuild = nullptr;
+}
+
 void free_scene(prosper_pt_ctx *ctx)
 {
+    discard_mesh_build(ctx);
+    for (ppt::AccelState *old : ctx->retiredAccel) delete old;
+    ctx->retiredAccel.clear();
     for (auto &a : ctx->sceneAllocations) (void)hipFree(a.ptr);
     ctx->sceneAllocations.clear();
     delete ctx->accel; // its device arrays are in the list above
@@ -213,16 +251,43 @@ int validate_scene(const prosper_pt_scene_view *v)
     return PROSPER_PT_OK;
 }
 
+// Where a hierarchy build puts its results: the context's own scene and AccelState (prosper_pt_upload_scene, the synchronous
+// rebuild - null stream, device idle), or the private ones of a background build (prosper_pt_update_meshes: its own stream,
+// nothing of the context is written until the result is installed).  The options are copied: the worker thread never reads
+// ctx->debug.
+struct GeometryTarget
+{
+    DeviceScene *s = nullptr;
+    AccelState *acc = nullptr;
+    prosper_pt_scene_stats *stats = nullptr;
+    uint64_t *alphaTriangleCount = nullptr;
+    hipStream_t stream = nullptr;
+    BvhBuildOptions buildOpt;
+    bool flatBvh = false, noUploadRefit = false, rawRecords = false;
+};
+GeometryTarget context_target(prosper_pt_ctx *ctx)
+{
+    GeometryTarget t;
+    t.s = &ctx->scene;
+    t.acc = ctx->accel;
+    t.stats = &ctx->stats;
+    t.alphaTriangleCount = &ctx->alphaTriangleCount;
+    t.buildOpt = build_options(ctx);
+    t.flatBvh = ctx->debug.flatBvh != 0;
+    t.noUploadRefit = ctx->debug.noUploadRefit != 0;
+    t.rawRecords = ctx->debug.rawRecords != 0; // (refused by prosper_pt_set_debug_options unless built with -DPPT_EXPERIMENTS)
+    return t;
+}
+
 // The refit's GPU work on `stream` for the node / triangle arrays of scene version `version`: exact bounds level by level,
 // every node re-encoded, the tree's surface-area measure into the version's cost slot (read back through hCost / costEvent).
-int enqueue_refit(prosper_pt_ctx *ctx, BvhNode *nodes, const WorldTriangle *tris, uint32_t version, hipStream_t stream)
+int enqueue_refit(AccelState *acc, float padCoeff, BvhNode *nodes, const WorldTriangle *tris, uint32_t version, hipStream_t stream)
 {
-    AccelState *acc = ctx->accel;
     const uint32_t slot = version % AccelState::kCostSlots;
     PPT_HIP(hipMemsetAsync(acc->dCost + slot, 0, sizeof(float), stream));
     launch_refit(
         nodes, tris, acc->dNodeBounds, acc->dRefitOrder, acc->levelOffsets.data(), (uint32_t)acc->levelOffsets.size() - 1u,
-        acc->nodeCount, bvh_pad_coefficient(build_options(ctx)), acc->dCost + slot, stream);
+        acc->nodeCount, padCoeff, acc->dCost + slot, stream);
     PPT_HIP(hipGetLastError());
     PPT_HIP(hipMemcpyAsync(acc->hCost + slot, acc->dCost + slot, sizeof(float), hipMemcpyDeviceToHost, stream));
     PPT_HIP(hipEventRecord(acc->costEvent[slot], stream));
@@ -252,9 +317,10 @@ int poll_refit_cost(AccelState *acc, bool wait)
 
 // Nodes + leaf-order triangles of a freshly built hierarchy to the device (the node array grows when it has to), and
 // what a later refit needs: the nodes ordered by height, every triangle's place in the leaf order, the bounds array.
-int upload_hierarchy(prosper_pt_ctx *ctx, const BvhBuildResult &bvh)
+// Everything runs on the target's stream, which has been waited for when this returns.
+int upload_hierarchy(prosper_pt_ctx *ctx, GeometryTarget &t, const BvhBuildResult &bvh)
 {
-    AccelState *acc = ctx->accel;
+    AccelState *acc = t.acc;
     const size_t nodeBytes = bvh.nodes.size() * sizeof(BvhNode);
     if (nodeBytes > acc->nodeCapacityBytes)
     {
@@ -262,7 +328,8 @@ int upload_hierarchy(prosper_pt_ctx *ctx, const BvhBuildResult &bvh)
         const size_t capacity = nodeBytes + nodeBytes / 4 + 4096; // headroom: a rebuild changes the node count a little
         const int rc = device_alloc(ctx, capacity, &d);
         if (rc != PROSPER_PT_OK) return rc;
-        // (callers have synchronised the device: nothing reads the old arrays any more)
+        // (a rebuild of the context's own hierarchy: its callers have synchronised the device, nothing reads the old
+        //  arrays any more; a background build starts without arrays)
         for (uint32_t ver = 0; ver < AccelState::kVersions; ++ver)
             if (acc->dNodesV[ver])
             {
@@ -274,15 +341,15 @@ int upload_hierarchy(prosper_pt_ctx *ctx, const BvhBuildResult &bvh)
         acc->nodeCapacityBytes = capacity;
     }
     for (uint32_t ver = 0; ver < AccelState::kVersions; ++ver) acc->nodesCurrent[ver] = ver == acc->cur;
-    PPT_HIP(hipMemcpy(acc->dNodes, bvh.nodes.data(), nodeBytes, hipMemcpyHostToDevice));
-    ctx->scene.nodes = acc->dNodes;
+    PPT_HIP(hipMemcpyAsync(acc->dNodes, bvh.nodes.data(), nodeBytes, hipMemcpyHostToDevice, t.stream));
+    t.s->nodes = acc->dNodes;
     if (acc->total)
     {
-        PPT_HIP(hipMemcpy(acc->dPerm, bvh.permutation.data(), bvh.permutation.size() * 4, hipMemcpyHostToDevice));
-        launch_permute_triangles(acc->dFlat, acc->dPerm, acc->dTris, (uint32_t)acc->total, nullptr);
+        PPT_HIP(hipMemcpyAsync(acc->dPerm, bvh.permutation.data(), bvh.permutation.size() * 4, hipMemcpyHostToDevice, t.stream));
+        launch_permute_triangles(acc->dFlat, acc->dPerm, acc->dTris, (uint32_t)acc->total, t.stream);
         PPT_HIP(hipGetLastError());
-        PPT_HIP(hipDeviceSynchronize());
     }
+    PPT_HIP(hipStreamSynchronize(t.stream)); // (the host arrays of `bvh` have been read)
 
     // ---- refit tables ----
     const size_t n = bvh.nodes.size();
@@ -312,7 +379,7 @@ int upload_hierarchy(prosper_pt_ctx *ctx, const BvhBuildResult &bvh)
         const size_t capacity = n + n / 4 + 64;
         void *d = nullptr;
         int rc;
-        // (callers have synchronised the device: no refit is reading the old tables)
+        // (as above: no refit is reading the old tables)
         if (acc->dNodeBounds) device_free(ctx, acc->dNodeBounds);
         if (acc->dRefitOrder) device_free(ctx, acc->dRefitOrder);
         acc->dNodeBounds = nullptr;
@@ -324,8 +391,8 @@ int upload_hierarchy(prosper_pt_ctx *ctx, const BvhBuildResult &bvh)
         acc->dRefitOrder = static_cast<uint32_t *>(d);
         acc->refitCapacityNodes = capacity;
     }
-    PPT_HIP(hipMemcpy(acc->dRefitOrder, order.data(), n * sizeof(uint32_t), hipMemcpyHostToDevice));
-    if (!acc->dLeafPosition) // (also after prosper_pt_update_meshes: the array follows the triangle count)
+    PPT_HIP(hipMemcpyAsync(acc->dRefitOrder, order.data(), n * sizeof(uint32_t), hipMemcpyHostToDevice, t.stream));
+    if (!acc->dLeafPosition)
     {
         void *d = nullptr;
         int rc;
@@ -342,30 +409,33 @@ int upload_hierarchy(prosper_pt_ctx *ctx, const BvhBuildResult &bvh)
         for (hipEvent_t &e : acc->costEvent) PPT_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
         PPT_HIP(hipEventCreateWithFlags(&acc->sceneEvent, hipEventDisableTiming));
     }
+    std::vector<uint32_t> position((size_t)acc->total);
     if (acc->total)
     {
-        std::vector<uint32_t> position((size_t)acc->total);
         for (size_t leaf = 0; leaf < bvh.permutation.size(); ++leaf) position[bvh.permutation[leaf]] = (uint32_t)leaf;
-        PPT_HIP(hipMemcpy(acc->dLeafPosition, position.data(), position.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+        PPT_HIP(hipMemcpyAsync(acc->dLeafPosition, position.data(), position.size() * sizeof(uint32_t), hipMemcpyHostToDevice, t.stream));
     }
     // one refit right away: the device encoder writes the bytes the emitter wrote (tested), and leaves the tree's
     // surface-area measure to compare later refits with
     // (debug option noUploadRefit keeps the emitter's own bytes, for the test that compares the two; the bounds array
     // and the measure are still computed)
-    const bool keepEmitted = ctx->debug.noUploadRefit != 0;
     for (bool &pending : acc->costPending) pending = false;
     acc->builtCost = 0.0f;
     if (acc->total)
     {
         // (an empty scene keeps the emitter's root - child boxes at +inf - as it is: the encoder has no bounds to write)
-        int rc = enqueue_refit(ctx, acc->dNodes, acc->dTris, acc->cur, nullptr);
+        int rc = enqueue_refit(acc, bvh_pad_coefficient(t.buildOpt), acc->dNodes, acc->dTris, acc->cur, t.stream);
         if (rc != PROSPER_PT_OK) return rc;
-        PPT_HIP(hipDeviceSynchronize());
-        if (keepEmitted) PPT_HIP(hipMemcpy(acc->dNodes, bvh.nodes.data(), nodeBytes, hipMemcpyHostToDevice));
+        PPT_HIP(hipStreamSynchronize(t.stream));
+        if (t.noUploadRefit)
+        {
+            PPT_HIP(hipMemcpyAsync(acc->dNodes, bvh.nodes.data(), nodeBytes, hipMemcpyHostToDevice, t.stream));
+        }
         const uint32_t slot = acc->cur % AccelState::kCostSlots;
         acc->costPending[slot] = false;
         acc->builtCost = acc->hCost[slot];
     }
+    PPT_HIP(hipStreamSynchronize(t.stream)); // (`order` and `position` have been read)
     acc->costRead = acc->refitSequence;
     acc->lastCostRatio = 1.0f;
     acc->movedSinceBuild.assign(acc->ranges.size(), 0);
@@ -444,76 +514,53 @@ struct BuildOutcome
 struct GeometryJob
 {
     // (a std::async future joins in its destructor: an early return of the caller waits for the build, which reads the
-    //  context's AccelState)
+    //  target's AccelState)
     std::future<BuildOutcome> build;
     std::chrono::steady_clock::time_point t0;
     uint64_t alphaTotal = 0;
 };
 
-// The layout into the AccelState, the world triangles (flatten kernel, copied to the host) and the hierarchy build started
-// on the host's threads.  `changed` == nullptr: everything is new (upload).  Otherwise the device is idle, the context holds
-// the arrays of the previous layout, which are released, and only the flagged ranges' subtrees are split again.
-int begin_geometry(prosper_pt_ctx *ctx, GeometryLayout &layout, const std::vector<uint8_t> *changed, GeometryJob &job)
+// The layout into the target's AccelState, the world triangles (flatten kernel, copied to the host) and the hierarchy build
+// started on the host's threads.  `changed` == nullptr: every subtree is new.  Otherwise the target's InstancedBvh holds the
+// subtrees of a previous layout with the same instances, and only the flagged ones are split again.
+int begin_geometry(prosper_pt_ctx *ctx, GeometryTarget &t, GeometryLayout &layout, const std::vector<uint8_t> *changed, GeometryJob &job)
 {
-    DeviceScene &s = ctx->scene;
-    AccelState *acc = ctx->accel;
-    const bool again = changed != nullptr;
+    DeviceScene &s = *t.s;
+    AccelState *acc = t.acc;
     int rc;
     void *d = nullptr;
     job.t0 = std::chrono::steady_clock::now();
     job.alphaTotal = layout.alphaTotal;
     const uint32_t drawInstanceCount = (uint32_t)ctx->geometry->drawInstances.size();
     const uint64_t total = layout.total;
-    if (again)
-    {
-        // everything sized by the triangle count goes; the per-draw-instance tables are rewritten in place
-        const void *gone[] = {acc->dFlat, acc->dPerm, acc->dLeafPosition, s.alphaTriangles, s.shadeTriangles, s.rawShadeTriangles};
-        for (const void *p : gone)
-            if (p) device_free(ctx, p);
-        for (uint32_t ver = 0; ver < AccelState::kVersions; ++ver)
-            if (acc->dTrisV[ver])
-            {
-                device_free(ctx, acc->dTrisV[ver]);
-                acc->dTrisV[ver] = nullptr;
-            }
-        acc->dFlat = acc->dTris = nullptr;
-        acc->dPerm = acc->dLeafPosition = nullptr;
-        s.alphaTriangles = nullptr;
-        s.shadeTriangles = nullptr;
-        s.rawShadeTriangles = nullptr;
-        s.triangles = nullptr;
-        PPT_HIP(hipMemcpy(const_cast<uint32_t *>(s.alphaOffsets), layout.alphaOffsets.data(), layout.alphaOffsets.size() * 4, hipMemcpyHostToDevice));
-        PPT_HIP(hipMemcpy(acc->dOffsets, layout.triOffsets.data(), layout.triOffsets.size() * 4, hipMemcpyHostToDevice));
-        PPT_HIP(hipMemcpy(acc->dFlags, layout.diFlags.data(), layout.diFlags.size() * 4, hipMemcpyHostToDevice));
-    }
-    else
-    {
-        if ((rc = upload(ctx, layout.alphaOffsets.data(), layout.alphaOffsets.size() * 4, &d))) return rc;
-        s.alphaOffsets = static_cast<const uint32_t *>(d);
-        if ((rc = upload(ctx, layout.triOffsets.data(), layout.triOffsets.size() * 4, &d))) return rc;
-        acc->dOffsets = static_cast<uint32_t *>(d);
-        if ((rc = upload(ctx, layout.diFlags.data(), layout.diFlags.size() * 4, &d))) return rc;
-        acc->dFlags = static_cast<uint32_t *>(d);
-    }
+    if ((rc = device_alloc(ctx, layout.alphaOffsets.size() * 4, &d))) return rc;
+    s.alphaOffsets = static_cast<const uint32_t *>(d);
+    PPT_HIP(hipMemcpyAsync(d, layout.alphaOffsets.data(), layout.alphaOffsets.size() * 4, hipMemcpyHostToDevice, t.stream));
+    if ((rc = device_alloc(ctx, layout.triOffsets.size() * 4, &d))) return rc;
+    acc->dOffsets = static_cast<uint32_t *>(d);
+    PPT_HIP(hipMemcpyAsync(d, layout.triOffsets.data(), layout.triOffsets.size() * 4, hipMemcpyHostToDevice, t.stream));
+    if ((rc = device_alloc(ctx, layout.diFlags.size() * 4, &d))) return rc;
+    acc->dFlags = static_cast<uint32_t *>(d);
+    PPT_HIP(hipMemcpyAsync(d, layout.diFlags.data(), layout.diFlags.size() * 4, hipMemcpyHostToDevice, t.stream));
     s.triangleOffsets = acc->dOffsets;
+
+    const size_t triBytes = sizeof(WorldTriangle) * (size_t)(total ? total : 1);
+    if ((rc = device_alloc(ctx, triBytes, &d))) return rc;
+    acc->dFlat = static_cast<WorldTriangle *>(d);
+    launch_flatten_triangles(s, acc->dOffsets, drawInstanceCount, acc->dFlags, acc->dFlat, nullptr, nullptr, (uint32_t)total, t.stream);
+    PPT_HIP(hipGetLastError());
+    acc->flat.resize((size_t)total);
+    if (total) PPT_HIP(hipMemcpyAsync(acc->flat.data(), acc->dFlat, sizeof(WorldTriangle) * (size_t)total, hipMemcpyDeviceToHost, t.stream));
+    PPT_HIP(hipStreamSynchronize(t.stream)); // (the layout's host arrays have been read, the world triangles are here)
     acc->triOffsets.swap(layout.triOffsets);
     acc->ranges.swap(layout.ranges);
     acc->rangeModelInstance.swap(layout.rangeModelInstance);
     acc->total = total;
     acc->drawInstanceCount = drawInstanceCount;
 
-    const size_t triBytes = sizeof(WorldTriangle) * (size_t)(total ? total : 1);
-    if ((rc = device_alloc(ctx, triBytes, &d))) return rc;
-    acc->dFlat = static_cast<WorldTriangle *>(d);
-    launch_flatten_triangles(s, acc->dOffsets, drawInstanceCount, acc->dFlags, acc->dFlat, nullptr, nullptr, (uint32_t)total, nullptr);
-    PPT_HIP(hipGetLastError());
-    acc->flat.resize((size_t)total);
-    if (total) PPT_HIP(hipMemcpy(acc->flat.data(), acc->dFlat, sizeof(WorldTriangle) * (size_t)total, hipMemcpyDeviceToHost));
-    PPT_HIP(hipDeviceSynchronize());
-    const BvhBuildOptions buildOpt = build_options(ctx);
-    const bool flatBvh = ctx->debug.flatBvh != 0;
-    // the subtrees of the last build can be kept where that build was an instanced one
-    const bool keep = again && acc->instanced && !flatBvh;
+    const BvhBuildOptions buildOpt = t.buildOpt;
+    const bool flatBvh = t.flatBvh;
+    const bool keep = changed != nullptr && !flatBvh;
     std::vector<uint8_t> flags = keep ? *changed : std::vector<uint8_t>();
     job.build = std::async(std::launch::async, [acc, total, buildOpt, flatBvh, keep, flags]() {
         BuildOutcome out;
@@ -549,27 +596,26 @@ int begin_geometry(prosper_pt_ctx *ctx, GeometryLayout &layout, const std::vecto
     return PROSPER_PT_OK;
 }
 
-// The arrays the flatten kernel fills for shading and any-hit (scene-lifetime, or until the next prosper_pt_update_meshes),
-// the leaf-order triangles, and the hierarchy the host's threads built meanwhile.
-int finish_geometry(prosper_pt_ctx *ctx, GeometryJob &job)
+// The arrays the flatten kernel fills for shading and any-hit (they live as long as this geometry), the leaf-order
+// triangles, and the hierarchy the host's threads built meanwhile.
+int finish_geometry(prosper_pt_ctx *ctx, GeometryTarget &t, GeometryJob &job)
 {
-    DeviceScene &s = ctx->scene;
-    AccelState *acc = ctx->accel;
+    DeviceScene &s = *t.s;
+    AccelState *acc = t.acc;
     const uint64_t total = acc->total;
     int rc;
     void *d = nullptr;
     if ((rc = device_alloc(ctx, sizeof(AlphaTriangle) * (size_t)(job.alphaTotal ? job.alphaTotal : 1), &d))) return rc;
     s.alphaTriangles = static_cast<const AlphaTriangle *>(d);
-    ctx->alphaTriangleCount = job.alphaTotal;
+    *t.alphaTriangleCount = job.alphaTotal;
     if ((rc = device_alloc(ctx, (size_t)(total ? total : 1) * 4, &d))) return rc;
     acc->dPerm = static_cast<uint32_t *>(d);
     // decoded 128-byte records; debug option rawRecords (an experiment) keeps the raw 64-byte form instead, decoded per hit (same
     // pixels, tested).  Measured and not made a default for any scene size (profiles/r03_raw_records.txt): even on
     // S-sponza-class, whose 33.6 MB of records outgrow the L2 and whose wf_shade runs at 6.7 TB/s, the ~150 instructions of
     // decoding cost more than the 64 bytes save (wf_shade 910 -> 931 us; C4 687 -> 721, C2 220 -> 248, FlightHelmet 97 -> 104)
-    const bool rawRecords = ctx->debug.rawRecords != 0; // (refused by prosper_pt_set_debug_options unless built with -DPPT_EXPERIMENTS)
     void *dShade = nullptr, *dRaw = nullptr;
-    if (rawRecords)
+    if (t.rawRecords)
     {
         if ((rc = device_alloc(ctx, sizeof(RawShadeTriangle) * (size_t)(total ? total : 1), &dRaw))) return rc;
     }
@@ -577,38 +623,35 @@ int finish_geometry(prosper_pt_ctx *ctx, GeometryJob &job)
         return rc;
     s.shadeTriangles = static_cast<const ShadeTriangle *>(dShade);
     s.rawShadeTriangles = static_cast<const RawShadeTriangle *>(dRaw);
-    ctx->rawRecords = rawRecords;
     const size_t triBytes = sizeof(WorldTriangle) * (size_t)(total ? total : 1);
     void *dTris = nullptr;
     if ((rc = device_alloc(ctx, triBytes, &dTris))) return rc;
-    PPT_HIP(hipMemset(dTris, 0, triBytes));
+    PPT_HIP(hipMemsetAsync(dTris, 0, triBytes, t.stream));
     acc->dTris = static_cast<WorldTriangle *>(dTris);
     acc->dTrisV[acc->cur] = acc->dTris;
     s.triangles = acc->dTris;
 
     launch_flatten_triangles(
         s, acc->dOffsets, acc->drawInstanceCount, acc->dFlags, acc->dFlat, static_cast<ShadeTriangle *>(dShade),
-        const_cast<AlphaTriangle *>(s.alphaTriangles), (uint32_t)total, nullptr, nullptr, nullptr,
+        const_cast<AlphaTriangle *>(s.alphaTriangles), (uint32_t)total, t.stream, nullptr, nullptr,
         static_cast<RawShadeTriangle *>(dRaw));
     PPT_HIP(hipGetLastError());
-    PPT_HIP(hipDeviceSynchronize());
+    PPT_HIP(hipStreamSynchronize(t.stream));
 
     BuildOutcome built = job.build.get();
     if (!built.error.empty()) return fail(PROSPER_PT_ERR_UNSUPPORTED, "BVH build failed: " + built.error);
     acc->instanced = built.instanced;
-    if ((rc = upload_hierarchy(ctx, built.bvh))) return rc;
+    if ((rc = upload_hierarchy(ctx, t, built.bvh))) return rc;
 
-    ctx->stats.triangleCount = total;
-    ctx->stats.nodeCount = built.bvh.nodes.size();
-    ctx->stats.nodeBytes = sizeof(BvhNode);
-    ctx->stats.triangleBytes = sizeof(WorldTriangle);
-    ctx->stats.maxDepth = built.bvh.maxDepth;
-    ctx->stats.deviceBytes = ctx->sceneBytes;
-    ctx->stats.buildSeconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - job.t0).count();
-    ctx->stats.bvhBuildSeconds = built.seconds;
-    ctx->stats.alphaTriangleCount = ctx->alphaTriangleCount;
-    ctx->stats.alphaBoundBytes = ctx->alphaBoundBytes;
-    ctx->sceneStamp++;
+    prosper_pt_scene_stats &st = *t.stats;
+    st.triangleCount = total;
+    st.nodeCount = built.bvh.nodes.size();
+    st.nodeBytes = sizeof(BvhNode);
+    st.triangleBytes = sizeof(WorldTriangle);
+    st.maxDepth = built.bvh.maxDepth;
+    st.buildSeconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - job.t0).count();
+    st.bvhBuildSeconds = built.seconds;
+    st.alphaTriangleCount = job.alphaTotal;
     return PROSPER_PT_OK;
 }
 
@@ -666,10 +709,11 @@ int upload_scene_impl(prosper_pt_ctx *ctx, const prosper_pt_scene_view *v)
     ctx->dTransforms = const_cast<prosper_ModelInstanceTransforms *>(s.modelInstanceTransforms);
     acc->dTransformsV[0] = ctx->dTransforms;
     GeometryJob job;
+    GeometryTarget target = context_target(ctx);
     {
         GeometryLayout layout;
         if ((rc = layout_geometry(*gs, v->materials, layout))) return rc;
-        if ((rc = begin_geometry(ctx, layout, nullptr, job))) return rc;
+        if ((rc = begin_geometry(ctx, target, layout, nullptr, job))) return rc;
     }
 
     // textures: one allocation each (256-B aligned by hipMalloc), re-laid out in 8x4-texel tiles of one cache line each
@@ -829,7 +873,11 @@ int upload_scene_impl(prosper_pt_ctx *ctx, const prosper_pt_scene_view *v)
         ms->blockBytes = ms->texturesOffset + align16(ms->textures.size() * sizeof(DeviceTexture));
     }
 
-    if ((rc = finish_geometry(ctx, job))) return rc;
+    if ((rc = finish_geometry(ctx, target, job))) return rc;
+    ctx->rawRecords = target.rawRecords;
+    ctx->stats.deviceBytes = ctx->sceneBytes;
+    ctx->stats.alphaBoundBytes = ctx->alphaBoundBytes;
+    ctx->sceneStamp++;
     ctx->stats.textureSeconds = textureSeconds;
     ctx->stats.uploadSeconds = seconds_since(tUpload);
     return PROSPER_PT_OK;
@@ -1229,6 +1277,7 @@ void prosper_pt_destroy(prosper_pt_ctx *ctx)
 {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
+    discard_mesh_build(ctx); // (a worker may still be launching)
     (void)hipDeviceSynchronize();
     destroy_tiling(ctx);
     free_scene(ctx);
@@ -1270,6 +1319,7 @@ int prosper_pt_upload_scene(prosper_pt_ctx *ctx, const prosper_pt_scene_view *sc
     int rc = validate_scene(scene);
     if (rc != PROSPER_PT_OK) return rc;
     PPT_HIP(hipSetDevice(ctx->device));
+    discard_mesh_build(ctx); // (a worker may still be launching)
     PPT_HIP(hipDeviceSynchronize());
     free_scene(ctx);
     rc = upload_scene_impl(ctx, scene);
@@ -1352,11 +1402,18 @@ int prosper_pt_update_lights(
 // The synchronous path: re-split the instances that moved since the last build, re-assemble, upload (what
 // prosper_pt_update_transforms did before the refit existed; prosper's own TLAS build is of this kind, on the GPU).
 static int flush_pending_update(prosper_pt_ctx *ctx, hipStream_t stream);
+static int poll_mesh_build(prosper_pt_ctx *ctx, bool wait);
+static int start_mesh_build(prosper_pt_ctx *ctx);
 static int rebuild_hierarchy_impl(prosper_pt_ctx *ctx)
 {
+    PPT_HIP(hipSetDevice(ctx->device));
+    {
+        // a background build of streamed-in meshes holds the subtrees: its result is installed first
+        const int prc = poll_mesh_build(ctx, true);
+        if (prc != PROSPER_PT_OK) return prc;
+    }
     AccelState *acc = ctx->accel;
     const auto t0 = std::chrono::steady_clock::now();
-    PPT_HIP(hipSetDevice(ctx->device));
     {
         const int frc = flush_pending_update(ctx, nullptr); // the moved triangles must be in the flat array
         if (frc != PROSPER_PT_OK) return frc;
@@ -1389,7 +1446,8 @@ static int rebuild_hierarchy_impl(prosper_pt_ctx *ctx)
         return fail(PROSPER_PT_ERR_UNSUPPORTED, std::string("BVH rebuild failed: ") + ex.what());
     }
     const double buildSeconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - tBuild).count();
-    const int rc = upload_hierarchy(ctx, bvh);
+    GeometryTarget target = context_target(ctx);
+    const int rc = upload_hierarchy(ctx, target, bvh);
     if (rc != PROSPER_PT_OK) return rc;
     acc->stale = false;
     acc->rebuilds++;
@@ -1472,7 +1530,7 @@ static int flush_pending_update(prosper_pt_ctx *ctx, hipStream_t stream)
         acc->dLeafPosition, acc->dTrisV[v]);
     PPT_HIP(hipGetLastError());
     acc->flatStale = true; // (the flat array now holds the new pose whatever happens next)
-    if (acc->total && (rc = enqueue_refit(ctx, acc->dNodesV[v], acc->dTrisV[v], v, stream))) return rc;
+    if (acc->total && (rc = enqueue_refit(acc, bvh_pad_coefficient(build_options(ctx)), acc->dNodesV[v], acc->dTrisV[v], v, stream))) return rc;
     PPT_HIP(hipEventRecord(acc->sceneEvent, stream));
     // ---- commit: the new version becomes the scene ----
     acc->sceneEventRecorded = true;
@@ -1570,6 +1628,168 @@ int prosper_pt_rebuild_hierarchy(prosper_pt_ctx *ctx)
     return rebuild_hierarchy_impl(ctx);
 }
 
+// ---- streamed-in meshes: the new geometry is made by a worker thread, beside the frame loop ----
+static int stage_transforms(prosper_pt_ctx *ctx, const prosper_ModelInstanceTransforms *transforms, uint32_t count);
+
+// A worker for what the mirrors hold now (the caller has made sure none is running).
+static int start_mesh_build(prosper_pt_ctx *ctx)
+{
+    GeometryState *gs = ctx->geometry;
+    MaterialState *ms = ctx->materialState;
+    AccelState *old = ctx->accel;
+    auto layout = std::make_shared<GeometryLayout>();
+    int rc;
+    if ((rc = layout_geometry(*gs, ms->materials.data(), *layout))) return rc;
+    // the subtrees that are split again: model instances that became complete, and those that moved since the last build
+    auto changed = std::make_shared<std::vector<uint8_t>>(layout->ranges.size(), 0);
+    for (size_t r = 0; r < layout->ranges.size(); ++r)
+        (*changed)[r] = (r >= old->ranges.size() || layout->ranges[r].count != old->ranges[r].count ||
+                         (r < old->movedSinceBuild.size() && old->movedSinceBuild[r])) ? 1 : 0;
+    MeshBuild *b = new (std::nothrow) MeshBuild();
+    if (b) b->acc = new (std::nothrow) AccelState();
+    if (!b || !b->acc)
+    {
+        delete b;
+        return fail(PROSPER_PT_ERR_INVALID_ARGUMENT, "out of host memory");
+    }
+    b->scene = ctx->scene;
+    b->stats = ctx->stats;
+    b->acc->transforms = old->transforms; // the newest the caller gave, flushed or not
+    // The subtrees of the last build move to the new generation.  (The old one keeps rendering with its node array; should it
+    // have to be rebuilt before the switch, prosper_pt_rebuild_hierarchy waits for this build instead.)
+    const bool keep = old->instanced && ctx->debug.flatBvh == 0;
+    if (keep)
+    {
+        b->acc->bvh.swap(old->bvh);
+        old->instanced = false;
+    }
+    // the flatten kernel copies every non-opaque triangle's AlphaMaterial into its any-hit record: from a private copy of
+    // the table as the mirrors hold it now - the versioned device tables rotate under the frame loop's hands
+    b->materialChanges = ms->changes;
+    void *d = nullptr;
+    const size_t alphaBytes = ms->alphaMaterials.size() * sizeof(AlphaMaterial);
+    auto snapshot = std::make_shared<std::vector<AlphaMaterial>>(ms->alphaMaterials);
+    if ((rc = device_alloc(ctx, alphaBytes, &d)))
+    {
+        delete b->acc;
+        delete b;
+        return rc;
+    }
+    b->dAlphaSnapshot = d;
+    b->scene.alphaMaterials = static_cast<const AlphaMaterial *>(d);
+    GeometryTarget t = context_target(ctx);
+    t.s = &b->scene;
+    t.acc = b->acc;
+    t.stats = &b->stats;
+    t.alphaTriangleCount = &b->alphaTriangleCount;
+    t.stream = gs->buildStream;
+    const int device = ctx->device;
+    gs->dirty = false;
+    ctx->meshBuild = b;
+    b->done = std::async(std::launch::async, [ctx, b, t, layout, changed, snapshot, keep, device, alphaBytes]() mutable -> int {
+        auto run = [&]() -> int {
+            PPT_HIP(hipSetDevice(device));
+            PPT_HIP(hipMemcpyAsync(b->dAlphaSnapshot, snapshot->data(), alphaBytes, hipMemcpyHostToDevice, t.stream));
+            // its own transform table: the newest transforms as of the start of this build
+            AccelState *acc = b->acc;
+            void *dT = nullptr;
+            int r = device_alloc(ctx, sizeof(prosper_ModelInstanceTransforms) * (acc->transforms.size() ? acc->transforms.size() : 1), &dT);
+            if (r != PROSPER_PT_OK) return r;
+            if (!acc->transforms.empty())
+                PPT_HIP(hipMemcpyAsync(dT, acc->transforms.data(), sizeof(prosper_ModelInstanceTransforms) * acc->transforms.size(), hipMemcpyHostToDevice, t.stream));
+            acc->dTransformsV[0] = static_cast<prosper_ModelInstanceTransforms *>(dT);
+            b->scene.modelInstanceTransforms = acc->dTransformsV[0];
+            GeometryJob job;
+            if ((r = begin_geometry(ctx, t, *layout, keep ? changed.get() : nullptr, job))) return r;
+            return finish_geometry(ctx, t, job);
+        };
+        const int r = run();
+        if (r != PROSPER_PT_OK) b->error = ppt::g_lastErrorStorage;
+        return r;
+    });
+    return PROSPER_PT_OK;
+}
+
+// The finished build becomes the scene; what went on meanwhile - moved instances, changed materials, more meshes - follows.
+// wait: block until nothing handed over so far is outstanding.
+static int poll_mesh_build(prosper_pt_ctx *ctx, bool wait)
+{
+    if (ctx->meshBuild) PPT_HIP(hipSetDevice(ctx->device));
+    while (MeshBuild *b = ctx->meshBuild)
+    {
+        if (!wait && b->done.wait_for(std::chrono::seconds(0)) != std::future_status::ready) return PROSPER_PT_OK;
+        const int built = b->done.get();
+        GeometryState *gs = ctx->geometry;
+        MaterialState *ms = ctx->materialState;
+        ctx->meshBuild = nullptr;
+        if (built != PROSPER_PT_OK)
+        {
+            // the scene stays as it is (without the subtrees that went with the build: its next hierarchy is built whole);
+            // the meshes wait for the next prosper_pt_update_meshes / _finish_mesh_updates
+            const std::string why = b->error;
+            delete b->acc;
+            delete b;
+            gs->dirty = true;
+            return fail(built, "the background build of the streamed-in meshes failed: " + why);
+        }
+        AccelState *old = ctx->accel, *acc = b->acc;
+        const std::vector<prosper_ModelInstanceTransforms> latest = old->transforms;
+        // the old generation: frames in flight may still read its arrays, and its events / pinned staging may be in use
+        const void *gone[] = {old->dFlat, old->dPerm, old->dLeafPosition, old->dOffsets, old->dFlags, old->dNodeBounds, old->dRefitOrder,
+                              old->dCost, ctx->scene.alphaOffsets, ctx->scene.alphaTriangles, ctx->scene.shadeTriangles,
+                              ctx->scene.rawShadeTriangles, b->dAlphaSnapshot};
+        for (const void *p : gone) retire(ctx, p);
+        for (uint32_t v = 0; v < AccelState::kVersions; ++v)
+        {
+            retire(ctx, old->dTrisV[v]);
+            retire(ctx, old->dNodesV[v]);
+            retire(ctx, old->dTransformsV[v]);
+        }
+        ctx->retiredAccel.push_back(old);
+        ctx->accel = acc;
+        DeviceScene &s = ctx->scene;
+        s.nodes = b->scene.nodes;
+        s.triangles = b->scene.triangles;
+        s.triangleOffsets = b->scene.triangleOffsets;
+        s.alphaOffsets = b->scene.alphaOffsets;
+        s.alphaTriangles = b->scene.alphaTriangles;
+        s.shadeTriangles = b->scene.shadeTriangles;
+        s.rawShadeTriangles = b->scene.rawShadeTriangles;
+        s.modelInstanceTransforms = b->scene.modelInstanceTransforms;
+        ctx->dTransforms = acc->dTransformsV[0];
+        ctx->alphaTriangleCount = b->alphaTriangleCount;
+        ctx->stats.triangleCount = b->stats.triangleCount;
+        ctx->stats.nodeCount = b->stats.nodeCount;
+        ctx->stats.maxDepth = b->stats.maxDepth;
+        ctx->stats.buildSeconds = b->stats.buildSeconds;
+        ctx->stats.bvhBuildSeconds = b->stats.bvhBuildSeconds;
+        ctx->stats.alphaTriangleCount = b->stats.alphaTriangleCount;
+        ctx->stats.deviceBytes = ctx->sceneBytes;
+        ctx->sceneStamp++;
+        gs->installs++;
+        // a material that changed while the build ran: its any-hit records are rewritten by the next flush of the tables
+        if (ms->changes != b->materialChanges && ctx->alphaTriangleCount)
+        {
+            ms->pending = true;
+            ms->pendingAlphaPatch = true;
+        }
+        delete b;
+        int rc;
+        // instances that moved while the build ran: a refit of the new generation at the head of the next render
+        if (!latest.empty() && std::memcmp(latest.data(), acc->transforms.data(), sizeof(prosper_ModelInstanceTransforms) * latest.size()) != 0)
+            if ((rc = stage_transforms(ctx, latest.data(), (uint32_t)latest.size()))) return rc;
+        if ((rc = collect_retired(ctx))) return rc;
+        if (gs->dirty && (rc = start_mesh_build(ctx))) return rc;
+    }
+    if (wait && ctx->geometry && ctx->geometry->dirty && ctx->accel)
+    {
+        // (a failed build left meshes waiting: try again)
+        const int rc = start_mesh_build(ctx);
+        return rc != PROSPER_PT_OK ? rc : poll_mesh_build(ctx, true);
+    }
+    return PROSPER_PT_OK;
+}
+
 // WorldData::pollMeshWorker + World::buildNextBlas for the meshes that arrived (prosper_pt.h "streamed-in meshes").
 int prosper_pt_update_meshes(prosper_pt_ctx *ctx, const prosper_pt_mesh_update *meshes, uint32_t count)
 {
@@ -1631,74 +1851,65 @@ int prosper_pt_update_meshes(prosper_pt_ctx *ctx, const prosper_pt_mesh_update *
         }
     }
 
-    // ---- the device comes to rest: staged updates first, so that the tables the flatten kernel reads are the current ones ----
+    // ---- the arrived bytes and tables: nothing in flight reads them (the meshes have no triangle anywhere yet), so they are
+    //      written in place, through a stream of their own ----
     PPT_HIP(hipSetDevice(ctx->device));
     int rc;
-    if ((rc = flush_pending_update(ctx, nullptr))) return rc;
-    if ((rc = flush_pending_materials(ctx, nullptr))) return rc;
-    PPT_HIP(hipDeviceSynchronize());
-    const auto t0 = std::chrono::steady_clock::now();
-
-    // From here on a failure leaves buffers, tables and hierarchy out of step: the scene goes, the caller uploads it again.
-    auto run = [&]() -> int {
-        void *d = nullptr;
-        for (uint32_t i = 0; i < count; ++i)
-        {
-            const prosper_pt_mesh_update &u = meshes[i];
-            const uint32_t b = u.metadata.bufferIndex;
-            if (gs->buffers.size() <= b)
-            {
-                gs->buffers.resize((size_t)b + 1, nullptr);
-                gs->bufferBytes.resize((size_t)b + 1, 0);
-            }
-            if (!gs->buffers[b])
-            {
-                if ((rc = device_alloc(ctx, (size_t)bufferBytes[b], &d))) return rc;
-                PPT_HIP(hipMemset(d, 0, (size_t)bufferBytes[b]));
-                gs->buffers[b] = d;
-                gs->bufferBytes[b] = bufferBytes[b];
-                PPT_HIP(hipMemcpy(gs->dBufferTable + b, &d, sizeof(void *), hipMemcpyHostToDevice));
-            }
-            if (u.byteCount)
-                PPT_HIP(hipMemcpy(static_cast<uint8_t *>(gs->buffers[b]) + u.byteOffset, u.bytes, (size_t)u.byteCount, hipMemcpyHostToDevice));
-            gs->metadatas[u.meshIndex] = u.metadata;
-            gs->infos[u.meshIndex] = u.info;
-            PPT_HIP(hipMemcpy(gs->dMetadatas + u.meshIndex, &u.metadata, sizeof(prosper_GeometryMetadata), hipMemcpyHostToDevice));
-        }
-        GeometryLayout layout;
-        if ((rc = layout_geometry(*gs, ms->materials.data(), layout))) return rc;
-        // the subtrees that are split again: model instances that draw an arrived mesh, and those that moved since the last build
-        std::vector<uint8_t> changed(layout.ranges.size(), 0);
-        {
-            size_t r = 0;
-            const uint32_t n = (uint32_t)gs->drawInstances.size();
-            for (uint32_t i = 0; i < n; ++r)
-            {
-                const uint32_t mi = gs->drawInstances[i].modelInstanceIndex;
-                for (; i < n && gs->drawInstances[i].modelInstanceIndex == mi; ++i)
-                    if (arriving[gs->drawInstances[i].meshIndex]) changed[r] = 1;
-                if (r < acc->movedSinceBuild.size() && acc->movedSinceBuild[r]) changed[r] = 1;
-            }
-        }
-        GeometryJob job;
-        if ((rc = begin_geometry(ctx, layout, &changed, job))) return rc;
-        return finish_geometry(ctx, job);
-    };
-    rc = run();
-    if (rc != PROSPER_PT_OK)
+    if ((rc = poll_mesh_build(ctx, false))) return rc; // (a finished build is installed first: its subtrees are the ones to keep)
+    if (!gs->copyStream) PPT_HIP(hipStreamCreateWithFlags(&gs->copyStream, hipStreamNonBlocking));
+    if (!gs->buildStream) PPT_HIP(hipStreamCreateWithFlags(&gs->buildStream, hipStreamNonBlocking));
+    void *d = nullptr;
+    for (uint32_t i = 0; i < count; ++i)
     {
-        (void)hipDeviceSynchronize();
-        free_scene(ctx);
-        return rc;
+        const prosper_pt_mesh_update &u = meshes[i];
+        const uint32_t b = u.metadata.bufferIndex;
+        if (gs->buffers.size() <= b)
+        {
+            gs->buffers.resize((size_t)b + 1, nullptr);
+            gs->bufferBytes.resize((size_t)b + 1, 0);
+        }
+        if (!gs->buffers[b])
+        {
+            if ((rc = device_alloc(ctx, (size_t)bufferBytes[b], &d))) return rc;
+            PPT_HIP(hipMemsetAsync(d, 0, (size_t)bufferBytes[b], gs->copyStream));
+            gs->buffers[b] = d;
+            gs->bufferBytes[b] = bufferBytes[b];
+            PPT_HIP(hipMemcpyAsync(gs->dBufferTable + b, &gs->buffers[b], sizeof(void *), hipMemcpyHostToDevice, gs->copyStream));
+            PPT_HIP(hipStreamSynchronize(gs->copyStream)); // (the pointer's host copy may move when `buffers` grows)
+        }
+        if (u.byteCount)
+            PPT_HIP(hipMemcpyAsync(static_cast<uint8_t *>(gs->buffers[b]) + u.byteOffset, u.bytes, (size_t)u.byteCount, hipMemcpyHostToDevice, gs->copyStream));
+        PPT_HIP(hipMemcpyAsync(gs->dMetadatas + u.meshIndex, &u.metadata, sizeof(prosper_GeometryMetadata), hipMemcpyHostToDevice, gs->copyStream));
+    }
+    PPT_HIP(hipStreamSynchronize(gs->copyStream)); // the caller's memory may go
+    for (uint32_t i = 0; i < count; ++i)
+    {
+        gs->metadatas[meshes[i].meshIndex] = meshes[i].metadata;
+        gs->infos[meshes[i].meshIndex] = meshes[i].info;
     }
     gs->meshUpdates++;
-    ctx->stats.uploadSeconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-    return PROSPER_PT_OK;
+    gs->dirty = true;
+    return ctx->meshBuild ? PROSPER_PT_OK : start_mesh_build(ctx);
+}
+
+int prosper_pt_finish_mesh_updates(prosper_pt_ctx *ctx)
+{
+    if (!ctx) return fail(PROSPER_PT_ERR_INVALID_ARGUMENT, "prosper_pt_finish_mesh_updates: null argument");
+    if (!ctx->haveScene || !ctx->accel) return fail(PROSPER_PT_ERR_NO_SCENE, "no scene uploaded");
+    PPT_HIP(hipSetDevice(ctx->device));
+    return poll_mesh_build(ctx, true);
 }
 
 int prosper_pt_get_hierarchy_state(prosper_pt_ctx *ctx, prosper_pt_hierarchy_state *out)
 {
     if (!ctx || !out) return fail(PROSPER_PT_ERR_INVALID_ARGUMENT, "prosper_pt_get_hierarchy_state: null argument");
+    *out = prosper_pt_hierarchy_state{};
+    if (ctx->geometry)
+    {
+        out->meshUpdates = ctx->geometry->meshUpdates;
+        out->geometryInstalls = ctx->geometry->installs;
+        out->geometryBuildRunning = (ctx->meshBuild || ctx->geometry->dirty) ? 1u : 0u;
+    }
     if (!ctx->haveScene || !ctx->accel) return fail(PROSPER_PT_ERR_NO_SCENE, "no scene uploaded");
     AccelState *acc = ctx->accel;
     PPT_HIP(hipSetDevice(ctx->device));
@@ -1799,6 +2010,12 @@ int prosper_pt_render_frames(
 {
     if (!ctx || !pc || !camera) return fail(PROSPER_PT_ERR_INVALID_ARGUMENT, "prosper_pt_render: null argument");
     if (!ctx->haveScene) return fail(PROSPER_PT_ERR_NO_SCENE, "prosper_pt_render called before prosper_pt_upload_scene");
+    if (ctx->meshBuild)
+    {
+        // streamed-in meshes whose geometry a worker has finished meanwhile: from this render on they are the scene
+        const int prc = poll_mesh_build(ctx, false);
+        if (prc != PROSPER_PT_OK) return prc;
+    }
     if (ctx->accel && ctx->accel->stale && !ctx->accel->pending) // (a staged update gets its chance below)
         return fail(PROSPER_PT_ERR_NO_SCENE, "the last prosper_pt_update_transforms failed: update the transforms again (or upload the scene) before rendering");
     if (width == 0 || height == 0 || frame_count == 0)
@@ -2124,6 +2341,11 @@ int prosper_pt_restir_di_trace(
     if (!ctx || !pc || !camera || !in || !in->albedoRoughness || !in->normalMetallic || !in->nonLinearDepth || !in->reservoirs)
         return fail(PROSPER_PT_ERR_INVALID_ARGUMENT, "prosper_pt_restir_di_trace: null argument");
     if (!ctx->haveScene) return fail(PROSPER_PT_ERR_NO_SCENE, "prosper_pt_restir_di_trace called before prosper_pt_upload_scene");
+    if (ctx->meshBuild)
+    {
+        const int prc = poll_mesh_build(ctx, false);
+        if (prc != PROSPER_PT_OK) return prc;
+    }
     if (ctx->accel && ctx->accel->stale && !ctx->accel->pending)
         return fail(PROSPER_PT_ERR_NO_SCENE, "the last prosper_pt_update_transforms failed: update the transforms again (or upload the scene) before tracing");
     if (width == 0 || height == 0) return fail(PROSPER_PT_ERR_INVALID_ARGUMENT, "prosper_pt_restir_di_trace: empty extent");

@@ -3,6 +3,8 @@
 
 #include <hip/hip_runtime.h>
 
+#include <atomic>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -182,6 +184,7 @@ struct MaterialState
     bool stagingUsed[2] = {false, false};
     uint32_t stagingNext = 0;
     bool pending = false;          // the mirrors differ from version `cur`
+    uint64_t changes = 0;          // bumped whenever an update changed a mirror (a background geometry build compares)
     bool pendingAlphaPatch = false; // ... in a MASK / BLEND material: the any-hit records' copies must follow
     hipStream_t uploadStream = nullptr; // texel copies, re-tiling / BC7 decode, packs, alpha bounds of an update
     hipEvent_t uploaded = nullptr;      // behind the last of them
@@ -225,8 +228,20 @@ struct GeometryState
     std::vector<uint64_t> bufferBytes;
     const void **dBufferTable = nullptr;           // device: [PROSPER_PT_MAX_GEOMETRY_BUFFERS]
     prosper_GeometryMetadata *dMetadatas = nullptr; // device: [meshCount]
-    uint32_t meshUpdates = 0;
+    // prosper_pt_update_meshes: the arrived bytes go through copyStream (waited for by the call itself); the new layout,
+    // hierarchy and per-triangle records are made by a worker thread on buildStream while the frame loop goes on with
+    // the geometry it has (MeshBuild, prosper_pt.cpp)
+    hipStream_t copyStream = nullptr, buildStream = nullptr;
+    bool dirty = false;      // meshes arrived that no build has taken up yet
+    uint32_t meshUpdates = 0; // calls that handed meshes over
+    uint32_t installs = 0;    // background builds whose result became the scene
+    ~GeometryState()
+    {
+        if (copyStream) (void)hipStreamDestroy(copyStream);
+        if (buildStream) (void)hipStreamDestroy(buildStream);
+    }
 };
+struct MeshBuild;
 
 // multi-GPU state of a context (pt_tiling.cpp): the communicator, its stream and the root's staging buffer
 struct TilingState;
@@ -252,7 +267,7 @@ struct prosper_pt_ctx
     uint32_t flags = 0;
     prosper_pt_debug_options debug = {}; // tuning / test options (prosper_pt_set_debug_options); never the environment
     std::vector<ppt::DeviceAllocation> sceneAllocations;
-    uint64_t sceneBytes = 0;
+    std::atomic<uint64_t> sceneBytes{0}; // (the worker thread of a mesh build allocates too)
     bool haveScene = false;
     ppt::DeviceScene scene = {};
     prosper_pt_scene_stats stats = {};
@@ -264,6 +279,9 @@ struct prosper_pt_ctx
     ppt::LightState *lights = nullptr; // the scene's light buffers (device copies in the scene's allocation list)
     ppt::MaterialState *materialState = nullptr; // mirrors + versions of the material / texture tables (pt_materials.cpp)
     ppt::GeometryState *geometry = nullptr;       // mirrors of the mesh tables and geometry buffers (prosper_pt_update_meshes)
+    ppt::MeshBuild *meshBuild = nullptr;          // the geometry a worker thread is building from them, if any
+    std::vector<ppt::AccelState *> retiredAccel;  // replaced generations: frames in flight may still use their events / staging
+    std::mutex allocMutex;                        // sceneAllocations / sceneBytes (the worker thread allocates too)
 
     float4 *hdr = nullptr; // current HDR buffer (internal or caller-owned)
     float4 *ownedHdr = nullptr;

@@ -155,8 +155,11 @@ bool wide_packs(const prosper_pt_ctx *ctx)
     return !texel_set_is_big(ctx->materialState->texelBytes);
 }
 
-size_t allocation_bytes(const prosper_pt_ctx *ctx, const void *p)
+} // namespace
+
+size_t allocation_bytes(prosper_pt_ctx *ctx, const void *p)
 {
+    const std::lock_guard<std::mutex> lock(ctx->allocMutex);
     for (const DeviceAllocation &a : ctx->sceneAllocations)
         if (a.ptr == p) return a.bytes;
     return 0;
@@ -181,8 +184,14 @@ int collect_retired(prosper_pt_ctx *ctx)
     for (const void *p : ms->retired) device_free(ctx, p);
     ms->retired.clear();
     ms->retiredBytes = 0;
+    // (the device is idle: the generations a geometry build replaced can go with their events and pinned staging)
+    for (AccelState *old : ctx->retiredAccel) delete old;
+    ctx->retiredAccel.clear();
     return PROSPER_PT_OK;
 }
+
+namespace
+{
 
 bool same_pack_inputs(const prosper_MaterialData &a, const prosper_MaterialData &b)
 {
@@ -241,7 +250,9 @@ int check_material(const MaterialState *ms, const prosper_MaterialData &m, uint3
         const uint32_t tex = ts[k] & 0xFFFFFFu, smp = ts[k] >> 24;
         if (tex > 0 && (tex >= ms->textures.size() || smp >= ms->samplers.size()))
             return fail(PROSPER_PT_ERR_SCENE, "material " + std::to_string(index) + " references a missing texture/sampler");
-        if (tex > 0 && !ms->textures[tex].texels)
+        // (a pack is rebuilt from its three textures' own texels - only when what it depends on changed: an entry that
+        //  keeps its textures and samplers keeps its pack, and prosper rewrites the WHOLE table every time)
+        if (tex > 0 && !ms->textures[tex].texels && !same_pack_inputs(ms->materials[index], m))
             return fail(
                 PROSPER_PT_ERR_UNSUPPORTED, "material " + std::to_string(index) + ": texture " + std::to_string(tex) +
                                                 " kept no texels of its own at upload (only packed materials sampled it): update that texture first");
@@ -401,6 +412,7 @@ int prosper_pt_update_textures(prosper_pt_ctx *ctx, const prosper_pt_texture_des
     PPT_HIP(hipEventRecord(ms->uploaded, ms->uploadStream));
     ms->uploadedRecorded = true;
     ms->pending = true;
+    ms->changes++;
     return PROSPER_PT_OK;
 }
 
@@ -438,6 +450,7 @@ int prosper_pt_update_materials(prosper_pt_ctx *ctx, const prosper_MaterialData 
     PPT_HIP(hipEventRecord(ms->uploaded, ms->uploadStream));
     ms->uploadedRecorded = true;
     ms->pending = true;
+    ms->changes++;
     return PROSPER_PT_OK;
 }
 

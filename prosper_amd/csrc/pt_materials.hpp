@@ -29,6 +29,11 @@ int build_alpha_material(
 // compact (8-byte) packs and batched texel fetches where the texel footprint outgrows the caches
 inline bool texel_set_is_big(uint64_t texelBytes) { return texelBytes > (32ull << 20); }
 
+// `p` (a scene allocation) was replaced by an update: nothing new will read it, a frame in flight still may.  Freed by
+// collect_retired once enough has piled up to be worth ONE device synchronisation, or with the scene.
+void retire(prosper_pt_ctx *ctx, const void *p);
+int collect_retired(prosper_pt_ctx *ctx);
+
 // the staged tables into the next device version, on the stream of the render that is about to read them
 int flush_pending_materials(prosper_pt_ctx *ctx, hipStream_t stream);
 

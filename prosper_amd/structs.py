@@ -273,7 +273,8 @@ class SceneStats(C.Structure):
 
 class HierarchyState(C.Structure):
     _fields_ = [("refits", C.c_uint32), ("rebuilds", C.c_uint32), ("costRatio", C.c_float), ("builtCost", C.c_float),
-                ("nodeCount", C.c_uint32), ("levels", C.c_uint32)]
+                ("nodeCount", C.c_uint32), ("levels", C.c_uint32), ("meshUpdates", C.c_uint32), ("geometryInstalls", C.c_uint32),
+                ("geometryBuildRunning", C.c_uint32), ("reserved", C.c_uint32)]
 
 
 class DebugOptions(C.Structure):

@@ -23,6 +23,7 @@ int main(int argc, char **argv)
     const int instances = 43, side = argc > 1 ? atoi(argv[1]) : 55;
     BvhBuildOptions opt;
     if (argc > 2) opt.buildThreads = (uint32_t)atoi(argv[2]); // host threads of the builder (default: all)
+    if (argc > 3) opt.buildTiming = (uint32_t)atoi(argv[3]);  // stage times of the assembly to stderr
     std::vector<WorldTriangle> tris;
     std::vector<InstancedBvh::Range> ranges;
     for (int i = 0; i < instances; ++i)

@@ -273,6 +273,15 @@ def test_a_texture_of_a_packed_material_replaced_after_a_full_upload(gpu_ctx, or
     with pytest.raises(capi.ProsperPtError) as e:
         gpu_ctx.update_textures(fresh_texels[:1], tb)
     assert e.value.code == -6 and "update it in the same call" in str(e.value)
+    # the whole table rewritten (as prosper does every time) with a factor changed: entries that keep their textures and
+    # samplers keep their packs and need no texels
+    world = copy.copy(world)
+    world._frozen = None
+    world.materials = list(world.materials)
+    slid = copy.copy(world.materials[world.materials.index(m)])
+    slid.roughnessFactor = 0.35
+    world.materials[world.materials.index(m)] = slid
+    gpu_ctx.update_materials(world.materials, 0)
     gpu_ctx.update_textures(fresh_texels, tb)
     gpu_ctx.render(pc, cam, w, h, frames=2, flags=S.RENDER_PIPELINED)
     got = gpu_ctx.read_hdr()

@@ -212,6 +212,7 @@ def test_what_update_meshes_refuses(gpu_ctx, oracle, cornell_world):
     gpu_ctx.render(pc, cam, w, h)
     assert same_bits(before, gpu_ctx.read_hdr()).all()
     assert update() == 0
+    gpu_ctx.finish_mesh_updates()
     gpu_ctx.render(pc, cam, w, h)
     fresh = capi.Context(device=0)
     try:
@@ -220,3 +221,81 @@ def test_what_update_meshes_refuses(gpu_ctx, oracle, cornell_world):
         assert same_bits(gpu_ctx.read_hdr(), fresh.read_hdr()).all()
     finally:
         fresh.close()
+
+
+@pytest.mark.gpu
+def test_frames_go_on_while_the_worker_builds_and_what_changed_meanwhile_follows(gpu_ctx, oracle):
+    """prosper_pt_update_meshes returns at once; frames rendered until the worker is done show the scene as it was, the first
+    one after it the new meshes - never anything in between.  An instance that moved and a MASK material that changed while
+    the worker ran are part of what is switched in."""
+    full = scenes.sponza_class(foliage=True, texture_size=32, sky_size=16, detail=0.5)
+    meshes = len(full.metadatas)
+    first = list(range(0, meshes, 2))
+    second = [i for i in range(meshes) if i not in first]
+    w, h = 200, 120
+    cam, fl = _camera(oracle, full, w, h)
+    pc = default_pc(S, fl, frame_index=7, max_bounces=2, ibl=True, skip_history=True)  # every render: the same one frame
+
+    def fresh_image(world):
+        fresh = capi.Context(device=0)
+        try:
+            fresh.upload_scene(world)
+            fresh.render(pc, cam, w, h)
+            return fresh.read_hdr()
+        finally:
+            fresh.close()
+
+    before = fresh_image(full.with_meshes_loaded(first))
+    after = fresh_image(full)
+    assert not same_bits(before, after).all()
+    gpu_ctx.upload_scene(full.with_meshes_loaded(first))
+    gpu_ctx.render(pc, cam, w, h)
+    assert same_bits(gpu_ctx.read_hdr(), before).all()
+    gpu_ctx.update_meshes(full, second, wait=False)
+    state = gpu_ctx.hierarchy_state()
+    assert state.meshUpdates == 1 and state.geometryBuildRunning == 1
+    seen_before = seen_after = 0
+    for _ in range(4000):
+        gpu_ctx.render(pc, cam, w, h, flags=S.RENDER_PIPELINED)
+        img = gpu_ctx.read_hdr()
+        if same_bits(img, before).all():
+            assert not seen_after, "the scene went back to the old geometry"
+            seen_before += 1
+        else:
+            assert same_bits(img, after).all(), "a frame shows neither the old nor the new scene"
+            seen_after += 1
+            if seen_after == 3:
+                break
+    assert seen_after == 3
+    state = gpu_ctx.hierarchy_state()
+    assert state.geometryInstalls == 1 and state.geometryBuildRunning == 0
+
+    # again, with an instance moved and a material changed while the worker runs
+    gpu_ctx.upload_scene(full.with_meshes_loaded(first))
+    gpu_ctx.render(pc, cam, w, h, flags=S.RENDER_PIPELINED)
+    gpu_ctx.update_meshes(full, second, wait=False)
+    moved = _moved(full, 3, (0.3, 0.2, -0.4))
+    moved.materials = list(full.materials)
+    masked = [i for i, m in enumerate(full.materials) if m.alphaMode != S.ALPHA_MODE_OPAQUE]
+    assert masked
+    for i in masked[:2]:
+        m = copy.copy(moved.materials[i])
+        m.alphaCutoff = 0.8
+        m.baseColorFactor = S.Vec4(0.9, 0.4, 0.3, 0.7)
+        moved.materials[i] = m
+    gpu_ctx.update_transforms(moved)
+    gpu_ctx.update_materials(moved.materials, 0)
+    gpu_ctx.render(pc, cam, w, h, flags=S.RENDER_PIPELINED)  # (old or new geometry, with the moved instance either way)
+    gpu_ctx.finish_mesh_updates()
+    gpu_ctx.render(pc, cam, w, h, flags=S.RENDER_PIPELINED)
+    assert same_bits(gpu_ctx.read_hdr(), fresh_image(moved)).all()
+    # meshes that arrive while a build is under way are taken up by the next one
+    gpu_ctx.upload_scene(full.with_meshes_loaded([]))
+    for k in range(0, meshes, 3):
+        gpu_ctx.update_meshes(full, list(range(k, min(k + 3, meshes))), wait=False)
+        gpu_ctx.render(pc, cam, w, h, flags=S.RENDER_PIPELINED)
+    gpu_ctx.finish_mesh_updates()
+    gpu_ctx.render(pc, cam, w, h, flags=S.RENDER_PIPELINED)
+    assert same_bits(gpu_ctx.read_hdr(), after).all()
+    state = gpu_ctx.hierarchy_state()
+    assert state.meshUpdates == (meshes + 2) // 3 and 1 <= state.geometryInstalls <= state.meshUpdates
