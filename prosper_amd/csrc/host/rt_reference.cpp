@@ -67,6 +67,20 @@ void World::uploadMaterialDatas(prosper_pt_ctx *ctx, const prosper_MaterialData 
         throw std::runtime_error(std::string("World::uploadMaterialDatas: ") + prosper_pt_last_error());
 }
 
+void World::adoptMeshes(prosper_pt_ctx *ctx, const prosper_pt_mesh_update *meshes, uint32_t count)
+{
+    PROSPER_ASSERT(uploadedTo(ctx));
+    if (prosper_pt_update_meshes(ctx, meshes, count) != PROSPER_PT_OK)
+        throw std::runtime_error(std::string("World::adoptMeshes: ") + prosper_pt_last_error());
+}
+
+void World::finishMeshAdoption(prosper_pt_ctx *ctx)
+{
+    PROSPER_ASSERT(uploadedTo(ctx));
+    if (prosper_pt_finish_mesh_updates(ctx) != PROSPER_PT_OK)
+        throw std::runtime_error(std::string("World::finishMeshAdoption: ") + prosper_pt_last_error());
+}
+
 } // namespace scene
 
 namespace render

@@ -48,6 +48,13 @@ class World
     // placeholders (WorldData.cpp:2208-2239) get their texture packs and alpha bounds.  Both take effect at the head of the
     // next record()'s launches; frames in flight keep what they started with.  Throw std::runtime_error on failure.
     void uploadMaterialDatas(prosper_pt_ctx *ctx, const prosper_MaterialData *materials, uint32_t count);
+    // WorldData::pollMeshWorker (WorldData.cpp:2003-2110): the meshes the mesh worker finished this frame - their metadata and
+    // MeshInfo slots and their bytes of a geometry buffer.  The scene was set with every mesh slot, the unloaded ones with
+    // bufferIndex 0xFFFFFFFF as prosper keeps them; a model instance shows once all its sub-meshes are there
+    // (World::buildNextBlas, World.cpp:598-606, 909-915).  Returns at once: the context builds the geometry beside the
+    // frame loop, and the first record() after that shows it.  finishMeshAdoption waits for everything handed over so far.
+    void adoptMeshes(prosper_pt_ctx *ctx, const prosper_pt_mesh_update *meshes, uint32_t count);
+    void finishMeshAdoption(prosper_pt_ctx *ctx);
     [[nodiscard]] bool uploadedTo(const prosper_pt_ctx *ctx) const { return m_ctx == ctx && !m_dirty; }
 
   private:

@@ -264,6 +264,16 @@ struct GeometryTarget
     hipStream_t stream = nullptr;
     BvhBuildOptions buildOpt;
     bool flatBvh = false, noUploadRefit = false, rawRecords = false;
+    // debug option buildTiming: where a build spends its time (stderr)
+    std::chrono::steady_clock::time_point tick = std::chrono::steady_clock::now();
+    void lap(const char *what)
+    {
+        const auto now = std::chrono::steady_clock::now();
+        if (buildOpt.buildTiming)
+            std::fprintf(stderr, "[geometry] %-22s %.2f ms (at %.1f)\n", what, std::chrono::duration<double, std::milli>(now - tick).count(),
+                         std::chrono::duration<double, std::milli>(now.time_since_epoch()).count() - 1e3 * std::floor(std::chrono::duration<double>(now.time_since_epoch()).count() / 100.0) * 100.0);
+        tick = now;
+    }
 };
 GeometryTarget context_target(prosper_pt_ctx *ctx)
 {
@@ -350,6 +360,7 @@ int upload_hierarchy(prosper_pt_ctx *ctx, GeometryTarget &t, const BvhBuildResul
         PPT_HIP(hipGetLastError());
     }
     PPT_HIP(hipStreamSynchronize(t.stream)); // (the host arrays of `bvh` have been read)
+    t.lap("  nodes + permute");
 
     // ---- refit tables ----
     const size_t n = bvh.nodes.size();
@@ -391,6 +402,7 @@ int upload_hierarchy(prosper_pt_ctx *ctx, GeometryTarget &t, const BvhBuildResul
         acc->dRefitOrder = static_cast<uint32_t *>(d);
         acc->refitCapacityNodes = capacity;
     }
+    t.lap("  refit tables (host)");
     PPT_HIP(hipMemcpyAsync(acc->dRefitOrder, order.data(), n * sizeof(uint32_t), hipMemcpyHostToDevice, t.stream));
     if (!acc->dLeafPosition)
     {
@@ -421,12 +433,15 @@ int upload_hierarchy(prosper_pt_ctx *ctx, GeometryTarget &t, const BvhBuildResul
     // and the measure are still computed)
     for (bool &pending : acc->costPending) pending = false;
     acc->builtCost = 0.0f;
+    t.lap("  table copies queued");
     if (acc->total)
     {
         // (an empty scene keeps the emitter's root - child boxes at +inf - as it is: the encoder has no bounds to write)
         int rc = enqueue_refit(acc, bvh_pad_coefficient(t.buildOpt), acc->dNodes, acc->dTris, acc->cur, t.stream);
         if (rc != PROSPER_PT_OK) return rc;
+        t.lap("  refit queued");
         PPT_HIP(hipStreamSynchronize(t.stream));
+        t.lap("  refit done");
         if (t.noUploadRefit)
         {
             PPT_HIP(hipMemcpyAsync(acc->dNodes, bvh.nodes.data(), nodeBytes, hipMemcpyHostToDevice, t.stream));
@@ -530,6 +545,7 @@ int begin_geometry(prosper_pt_ctx *ctx, GeometryTarget &t, GeometryLayout &layou
     int rc;
     void *d = nullptr;
     job.t0 = std::chrono::steady_clock::now();
+    t.lap("(start)");
     job.alphaTotal = layout.alphaTotal;
     const uint32_t drawInstanceCount = (uint32_t)ctx->geometry->drawInstances.size();
     const uint64_t total = layout.total;
@@ -547,11 +563,13 @@ int begin_geometry(prosper_pt_ctx *ctx, GeometryTarget &t, GeometryLayout &layou
     const size_t triBytes = sizeof(WorldTriangle) * (size_t)(total ? total : 1);
     if ((rc = device_alloc(ctx, triBytes, &d))) return rc;
     acc->dFlat = static_cast<WorldTriangle *>(d);
+    t.lap("tables, allocations");
     launch_flatten_triangles(s, acc->dOffsets, drawInstanceCount, acc->dFlags, acc->dFlat, nullptr, nullptr, (uint32_t)total, t.stream);
     PPT_HIP(hipGetLastError());
     acc->flat.resize((size_t)total);
     if (total) PPT_HIP(hipMemcpyAsync(acc->flat.data(), acc->dFlat, sizeof(WorldTriangle) * (size_t)total, hipMemcpyDeviceToHost, t.stream));
     PPT_HIP(hipStreamSynchronize(t.stream)); // (the layout's host arrays have been read, the world triangles are here)
+    t.lap("flatten + read back");
     acc->triOffsets.swap(layout.triOffsets);
     acc->ranges.swap(layout.ranges);
     acc->rangeModelInstance.swap(layout.rangeModelInstance);
@@ -626,6 +644,7 @@ int finish_geometry(prosper_pt_ctx *ctx, GeometryTarget &t, GeometryJob &job)
     const size_t triBytes = sizeof(WorldTriangle) * (size_t)(total ? total : 1);
     void *dTris = nullptr;
     if ((rc = device_alloc(ctx, triBytes, &dTris))) return rc;
+    t.lap("record allocations");
     PPT_HIP(hipMemsetAsync(dTris, 0, triBytes, t.stream));
     acc->dTris = static_cast<WorldTriangle *>(dTris);
     acc->dTrisV[acc->cur] = acc->dTris;
@@ -637,11 +656,14 @@ int finish_geometry(prosper_pt_ctx *ctx, GeometryTarget &t, GeometryJob &job)
         static_cast<RawShadeTriangle *>(dRaw));
     PPT_HIP(hipGetLastError());
     PPT_HIP(hipStreamSynchronize(t.stream));
+    t.lap("records");
 
     BuildOutcome built = job.build.get();
+    t.lap("wait for host build");
     if (!built.error.empty()) return fail(PROSPER_PT_ERR_UNSUPPORTED, "BVH build failed: " + built.error);
     acc->instanced = built.instanced;
     if ((rc = upload_hierarchy(ctx, t, built.bvh))) return rc;
+    t.lap("hierarchy upload + refit");
 
     prosper_pt_scene_stats &st = *t.stats;
     st.triangleCount = total;
@@ -655,6 +677,7 @@ int finish_geometry(prosper_pt_ctx *ctx, GeometryTarget &t, GeometryJob &job)
     return PROSPER_PT_OK;
 }
 
+int ensure_mesh_streams(GeometryState *gs);
 int upload_scene_impl(prosper_pt_ctx *ctx, const prosper_pt_scene_view *v)
 {
     DeviceScene &s = ctx->scene;
@@ -874,6 +897,14 @@ int upload_scene_impl(prosper_pt_ctx *ctx, const prosper_pt_scene_view *v)
     }
 
     if ((rc = finish_geometry(ctx, target, job))) return rc;
+    for (const prosper_GeometryMetadata &m : gs->metadatas)
+        if (!mesh_loaded(m))
+        {
+            // meshes are still loading: the streams prosper_pt_update_meshes works with (creating them costs milliseconds -
+            // here, not in the frame loop)
+            if ((rc = ensure_mesh_streams(gs))) return rc;
+            break;
+        }
     ctx->rawRecords = target.rawRecords;
     ctx->stats.deviceBytes = ctx->sceneBytes;
     ctx->stats.alphaBoundBytes = ctx->alphaBoundBytes;
@@ -1629,6 +1660,22 @@ int prosper_pt_rebuild_hierarchy(prosper_pt_ctx *ctx)
 }
 
 // ---- streamed-in meshes: the new geometry is made by a worker thread, beside the frame loop ----
+} // extern "C"
+namespace
+{
+int ensure_mesh_streams(GeometryState *gs)
+{
+    if (gs->copyStream) return PROSPER_PT_OK;
+    // the highest priority the device has: what the worker enqueues is short (copies, a few dozen small kernels) and must
+    // not queue up behind whole frames
+    int least = 0, greatest = 0;
+    PPT_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
+    PPT_HIP(hipStreamCreateWithPriority(&gs->copyStream, hipStreamNonBlocking, greatest));
+    PPT_HIP(hipStreamCreateWithPriority(&gs->buildStream, hipStreamNonBlocking, greatest));
+    return PROSPER_PT_OK;
+}
+} // namespace
+extern "C" {
 static int stage_transforms(prosper_pt_ctx *ctx, const prosper_ModelInstanceTransforms *transforms, uint32_t count);
 
 // A worker for what the mirrors hold now (the caller has made sure none is running).
@@ -1767,6 +1814,12 @@ static int poll_mesh_build(prosper_pt_ctx *ctx, bool wait)
         ctx->stats.deviceBytes = ctx->sceneBytes;
         ctx->sceneStamp++;
         gs->installs++;
+        if (ctx->debug.buildTiming)
+        {
+            const auto now = std::chrono::steady_clock::now();
+            std::fprintf(stderr, "[geometry] installed (at %.1f)\n",
+                         std::chrono::duration<double, std::milli>(now.time_since_epoch()).count() - 1e3 * std::floor(std::chrono::duration<double>(now.time_since_epoch()).count() / 100.0) * 100.0);
+        }
         // a material that changed while the build ran: its any-hit records are rewritten by the next flush of the tables
         if (ms->changes != b->materialChanges && ctx->alphaTriangleCount)
         {
@@ -1856,8 +1909,7 @@ int prosper_pt_update_meshes(prosper_pt_ctx *ctx, const prosper_pt_mesh_update *
     PPT_HIP(hipSetDevice(ctx->device));
     int rc;
     if ((rc = poll_mesh_build(ctx, false))) return rc; // (a finished build is installed first: its subtrees are the ones to keep)
-    if (!gs->copyStream) PPT_HIP(hipStreamCreateWithFlags(&gs->copyStream, hipStreamNonBlocking));
-    if (!gs->buildStream) PPT_HIP(hipStreamCreateWithFlags(&gs->buildStream, hipStreamNonBlocking));
+    if ((rc = ensure_mesh_streams(gs))) return rc;
     void *d = nullptr;
     for (uint32_t i = 0; i < count; ++i)
     {

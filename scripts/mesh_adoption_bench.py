@@ -18,6 +18,7 @@ from prosper_amd.rt_reference import Camera  # noqa: E402
 
 def main():
     per_call = int(sys.argv[1]) if len(sys.argv) > 1 else 4
+    pause = float(sys.argv[2]) * 1e-3 if len(sys.argv) > 2 else 0.0  # host-side gap between frames, ms
     hip = ctypes.CDLL("libamdhip64.so")
     full = scenes.sponza_class()
     meshes = len(full.metadatas)
@@ -34,31 +35,104 @@ def main():
         st.triangleCount, whole, st.textureSeconds * 1e3, st.bvhBuildSeconds * 1e3), flush=True)
     ctx.upload_scene(full.with_meshes_loaded([]))
     frame = [0]
+    # the host is paced like a swapchain paces prosper: it waits for the frame of three renders ago (an event on the
+    # caller's stream, which every render joins), so three frames are in flight and none is enqueued further ahead
+    fences = []
+    for _ in range(3):
+        e = ctypes.c_void_p()
+        assert hip.hipEventCreate(ctypes.byref(e)) == 0
+        fences.append(e)
 
     def frames(n):
         for _ in range(n):
             pc = S.ReferencePC(0, flags | (S.PC_FLAG_SKIP_HISTORY if frame[0] == 0 else 0), 1 + frame[0], 1e-5, 1.0, focal, 3, 4)
+            e = fences[frame[0] % 3]
+            if frame[0] >= 3:
+                assert hip.hipEventSynchronize(e) == 0
             ctx.render(pc, cam, w, h, frames=1, flags=S.RENDER_PIPELINED)
+            assert hip.hipEventRecord(e, None) == 0
             frame[0] += 1
+            if pause:
+                time.sleep(pause)
     frames(3)
-    print("%d meshes per call; per call: host time of prosper_pt_update_meshes (device idle when it returns), of which the"
-          " hierarchy (subtrees of the completed model instances + assembly), triangles afterwards" % per_call)
+    plain = None
+    hip.hipDeviceSynchronize()
+    t0 = time.perf_counter()
+    frames(30)
+    hip.hipDeviceSynchronize()
+    plain = (time.perf_counter() - t0) / 30 * 1e3
+    print("1-spp frames of the empty scene, three in flight: %.3f ms per frame" % plain)
+    print("%d meshes per call, one call per frame, the frame loop never waits (prosper_pt_update_meshes returns once the bytes are"
+          " on the device; a worker thread builds the geometry; the first render after it is done switches):" % per_call)
     loaded = 0
-    total = 0.0
+    calls = []
+    t_all = time.perf_counter()
+    n_frames = 0
     while loaded < meshes:
         n = min(per_call, meshes - loaded)
         t0 = time.perf_counter()
-        ctx.update_meshes(full, list(range(loaded, loaded + n)))
-        ms = (time.perf_counter() - t0) * 1e3
-        total += ms
+        ctx.update_meshes(full, list(range(loaded, loaded + n)), wait=False)
+        calls.append((time.perf_counter() - t0) * 1e3)
+        loaded += n
+        frames(1)
+        n_frames += 1
+    handed = (time.perf_counter() - t_all) * 1e3
+    while ctx.hierarchy_state().geometryBuildRunning:
+        frames(1)
+        n_frames += 1
+    hip.hipDeviceSynchronize()
+    total = (time.perf_counter() - t_all) * 1e3
+    st = ctx.hierarchy_state()
+    print("  prosper_pt_update_meshes: %.2f ms per call on the host (median; the calls: %s)" % (
+        sorted(calls)[len(calls) // 2], " ".join("%.2f" % c for c in calls)))
+    print("  all %d meshes handed over after %.1f ms, in the scene after %.1f ms and %d frames (%.2f ms per frame); %d builds for %d calls" % (
+        meshes, handed, total, n_frames, total / n_frames, st.geometryInstalls, st.meshUpdates))
+    print("  against %.1f ms for ONE upload of the finished scene" % whole)
+    # the same, waiting for every call's build (what a synchronous adoption costs)
+    ctx.upload_scene(full.with_meshes_loaded([]))
+    frame[0] = 0
+    frames(3)
+    loaded = 0
+    sync_ms = []
+    while loaded < meshes:
+        n = min(per_call, meshes - loaded)
+        t0 = time.perf_counter()
+        ctx.update_meshes(full, list(range(loaded, loaded + n)), wait=True)
+        sync_ms.append((time.perf_counter() - t0) * 1e3)
         loaded += n
         st = ctx.scene_stats()
-        print("  meshes %2d..%2d: %6.1f ms (hierarchy %5.1f ms)  -> %7d triangles, %6d nodes" % (
-            loaded - n, loaded - 1, ms, st.bvhBuildSeconds * 1e3, st.triangleCount, st.nodeCount), flush=True)
+        print("  waited for: meshes %2d..%2d %6.1f ms (hierarchy %5.1f ms) -> %7d triangles" % (loaded - n, loaded - 1, sync_ms[-1], st.bvhBuildSeconds * 1e3, st.triangleCount), flush=True)
         frames(2)
-    hip.hipDeviceSynchronize()
-    print("all %d meshes adopted in %d calls: %.1f ms in all, against %.1f ms for ONE upload of the finished scene and"
-          " %d uploads of the growing one otherwise" % (meshes, (meshes + per_call - 1) // per_call, total, whole, (meshes + per_call - 1) // per_call))
+    print("  waiting for each build: %.1f ms in all" % sum(sync_ms))
+    # the frame loop of a scene that is half there while the other half arrives: frame times with and without a build
+    # under way (host time from one render call to the next, paced by the frame of three renders ago)
+    half = list(range(0, meshes, 2))
+    rest = [i for i in range(meshes) if i not in half]
+    ctx.upload_scene(full.with_meshes_loaded(half))
+    frame[0] = 0
+    frames(12)
+
+    def frame_times(n):
+        out = []
+        for _ in range(n):
+            t0 = time.perf_counter()
+            frames(1)
+            out.append((time.perf_counter() - t0) * 1e3)
+        return out
+    quiet = frame_times(60)
+    busy = []
+    t0 = time.perf_counter()
+    for k in range(0, len(rest), per_call):
+        ctx.update_meshes(full, rest[k:k + per_call], wait=False)
+        busy += frame_times(1)
+    while ctx.hierarchy_state().geometryBuildRunning:
+        busy += frame_times(1)
+    took = (time.perf_counter() - t0) * 1e3
+    after = frame_times(60)
+    med = lambda v: sorted(v)[len(v) // 2]
+    print("half of the scene (%d meshes) rendering while the other half arrives %d per frame: frames %.3f ms (median) before,"
+          " %.3f ms median / %.3f ms worst of the %d frames while the builds ran (%.1f ms), %.3f ms after" % (
+              len(half), per_call, med(quiet), med(busy), max(busy), len(busy), took, med(after)))
     # the hierarchy an adoption leaves behind against a fresh build: frame time
     def timed(n=30):
         frames(6)

@@ -68,6 +68,21 @@ def run(cases, seed, scene_names, log=print):
                 if cut != images:  # a frame of the half-loaded scene stays in flight while the next images arrive
                     ctx.render(S.ReferencePC(0, S.PC_FLAG_SKIP_HISTORY, 1, 1e-5, 1.0, warm_fl, 3, 2), warm_cam, 64, 48, flags=S.RENDER_PIPELINED)
             streamed_note = " streamed %s" % "+".join(str(c) for c in cuts)
+        elif len(world.metadatas) >= 3 and rng.random() < 0.3:
+            # a third of the others: the MESHES arrive after the upload (prosper_pt_update_meshes: a worker thread builds the
+            # new geometry while frames stay in flight; model instances show once all their sub-meshes are there)
+            meshes = len(world.metadatas)
+            order = [int(x) for x in rng.permutation(meshes)]
+            cuts = sorted(set(int(x) for x in rng.integers(0, meshes + 1, size=int(rng.integers(1, 4))))) + [meshes]
+            ctx.upload_scene(world.with_meshes_loaded(order[:cuts[0]]))
+            warm_cam, warm_fl = O.camera_uniforms(world.camera["eye"], world.camera["target"], world.camera["up"], world.camera["fov"],
+                                                  world.camera["zN"], world.camera["zF"], 64, 48)
+            for a, b in zip(cuts, cuts[1:]):
+                ctx.render(S.ReferencePC(0, S.PC_FLAG_SKIP_HISTORY, 1, 1e-5, 1.0, warm_fl, 3, 2), warm_cam, 64, 48, flags=S.RENDER_PIPELINED)
+                if b > a:
+                    ctx.update_meshes(world, order[a:b], wait=bool(rng.random() < 0.5))
+            ctx.finish_mesh_updates()
+            streamed_note = " meshes %s" % "+".join(str(c) for c in cuts)
         else:
             ctx.upload_scene(world)
         # a third of the cases on instanced scenes: some instances moved by prosper_pt_update_transforms (the GPU refit)
