@@ -91,6 +91,44 @@ int main(int argc, char **argv)
         t1 = now();
         printf("rebuild after moving 1 instance: %.1f ms, %zu nodes, digest %016llx\n", ms(t0, t1), res.nodes.size(), digest(res));
     }
+    // streamed-in meshes (InstancedBvh::adopt): the scene with every third instance still empty, the missing ones arriving in
+    // two steps - kept subtrees are moved to the new layout, and the result must be THE tree a fresh build of that state gives
+    {
+        auto state = [&](int arrivedUpTo, std::vector<WorldTriangle> &t, std::vector<InstancedBvh::Range> &r) {
+            t.clear();
+            r.clear();
+            for (int i = 0; i < instances; ++i)
+            {
+                const bool there = i % 3 != 0 || i < arrivedUpTo;
+                InstancedBvh::Range range{(uint32_t)t.size(), there ? ranges[(size_t)i].count : 0u};
+                if (there) t.insert(t.end(), tris.begin() + ranges[(size_t)i].first, tris.begin() + ranges[(size_t)i].first + ranges[(size_t)i].count);
+                r.push_back(range);
+            }
+        };
+        std::vector<WorldTriangle> t0s, t1s;
+        std::vector<InstancedBvh::Range> r0, r1;
+        state(0, t0s, r0);
+        InstancedBvh streamed;
+        BvhBuildResult a = streamed.build(t0s.data(), t0s.size(), r0, opt);
+        bool ok = true;
+        for (int upTo : {instances / 2, instances})
+        {
+            state(upTo, t1s, r1);
+            std::vector<uint8_t> changed((size_t)instances, 0);
+            for (int i = 0; i < instances; ++i) changed[(size_t)i] = r1[(size_t)i].count != r0[(size_t)i].count;
+            t0 = now();
+            a = streamed.adopt(t1s.data(), t1s.size(), r1, changed, opt);
+            t1 = now();
+            InstancedBvh fresh;
+            const BvhBuildResult b = fresh.build(t1s.data(), t1s.size(), r1, opt);
+            const bool same = digest(a) == digest(b);
+            ok = ok && same;
+            printf("adopt up to instance %d: %.1f ms, %zu triangles, %zu nodes, %s a fresh build\n", upTo, ms(t0, t1), t1s.size(),
+                   a.nodes.size(), same ? "equal to" : "DIFFERENT FROM");
+            r0 = r1;
+        }
+        if (!ok) return 1;
+    }
     t0 = now();
     res = build_bvh(tris.data(), tris.size(), opt);
     t1 = now();

@@ -1,5 +1,5 @@
 """The host-side hierarchy builder (prosper_amd/csrc/bvh_build.cpp: per-instance subtrees built on the host's threads, the
-re-braided top level, the 4-wide emitter, rebuilds after a moved instance) under AddressSanitizer + UBSan and under
+re-braided top level, the 4-wide emitter, rebuilds after a moved instance, subtrees kept while meshes stream in) under AddressSanitizer + UBSan and under
 ThreadSanitizer, through scripts/bvh_bench.cpp on a small synthetic scene.  CPU only: sanitizers cannot run on the GPU box."""
 import os
 import shutil
@@ -28,6 +28,7 @@ def test_bvh_builder_under_sanitizers(tmp_path, sanitizer):
         assert out.returncode == 0, text[-2000:]
         assert "runtime error" not in text and "Sanitizer" not in text, text[-2000:]
         assert "flat build" in text
+        assert text.count("equal to a fresh build") == 2  # InstancedBvh::adopt (streamed-in meshes)
 
 
 _ORACLE_RENDER = r"""
