@@ -299,3 +299,56 @@ def test_frames_go_on_while_the_worker_builds_and_what_changed_meanwhile_follows
     assert same_bits(gpu_ctx.read_hdr(), after).all()
     state = gpu_ctx.hierarchy_state()
     assert state.meshUpdates == (meshes + 2) // 3 and 1 <= state.geometryInstalls <= state.meshUpdates
+
+
+@pytest.mark.gpu
+def test_flight_helmet_loads_the_way_prosper_loads_it(gpu_ctx, oracle):
+    """The reference's bundled asset through prosper's whole loading sequence (WorldData::handleDeferredLoading,
+    WorldData.cpp:588-647): first the meshes, a few per frame, under placeholder materials; once all meshes are there the
+    images, a few per frame, each material switching from its placeholder when its images have arrived - frames in flight
+    throughout, nothing waited for until the end.  The last frame is the oracle's image of the loaded asset; a frame in the
+    middle of each phase equals a fresh upload of that state."""
+    from prosper_amd import flight_helmet
+    from test_adoption import streamed_state
+    full = flight_helmet.load_fixture(texture_size=256)
+    meshes, images = len(full.metadatas), len(full.textures) - 1
+    w, h = 320, 200
+    cam, fl = _camera(oracle, full, w, h)
+    pc = default_pc(S, fl, max_bounces=3, ibl=True)
+    placeholders = streamed_state(full, 0)
+    gpu_ctx.upload_scene(placeholders.with_meshes_loaded([]))
+    checks = []
+    loaded = 0
+    while loaded < meshes:
+        n = min(2, meshes - loaded)
+        gpu_ctx.update_meshes(placeholders, list(range(loaded, loaded + n)), wait=False)
+        loaded += n
+        gpu_ctx.render(pc, cam, w, h, frames=1, flags=S.RENDER_PIPELINED)
+        if loaded == 2 * ((meshes // 2 + 1) // 2):
+            gpu_ctx.finish_mesh_updates()
+            gpu_ctx.render(pc, cam, w, h, frames=2, flags=S.RENDER_PIPELINED)
+            checks.append((gpu_ctx.read_hdr(), placeholders.with_meshes_loaded(range(loaded))))
+    gpu_ctx.finish_mesh_updates()  # "Meshes should have been loaded before textures" (WorldData.cpp:601-604)
+    arrived = 0
+    while arrived < images:
+        n = min(4, images - arrived)
+        state = streamed_state(full, arrived + n)
+        gpu_ctx.update_textures(full.textures[arrived + 1:arrived + 1 + n], arrived + 1)
+        gpu_ctx.update_materials(state.materials, 0)
+        arrived += n
+        gpu_ctx.render(pc, cam, w, h, frames=1, flags=S.RENDER_PIPELINED)
+        if arrived == 8:
+            gpu_ctx.render(pc, cam, w, h, frames=2, flags=S.RENDER_PIPELINED)
+            checks.append((gpu_ctx.read_hdr(), state))
+    gpu_ctx.render(pc, cam, w, h, frames=2, flags=S.RENDER_PIPELINED)
+    last = gpu_ctx.read_hdr()
+    assert len(checks) == 2
+    fresh = capi.Context(device=0)
+    try:
+        for k, (got, state) in enumerate(checks):
+            fresh.upload_scene(state)
+            fresh.render(pc, cam, w, h, frames=2)
+            assert same_bits(got, fresh.read_hdr()).all(), "phase %d" % k
+    finally:
+        fresh.close()
+    assert same_bits(last, _oracle_image(oracle, full, cam, fl, w, h, max_bounces=3, ibl=True)).all()
