@@ -32,6 +32,8 @@ using namespace ppt;
 namespace ppt
 {
 thread_local std::string g_lastErrorStorage;
+// set by the worker thread of a mesh build: its scene allocations, so that a build that fails can give them back
+thread_local std::vector<void *> *g_allocationLog = nullptr;
 int fail(int code, const std::string &msg)
 {
     g_lastErrorStorage = msg;
@@ -50,6 +52,7 @@ int device_alloc(prosper_pt_ctx *ctx, size_t bytes, void **out)
     if (bytes == 0) bytes = 16;
     void *p = nullptr;
     PPT_HIP(hipMalloc(&p, bytes));
+    if (g_allocationLog) g_allocationLog->push_back(p);
     const std::lock_guard<std::mutex> lock(ctx->allocMutex);
     ctx->sceneAllocations.push_back({p, bytes});
     ctx->sceneBytes += bytes;
@@ -127,6 +130,7 @@ struct MeshBuild
     std::string error;        // ... and message (fail() is thread-local)
     uint64_t materialChanges = 0; // MaterialState::changes when the build took its copy of the alpha-material table
     void *dAlphaSnapshot = nullptr;
+    std::vector<void *> allocations; // what the worker allocated (given back if the build fails)
 };
 } // namespace ppt
 
@@ -1731,9 +1735,13 @@ static int start_mesh_build(prosper_pt_ctx *ctx)
     t.alphaTriangleCount = &b->alphaTriangleCount;
     t.stream = gs->buildStream;
     const int device = ctx->device;
+    // debug option failNextUpdate: the worker gives up half way (the test of what a failed build leaves behind)
+    const bool failHalfWay = ctx->debug.failNextUpdate != 0;
+    ctx->debug.failNextUpdate = 0;
     gs->dirty = false;
     ctx->meshBuild = b;
-    b->done = std::async(std::launch::async, [ctx, b, t, layout, changed, snapshot, keep, device, alphaBytes]() mutable -> int {
+    b->done = std::async(std::launch::async, [ctx, b, t, layout, changed, snapshot, keep, device, alphaBytes, failHalfWay]() mutable -> int {
+        ppt::g_allocationLog = &b->allocations;
         auto run = [&]() -> int {
             PPT_HIP(hipSetDevice(device));
             PPT_HIP(hipMemcpyAsync(b->dAlphaSnapshot, snapshot->data(), alphaBytes, hipMemcpyHostToDevice, t.stream));
@@ -1748,6 +1756,7 @@ static int start_mesh_build(prosper_pt_ctx *ctx)
             b->scene.modelInstanceTransforms = acc->dTransformsV[0];
             GeometryJob job;
             if ((r = begin_geometry(ctx, t, *layout, keep ? changed.get() : nullptr, job))) return r;
+            if (failHalfWay) return fail(PROSPER_PT_ERR_UNSUPPORTED, "debug option failNextUpdate is set");
             return finish_geometry(ctx, t, job);
         };
         const int r = run();
@@ -1774,6 +1783,10 @@ static int poll_mesh_build(prosper_pt_ctx *ctx, bool wait)
             // the scene stays as it is (without the subtrees that went with the build: its next hierarchy is built whole);
             // the meshes wait for the next prosper_pt_update_meshes / _finish_mesh_updates
             const std::string why = b->error;
+            // nothing of it was ever installed: once its stream is idle its arrays can go
+            (void)hipStreamSynchronize(gs->buildStream);
+            for (void *p : b->allocations) device_free(ctx, p);
+            device_free(ctx, b->dAlphaSnapshot);
             delete b->acc;
             delete b;
             gs->dirty = true;

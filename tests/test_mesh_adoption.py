@@ -352,3 +352,39 @@ def test_flight_helmet_loads_the_way_prosper_loads_it(gpu_ctx, oracle):
     finally:
         fresh.close()
     assert same_bits(last, _oracle_image(oracle, full, cam, fl, w, h, max_bounces=3, ibl=True)).all()
+
+
+@pytest.mark.gpu
+def test_a_failed_background_build_leaves_the_scene_as_it_was(gpu_ctx, oracle, cornell_world):
+    """The worker gives up half way (debug option failNextUpdate): the call that would have switched to its result reports
+    it, the scene renders as before, what the worker had allocated is given back, and the meshes are taken up by the next
+    build - prosper_pt_finish_mesh_updates starts it."""
+    full = cornell_world
+    meshes = len(full.metadatas)
+    w, h = 96, 64
+    cam, fl = _camera(oracle, full, w, h)
+    pc = default_pc(S, fl, max_bounces=2)
+    gpu_ctx.upload_scene(full.with_meshes_loaded(range(meshes - 2)))
+    gpu_ctx.render(pc, cam, w, h)
+    before = gpu_ctx.read_hdr()
+    bytes_before = gpu_ctx.scene_stats().deviceBytes
+    gpu_ctx.set_debug(failNextUpdate=1)
+    gpu_ctx.update_meshes(full, [meshes - 2, meshes - 1], wait=False)
+    with pytest.raises(capi.ProsperPtError) as e:
+        for _ in range(2000):
+            gpu_ctx.render(pc, cam, w, h)
+    assert e.value.code == -6 and "background build" in str(e.value)
+    gpu_ctx.set_debug(failNextUpdate=0)
+    gpu_ctx.render(pc, cam, w, h)
+    assert same_bits(before, gpu_ctx.read_hdr()).all()
+    assert gpu_ctx.scene_stats().deviceBytes == bytes_before
+    assert gpu_ctx.hierarchy_state().geometryBuildRunning == 1  # the meshes still wait
+    gpu_ctx.finish_mesh_updates()
+    gpu_ctx.render(pc, cam, w, h)
+    fresh = capi.Context(device=0)
+    try:
+        fresh.upload_scene(full)
+        fresh.render(pc, cam, w, h)
+        assert same_bits(gpu_ctx.read_hdr(), fresh.read_hdr()).all()
+    finally:
+        fresh.close()
