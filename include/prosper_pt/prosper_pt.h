@@ -27,8 +27,9 @@
  *
  * All entry points are `extern "C"`, take PODs / plain pointers and sizes, never throw and return
  * PROSPER_PT_OK (0) or a negative error code; prosper_pt_last_error() returns the message of the
- * calling thread's last failure.  A context is single-threaded (the reference makes all pass calls
- * on the main thread, src/Allocators.hpp:9); use one context per GPU.
+ * calling thread's last failure.  A context is single-threaded for its callers (the reference makes all pass
+ * calls on the main thread, src/Allocators.hpp:9); use one context per GPU.  While meshes stream in the context
+ * runs ONE worker thread of its own (prosper_pt_update_meshes), which touches nothing a caller can see.
  *
  * Host pointers inside prosper_pt_scene_view are borrowed for the duration of the call only.
  */
