@@ -307,7 +307,7 @@ typedef struct prosper_pt_debug_options
                                 * strided over all of it (measured slower: profiles/r04_banded_batches.txt); -1 / 0: strided */
     /* ---- updates ---- */
     float rebuildCostRatio;    /* 0: 1.3 - growth of the tree's surface-area measure at which an update also rebuilds */
-    uint32_t alwaysRebuild;    /* rebuild with every update */
+    uint32_t alwaysRebuild;    /* rebuild with every update, synchronously */
     uint32_t failNextUpdate;   /* the next host-side rebuild fails (the recovery test); cleared by that failure */
     /* ---- measured-slower experiments: only in a library built with -DPPT_EXPERIMENTS (prosper_pt_has_experiments);
      *      setting any of them in the default build fails with PROSPER_PT_ERR_UNSUPPORTED ---- */
@@ -352,8 +352,11 @@ int prosper_pt_update_lights(
  * stream, the null stream included); without the flag it stages like prosper_pt_update_transforms and ignores `stream`.  Same
  * pixels as a fresh prosper_pt_upload_scene of the moved scene (hits do not depend on the hierarchy).  A refit cannot keep
  * the tree good when instances travel far: each one leaves the tree's surface-area measure behind, and when that has
- * grown by 30 % (debug option rebuildCostRatio) over its value at the last build, the next update also rebuilds -
- * synchronously, like prosper_pt_rebuild_hierarchy. */
+ * grown by 30 % (debug option rebuildCostRatio) over its value at the last build, the next update has the moved
+ * instances split again - by the context's worker thread, into a new generation of the geometry that the first render
+ * after it is done switches to, like streamed-in meshes (prosper_pt_update_meshes); the frame loop goes on refitting and
+ * rendering meanwhile.  prosper_pt_finish_mesh_updates waits for it too; prosper_pt_rebuild_hierarchy does the same work
+ * at once, synchronously. */
 int prosper_pt_update_transforms(prosper_pt_ctx *ctx, const prosper_ModelInstanceTransforms *transforms, uint32_t count);
 enum
 {

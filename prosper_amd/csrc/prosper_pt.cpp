@@ -681,7 +681,7 @@ int finish_geometry(prosper_pt_ctx *ctx, GeometryTarget &t, GeometryJob &job)
     return PROSPER_PT_OK;
 }
 
-int ensure_mesh_streams(GeometryState *gs);
+int ensure_mesh_streams(prosper_pt_ctx *ctx);
 int upload_scene_impl(prosper_pt_ctx *ctx, const prosper_pt_scene_view *v)
 {
     DeviceScene &s = ctx->scene;
@@ -901,14 +901,7 @@ int upload_scene_impl(prosper_pt_ctx *ctx, const prosper_pt_scene_view *v)
     }
 
     if ((rc = finish_geometry(ctx, target, job))) return rc;
-    for (const prosper_GeometryMetadata &m : gs->metadatas)
-        if (!mesh_loaded(m))
-        {
-            // meshes are still loading: the streams prosper_pt_update_meshes works with (creating them costs milliseconds -
-            // here, not in the frame loop)
-            if ((rc = ensure_mesh_streams(gs))) return rc;
-            break;
-        }
+    if ((rc = ensure_mesh_streams(ctx))) return rc; // (made by prosper_pt_create; the new GeometryState learns of them)
     ctx->rawRecords = target.rawRecords;
     ctx->stats.deviceBytes = ctx->sceneBytes;
     ctx->stats.alphaBoundBytes = ctx->alphaBoundBytes;
@@ -1297,6 +1290,7 @@ int prosper_pt_create(const prosper_pt_device_desc *desc, prosper_pt_ctx **out_c
         eventsOk = eventsOk && hipEventCreateWithFlags(&slot.free, hipEventDisableTiming) == hipSuccess;
     }
     eventsOk = eventsOk && hipEventCreateWithFlags(&ctx->chainFork, hipEventDisableTiming) == hipSuccess;
+    eventsOk = eventsOk && ensure_mesh_streams(ctx) == PROSPER_PT_OK;
     if (!eventsOk || hipMalloc((void **)&ctx->dCounters, kStageCount * kCounterCount * sizeof(unsigned long long)) != hipSuccess ||
         hipMemset(ctx->dCounters, 0, kStageCount * kCounterCount * sizeof(unsigned long long)) != hipSuccess ||
         hipMalloc((void **)&ctx->dWorkCounter, 64) != hipSuccess)
@@ -1343,6 +1337,8 @@ void prosper_pt_destroy(prosper_pt_ctx *ctx)
     for (auto &ws : ctx->workStreams)
         if (ws) (void)hipStreamDestroy(ws);
     for (auto &ws : ctx->extraStreams)
+        if (ws) (void)hipStreamDestroy(ws);
+    for (auto &ws : ctx->meshStreams)
         if (ws) (void)hipStreamDestroy(ws);
     if (ctx->chainFork) (void)hipEventDestroy(ctx->chainFork);
     delete ctx;
@@ -1438,7 +1434,11 @@ int prosper_pt_update_lights(
 // prosper_pt_update_transforms did before the refit existed; prosper's own TLAS build is of this kind, on the GPU).
 static int flush_pending_update(prosper_pt_ctx *ctx, hipStream_t stream);
 static int poll_mesh_build(prosper_pt_ctx *ctx, bool wait);
-static int start_mesh_build(prosper_pt_ctx *ctx);
+static int start_mesh_build(prosper_pt_ctx *ctx, bool rebuild = false);
+namespace
+{
+int ensure_mesh_streams(prosper_pt_ctx *ctx);
+}
 static int rebuild_hierarchy_impl(prosper_pt_ctx *ctx)
 {
     PPT_HIP(hipSetDevice(ctx->device));
@@ -1621,8 +1621,17 @@ static int stage_transforms(prosper_pt_ctx *ctx, const prosper_ModelInstanceTran
     acc->transforms.assign(transforms, transforms + count);
     ctx->stats.bvhBuildSeconds = 0.0;
     ctx->stats.buildSeconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-    if (any && (acc->lastCostRatio > rebuild_cost_ratio(ctx) || ctx->debug.alwaysRebuild))
-        return rebuild_hierarchy_impl(ctx);
+    if (any && ctx->debug.alwaysRebuild) return rebuild_hierarchy_impl(ctx); // (debug option: the synchronous path, every time)
+    if (any && acc->lastCostRatio > rebuild_cost_ratio(ctx) && !ctx->meshBuild)
+    {
+        // The refits have degraded the tree: the instances that moved since the last build are split again - by the worker
+        // thread that also takes up streamed-in meshes, into a new geometry generation, while the frame loop goes on
+        // refitting and rendering this one (until round 4 this was a 60-75 ms synchronous rebuild in the middle of the
+        // frame loop).  The generation is switched in by the first render after it is done.
+        int rc = ensure_mesh_streams(ctx);
+        if (rc == PROSPER_PT_OK) rc = start_mesh_build(ctx, true);
+        return rc;
+    }
     return PROSPER_PT_OK;
 }
 
@@ -1667,15 +1676,31 @@ int prosper_pt_rebuild_hierarchy(prosper_pt_ctx *ctx)
 } // extern "C"
 namespace
 {
-int ensure_mesh_streams(GeometryState *gs)
+int ensure_mesh_streams(prosper_pt_ctx *ctx)
 {
-    if (gs->copyStream) return PROSPER_PT_OK;
-    // the highest priority the device has: what the worker enqueues is short (copies, a few dozen small kernels) and must
-    // not queue up behind whole frames
-    int least = 0, greatest = 0;
-    PPT_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
-    PPT_HIP(hipStreamCreateWithPriority(&gs->copyStream, hipStreamNonBlocking, greatest));
-    PPT_HIP(hipStreamCreateWithPriority(&gs->buildStream, hipStreamNonBlocking, greatest));
+    if (!ctx->meshStreams[0])
+    {
+        // Plain streams: they share the device's four hardware queues with the frame loop's, so what the worker enqueues
+        // (copies, a few dozen small kernels) waits behind the frames already queued there - three with a paced host, which
+        // costs a build a few milliseconds.  High-priority streams get hardware queues of their own and never wait, but two
+        // more queues alive cost the frame loop itself 2-5 % with frames in flight and 10-17 % in order
+        // (profiles/r04_mesh_streams.txt), scene loaded or not.
+        for (hipStream_t &st : ctx->meshStreams)
+        {
+            PPT_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+            // (its hardware queue comes into being with its first command)
+            hipEvent_t e = nullptr;
+            PPT_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+            PPT_HIP(hipEventRecord(e, st));
+            PPT_HIP(hipStreamSynchronize(st));
+            PPT_HIP(hipEventDestroy(e));
+        }
+    }
+    if (ctx->geometry)
+    {
+        ctx->geometry->copyStream = ctx->meshStreams[0];
+        ctx->geometry->buildStream = ctx->meshStreams[1];
+    }
     return PROSPER_PT_OK;
 }
 } // namespace
@@ -1683,7 +1708,7 @@ extern "C" {
 static int stage_transforms(prosper_pt_ctx *ctx, const prosper_ModelInstanceTransforms *transforms, uint32_t count);
 
 // A worker for what the mirrors hold now (the caller has made sure none is running).
-static int start_mesh_build(prosper_pt_ctx *ctx)
+static int start_mesh_build(prosper_pt_ctx *ctx, bool rebuild)
 {
     GeometryState *gs = ctx->geometry;
     MaterialState *ms = ctx->materialState;
@@ -1706,6 +1731,8 @@ static int start_mesh_build(prosper_pt_ctx *ctx)
     b->scene = ctx->scene;
     b->stats = ctx->stats;
     b->acc->transforms = old->transforms; // the newest the caller gave, flushed or not
+    b->acc->refits = old->refits;
+    b->acc->rebuilds = old->rebuilds + (rebuild ? 1u : 0u);
     // The subtrees of the last build move to the new generation.  (The old one keeps rendering with its node array; should it
     // have to be rebuilt before the switch, prosper_pt_rebuild_hierarchy waits for this build instead.)
     const bool keep = old->instanced && ctx->debug.flatBvh == 0;
@@ -1922,7 +1949,7 @@ int prosper_pt_update_meshes(prosper_pt_ctx *ctx, const prosper_pt_mesh_update *
     PPT_HIP(hipSetDevice(ctx->device));
     int rc;
     if ((rc = poll_mesh_build(ctx, false))) return rc; // (a finished build is installed first: its subtrees are the ones to keep)
-    if ((rc = ensure_mesh_streams(gs))) return rc;
+    if ((rc = ensure_mesh_streams(ctx))) return rc;
     void *d = nullptr;
     for (uint32_t i = 0; i < count; ++i)
     {

@@ -231,15 +231,10 @@ struct GeometryState
     // prosper_pt_update_meshes: the arrived bytes go through copyStream (waited for by the call itself); the new layout,
     // hierarchy and per-triangle records are made by a worker thread on buildStream while the frame loop goes on with
     // the geometry it has (MeshBuild, prosper_pt.cpp)
-    hipStream_t copyStream = nullptr, buildStream = nullptr;
+    hipStream_t copyStream = nullptr, buildStream = nullptr; // the context's (prosper_pt_ctx::meshStreams)
     bool dirty = false;      // meshes arrived that no build has taken up yet
     uint32_t meshUpdates = 0; // calls that handed meshes over
     uint32_t installs = 0;    // background builds whose result became the scene
-    ~GeometryState()
-    {
-        if (copyStream) (void)hipStreamDestroy(copyStream);
-        if (buildStream) (void)hipStreamDestroy(buildStream);
-    }
 };
 struct MeshBuild;
 
@@ -282,6 +277,9 @@ struct prosper_pt_ctx
     ppt::MeshBuild *meshBuild = nullptr;          // the geometry a worker thread is building from them, if any
     std::vector<ppt::AccelState *> retiredAccel;  // replaced generations: frames in flight may still use their events / staging
     std::mutex allocMutex;                        // sceneAllocations / sceneBytes (the worker thread allocates too)
+    // [0] copies of arrived mesh bytes, [1] the worker thread's launches: made (and used once) by prosper_pt_create - plain
+    // streams, whose first use costs nothing later; see ensure_mesh_streams for why not high-priority ones
+    hipStream_t meshStreams[2] = {};
 
     float4 *hdr = nullptr; // current HDR buffer (internal or caller-owned)
     float4 *ownedHdr = nullptr;

@@ -1149,8 +1149,9 @@ def test_update_enqueued_on_a_stream_of_the_callers(gpu_ctx, oracle):
 
 def test_far_moves_trigger_the_host_side_rebuild(gpu_ctx, oracle):
     """A refit keeps the tree's shape: instances that travel far leave it with fat boxes.  The refit's surface-area measure
-    notices (costRatio well above 1.3 after three instances crossed the hall), and the NEXT update re-splits them on the
-    host (rebuilds == 1, the measure back at 1): the image is the oracle's before and after."""
+    notices (costRatio well above 1.3 after three instances crossed the hall), and the NEXT update has them re-split on the
+    host - in the background, switched in once done (rebuilds == 1, the measure back at 1): the image is the oracle's before
+    and after."""
     from prosper_amd.world import translate
 
     def pose(shift):
@@ -1166,6 +1167,7 @@ def test_far_moves_trigger_the_host_side_rebuild(gpu_ctx, oracle):
     gpu_ctx.upload_scene(still)
     for world, rebuilds in ((far, 0), (farther, 1)):
         gpu_ctx.update_transforms(world)
+        gpu_ctx.finish_mesh_updates()  # (the re-split runs on the context's worker thread: wait for it)
         gpu_ctx.render(pc, cam, w, h, frames=2)
         got = gpu_ctx.read_hdr()
         hs = gpu_ctx.hierarchy_state()
@@ -1279,6 +1281,7 @@ def test_drifting_instances_trigger_the_rebuild_with_frames_in_flight(gpu_ctx, o
         gpu_ctx.update_transforms(world)  # staged; the refit runs at the head of the render's own chain
         gpu_ctx.render(pc, cam, w, h, frames=8, flags=S.RENDER_PIPELINED)
     last = gpu_ctx.read_hdr()
+    gpu_ctx.finish_mesh_updates()  # (a re-split may still be under way on the worker thread)
     after = gpu_ctx.hierarchy_state()
     assert after.rebuilds > before.rebuilds, "refits %d, rebuilds %d, measure x%.3f" % (after.refits, after.rebuilds, after.costRatio)
     assert after.costRatio < 1.3  # the tree is good again
