@@ -11,6 +11,7 @@
 #include <algorithm>
 #include <chrono>
 #include <future>
+#include <memory>
 #include <cmath>
 #include <cstdlib>
 #include <cstdio>
@@ -1708,7 +1709,19 @@ extern "C" {
 static int stage_transforms(prosper_pt_ctx *ctx, const prosper_ModelInstanceTransforms *transforms, uint32_t count);
 
 // A worker for what the mirrors hold now (the caller has made sure none is running).
+static int start_mesh_build_impl(prosper_pt_ctx *ctx, bool rebuild);
 static int start_mesh_build(prosper_pt_ctx *ctx, bool rebuild)
+{
+    try
+    {
+        return start_mesh_build_impl(ctx, rebuild);
+    }
+    catch (const std::exception &ex)
+    {
+        return fail(PROSPER_PT_ERR_INVALID_ARGUMENT, std::string("starting the background geometry build: ") + ex.what());
+    }
+}
+static int start_mesh_build_impl(prosper_pt_ctx *ctx, bool rebuild)
 {
     GeometryState *gs = ctx->geometry;
     MaterialState *ms = ctx->materialState;
@@ -1728,6 +1741,11 @@ static int start_mesh_build(prosper_pt_ctx *ctx, bool rebuild)
         delete b;
         return fail(PROSPER_PT_ERR_INVALID_ARGUMENT, "out of host memory");
     }
+    // (until the worker runs, a failure below - an exception included - drops the build)
+    std::unique_ptr<MeshBuild, void (*)(MeshBuild *)> guard(b, [](MeshBuild *p) {
+        delete p->acc;
+        delete p;
+    });
     b->scene = ctx->scene;
     b->stats = ctx->stats;
     b->acc->transforms = old->transforms; // the newest the caller gave, flushed or not
@@ -1747,12 +1765,7 @@ static int start_mesh_build(prosper_pt_ctx *ctx, bool rebuild)
     void *d = nullptr;
     const size_t alphaBytes = ms->alphaMaterials.size() * sizeof(AlphaMaterial);
     auto snapshot = std::make_shared<std::vector<AlphaMaterial>>(ms->alphaMaterials);
-    if ((rc = device_alloc(ctx, alphaBytes, &d)))
-    {
-        delete b->acc;
-        delete b;
-        return rc;
-    }
+    if ((rc = device_alloc(ctx, alphaBytes, &d))) return rc;
     b->dAlphaSnapshot = d;
     b->scene.alphaMaterials = static_cast<const AlphaMaterial *>(d);
     GeometryTarget t = context_target(ctx);
@@ -1765,8 +1778,6 @@ static int start_mesh_build(prosper_pt_ctx *ctx, bool rebuild)
     // debug option failNextUpdate: the worker gives up half way (the test of what a failed build leaves behind)
     const bool failHalfWay = ctx->debug.failNextUpdate != 0;
     ctx->debug.failNextUpdate = 0;
-    gs->dirty = false;
-    ctx->meshBuild = b;
     b->done = std::async(std::launch::async, [ctx, b, t, layout, changed, snapshot, keep, device, alphaBytes, failHalfWay]() mutable -> int {
         ppt::g_allocationLog = &b->allocations;
         auto run = [&]() -> int {
@@ -1786,10 +1797,21 @@ static int start_mesh_build(prosper_pt_ctx *ctx, bool rebuild)
             if (failHalfWay) return fail(PROSPER_PT_ERR_UNSUPPORTED, "debug option failNextUpdate is set");
             return finish_geometry(ctx, t, job);
         };
-        const int r = run();
+        int r;
+        try
+        {
+            r = run();
+        }
+        catch (const std::exception &ex) // (the C-ABI never throws: the main thread's future.get() must not either)
+        {
+            r = fail(PROSPER_PT_ERR_INVALID_ARGUMENT, std::string("worker thread: ") + ex.what());
+        }
         if (r != PROSPER_PT_OK) b->error = ppt::g_lastErrorStorage;
         return r;
     });
+    guard.release();
+    gs->dirty = false;
+    ctx->meshBuild = b;
     return PROSPER_PT_OK;
 }
 
