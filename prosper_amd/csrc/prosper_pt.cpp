@@ -132,6 +132,8 @@ struct MeshBuild
     uint64_t materialChanges = 0; // MaterialState::changes when the build took its copy of the alpha-material table
     void *dAlphaSnapshot = nullptr;
     std::vector<void *> allocations; // what the worker allocated (given back if the build fails)
+    std::vector<GeometryState::ArrivedMesh> arrived; // the meshes whose bytes this build writes to the device
+    std::vector<void *> newBuffers;  // geometry buffers it created (they stay: their bytes are on the device)
 };
 } // namespace ppt
 
@@ -682,7 +684,6 @@ int finish_geometry(prosper_pt_ctx *ctx, GeometryTarget &t, GeometryJob &job)
     return PROSPER_PT_OK;
 }
 
-int ensure_mesh_streams(prosper_pt_ctx *ctx);
 int upload_scene_impl(prosper_pt_ctx *ctx, const prosper_pt_scene_view *v)
 {
     DeviceScene &s = ctx->scene;
@@ -702,12 +703,15 @@ int upload_scene_impl(prosper_pt_ctx *ctx, const prosper_pt_scene_view *v)
     gs->drawInstances.assign(v->drawInstances, v->drawInstances + v->drawInstanceCount);
     std::vector<const void *> bufferPtrs(std::max<size_t>(v->geometryBufferCount, PROSPER_PT_MAX_GEOMETRY_BUFFERS), nullptr);
     void *d = nullptr;
+    // (fixed sizes: while a mesh build runs the calling thread and the worker both index these, neither may move them)
+    gs->buffers.assign(bufferPtrs.size(), nullptr);
+    gs->bufferBytes.assign(bufferPtrs.size(), 0);
     for (uint32_t i = 0; i < v->geometryBufferCount; ++i)
     {
         if ((rc = upload(ctx, v->geometryBuffers[i], (size_t)v->geometryBufferByteSizes[i], &d))) return rc;
         bufferPtrs[i] = d;
-        gs->buffers.push_back(d);
-        gs->bufferBytes.push_back(v->geometryBufferByteSizes[i]);
+        gs->buffers[i] = d;
+        gs->bufferBytes[i] = v->geometryBufferByteSizes[i];
     }
     if ((rc = upload(ctx, bufferPtrs.data(), bufferPtrs.size() * sizeof(void *), &d))) return rc;
     gs->dBufferTable = static_cast<const void **>(d);
@@ -902,7 +906,6 @@ int upload_scene_impl(prosper_pt_ctx *ctx, const prosper_pt_scene_view *v)
     }
 
     if ((rc = finish_geometry(ctx, target, job))) return rc;
-    if ((rc = ensure_mesh_streams(ctx))) return rc; // (made by prosper_pt_create; the new GeometryState learns of them)
     ctx->rawRecords = target.rawRecords;
     ctx->stats.deviceBytes = ctx->sceneBytes;
     ctx->stats.alphaBoundBytes = ctx->alphaBoundBytes;
@@ -1291,7 +1294,12 @@ int prosper_pt_create(const prosper_pt_device_desc *desc, prosper_pt_ctx **out_c
         eventsOk = eventsOk && hipEventCreateWithFlags(&slot.free, hipEventDisableTiming) == hipSuccess;
     }
     eventsOk = eventsOk && hipEventCreateWithFlags(&ctx->chainFork, hipEventDisableTiming) == hipSuccess;
-    eventsOk = eventsOk && ensure_mesh_streams(ctx) == PROSPER_PT_OK;
+    // Every work stream is used once here, so that the device's four hardware queues go to the caller's stream and these
+    // three, in this order: a stream that comes into use later (the two of prosper_pt_update_meshes, made at first need)
+    // then SHARES a queue.  Streams that claim queues before the work streams do leave two of those sharing one for the
+    // life of the context: 4 % on FlightHelmet, 2 % on S-sponza-class, 60 % on a 256 x 256 frame (profiles/r04_mesh_streams.txt).
+    for (auto &ws : ctx->workStreams)
+        eventsOk = eventsOk && ws && hipEventRecord(ctx->chainFork, ws) == hipSuccess && hipStreamSynchronize(ws) == hipSuccess;
     if (!eventsOk || hipMalloc((void **)&ctx->dCounters, kStageCount * kCounterCount * sizeof(unsigned long long)) != hipSuccess ||
         hipMemset(ctx->dCounters, 0, kStageCount * kCounterCount * sizeof(unsigned long long)) != hipSuccess ||
         hipMalloc((void **)&ctx->dWorkCounter, 64) != hipSuccess)
@@ -1339,8 +1347,7 @@ void prosper_pt_destroy(prosper_pt_ctx *ctx)
         if (ws) (void)hipStreamDestroy(ws);
     for (auto &ws : ctx->extraStreams)
         if (ws) (void)hipStreamDestroy(ws);
-    for (auto &ws : ctx->meshStreams)
-        if (ws) (void)hipStreamDestroy(ws);
+    if (ctx->buildStream) (void)hipStreamDestroy(ctx->buildStream);
     if (ctx->chainFork) (void)hipEventDestroy(ctx->chainFork);
     delete ctx;
 }
@@ -1436,10 +1443,6 @@ int prosper_pt_update_lights(
 static int flush_pending_update(prosper_pt_ctx *ctx, hipStream_t stream);
 static int poll_mesh_build(prosper_pt_ctx *ctx, bool wait);
 static int start_mesh_build(prosper_pt_ctx *ctx, bool rebuild = false);
-namespace
-{
-int ensure_mesh_streams(prosper_pt_ctx *ctx);
-}
 static int rebuild_hierarchy_impl(prosper_pt_ctx *ctx)
 {
     PPT_HIP(hipSetDevice(ctx->device));
@@ -1629,9 +1632,7 @@ static int stage_transforms(prosper_pt_ctx *ctx, const prosper_ModelInstanceTran
         // thread that also takes up streamed-in meshes, into a new geometry generation, while the frame loop goes on
         // refitting and rendering this one (until round 4 this was a 60-75 ms synchronous rebuild in the middle of the
         // frame loop).  The generation is switched in by the first render after it is done.
-        int rc = ensure_mesh_streams(ctx);
-        if (rc == PROSPER_PT_OK) rc = start_mesh_build(ctx, true);
-        return rc;
+        return start_mesh_build(ctx, true);
     }
     return PROSPER_PT_OK;
 }
@@ -1677,31 +1678,16 @@ int prosper_pt_rebuild_hierarchy(prosper_pt_ctx *ctx)
 } // extern "C"
 namespace
 {
-int ensure_mesh_streams(prosper_pt_ctx *ctx)
+// The worker's stream, made by the worker thread the first time a context needs it - AFTER prosper_pt_create has given the
+// device's hardware queues to the work streams: a plain stream, which then shares a queue with one of those.  What the worker
+// enqueues (copies, a few dozen small kernels) waits behind the frames already queued there - three with a paced host, a
+// few milliseconds per build.  A high-priority stream gets a hardware queue of its own and never waits, but its first use costs
+// 20 ms, and more queues alive cost the frame loop 2-5 % with frames in flight and 10-17 % in order; a plain stream that claims
+// a queue BEFORE the work streams do leaves two of those sharing one (profiles/r04_mesh_streams.txt).  Its creation takes 7 ms:
+// on the worker, not in the frame loop.
+int ensure_build_stream(prosper_pt_ctx *ctx)
 {
-    if (!ctx->meshStreams[0])
-    {
-        // Plain streams: they share the device's four hardware queues with the frame loop's, so what the worker enqueues
-        // (copies, a few dozen small kernels) waits behind the frames already queued there - three with a paced host, which
-        // costs a build a few milliseconds.  High-priority streams get hardware queues of their own and never wait, but two
-        // more queues alive cost the frame loop itself 2-5 % with frames in flight and 10-17 % in order
-        // (profiles/r04_mesh_streams.txt), scene loaded or not.
-        for (hipStream_t &st : ctx->meshStreams)
-        {
-            PPT_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
-            // (its hardware queue comes into being with its first command)
-            hipEvent_t e = nullptr;
-            PPT_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-            PPT_HIP(hipEventRecord(e, st));
-            PPT_HIP(hipStreamSynchronize(st));
-            PPT_HIP(hipEventDestroy(e));
-        }
-    }
-    if (ctx->geometry)
-    {
-        ctx->geometry->copyStream = ctx->meshStreams[0];
-        ctx->geometry->buildStream = ctx->meshStreams[1];
-    }
+    if (!ctx->buildStream) PPT_HIP(hipStreamCreateWithFlags(&ctx->buildStream, hipStreamNonBlocking));
     return PROSPER_PT_OK;
 }
 } // namespace
@@ -1773,7 +1759,7 @@ static int start_mesh_build_impl(prosper_pt_ctx *ctx, bool rebuild)
     t.acc = b->acc;
     t.stats = &b->stats;
     t.alphaTriangleCount = &b->alphaTriangleCount;
-    t.stream = gs->buildStream;
+    b->arrived.swap(gs->arrived);
     const int device = ctx->device;
     // debug option failNextUpdate: the worker gives up half way (the test of what a failed build leaves behind)
     const bool failHalfWay = ctx->debug.failNextUpdate != 0;
@@ -1782,11 +1768,39 @@ static int start_mesh_build_impl(prosper_pt_ctx *ctx, bool rebuild)
         ppt::g_allocationLog = &b->allocations;
         auto run = [&]() -> int {
             PPT_HIP(hipSetDevice(device));
+            int r = ensure_build_stream(ctx);
+            if (r != PROSPER_PT_OK) return r;
+            t.stream = ctx->buildStream;
+            // the arrived meshes: new geometry buffers, bytes, metadata entries
+            GeometryState *gs = ctx->geometry;
+            for (const GeometryState::ArrivedMesh &a : b->arrived)
+            {
+                if (!gs->buffers[a.bufferIndex])
+                {
+                    void *nb = nullptr;
+                    const size_t bytes = (size_t)gs->bufferBytes[a.bufferIndex];
+                    PPT_HIP(hipMalloc(&nb, bytes ? bytes : 16)); // (not through the log of what a failed build gives back)
+                    {
+                        const std::lock_guard<std::mutex> lock(ctx->allocMutex);
+                        ctx->sceneAllocations.push_back({nb, bytes});
+                        ctx->sceneBytes += bytes;
+                    }
+                    PPT_HIP(hipMemsetAsync(nb, 0, bytes, t.stream));
+                    gs->buffers[a.bufferIndex] = nb;
+                    b->newBuffers.push_back(nb);
+                    PPT_HIP(hipMemcpyAsync(gs->dBufferTable + a.bufferIndex, &b->newBuffers.back(), sizeof(void *), hipMemcpyHostToDevice, t.stream));
+                    PPT_HIP(hipStreamSynchronize(t.stream)); // (newBuffers may move when it grows)
+                }
+                if (!a.bytes.empty())
+                    PPT_HIP(hipMemcpyAsync(static_cast<uint8_t *>(gs->buffers[a.bufferIndex]) + a.byteOffset, a.bytes.data(), a.bytes.size(), hipMemcpyHostToDevice, t.stream));
+                PPT_HIP(hipMemcpyAsync(gs->dMetadatas + a.meshIndex, &a.metadata, sizeof(prosper_GeometryMetadata), hipMemcpyHostToDevice, t.stream));
+            }
             PPT_HIP(hipMemcpyAsync(b->dAlphaSnapshot, snapshot->data(), alphaBytes, hipMemcpyHostToDevice, t.stream));
+            PPT_HIP(hipStreamSynchronize(t.stream));
             // its own transform table: the newest transforms as of the start of this build
             AccelState *acc = b->acc;
             void *dT = nullptr;
-            int r = device_alloc(ctx, sizeof(prosper_ModelInstanceTransforms) * (acc->transforms.size() ? acc->transforms.size() : 1), &dT);
+            r = device_alloc(ctx, sizeof(prosper_ModelInstanceTransforms) * (acc->transforms.size() ? acc->transforms.size() : 1), &dT);
             if (r != PROSPER_PT_OK) return r;
             if (!acc->transforms.empty())
                 PPT_HIP(hipMemcpyAsync(dT, acc->transforms.data(), sizeof(prosper_ModelInstanceTransforms) * acc->transforms.size(), hipMemcpyHostToDevice, t.stream));
@@ -1833,7 +1847,9 @@ static int poll_mesh_build(prosper_pt_ctx *ctx, bool wait)
             // the meshes wait for the next prosper_pt_update_meshes / _finish_mesh_updates
             const std::string why = b->error;
             // nothing of it was ever installed: once its stream is idle its arrays can go
-            (void)hipStreamSynchronize(gs->buildStream);
+            if (ctx->buildStream) (void)hipStreamSynchronize(ctx->buildStream);
+            for (GeometryState::ArrivedMesh &a : gs->arrived) b->arrived.push_back(std::move(a)); // (those that came meanwhile, behind)
+            gs->arrived.swap(b->arrived);
             for (void *p : b->allocations) device_free(ctx, p);
             device_free(ctx, b->dAlphaSnapshot);
             delete b->acc;
@@ -1918,8 +1934,7 @@ int prosper_pt_update_meshes(prosper_pt_ctx *ctx, const prosper_pt_mesh_update *
 
     // ---- everything is checked against the mirrors before anything is touched ----
     std::vector<uint64_t> bufferBytes(PROSPER_PT_MAX_GEOMETRY_BUFFERS, 0);
-    for (size_t b = 0; b < gs->buffers.size(); ++b)
-        if (gs->buffers[b]) bufferBytes[b] = gs->bufferBytes[b];
+    for (size_t b = 0; b < gs->bufferBytes.size(); ++b) bufferBytes[b] = gs->bufferBytes[b]; // (0: no such buffer yet)
     std::vector<uint8_t> arriving(gs->metadatas.size(), 0);
     for (uint32_t i = 0; i < count; ++i)
     {
@@ -1966,38 +1981,34 @@ int prosper_pt_update_meshes(prosper_pt_ctx *ctx, const prosper_pt_mesh_update *
         }
     }
 
-    // ---- the arrived bytes and tables: nothing in flight reads them (the meshes have no triangle anywhere yet), so they are
-    //      written in place, through a stream of their own ----
+    // ---- the arrived bytes are kept (the caller's memory may go when this returns); the worker thread of the next build
+    //      writes them and the metadata into the device's geometry buffers and tables IN PLACE - nothing in flight reads
+    //      those places, the meshes have no triangle anywhere yet ----
     PPT_HIP(hipSetDevice(ctx->device));
     int rc;
     if ((rc = poll_mesh_build(ctx, false))) return rc; // (a finished build is installed first: its subtrees are the ones to keep)
-    if ((rc = ensure_mesh_streams(ctx))) return rc;
-    void *d = nullptr;
-    for (uint32_t i = 0; i < count; ++i)
+    try
     {
-        const prosper_pt_mesh_update &u = meshes[i];
-        const uint32_t b = u.metadata.bufferIndex;
-        if (gs->buffers.size() <= b)
+        for (uint32_t i = 0; i < count; ++i)
         {
-            gs->buffers.resize((size_t)b + 1, nullptr);
-            gs->bufferBytes.resize((size_t)b + 1, 0);
+            const prosper_pt_mesh_update &u = meshes[i];
+            GeometryState::ArrivedMesh a;
+            a.meshIndex = u.meshIndex;
+            a.bufferIndex = u.metadata.bufferIndex;
+            a.byteOffset = u.byteOffset;
+            a.bytes.assign(static_cast<const uint8_t *>(u.bytes), static_cast<const uint8_t *>(u.bytes) + u.byteCount);
+            a.metadata = u.metadata;
+            gs->arrived.push_back(std::move(a));
         }
-        if (!gs->buffers[b])
-        {
-            if ((rc = device_alloc(ctx, (size_t)bufferBytes[b], &d))) return rc;
-            PPT_HIP(hipMemsetAsync(d, 0, (size_t)bufferBytes[b], gs->copyStream));
-            gs->buffers[b] = d;
-            gs->bufferBytes[b] = bufferBytes[b];
-            PPT_HIP(hipMemcpyAsync(gs->dBufferTable + b, &gs->buffers[b], sizeof(void *), hipMemcpyHostToDevice, gs->copyStream));
-            PPT_HIP(hipStreamSynchronize(gs->copyStream)); // (the pointer's host copy may move when `buffers` grows)
-        }
-        if (u.byteCount)
-            PPT_HIP(hipMemcpyAsync(static_cast<uint8_t *>(gs->buffers[b]) + u.byteOffset, u.bytes, (size_t)u.byteCount, hipMemcpyHostToDevice, gs->copyStream));
-        PPT_HIP(hipMemcpyAsync(gs->dMetadatas + u.meshIndex, &u.metadata, sizeof(prosper_GeometryMetadata), hipMemcpyHostToDevice, gs->copyStream));
     }
-    PPT_HIP(hipStreamSynchronize(gs->copyStream)); // the caller's memory may go
+    catch (const std::exception &ex)
+    {
+        return fail(PROSPER_PT_ERR_INVALID_ARGUMENT, std::string("prosper_pt_update_meshes: ") + ex.what());
+    }
     for (uint32_t i = 0; i < count; ++i)
     {
+        const uint32_t bi = meshes[i].metadata.bufferIndex;
+        if (gs->bufferBytes[bi] == 0) gs->bufferBytes[bi] = bufferBytes[bi]; // (a new buffer: no worker knows of it yet)
         gs->metadatas[meshes[i].meshIndex] = meshes[i].metadata;
         gs->infos[meshes[i].meshIndex] = meshes[i].info;
     }
@@ -2267,6 +2278,9 @@ int prosper_pt_render_frames(
         const uint32_t slotIndex = pipelined ? (ctx->lastSlot + 1u) % prosper_pt_ctx::kRenderSlots : 0u;
         RenderSlot &slot = ctx->slots[slotIndex];
         ctx->lastSlot = slotIndex;
+#ifdef PPT_EXPERIMENT_MESH_STREAMS_AFTER_FIRST_RENDER // (A/B: does the worker's stream cost anything once it shares a queue?)
+        (void)ensure_build_stream(ctx);
+#endif
         WavefrontChains chains;
         LaunchTimer chainTimers[kMaxChains];
         chains.count = (pipelined || (ctx->flags & PROSPER_PT_CREATE_SINGLE_CHAIN)) ? 1u : 2u;

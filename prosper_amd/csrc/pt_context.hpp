@@ -228,10 +228,18 @@ struct GeometryState
     std::vector<uint64_t> bufferBytes;
     const void **dBufferTable = nullptr;           // device: [PROSPER_PT_MAX_GEOMETRY_BUFFERS]
     prosper_GeometryMetadata *dMetadatas = nullptr; // device: [meshCount]
-    // prosper_pt_update_meshes: the arrived bytes go through copyStream (waited for by the call itself); the new layout,
-    // hierarchy and per-triangle records are made by a worker thread on buildStream while the frame loop goes on with
-    // the geometry it has (MeshBuild, prosper_pt.cpp)
-    hipStream_t copyStream = nullptr, buildStream = nullptr; // the context's (prosper_pt_ctx::meshStreams)
+    // prosper_pt_update_meshes keeps the arrived bytes in host memory (`arrived`); the worker thread of the next geometry build
+    // (MeshBuild, prosper_pt.cpp) copies them to the device, on its own stream, before it lays the triangles out - the
+    // calling thread touches no stream.  While a build runs `buffers` belongs to the worker (it allocates new geometry
+    // buffers); the calling thread goes by bufferBytes (0: no such buffer yet).
+    struct ArrivedMesh
+    {
+        uint32_t meshIndex = 0, bufferIndex = 0;
+        uint64_t byteOffset = 0;
+        std::vector<uint8_t> bytes;
+        prosper_GeometryMetadata metadata = {};
+    };
+    std::vector<ArrivedMesh> arrived;
     bool dirty = false;      // meshes arrived that no build has taken up yet
     uint32_t meshUpdates = 0; // calls that handed meshes over
     uint32_t installs = 0;    // background builds whose result became the scene
@@ -277,9 +285,9 @@ struct prosper_pt_ctx
     ppt::MeshBuild *meshBuild = nullptr;          // the geometry a worker thread is building from them, if any
     std::vector<ppt::AccelState *> retiredAccel;  // replaced generations: frames in flight may still use their events / staging
     std::mutex allocMutex;                        // sceneAllocations / sceneBytes (the worker thread allocates too)
-    // [0] copies of arrived mesh bytes, [1] the worker thread's launches: made (and used once) by prosper_pt_create - plain
-    // streams, whose first use costs nothing later; see ensure_mesh_streams for why not high-priority ones
-    hipStream_t meshStreams[2] = {};
+    // the worker thread's stream: a plain one, made by the worker at first need - after prosper_pt_create has given the
+    // hardware queues to the work streams (ensure_build_stream)
+    hipStream_t buildStream = nullptr;
 
     float4 *hdr = nullptr; // current HDR buffer (internal or caller-owned)
     float4 *ownedHdr = nullptr;

@@ -296,6 +296,12 @@ int flush_pending_materials(prosper_pt_ctx *ctx, hipStream_t stream)
     // the block's last readers (three flushes ago), the texel arrays / packs / bounds the tables point at
     if (ms->versionUsed[v]) PPT_HIP(hipStreamWaitEvent(stream, ms->versionFree[v], 0));
     if (ms->uploadedRecorded) PPT_HIP(hipStreamWaitEvent(stream, ms->uploaded, 0));
+    // ... and the previous flush, which ran on another render's stream: its rewrite of the any-hit records (they exist
+    // once, for every version) must be done before this render reads them.  `ready` is recorded anew below, so this wait is
+    // the only thing that orders the render behind the earlier record: without it a frame whose own flush patches nothing
+    // could overtake the patch of the flush before (found when a fifth stream changed which streams share a hardware
+    // queue: 927 pixels of FlightHelmet's lenses, one frame in six).
+    if (ms->readyRecorded) PPT_HIP(hipStreamWaitEvent(stream, ms->ready, 0));
     PPT_HIP(hipMemcpyAsync(ms->dBlocks[v], img, ms->blockBytes, hipMemcpyHostToDevice, stream));
     PPT_HIP(hipEventRecord(ms->stagingDone[k], stream));
     ms->stagingUsed[k] = true;

@@ -63,11 +63,21 @@ def _download(hip, ptr, h, w):
     return img
 
 
-@pytest.mark.parametrize("texture_size", [None, 256])
-def test_flight_helmet_streams_in_over_frames_in_flight(gpu_ctx, oracle, texture_size):
+@pytest.mark.parametrize("texture_size,fifth_stream", [(None, False), (256, False), (None, True)])
+def test_flight_helmet_streams_in_over_frames_in_flight(gpu_ctx, oracle, texture_size, fifth_stream):
     """The reference's bundled asset: fifteen images and six materials (one of them BLEND) adopted over five frames in
-    flight; every frame equals a fresh context's render of that frame's state."""
+    flight; every frame equals a fresh context's render of that frame's state.
+    fifth_stream: one more stream alive in the process changes which streams share a hardware queue, and with it the order
+    in which the frames' streams get to run - this is how a missing dependency between two flushes of the material tables
+    showed (the frame after the one that rewrote the any-hit records of the BLEND lenses overtook that rewrite)."""
     from prosper_amd import flight_helmet
+    extra = None
+    if fifth_stream:
+        hip0 = ctypes.CDLL("libamdhip64.so")
+        extra, ev = ctypes.c_void_p(), ctypes.c_void_p()
+        assert hip0.hipStreamCreateWithFlags(ctypes.byref(extra), 1) == 0 and hip0.hipEventCreate(ctypes.byref(ev)) == 0
+        assert hip0.hipEventRecord(ev, extra) == 0 and hip0.hipStreamSynchronize(extra) == 0  # (its queue exists from now on)
+        hip0.hipEventDestroy(ev)
     full = flight_helmet.load_fixture(texture_size=texture_size)
     images = len(full.textures) - 1
     steps = [0, 3, 6, 9, 12, images]
@@ -98,7 +108,10 @@ def test_flight_helmet_streams_in_over_frames_in_flight(gpu_ctx, oracle, texture
         for k, state in enumerate(states):
             fresh.upload_scene(state)
             fresh.render(pc, cam, w, h, frames=2)
-            assert same_bits(got[k], fresh.read_hdr()).all(), "frame %d (%d images)" % (k, steps[k])
+            same = same_bits(got[k], fresh.read_hdr()).all(axis=2)
+            rows, cols = np.nonzero(~same)
+            assert same.all(), "frame %d (%d images): %d pixels differ, rows %d-%d, columns %d-%d" % (
+                k, steps[k], rows.size, rows.min(), rows.max(), cols.min(), cols.max())
     finally:
         fresh.close()
     # and the last one is the oracle's image of the whole asset
@@ -107,6 +120,8 @@ def test_flight_helmet_streams_in_over_frames_in_flight(gpu_ctx, oracle, texture
     for f in (1, 2):
         want, _ = osc.render(default_pc(S, fl, frame_index=f, max_bounces=3, ibl=True, skip_history=(f == 1)), cam, w, h, history=want)
     assert same_bits(got[-1], want).all()
+    if extra is not None:
+        hip.hipStreamDestroy(extra)
 
 
 def test_alpha_textures_and_bc7_adopted_between_frames_in_flight(gpu_ctx, oracle):
