@@ -397,9 +397,10 @@ int prosper_pt_update_materials(prosper_pt_ctx *ctx, const prosper_MaterialData 
  * there.  prosper_pt_update_meshes hands over the meshes that arrived: metadata and MeshInfo as pollMeshWorker stores them,
  * and the bytes the worker wrote (`bytes`, borrowed for the call) with their place in geometryBuffers[metadata.bufferIndex].
  * A buffer index the scene has not seen yet creates that buffer, `bufferByteSize` bytes large (ignored otherwise).
- * The call copies the bytes, notes the tables and returns: a worker thread of the context lays the triangles out again,
- * builds the subtrees of the model instances that became complete (the others are kept), re-assembles the hierarchy and
- * writes the per-triangle records - all into arrays of its own, on a stream of its own - while the frame loop goes on
+ * The call keeps a copy of the bytes, notes the tables and returns (0.1 ms): a worker thread of the context writes the
+ * bytes to the device, lays the triangles out again, builds the subtrees of the model instances that became complete (the
+ * others are kept), re-assembles the hierarchy and writes the per-triangle records - all into arrays of its own, on a
+ * stream of its own (the calling thread touches no stream) - while the frame loop goes on
  * rendering the geometry it has, frames in flight included.  The first render (or prosper_pt_update_meshes, or
  * prosper_pt_finish_mesh_updates) after the worker is done switches to the new geometry; instances that moved or materials
  * that changed meanwhile are brought up to date by that switch.  This is prosper's own timing: a BLAS is built on the
