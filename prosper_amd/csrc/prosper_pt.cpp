@@ -1421,13 +1421,13 @@ int prosper_pt_update_lights(
         return PROSPER_PT_OK;
     PPT_HIP(hipSetDevice(ctx->device));
     const uint32_t k = ls->pending ? ls->pendingStaging : ls->stagingNext;
-    if (!ls->pending) ls->stagingNext ^= 1u;
+    if (!ls->pending) ls->stagingNext = (ls->stagingNext + 1u) % kStagingBuffers;
     if (!ls->staging[k])
     {
         PPT_HIP(hipHostMalloc((void **)&ls->staging[k], sizeof(LightBlock), hipHostMallocDefault));
         PPT_HIP(hipEventCreateWithFlags(&ls->stagingDone[k], hipEventDisableTiming));
     }
-    if (ls->stagingUsed[k]) PPT_HIP(hipEventSynchronize(ls->stagingDone[k])); // the copy of two updates ago
+    if (ls->stagingUsed[k]) PPT_HIP(hipEventSynchronize(ls->stagingDone[k])); // the copy of four updates ago
     ls->stagingUsed[k] = false;
     ls->staging[k]->directional = *directionalLight;
     ls->staging[k]->points = *pointLights;
@@ -1610,13 +1610,13 @@ static int stage_transforms(prosper_pt_ctx *ctx, const prosper_ModelInstanceTran
     // into pinned staging (a pageable source would make the later copy synchronous).  An update that was never consumed
     // is simply replaced: its staging buffer is reused.
     const uint32_t k = acc->pending ? acc->pendingStaging : acc->stagingNext;
-    if (!acc->pending) acc->stagingNext ^= 1u;
+    if (!acc->pending) acc->stagingNext = (acc->stagingNext + 1u) % kStagingBuffers;
     if (!acc->staging[k])
     {
         PPT_HIP(hipHostMalloc((void **)&acc->staging[k], sizeof(prosper_ModelInstanceTransforms) * (count ? count : 1), hipHostMallocDefault));
         PPT_HIP(hipEventCreateWithFlags(&acc->stagingDone[k], hipEventDisableTiming));
     }
-    if (acc->stagingUsed[k]) PPT_HIP(hipEventSynchronize(acc->stagingDone[k])); // the copy of two updates ago
+    if (acc->stagingUsed[k]) PPT_HIP(hipEventSynchronize(acc->stagingDone[k])); // the copy of four updates ago
     acc->stagingUsed[k] = false;
     std::memcpy(acc->staging[k], transforms, sizeof(prosper_ModelInstanceTransforms) * count);
     acc->pending = true;
@@ -1675,9 +1675,6 @@ int prosper_pt_rebuild_hierarchy(prosper_pt_ctx *ctx)
 }
 
 // ---- streamed-in meshes: the new geometry is made by a worker thread, beside the frame loop ----
-} // extern "C"
-namespace
-{
 // The worker's stream, made by the worker thread the first time a context needs it - AFTER prosper_pt_create has given the
 // device's hardware queues to the work streams: a plain stream, which then shares a queue with one of those.  What the worker
 // enqueues (copies, a few dozen small kernels) waits behind the frames already queued there - three with a paced host, a
@@ -1685,13 +1682,11 @@ namespace
 // 20 ms, and more queues alive cost the frame loop 2-5 % with frames in flight and 10-17 % in order; a plain stream that claims
 // a queue BEFORE the work streams do leaves two of those sharing one (profiles/r04_mesh_streams.txt).  Its creation takes 7 ms:
 // on the worker, not in the frame loop.
-int ensure_build_stream(prosper_pt_ctx *ctx)
+static int ensure_build_stream(prosper_pt_ctx *ctx)
 {
     if (!ctx->buildStream) PPT_HIP(hipStreamCreateWithFlags(&ctx->buildStream, hipStreamNonBlocking));
     return PROSPER_PT_OK;
 }
-} // namespace
-extern "C" {
 static int stage_transforms(prosper_pt_ctx *ctx, const prosper_ModelInstanceTransforms *transforms, uint32_t count);
 
 // A worker for what the mirrors hold now (the caller has made sure none is running).

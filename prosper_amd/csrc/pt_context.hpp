@@ -31,6 +31,11 @@ int fail(int code, const std::string &msg);
 // The three light buffers of the scene (World.cpp:531-535 rewrites them every frame), versioned like the instance
 // transforms: an update is staged by the call (an unchanged set is a no-op) and copied by the next render's own chain
 // into the next of three device copies, so the frames in flight keep theirs and nothing synchronises the device.
+// Pinned staging buffers per kind of update (transforms, lights, material tables): an update's copy is enqueued at the head
+// of the next render's chain, i.e. BEHIND the frames in flight; with two buffers the update after next may wait on the host
+// for that copy - with one buffer more than frames in flight it never does.
+constexpr uint32_t kStagingBuffers = 4;
+
 struct LightBlock
 {
     alignas(16) prosper_DirectionalLightParameters directional;
@@ -46,9 +51,9 @@ struct LightState
     hipStream_t versionStream[kVersions] = {}; // the stream versionFree was last recorded on
     uint32_t cur = 0;
     LightBlock *mirror = nullptr;         // host copy of what the device holds (or will hold once `pending` is flushed)
-    LightBlock *staging[2] = {nullptr, nullptr}; // pinned
-    hipEvent_t stagingDone[2] = {nullptr, nullptr};
-    bool stagingUsed[2] = {false, false};
+    LightBlock *staging[kStagingBuffers] = {}; // pinned
+    hipEvent_t stagingDone[kStagingBuffers] = {};
+    bool stagingUsed[kStagingBuffers] = {};
     uint32_t stagingNext = 0, pendingStaging = 0;
     bool pending = false;
     hipEvent_t ready = nullptr; // behind the last flush: every later render's chains wait for it
@@ -57,7 +62,7 @@ struct LightState
     ~LightState()
     {
         delete mirror;
-        for (int i = 0; i < 2; ++i)
+        for (uint32_t i = 0; i < kStagingBuffers; ++i)
         {
             if (staging[i]) (void)hipHostFree(staging[i]);
             if (stagingDone[i]) (void)hipEventDestroy(stagingDone[i]);
@@ -110,9 +115,9 @@ struct AccelState
     std::vector<uint8_t> movedSinceBuild; // per range: its subtree is out of date in `bvh` and `flat`
     bool flatStale = false;
     // the update's transforms go through pinned staging (a pageable source would make the async copy synchronous)
-    prosper_ModelInstanceTransforms *staging[2] = {nullptr, nullptr};
-    hipEvent_t stagingDone[2] = {nullptr, nullptr};
-    bool stagingUsed[2] = {false, false};
+    prosper_ModelInstanceTransforms *staging[kStagingBuffers] = {};
+    hipEvent_t stagingDone[kStagingBuffers] = {};
+    bool stagingUsed[kStagingBuffers] = {};
     uint32_t stagingNext = 0;
     // recorded on the updating stream behind the refit: every later render's path stages wait for it
     hipEvent_t sceneEvent = nullptr;
@@ -139,7 +144,7 @@ struct AccelState
 
     ~AccelState()
     {
-        for (int i = 0; i < 2; ++i)
+        for (uint32_t i = 0; i < kStagingBuffers; ++i)
         {
             if (staging[i]) (void)hipHostFree(staging[i]);
             if (stagingDone[i]) (void)hipEventDestroy(stagingDone[i]);
@@ -179,9 +184,9 @@ struct MaterialState
     bool versionUsed[kVersions] = {};
     hipStream_t versionStream[kVersions] = {};
     uint32_t cur = 0;
-    uint8_t *staging[2] = {nullptr, nullptr}; // pinned images of the block
-    hipEvent_t stagingDone[2] = {nullptr, nullptr};
-    bool stagingUsed[2] = {false, false};
+    uint8_t *staging[kStagingBuffers] = {}; // pinned images of the block
+    hipEvent_t stagingDone[kStagingBuffers] = {};
+    bool stagingUsed[kStagingBuffers] = {};
     uint32_t stagingNext = 0;
     bool pending = false;          // the mirrors differ from version `cur`
     uint64_t changes = 0;          // bumped whenever an update changed a mirror (a background geometry build compares)
@@ -201,7 +206,7 @@ struct MaterialState
     static constexpr uint64_t kRetireBytes = 256ull << 20;
     ~MaterialState()
     {
-        for (int i = 0; i < 2; ++i)
+        for (uint32_t i = 0; i < kStagingBuffers; ++i)
         {
             if (staging[i]) (void)hipHostFree(staging[i]);
             if (stagingDone[i]) (void)hipEventDestroy(stagingDone[i]);

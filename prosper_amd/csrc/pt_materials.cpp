@@ -286,7 +286,7 @@ int flush_pending_materials(prosper_pt_ctx *ctx, hipStream_t stream)
         PPT_HIP(hipHostMalloc((void **)&ms->staging[k], ms->blockBytes, hipHostMallocDefault));
         PPT_HIP(hipEventCreateWithFlags(&ms->stagingDone[k], hipEventDisableTiming));
     }
-    if (ms->stagingUsed[k]) PPT_HIP(hipEventSynchronize(ms->stagingDone[k])); // the copy of two flushes ago
+    if (ms->stagingUsed[k]) PPT_HIP(hipEventSynchronize(ms->stagingDone[k])); // the copy of four flushes ago
     ms->stagingUsed[k] = false;
     uint8_t *img = ms->staging[k];
     std::memcpy(img, ms->materials.data(), ms->materials.size() * sizeof(prosper_MaterialData));
@@ -305,7 +305,7 @@ int flush_pending_materials(prosper_pt_ctx *ctx, hipStream_t stream)
     PPT_HIP(hipMemcpyAsync(ms->dBlocks[v], img, ms->blockBytes, hipMemcpyHostToDevice, stream));
     PPT_HIP(hipEventRecord(ms->stagingDone[k], stream));
     ms->stagingUsed[k] = true;
-    ms->stagingNext = k ^ 1u;
+    ms->stagingNext = (k + 1u) % kStagingBuffers;
     const AlphaMaterial *dAlpha = reinterpret_cast<const AlphaMaterial *>(ms->dBlocks[v] + ms->alphaOffset);
     if (ms->pendingAlphaPatch && ctx->alphaTriangleCount)
     {
