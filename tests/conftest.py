@@ -35,6 +35,27 @@ def _no_debug_options_leak():
     capi.debug()
 
 
+@pytest.fixture(scope="session", autouse=True)
+def _extra_streams():
+    """PROSPER_TEST_EXTRA_STREAMS=n: n more HIP streams alive (and used once) for the whole session.  Which streams share a
+    hardware queue - and with it the order in which the frames' streams get to run - depends on the streams alive in the
+    process: a dependency that is missing between two of the library's streams can hide behind one sharing and show behind
+    another (it did: tests/test_adoption.py "fifth_stream").  Run the GPU suite with 1 and 2 now and then."""
+    n = int(os.environ.get("PROSPER_TEST_EXTRA_STREAMS", "0"))
+    streams = []
+    if n:
+        import ctypes
+        hip = ctypes.CDLL("libamdhip64.so")
+        for _ in range(n):
+            st, ev = ctypes.c_void_p(), ctypes.c_void_p()
+            assert hip.hipStreamCreateWithFlags(ctypes.byref(st), 1) == 0 and hip.hipEventCreate(ctypes.byref(ev)) == 0
+            assert hip.hipEventRecord(ev, st) == 0 and hip.hipStreamSynchronize(st) == 0
+            hip.hipEventDestroy(ev)
+            streams.append(st)
+    yield
+    # (left alive: contexts of the session fixture are closed after this one)
+
+
 @pytest.fixture(scope="session")
 def oracle():
     from oracle import binding

@@ -374,7 +374,7 @@ def test_a_failed_background_build_leaves_the_scene_as_it_was(gpu_ctx, oracle, c
         for _ in range(2000):
             gpu_ctx.render(pc, cam, w, h)
     assert e.value.code == -6 and "background build" in str(e.value)
-    gpu_ctx.set_debug(failNextUpdate=0)
+    gpu_ctx.set_debug(failNextUpdate=None)  # (cleared, not left at 0: the context's own options override the process-wide ones)
     gpu_ctx.render(pc, cam, w, h)
     assert same_bits(before, gpu_ctx.read_hdr()).all()
     assert gpu_ctx.scene_stats().deviceBytes == bytes_before
