@@ -388,3 +388,66 @@ def test_a_failed_background_build_leaves_the_scene_as_it_was(gpu_ctx, oracle, c
         assert same_bits(gpu_ctx.read_hdr(), fresh.read_hdr()).all()
     finally:
         fresh.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_random_interleavings_of_everything_that_can_happen_while_a_scene_loads(gpu_ctx, oracle, seed):
+    """Meshes arriving (waited for or not), instances moving, MASK / BLEND and opaque materials changing, frames in flight,
+    in a random order: at every checkpoint - after prosper_pt_finish_mesh_updates - the frame equals a fresh upload of the
+    state the calls have described so far."""
+    rng = np.random.default_rng(seed)
+    full = scenes.sponza_class(foliage=True, texture_size=32, sky_size=16, detail=0.25)
+    meshes = len(full.metadatas)
+    remaining = [int(i) for i in rng.permutation(meshes)]
+    loaded = []
+    state = full
+    w, h = 200, 120
+    cam, fl = _camera(oracle, full, w, h)
+    pc = default_pc(S, fl, max_bounces=2, ibl=True)
+    gpu_ctx.upload_scene(state.with_meshes_loaded(loaded))
+    fresh = capi.Context(device=0)
+    try:
+        checkpoints = 0
+        for step in range(48):
+            op = rng.integers(0, 6) if remaining else rng.integers(1, 6)
+            if op == 0:
+                n = int(rng.integers(1, 5))
+                arrivals, remaining = remaining[:n], remaining[n:]
+                gpu_ctx.update_meshes(state, arrivals, wait=bool(rng.random() < 0.3))
+                loaded += arrivals
+            elif op == 1:
+                state = _moved(state, int(rng.integers(0, len(state.model_instances))), tuple(rng.normal(0.0, 0.3, 3)))
+                gpu_ctx.update_transforms(state)
+            elif op == 2:
+                state = copy.copy(state)
+                state._frozen = None
+                state.materials = list(state.materials)
+                i = int(rng.integers(1, len(state.materials)))
+                m = copy.copy(state.materials[i])
+                m.roughnessFactor = float(rng.uniform(0.1, 1.0))
+                m.alphaCutoff = float(rng.uniform(0.2, 0.8))
+                m.baseColorFactor = S.Vec4(float(rng.uniform(0.3, 1.0)), 0.8, 0.7, float(rng.uniform(0.3, 1.0)) if m.alphaMode else 1.0)
+                state.materials[i] = m
+                gpu_ctx.update_materials(state.materials, 0)
+            elif op in (3, 4):
+                gpu_ctx.render(pc, cam, w, h, frames=int(rng.integers(1, 3)), flags=S.RENDER_PIPELINED)
+            else:
+                gpu_ctx.finish_mesh_updates()
+                gpu_ctx.render(pc, cam, w, h, frames=2, flags=S.RENDER_PIPELINED)
+                got = gpu_ctx.read_hdr()
+                fresh.upload_scene(state.with_meshes_loaded(loaded))
+                fresh.render(pc, cam, w, h, frames=2)
+                assert same_bits(got, fresh.read_hdr()).all(), "seed %d, step %d, %d meshes" % (seed, step, len(loaded))
+                checkpoints += 1
+        if remaining:
+            gpu_ctx.update_meshes(state, remaining, wait=False)
+            loaded += remaining
+        gpu_ctx.finish_mesh_updates()
+        gpu_ctx.render(pc, cam, w, h, frames=2, flags=S.RENDER_PIPELINED)
+        fresh.upload_scene(state)
+        fresh.render(pc, cam, w, h, frames=2)
+        assert same_bits(gpu_ctx.read_hdr(), fresh.read_hdr()).all()
+        assert checkpoints >= 2
+    finally:
+        fresh.close()
