@@ -294,7 +294,7 @@ typedef struct prosper_pt_debug_options
     uint32_t topEntries;       /* 0: one per four triangles */
     int32_t nodeOrder;         /* -1: 2 (first 4096 nodes breadth-first, then depth-first subtrees); 0 depth-first; 1 breadth-first */
     int32_t childOrder;        /* -1 / 1: smallest box first; 0: build order */
-    uint32_t buildTiming;      /* the assembly's stage times to stderr */
+    uint32_t buildTiming;      /* stage times of the hierarchy assembly and of a geometry build to stderr */
     /* ---- render ---- */
     uint32_t segments;         /* target segment count of the wavefront workspace */
     uint32_t segmentLength;    /* segment length in slots (a multiple of 64) */

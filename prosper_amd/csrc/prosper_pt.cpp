@@ -276,9 +276,7 @@ struct GeometryTarget
     void lap(const char *what)
     {
         const auto now = std::chrono::steady_clock::now();
-        if (buildOpt.buildTiming)
-            std::fprintf(stderr, "[geometry] %-22s %.2f ms (at %.1f)\n", what, std::chrono::duration<double, std::milli>(now - tick).count(),
-                         std::chrono::duration<double, std::milli>(now.time_since_epoch()).count() - 1e3 * std::floor(std::chrono::duration<double>(now.time_since_epoch()).count() / 100.0) * 100.0);
+        if (buildOpt.buildTiming) std::fprintf(stderr, "[geometry] %-24s %.2f ms\n", what, std::chrono::duration<double, std::milli>(now - tick).count());
         tick = now;
     }
 };
@@ -1887,12 +1885,6 @@ static int poll_mesh_build(prosper_pt_ctx *ctx, bool wait)
         ctx->stats.deviceBytes = ctx->sceneBytes;
         ctx->sceneStamp++;
         gs->installs++;
-        if (ctx->debug.buildTiming)
-        {
-            const auto now = std::chrono::steady_clock::now();
-            std::fprintf(stderr, "[geometry] installed (at %.1f)\n",
-                         std::chrono::duration<double, std::milli>(now.time_since_epoch()).count() - 1e3 * std::floor(std::chrono::duration<double>(now.time_since_epoch()).count() / 100.0) * 100.0);
-        }
         // a material that changed while the build ran: its any-hit records are rewritten by the next flush of the tables
         if (ms->changes != b->materialChanges && ctx->alphaTriangleCount)
         {
