@@ -234,7 +234,7 @@ struct GeometryState
     const void **dBufferTable = nullptr;           // device: [PROSPER_PT_MAX_GEOMETRY_BUFFERS]
     prosper_GeometryMetadata *dMetadatas = nullptr; // device: [meshCount]
     // prosper_pt_update_meshes keeps the arrived bytes in host memory (`arrived`); the worker thread of the next geometry build
-    // (MeshBuild, prosper_pt.cpp) copies them to the device, on its own stream, before it lays the triangles out - the
+    // (MeshBuild, pt_geometry.cpp) copies them to the device, on its own stream, before it lays the triangles out - the
     // calling thread touches no stream.  While a build runs `buffers` belongs to the worker (it allocates new geometry
     // buffers); the calling thread goes by bufferBytes (0: no such buffer yet).
     struct ArrivedMesh

@@ -16,5 +16,5 @@ if [ -n "$HOST_DEFS" ]; then
   bvh=/tmp/variant_$name/bvh_build.o
 fi
 wait
-/opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 -o ../../build/variants/lib_$name.so prosper_pt.o pt_materials.o pt_tiling.o $bvh host/camera.o host/rt_reference.o host/tiled_rt_reference.o host/tone_map.o /tmp/variant_$name/pt_kernels.o /tmp/variant_$name/pt_wavefront.o -ldl
+/opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 -o ../../build/variants/lib_$name.so prosper_pt.o pt_geometry.o pt_materials.o pt_tiling.o $bvh host/camera.o host/rt_reference.o host/tiled_rt_reference.o host/tone_map.o /tmp/variant_$name/pt_kernels.o /tmp/variant_$name/pt_wavefront.o -ldl
 echo built build/variants/lib_$name.so
