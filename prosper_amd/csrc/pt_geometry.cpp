@@ -516,7 +516,7 @@ static int start_mesh_build_impl(prosper_pt_ctx *ctx, bool rebuild)
     // debug option failNextUpdate: the worker gives up half way (the test of what a failed build leaves behind)
     const bool failHalfWay = ctx->debug.failNextUpdate != 0;
     ctx->debug.failNextUpdate = 0;
-    b->done = std::async(std::launch::async, [ctx, b, t, layout, changed, snapshot, keep, device, alphaBytes, failHalfWay]() mutable -> int {
+    auto work = [ctx, b, t, layout, changed, snapshot, keep, device, alphaBytes, failHalfWay]() mutable -> int {
         ppt::g_allocationLog = &b->allocations;
         auto run = [&]() -> int {
             PPT_HIP(hipSetDevice(device));
@@ -574,7 +574,19 @@ static int start_mesh_build_impl(prosper_pt_ctx *ctx, bool rebuild)
         }
         if (r != PROSPER_PT_OK) b->error = ppt::g_lastErrorStorage;
         return r;
-    });
+    };
+    try
+    {
+        b->done = std::async(std::launch::async, std::move(work));
+    }
+    catch (const std::exception &) // (std::system_error: no thread to be had)
+    {
+    }
+    if (!b->done.valid())
+    {
+        gs->arrived.swap(b->arrived); // (no worker: the meshes wait for the next build)
+        return fail(PROSPER_PT_ERR_INVALID_ARGUMENT, "the worker thread of the geometry build could not be started");
+    }
     guard.release();
     gs->dirty = false;
     ctx->meshBuild = b;
