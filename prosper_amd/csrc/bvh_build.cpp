@@ -397,9 +397,9 @@ struct Emitter
 
     uint32_t triangles_of(int32_t t) const { return tmp[(size_t)t].left < 0 ? tmp[(size_t)t].count : plans[(size_t)t].triangles; }
 
-    void plan(int32_t t)
+    // the children of the 4-wide node that binary node t becomes (the collapse), in storage order
+    void select_kids(int32_t t, Plan &p) const
     {
-        Plan p;
         int32_t *kids = p.kids;
         uint32_t k = 0;
         if (tmp[t].left < 0)
@@ -434,25 +434,75 @@ struct Emitter
                 return tmp[a].box.half_area() < tmp[b].box.half_area();
             });
         p.k = k;
+    }
+    bool inner_kid(int32_t t, int32_t kid) const { return tmp[kid].left >= 0 && kid != t; }
+    // sizes and stack need of t's subtree, once its inner children have their plans
+    void finish_plan(int32_t t, Plan &p) const
+    {
         p.nodes = 1;
+        p.triangles = 0;
         uint32_t deepest = 0;
-        for (uint32_t c = 0; c < k; ++c)
+        for (uint32_t c = 0; c < p.k; ++c)
         {
-            if (tmp[kids[c]].left < 0 && !(kids[c] == t))
-                p.triangles += tmp[kids[c]].count;
-            else if (kids[c] == t) // a lone leaf wrapped as the root
-                p.triangles += tmp[t].count;
+            const int32_t kid = p.kids[c];
+            if (!inner_kid(t, kid))
+                p.triangles += tmp[kid].count; // a leaf (or a lone leaf wrapped as the root)
             else
             {
-                plan(kids[c]);
-                p.nodes += plans[(size_t)kids[c]].nodes;
-                p.triangles += plans[(size_t)kids[c]].triangles;
-                deepest = std::max(deepest, plans[(size_t)kids[c]].stackNeed);
+                p.nodes += plans[(size_t)kid].nodes;
+                p.triangles += plans[(size_t)kid].triangles;
+                deepest = std::max(deepest, plans[(size_t)kid].stackNeed);
             }
         }
         // visiting this node leaves at most k-1 siblings on the stack while a child subtree is walked
-        p.stackNeed = (k > 0 ? k - 1 : 0) + deepest;
+        p.stackNeed = (p.k > 0 ? p.k - 1 : 0) + deepest;
+    }
+    void plan(int32_t t)
+    {
+        Plan p;
+        select_kids(t, p);
+        for (uint32_t c = 0; c < p.k; ++c)
+            if (inner_kid(t, p.kids[c])) plan(p.kids[c]);
+        finish_plan(t, p);
         plans[(size_t)t] = p;
+    }
+    // plan(root) with the subtrees below the first few levels planned on the host's threads (they write disjoint plans)
+    void plan_parallel(int32_t root, const BvhBuildOptions &opt)
+    {
+        const unsigned threads = host_threads(opt);
+        if (threads < 2 || tmp.size() < 16384)
+        {
+            plan(root);
+            return;
+        }
+        uint32_t levels = 1;
+        for (uint64_t n = 4; n < 8ull * threads; n *= 4) ++levels; // >= 8 subtrees per thread if the tree were full
+        std::vector<int32_t> top, frontier; // the shallow nodes in pre-order; the roots below them
+        std::vector<std::pair<int32_t, uint32_t>> stack{{root, 0u}};
+        while (!stack.empty())
+        {
+            const auto [t, depth] = stack.back();
+            stack.pop_back();
+            Plan p;
+            select_kids(t, p);
+            plans[(size_t)t] = p;
+            top.push_back(t);
+            for (uint32_t c = 0; c < p.k; ++c)
+                if (inner_kid(t, p.kids[c]))
+                {
+                    if (depth + 1 < levels)
+                        stack.push_back({p.kids[c], depth + 1});
+                    else
+                        frontier.push_back(p.kids[c]);
+                }
+        }
+        run_parallel(opt, frontier.size(), [&](size_t j) { plan(frontier[j]); });
+        for (size_t i = top.size(); i-- > 0;) // children after their parents in `top`: backwards, every child is done
+        {
+            Plan p = plans[(size_t)top[i]];
+            finish_plan(top[i], p);
+            plans[(size_t)top[i]] = p;
+        }
     }
 
     struct Job
@@ -509,8 +559,16 @@ void emit_tree(
 {
     const float slack = enc_slack(enc_box(tmp[(size_t)root].box));
     Emitter emitter{tmp, prims, out, slack, pad_coefficient(opt), opt.childOrder != 0, {}};
+    auto tick = std::chrono::steady_clock::now();
+    auto lap = [&](const char *what) {
+        const auto now = std::chrono::steady_clock::now();
+        if (opt.buildTiming) std::fprintf(stderr, "[bvh]   %-12s %.1f ms\n", what, std::chrono::duration<double, std::milli>(now - tick).count());
+        tick = now;
+    };
     emitter.plans.resize(tmp.size());
-    emitter.plan(root);
+    lap("plans alloc");
+    emitter.plan_parallel(root, opt);
+    lap("plan");
     const Emitter::Plan &top = emitter.plans[(size_t)root];
     out.maxDepth = top.stackNeed + 1; // entries the traversal stack must hold in the worst case
     if (out.maxDepth > kMaxStackBound)
@@ -521,8 +579,11 @@ void emit_tree(
     std::vector<Emitter::Job> jobs;
     const uint32_t chunk = std::max(256u, top.nodes / (8u * host_threads(opt)));
     emitter.emit(root, 0u, 0u, chunk, host_threads(opt) > 1 ? &jobs : nullptr);
+    lap("emit top");
     run_parallel(opt, jobs.size(), [&](size_t j) { emitter.emit(jobs[j].t, jobs[j].self, jobs[j].triBase, 0u, nullptr); });
+    lap("emit jobs");
     relayout_nodes(out.nodes, opt);
+    lap("relayout");
 }
 
 } // namespace
@@ -654,13 +715,7 @@ struct InstancedBvh::Impl
         size_t total = 0;
         for (const Subtree &st : subtrees) total += st.nodes.size();
         merged.reserve(total + 2 * kMaxTopEntries);
-        struct Entry
-        {
-            float area;
-            int32_t node; // index into `merged`
-            bool operator<(const Entry &o) const { return area < o.area; }
-        };
-        std::vector<Entry> heap;
+        std::vector<int32_t> roots;
         for (const Subtree &st : subtrees)
         {
             if (st.root < 0) continue;
@@ -674,31 +729,58 @@ struct InstancedBvh::Impl
                 }
                 merged.push_back(n);
             }
-            heap.push_back(Entry{merged[(size_t)(shift + st.root)].box.half_area(), shift + st.root});
+            roots.push_back(shift + st.root);
         }
-        if (heap.empty()) return build_bvh(nullptr, 0, opt);
+        if (roots.empty()) return build_bvh(nullptr, 0, opt);
+        total = merged.size();
         lap("merge");
         size_t target = std::min(std::max(kMinTopEntries, (size_t)(count / kTrianglesPerTopEntry)), kMaxTopEntries);
         if (opt.topEntries) target = (size_t)opt.topEntries;
-        std::make_heap(heap.begin(), heap.end());
+        // Opening "the entry with the largest box" until there are `target` entries opens the inner nodes in the order of
+        // their boxes' areas, and a child's box never has a larger area than its parent's: what gets opened is the
+        // k = target - roots inner nodes with the largest areas, whatever the order.  So instead of k rounds of a heap
+        // (7 ms for 65 k entries) the k-th largest area is SELECTED (nth_element) and one walk from the roots opens every
+        // inner node above it - and as many of those exactly at it as the count still allows.
         std::vector<int32_t> entries; // subtree nodes that become top-level leaves
-        while (!heap.empty() && heap.size() + entries.size() < target)
+        if (roots.size() >= target)
+            entries = roots;
+        else
         {
-            std::pop_heap(heap.begin(), heap.end());
-            const Entry e = heap.back();
-            heap.pop_back();
-            const TmpNode &n = merged[(size_t)e.node];
-            if (n.left < 0)
+            const size_t k = target - roots.size();
+            std::vector<float> areas;
+            areas.reserve(total / 2 + 1);
+            for (size_t i = 0; i < total; ++i)
+                if (merged[i].left >= 0) areas.push_back(merged[i].box.half_area());
+            float tau = -1.0f; // (areas are >= 0: everything opens)
+            size_t atTau = 0;
+            if (k < areas.size())
             {
-                entries.push_back(e.node); // a triangle leaf cannot be opened
-                continue;
+                std::nth_element(areas.begin(), areas.begin() + (long)(k - 1), areas.end(), std::greater<float>());
+                tau = areas[k - 1];
+                size_t above = 0;
+                for (size_t i = 0; i < k; ++i) above += areas[i] > tau ? 1u : 0u;
+                atTau = k - above;
             }
-            heap.push_back(Entry{merged[(size_t)n.left].box.half_area(), n.left});
-            std::push_heap(heap.begin(), heap.end());
-            heap.push_back(Entry{merged[(size_t)n.right].box.half_area(), n.right});
-            std::push_heap(heap.begin(), heap.end());
+            std::vector<int32_t> stack(roots.rbegin(), roots.rend());
+            while (!stack.empty())
+            {
+                const int32_t at = stack.back();
+                stack.pop_back();
+                const TmpNode &n = merged[(size_t)at];
+                if (n.left >= 0)
+                {
+                    const float a = n.box.half_area();
+                    if (a > tau || (a == tau && atTau > 0))
+                    {
+                        if (!(a > tau)) --atTau;
+                        stack.push_back(n.right);
+                        stack.push_back(n.left);
+                        continue;
+                    }
+                }
+                entries.push_back(at); // a triangle leaf, or an inner node that stays closed
+            }
         }
-        for (const Entry &e : heap) entries.push_back(e.node);
         lap("open");
 
         std::vector<Prim> top(entries.size());
