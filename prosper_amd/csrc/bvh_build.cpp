@@ -6,6 +6,9 @@
 
 #include <algorithm>
 #include <atomic>
+#include <condition_variable>
+#include <functional>
+#include <memory>
 #include <cstdio>
 #include <chrono>
 #include <cmath>
@@ -98,10 +101,122 @@ unsigned host_threads(const BvhBuildOptions &opt)
     return threads;
 }
 
+// The host's threads for ONE build: made once by the build's entry point (PoolScope) and reused by every parallel phase of
+// it - subtrees, the top level's subranges, the emitter's plan and emit passes.  Making and joining 15 threads per phase cost
+// 1.5-3 ms each on the 16-core host of an MI355X box, five times per build.  The pool dies with the build: the library
+// keeps no thread of its own alive between calls.
+class WorkerPool
+{
+  public:
+    explicit WorkerPool(unsigned workers)
+    {
+        for (unsigned i = 0; i < workers; ++i) threads.emplace_back([this] { loop(); });
+    }
+    ~WorkerPool()
+    {
+        {
+            std::lock_guard<std::mutex> g(m);
+            stop = true;
+        }
+        wake.notify_all();
+        for (std::thread &t : threads) t.join();
+    }
+    WorkerPool(const WorkerPool &) = delete;
+    WorkerPool &operator=(const WorkerPool &) = delete;
+    [[nodiscard]] unsigned workers() const { return (unsigned)threads.size(); }
+    // job(0) .. job(n - 1) on the pool's threads and the caller's; rethrows the first exception
+    void run(size_t n, const std::function<void(size_t)> &job)
+    {
+        {
+            std::lock_guard<std::mutex> g(m);
+            current = &job;
+            count = n;
+            next.store(0);
+            active = threads.size();
+            failure = nullptr;
+            ++generation;
+        }
+        wake.notify_all();
+        work();
+        std::exception_ptr failed;
+        {
+            std::unique_lock<std::mutex> lk(m);
+            done.wait(lk, [&] { return active == 0; });
+            current = nullptr;
+            failed = failure;
+        }
+        if (failed) std::rethrow_exception(failed);
+    }
+
+  private:
+    void work()
+    {
+        for (size_t j = next.fetch_add(1); j < count; j = next.fetch_add(1))
+        {
+            try
+            {
+                (*current)(j);
+            }
+            catch (...)
+            {
+                std::lock_guard<std::mutex> g(m);
+                failure = std::current_exception();
+            }
+        }
+    }
+    void loop()
+    {
+        uint64_t seen = 0;
+        std::unique_lock<std::mutex> lk(m);
+        for (;;)
+        {
+            wake.wait(lk, [&] { return stop || generation != seen; });
+            if (stop) return;
+            seen = generation;
+            lk.unlock();
+            work();
+            lk.lock();
+            if (--active == 0) done.notify_one();
+        }
+    }
+    std::vector<std::thread> threads;
+    std::mutex m;
+    std::condition_variable wake, done;
+    const std::function<void(size_t)> *current = nullptr;
+    size_t count = 0;
+    std::atomic<size_t> next{0};
+    size_t active = 0;
+    uint64_t generation = 0;
+    bool stop = false;
+    std::exception_ptr failure;
+};
+thread_local WorkerPool *tlPool = nullptr; // the pool of the build running on this thread, if any
+struct PoolScope
+{
+    WorkerPool *previous;
+    std::unique_ptr<WorkerPool> pool;
+    explicit PoolScope(const BvhBuildOptions &opt) : previous(tlPool)
+    {
+        const unsigned threads = host_threads(opt);
+        if (!previous && threads > 1)
+        {
+            pool.reset(new WorkerPool(threads - 1));
+            tlPool = pool.get();
+        }
+    }
+    ~PoolScope() { tlPool = previous; }
+};
+
 // Runs job(0) .. job(n - 1) on the host's threads (the caller's included); rethrows the first exception.
 template <class Job>
 void run_parallel(const BvhBuildOptions &opt, size_t n, Job &&job)
 {
+    if (tlPool && n > 1)
+    {
+        const std::function<void(size_t)> fn = [&](size_t j) { job(j); };
+        tlPool->run(n, fn);
+        return;
+    }
     const unsigned threads = (unsigned)std::min<size_t>(host_threads(opt), n ? n : 1);
     std::atomic<size_t> next{0};
     std::exception_ptr failure;
@@ -151,9 +266,17 @@ struct Builder
     {
         const unsigned threads = host_threads(opt);
         if (threads < 2 || count < 8192u) return build(first, count, depth);
+        auto tick = std::chrono::steady_clock::now();
+        auto lap = [&](const char *what) {
+            const auto now = std::chrono::steady_clock::now();
+            if (opt.buildTiming && count >= 32768u)
+                std::fprintf(stderr, "[bvh]   %-12s %.1f ms (%u prims)\n", what, std::chrono::duration<double, std::milli>(now - tick).count(), count);
+            tick = now;
+        };
         deferBelow = std::max(1024u, count / (4u * threads));
         const int32_t root = build(first, count, depth);
         deferBelow = 0;
+        lap("split top");
         std::vector<Deferred> jobs;
         jobs.swap(deferred);
         std::sort(jobs.begin(), jobs.end(), [](const Deferred &a, const Deferred &b) { return a.count > b.count; });
@@ -166,6 +289,10 @@ struct Builder
             roots[j] = local.build(jobs[j].first, jobs[j].count, jobs[j].depth);
             built[j].swap(local.nodes);
         });
+        lap("split jobs");
+        size_t gathered = nodes.size();
+        for (const std::vector<TmpNode> &part : built) gathered += part.size();
+        nodes.reserve(gathered);
         for (size_t j = 0; j < jobs.size(); ++j)
         {
             const int32_t shift = (int32_t)nodes.size();
@@ -179,7 +306,11 @@ struct Builder
                 nodes.push_back(n);
             }
             nodes[(size_t)jobs[j].self] = nodes[(size_t)(shift + roots[j])]; // the placeholder becomes the job's root
+            TmpNode &copy = nodes[(size_t)(shift + roots[j])]; // ... and its copy, which nothing points at any more, an empty
+            copy.left = copy.right = -1;                       // leaf: whoever counts inner nodes must not depend on how
+            copy.first = copy.count = 0;                       // many jobs - i.e. threads - there were
         }
+        lap("gather");
         return root;
     }
 
@@ -592,6 +723,7 @@ float bvh_pad_coefficient(const BvhBuildOptions &opt) { return pad_coefficient(o
 
 BvhBuildResult build_bvh(const WorldTriangle *triangles, uint64_t count, const BvhBuildOptions &opt)
 {
+    const PoolScope threads(opt);
     BvhBuildResult out;
     // An unused child slot gets the box lo = hi = +inf: the slab tests (pt_device.hpp,
     // pt_trace_stream.hpp) then report an entry distance of +inf at best, which the traversal treats
@@ -664,7 +796,7 @@ struct InstancedBvh::Impl
         }
     }
 
-    void build_subtree(const WorldTriangle *triangles, size_t i, uint32_t depth0)
+    void build_subtree(const WorldTriangle *triangles, size_t i, uint32_t depth0, bool parallel = false)
     {
         const Range &r = instances[i];
         Subtree &st = subtrees[i];
@@ -674,7 +806,7 @@ struct InstancedBvh::Impl
         fill_prims(triangles, r);
         Builder b(prims, opt);
         b.nodes.reserve((size_t)r.count * 2);
-        st.root = b.build(r.first, r.count, depth0);
+        st.root = parallel ? b.build_parallel(r.first, r.count, depth0) : b.build(r.first, r.count, depth0);
         st.nodes.swap(b.nodes);
     }
 
@@ -687,7 +819,14 @@ struct InstancedBvh::Impl
             if (which.empty() || which[i]) todo.push_back(i);
         // largest first, so that the last thread to finish holds a small one
         std::sort(todo.begin(), todo.end(), [&](size_t a, size_t b) { return instances[a].count > instances[b].count; });
-        run_parallel(opt, todo.size(), [&](size_t j) { build_subtree(triangles, todo[j], depth0); });
+        // An instance with a large share of the triangles would keep one thread busy long after the others are done (S-sponza-
+        // class: the hall, a quarter of the scene): those are split one after the other, each on all threads (the same
+        // tree: Builder::build_parallel), the rest one per thread.
+        size_t big = 0;
+        if (host_threads(opt) > 1)
+            while (big < todo.size() && instances[todo[big]].count >= 16384u && (uint64_t)instances[todo[big]].count * 8u >= count) ++big;
+        for (size_t j = 0; j < big; ++j) build_subtree(triangles, todo[j], depth0, true);
+        run_parallel(opt, todo.size() - big, [&](size_t j) { build_subtree(triangles, todo[big + j], depth0); });
     }
 
     // Top level over the instances, spliced with their subtrees into one binary tree, emitted as 4-wide nodes.
@@ -838,6 +977,7 @@ static void check_ranges_tile(const std::vector<InstancedBvh::Range> &instances,
 BvhBuildResult InstancedBvh::build(
     const WorldTriangle *triangles, uint64_t count, const std::vector<Range> &instances, const BvhBuildOptions &opt)
 {
+    const PoolScope threads(opt);
     m->opt = opt;
     if (count >= (1ull << 28)) throw std::runtime_error("too many triangles for the leaf reference encoding");
     check_ranges_tile(instances, count);
@@ -853,6 +993,7 @@ BvhBuildResult InstancedBvh::adopt(
     const WorldTriangle *triangles, uint64_t count, const std::vector<Range> &instances, const std::vector<uint8_t> &changed,
     const BvhBuildOptions &opt)
 {
+    const PoolScope threads(opt);
     m->opt = opt;
     if (count >= (1ull << 28)) throw std::runtime_error("too many triangles for the leaf reference encoding");
     if (instances.size() != m->instances.size() || changed.size() != instances.size())
@@ -883,6 +1024,7 @@ BvhBuildResult InstancedBvh::adopt(
 
 BvhBuildResult InstancedBvh::rebuild(const WorldTriangle *triangles, const std::vector<uint8_t> &changed, const BvhBuildOptions &opt)
 {
+    const PoolScope threads(opt);
     m->opt = opt;
     if (changed.size() != m->instances.size()) throw std::runtime_error("InstancedBvh::rebuild: one flag per instance");
     m->build_subtrees(triangles, changed);
