@@ -20,6 +20,7 @@
 #include <queue>
 #include <stdexcept>
 #include <thread>
+#include <type_traits>
 
 namespace ppt
 {
@@ -509,7 +510,8 @@ void relayout_nodes(std::vector<BvhNode> &nodes, const BvhBuildOptions &opt)
 // fill disjoint parts of the output on the host's threads.
 struct Emitter
 {
-    const std::vector<TmpNode> &tmp;
+    const TmpNode *tmp; // the binary tree (tmpCount nodes)
+    size_t tmpCount;
     const std::vector<Prim> &prims;
     BvhBuildResult &out;
     float slack;
@@ -601,7 +603,7 @@ struct Emitter
     void plan_parallel(int32_t root, const BvhBuildOptions &opt)
     {
         const unsigned threads = host_threads(opt);
-        if (threads < 2 || tmp.size() < 16384)
+        if (threads < 2 || tmpCount < 16384)
         {
             plan(root);
             return;
@@ -685,18 +687,18 @@ struct Emitter
 
 // Emits the binary tree `tmp` rooted at `root` as 4-wide nodes + leaf-order permutation into `out`.
 void emit_tree(
-    const std::vector<TmpNode> &tmp, int32_t root, const std::vector<Prim> &prims, uint64_t count, BvhBuildResult &out,
+    const TmpNode *tmp, size_t tmpCount, int32_t root, const std::vector<Prim> &prims, uint64_t count, BvhBuildResult &out,
     const BvhBuildOptions &opt)
 {
     const float slack = enc_slack(enc_box(tmp[(size_t)root].box));
-    Emitter emitter{tmp, prims, out, slack, pad_coefficient(opt), opt.childOrder != 0, {}};
+    Emitter emitter{tmp, tmpCount, prims, out, slack, pad_coefficient(opt), opt.childOrder != 0, {}};
     auto tick = std::chrono::steady_clock::now();
     auto lap = [&](const char *what) {
         const auto now = std::chrono::steady_clock::now();
         if (opt.buildTiming) std::fprintf(stderr, "[bvh]   %-12s %.1f ms\n", what, std::chrono::duration<double, std::milli>(now - tick).count());
         tick = now;
     };
-    emitter.plans.resize(tmp.size());
+    emitter.plans.resize(tmpCount);
     lap("plans alloc");
     emitter.plan_parallel(root, opt);
     lap("plan");
@@ -762,7 +764,7 @@ BvhBuildResult build_bvh(const WorldTriangle *triangles, uint64_t count, const B
     Builder builder(prims, opt);
     builder.nodes.reserve((size_t)count * 2);
     const int32_t rootTmp = builder.build_parallel(0, (uint32_t)count, 0);
-    emit_tree(builder.nodes, rootTmp, prims, count, out, opt);
+    emit_tree(builder.nodes.data(), builder.nodes.size(), rootTmp, prims, count, out, opt);
     return out;
 }
 
@@ -839,6 +841,8 @@ struct InstancedBvh::Impl
     // chain; profiles/r02_bvh_instancing.txt): C3 15.9 / 15.75 / 15.65 / 15.9 ms at 1 k / 4 k / 16 k / 64 k entries (one flat
     // SAH tree: 15.98); C4, whose foliage interleaves with everything, 42.7 / 40.4 / 41.3 / 37.1 ms (flat: 37.9).
     static constexpr size_t kTrianglesPerTopEntry = 4, kMinTopEntries = 1024, kMaxTopEntries = 65536;
+    // (a top level of n entries has 2 n - 1 nodes + one unreferenced copy per job of Builder::build_parallel: at most 8 per thread)
+    static constexpr size_t kTopSlack = 4096;
     BvhBuildResult assemble()
     {
         BvhBuildResult out;
@@ -849,32 +853,51 @@ struct InstancedBvh::Impl
             if (timing) std::fprintf(stderr, "[bvh] %-14s %.1f ms\n", what, std::chrono::duration<double, std::milli>(now - tick).count());
             tick = now;
         };
-        // merged node array: every subtree with its indices shifted (top-level nodes are appended afterwards)
-        std::vector<TmpNode> merged;
+        // merged node array: every subtree with its indices shifted, the top-level nodes behind them.  Raw storage filled on
+        // the host's threads: 26 MB of nodes for S-sponza-class that a std::vector would first construct, then overwrite.
+        std::vector<size_t> offset(subtrees.size(), 0);
         size_t total = 0;
-        for (const Subtree &st : subtrees) total += st.nodes.size();
-        merged.reserve(total + 2 * kMaxTopEntries);
         std::vector<int32_t> roots;
-        for (const Subtree &st : subtrees)
+        for (size_t i = 0; i < subtrees.size(); ++i)
         {
-            if (st.root < 0) continue;
-            const int32_t shift = (int32_t)merged.size();
-            for (TmpNode n : st.nodes)
+            offset[i] = total;
+            if (subtrees[i].root < 0) continue;
+            roots.push_back((int32_t)(total + (size_t)subtrees[i].root));
+            total += subtrees[i].nodes.size();
+        }
+        if (roots.empty()) return build_bvh(nullptr, 0, opt);
+        size_t target = std::min(std::max(kMinTopEntries, (size_t)(count / kTrianglesPerTopEntry)), kMaxTopEntries);
+        if (opt.topEntries) target = (size_t)opt.topEntries;
+        static_assert(std::is_trivially_copyable<TmpNode>::value && std::is_trivially_destructible<TmpNode>::value, "raw storage");
+        struct Raw
+        {
+            TmpNode *p;
+            explicit Raw(size_t n) : p(static_cast<TmpNode *>(std::malloc(n * sizeof(TmpNode))))
             {
+                if (!p) throw std::bad_alloc();
+            }
+            ~Raw() { std::free(p); }
+            Raw(const Raw &) = delete;
+            Raw &operator=(const Raw &) = delete;
+        } storage(total + 2 * target + kTopSlack);
+        TmpNode *merged = storage.p;
+        run_parallel(opt, subtrees.size(), [&](size_t i) {
+            const Subtree &st = subtrees[i];
+            if (st.root < 0) return;
+            const int32_t shift = (int32_t)offset[i];
+            TmpNode *dst = merged + offset[i];
+            for (size_t k = 0; k < st.nodes.size(); ++k)
+            {
+                TmpNode n = st.nodes[k];
                 if (n.left >= 0)
                 {
                     n.left += shift;
                     n.right += shift;
                 }
-                merged.push_back(n);
+                dst[k] = n;
             }
-            roots.push_back(shift + st.root);
-        }
-        if (roots.empty()) return build_bvh(nullptr, 0, opt);
-        total = merged.size();
+        });
         lap("merge");
-        size_t target = std::min(std::max(kMinTopEntries, (size_t)(count / kTrianglesPerTopEntry)), kMaxTopEntries);
-        if (opt.topEntries) target = (size_t)opt.topEntries;
         // Opening "the entry with the largest box" until there are `target` entries opens the inner nodes in the order of
         // their boxes' areas, and a child's box never has a larger area than its parent's: what gets opened is the
         // k = target - roots inner nodes with the largest areas, whatever the order.  So instead of k rounds of a heap
@@ -933,7 +956,8 @@ struct InstancedBvh::Impl
         tb.kMaxLeaf = 1; // a top-level leaf is exactly one entry
         const int32_t topRoot = tb.build_parallel(0, (uint32_t)top.size(), 0);
         lap("top level");
-        const int32_t shift = (int32_t)merged.size();
+        const int32_t shift = (int32_t)total;
+        size_t mergedCount = total;
         auto entry_of = [&](int32_t topLeaf) { return entries[top[tb.nodes[(size_t)topLeaf].first].index]; };
         int32_t root;
         if (tb.nodes[(size_t)topRoot].left < 0)
@@ -941,19 +965,25 @@ struct InstancedBvh::Impl
         else
         {
             root = shift + topRoot;
-            for (size_t t = 0; t < tb.nodes.size(); ++t)
-            {
-                TmpNode n = tb.nodes[t];
-                if (n.left >= 0)
+            if (tb.nodes.size() > 2 * target + kTopSlack) throw std::runtime_error("top level larger than its storage");
+            mergedCount = total + tb.nodes.size(); // (top-level leaves are copied too but nothing points at them any more)
+            const size_t chunk = 4096, chunks = (tb.nodes.size() + chunk - 1) / chunk;
+            run_parallel(opt, chunks, [&](size_t c) {
+                const size_t end = std::min(tb.nodes.size(), (c + 1) * chunk);
+                for (size_t t = c * chunk; t < end; ++t)
                 {
-                    n.left = tb.nodes[(size_t)n.left].left < 0 ? entry_of(n.left) : n.left + shift;
-                    n.right = tb.nodes[(size_t)n.right].left < 0 ? entry_of(n.right) : n.right + shift;
+                    TmpNode n = tb.nodes[t];
+                    if (n.left >= 0)
+                    {
+                        n.left = tb.nodes[(size_t)n.left].left < 0 ? entry_of(n.left) : n.left + shift;
+                        n.right = tb.nodes[(size_t)n.right].left < 0 ? entry_of(n.right) : n.right + shift;
+                    }
+                    merged[(size_t)shift + t] = n;
                 }
-                merged.push_back(n); // (top-level leaves are copied too but nothing points at them any more)
-            }
+            });
         }
         lap("splice");
-        emit_tree(merged, root, prims, count, out, opt);
+        emit_tree(merged, mergedCount, root, prims, count, out, opt);
         lap("emit");
         return out;
     }
