@@ -526,7 +526,7 @@ struct Emitter
         uint32_t triangles = 0; // triangles in the subtree
         uint32_t stackNeed = 0;
     };
-    std::vector<Plan> plans; // by binary node index; filled for the nodes that become 4-wide nodes
+    Plan *plans; // by binary node index; WRITTEN for the nodes that become 4-wide nodes before anything reads them (raw storage)
 
     uint32_t triangles_of(int32_t t) const { return tmp[(size_t)t].left < 0 ? tmp[(size_t)t].count : plans[(size_t)t].triangles; }
 
@@ -691,15 +691,16 @@ void emit_tree(
     const BvhBuildOptions &opt)
 {
     const float slack = enc_slack(enc_box(tmp[(size_t)root].box));
-    Emitter emitter{tmp, tmpCount, prims, out, slack, pad_coefficient(opt), opt.childOrder != 0, {}};
+    static_assert(std::is_trivially_copyable<Emitter::Plan>::value && std::is_trivially_destructible<Emitter::Plan>::value, "raw storage");
+    std::unique_ptr<void, void (*)(void *)> planStorage(std::malloc((tmpCount ? tmpCount : 1) * sizeof(Emitter::Plan)), std::free);
+    if (!planStorage) throw std::bad_alloc();
+    Emitter emitter{tmp, tmpCount, prims, out, slack, pad_coefficient(opt), opt.childOrder != 0, static_cast<Emitter::Plan *>(planStorage.get())};
     auto tick = std::chrono::steady_clock::now();
     auto lap = [&](const char *what) {
         const auto now = std::chrono::steady_clock::now();
         if (opt.buildTiming) std::fprintf(stderr, "[bvh]   %-12s %.1f ms\n", what, std::chrono::duration<double, std::milli>(now - tick).count());
         tick = now;
     };
-    emitter.plans.resize(tmpCount);
-    lap("plans alloc");
     emitter.plan_parallel(root, opt);
     lap("plan");
     const Emitter::Plan &top = emitter.plans[(size_t)root];
