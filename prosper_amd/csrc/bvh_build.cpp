@@ -274,7 +274,9 @@ struct Builder
                 std::fprintf(stderr, "[bvh]   %-12s %.1f ms (%u prims)\n", what, std::chrono::duration<double, std::milli>(now - tick).count(), count);
             tick = now;
         };
-        deferBelow = std::max(1024u, count / (4u * threads));
+        // (the nodes above it are walked by ONE thread: as few levels as still give every thread its share below.  Gathering
+        //  those nodes' bounds and bins on the pool's threads was tried: waking fifteen threads costs what it saves)
+        deferBelow = std::max(1024u, count / threads);
         const int32_t root = build(first, count, depth);
         deferBelow = 0;
         lap("split top");
