@@ -22,6 +22,7 @@ def test_bvh_builder_under_sanitizers(tmp_path, sanitizer):
            os.path.join(ROOT, "prosper_amd", "csrc", "bvh_build.cpp"), "-lpthread", "-o", exe]
     subprocess.check_call(cmd)
     env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0", TSAN_OPTIONS="halt_on_error=1")
+    digests = {}
     for threads in ("1", "4"):
         out = subprocess.run([exe, "12", threads], env=env, capture_output=True, text=True, timeout=600)
         text = out.stdout + out.stderr
@@ -29,6 +30,10 @@ def test_bvh_builder_under_sanitizers(tmp_path, sanitizer):
         assert "runtime error" not in text and "Sanitizer" not in text, text[-2000:]
         assert "flat build" in text
         assert text.count("equal to a fresh build") == 2  # InstancedBvh::adopt (streamed-in meshes)
+        digests[threads] = [line.split("digest")[1].strip() for line in text.splitlines() if "digest" in line]
+    # the trees (nodes + permutation) do not depend on how many threads built them: worker pool, deferred subranges,
+    # the one-thread-per-instance and all-threads-per-instance paths
+    assert digests["1"] == digests["4"] and len(digests["1"]) >= 5
 
 
 _ORACLE_RENDER = r"""
