@@ -20,7 +20,7 @@ static float rnd()
 
 int main(int argc, char **argv)
 {
-    const int instances = 43, side = argc > 1 ? atoi(argv[1]) : 55;
+    const int instances = 43, patchSide = argc > 1 ? atoi(argv[1]) : 55;
     BvhBuildOptions opt;
     if (argc > 2) opt.buildThreads = (uint32_t)atoi(argv[2]); // host threads of the builder (default: all)
     if (argc > 3) opt.buildTiming = (uint32_t)atoi(argv[3]);  // stage times of the assembly to stderr
@@ -32,6 +32,9 @@ int main(int argc, char **argv)
         const float ux = rnd() - 0.5f, uy = rnd() - 0.5f, uz = rnd() - 0.5f, vx = rnd() - 0.5f, vy = rnd() - 0.5f, vz = rnd() - 0.5f;
         const float size = 2.0f + 6.0f * rnd();
         InstancedBvh::Range r{(uint32_t)tris.size(), 0};
+        // (instance 0 is 64 times the others when the patches are small: one instance with a large share of the triangles is
+        //  split on all threads, a path of its own in the builder)
+        const int side = i == 0 && patchSide <= 16 ? patchSide * 8 : patchSide;
         for (int a = 0; a < side; ++a)
             for (int b = 0; b < side; ++b)
                 for (int h = 0; h < 2; ++h)
