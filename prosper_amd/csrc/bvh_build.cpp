@@ -111,17 +111,17 @@ class WorkerPool
   public:
     explicit WorkerPool(unsigned workers)
     {
-        for (unsigned i = 0; i < workers; ++i) threads.emplace_back([this] { loop(); });
-    }
-    ~WorkerPool()
-    {
+        try
         {
-            std::lock_guard<std::mutex> g(m);
-            stop = true;
+            for (unsigned i = 0; i < workers; ++i) threads.emplace_back([this] { loop(); });
         }
-        wake.notify_all();
-        for (std::thread &t : threads) t.join();
+        catch (...) // (no more threads to be had: the ones that did start must be joined before the vector goes)
+        {
+            shut_down();
+            throw;
+        }
     }
+    ~WorkerPool() { shut_down(); }
     WorkerPool(const WorkerPool &) = delete;
     WorkerPool &operator=(const WorkerPool &) = delete;
     [[nodiscard]] unsigned workers() const { return (unsigned)threads.size(); }
@@ -150,6 +150,16 @@ class WorkerPool
     }
 
   private:
+    void shut_down()
+    {
+        {
+            std::lock_guard<std::mutex> g(m);
+            stop = true;
+        }
+        wake.notify_all();
+        for (std::thread &t : threads) t.join();
+        threads.clear();
+    }
     void work()
     {
         for (size_t j = next.fetch_add(1); j < count; j = next.fetch_add(1))
