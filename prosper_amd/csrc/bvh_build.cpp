@@ -94,10 +94,43 @@ uint32_t ceil_log2(uint64_t n)
     return l;
 }
 
+// CPUs this process may actually use at once: a container's CPU quota (cgroup v2 cpu.max, v1 cfs_quota_us / cfs_period_us) is
+// usually far below the CPUs it can SEE (an MI355X box: 256 visible, a quota of 16), and threads beyond the quota do not run
+// in parallel - they use the quota up early and the whole process, its frame loop included, sits out the rest of the period.
+unsigned cpu_quota()
+{
+    static const unsigned cached = [] {
+        double quota = -1.0, period = 0.0;
+        if (FILE *f = std::fopen("/sys/fs/cgroup/cpu.max", "r"))
+        {
+            char first[32] = {};
+            if (std::fscanf(f, "%31s %lf", first, &period) == 2 && std::strcmp(first, "max") != 0) quota = std::atof(first);
+            std::fclose(f);
+        }
+        else
+        {
+            if (FILE *q = std::fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r"))
+            {
+                if (std::fscanf(q, "%lf", &quota) != 1) quota = -1.0;
+                std::fclose(q);
+            }
+            if (FILE *p = std::fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r"))
+            {
+                if (std::fscanf(p, "%lf", &period) != 1) period = 0.0;
+                std::fclose(p);
+            }
+        }
+        if (quota > 0.0 && period > 0.0) return (unsigned)std::max(1.0, std::ceil(quota / period));
+        return 0u; // no quota
+    }();
+    return cached;
+}
+
 unsigned host_threads(const BvhBuildOptions &opt)
 {
     unsigned threads = std::thread::hardware_concurrency();
     threads = std::max(1u, std::min(threads ? threads : 1u, 32u));
+    if (const unsigned quota = cpu_quota()) threads = std::min(threads, quota);
     if (opt.buildThreads) threads = opt.buildThreads;
     return threads;
 }
@@ -735,6 +768,7 @@ void emit_tree(
 } // namespace
 
 float bvh_pad_coefficient(const BvhBuildOptions &opt) { return pad_coefficient(opt); }
+unsigned default_build_threads() { return host_threads(BvhBuildOptions()); }
 
 BvhBuildResult build_bvh(const WorldTriangle *triangles, uint64_t count, const BvhBuildOptions &opt)
 {

@@ -28,12 +28,15 @@ struct BvhBuildOptions
     float sahTraversalCost = 0.0f; // SAH cost of a node visit relative to a triangle test (default 1)
     float boxPad = 0.0f;           // box padding coefficient (default and minimum 1.6e-5)
     uint32_t leafSize = 0;         // most triangles per leaf, 1..8 (default kMaxLeafTriangles)
-    uint32_t buildThreads = 0;     // host threads (default: hardware concurrency, at most 32)
+    uint32_t buildThreads = 0;     // host threads (default: hardware concurrency, at most 32 and at most the container's CPU quota)
     uint32_t topEntries = 0;       // entries of the re-braided top level (default: one per four triangles, 1 k .. 64 k)
     int32_t nodeOrder = -1;        // 0 depth-first as emitted, 1 breadth-first, 2 first 4096 breadth-first (default)
     int32_t childOrder = -1;       // 0: children in build order instead of smallest box first
     uint32_t buildTiming = 0;      // stage times of the assembly to stderr
 };
+
+// the host threads a build takes by default (what BvhBuildOptions::buildThreads = 0 means)
+unsigned default_build_threads();
 
 // box padding coefficient of the emitter (1.6e-5, or BvhBuildOptions::boxPad): the device refit pads with the same value
 float bvh_pad_coefficient(const BvhBuildOptions &opt);

@@ -7,6 +7,7 @@
 #include <exception>
 #include <memory>
 #include <stdexcept>
+#include <thread>
 
 #include "pt_kernels.hpp"
 #include "pt_materials.hpp"
@@ -507,6 +508,9 @@ static int start_mesh_build_impl(prosper_pt_ctx *ctx, bool rebuild)
     b->dAlphaSnapshot = d;
     b->scene.alphaMaterials = static_cast<const AlphaMaterial *>(d);
     GeometryTarget t = context_target(ctx);
+    // A build beside the frame loop leaves the application half of the host's threads (of the container's CPU quota, where
+    // there is one: bvh_build.cpp cpu_quota).
+    if (t.buildOpt.buildThreads == 0) t.buildOpt.buildThreads = std::max(1u, default_build_threads() / 2u);
     t.s = &b->scene;
     t.acc = b->acc;
     t.stats = &b->stats;
