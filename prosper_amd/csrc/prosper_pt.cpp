@@ -877,6 +877,7 @@ void prosper_pt_destroy(prosper_pt_ctx *ctx)
     for (auto &ws : ctx->extraStreams)
         if (ws) (void)hipStreamDestroy(ws);
     if (ctx->buildStream) (void)hipStreamDestroy(ctx->buildStream);
+    if (ctx->pinnedStaging) (void)hipHostFree(ctx->pinnedStaging);
     if (ctx->chainFork) (void)hipEventDestroy(ctx->chainFork);
     delete ctx;
 }

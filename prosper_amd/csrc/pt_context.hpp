@@ -198,6 +198,8 @@ struct MaterialState
     bool readyRecorded = false;
     void *linearStaging = nullptr;      // device: the texels of an update as the caller holds them, before re-tiling
     size_t linearStagingBytes = 0;
+    void *pinnedStaging = nullptr;      // host, pinned: the same bytes on their way there (pt_materials.hpp create_device_texture)
+    size_t pinnedStagingBytes = 0;
     uint32_t updates = 0;
     // texel arrays, packs and alpha bounds an update replaced: a frame in flight may still read them, so they stay until
     // enough has piled up to be worth ONE device synchronisation (kRetireBytes), or the scene goes
@@ -217,6 +219,7 @@ struct MaterialState
         if (ready) (void)hipEventDestroy(ready);
         if (uploadStream) (void)hipStreamDestroy(uploadStream);
         if (linearStaging) (void)hipFree(linearStaging);
+        if (pinnedStaging) (void)hipHostFree(pinnedStaging);
     }
 };
 
@@ -293,6 +296,11 @@ struct prosper_pt_ctx
     // the worker thread's stream: a plain one, made by the worker at first need - after prosper_pt_create has given the
     // hardware queues to the work streams (ensure_build_stream)
     hipStream_t buildStream = nullptr;
+    // Pinned staging for the large host <-> device copies of a geometry build (pt_geometry.cpp staged_copy): a copy from
+    // pageable memory has the runtime pin the caller's pages for its duration, and when those pages are freed soon after - the
+    // builder's vectors are - the unmapping goes through the GPU driver and stops every queue of the process for 20-30 ms
+    void *pinnedStaging = nullptr;
+    size_t pinnedStagingBytes = 0;
 
     float4 *hdr = nullptr; // current HDR buffer (internal or caller-owned)
     float4 *ownedHdr = nullptr;

@@ -46,6 +46,43 @@ GeometryTarget context_target(prosper_pt_ctx *ctx)
     return t;
 }
 
+// A large copy between host memory the build is about to FREE (the builder's vectors, the arrived meshes' bytes) and the
+// device, through the context's pinned staging area and waited for: see prosper_pt_ctx::pinnedStaging.  Small copies take the
+// runtime's own staging path.
+constexpr size_t kStagedCopyBytes = 64u << 10;
+static int staged_copy(prosper_pt_ctx *ctx, hipStream_t stream, void *dst, const void *src, size_t bytes, hipMemcpyKind kind)
+{
+    if (bytes == 0) return PROSPER_PT_OK;
+    if (bytes < kStagedCopyBytes)
+    {
+        PPT_HIP(hipMemcpyAsync(dst, src, bytes, kind, stream));
+        PPT_HIP(hipStreamSynchronize(stream));
+        return PROSPER_PT_OK;
+    }
+    if (bytes > ctx->pinnedStagingBytes)
+    {
+        if (ctx->pinnedStaging) PPT_HIP(hipHostFree(ctx->pinnedStaging));
+        ctx->pinnedStaging = nullptr;
+        ctx->pinnedStagingBytes = 0;
+        const size_t capacity = bytes + bytes / 4;
+        PPT_HIP(hipHostMalloc(&ctx->pinnedStaging, capacity, hipHostMallocDefault));
+        ctx->pinnedStagingBytes = capacity;
+    }
+    if (kind == hipMemcpyHostToDevice)
+    {
+        std::memcpy(ctx->pinnedStaging, src, bytes);
+        PPT_HIP(hipMemcpyAsync(dst, ctx->pinnedStaging, bytes, kind, stream));
+        PPT_HIP(hipStreamSynchronize(stream));
+    }
+    else
+    {
+        PPT_HIP(hipMemcpyAsync(ctx->pinnedStaging, src, bytes, kind, stream));
+        PPT_HIP(hipStreamSynchronize(stream));
+        std::memcpy(dst, ctx->pinnedStaging, bytes);
+    }
+    return PROSPER_PT_OK;
+}
+
 // The refit's GPU work on `stream` for the node / triangle arrays of scene version `version`: exact bounds level by level,
 // every node re-encoded, the tree's surface-area measure into the version's cost slot (read back through hCost / costEvent).
 int enqueue_refit(AccelState *acc, float padCoeff, BvhNode *nodes, const WorldTriangle *tris, uint32_t version, hipStream_t stream)
@@ -108,11 +145,15 @@ int upload_hierarchy(prosper_pt_ctx *ctx, GeometryTarget &t, const BvhBuildResul
         acc->nodeCapacityBytes = capacity;
     }
     for (uint32_t ver = 0; ver < AccelState::kVersions; ++ver) acc->nodesCurrent[ver] = ver == acc->cur;
-    PPT_HIP(hipMemcpyAsync(acc->dNodes, bvh.nodes.data(), nodeBytes, hipMemcpyHostToDevice, t.stream));
+    {
+        const int src = staged_copy(ctx, t.stream, acc->dNodes, bvh.nodes.data(), nodeBytes, hipMemcpyHostToDevice);
+        if (src != PROSPER_PT_OK) return src;
+    }
     t.s->nodes = acc->dNodes;
     if (acc->total)
     {
-        PPT_HIP(hipMemcpyAsync(acc->dPerm, bvh.permutation.data(), bvh.permutation.size() * 4, hipMemcpyHostToDevice, t.stream));
+        const int src = staged_copy(ctx, t.stream, acc->dPerm, bvh.permutation.data(), bvh.permutation.size() * 4, hipMemcpyHostToDevice);
+        if (src != PROSPER_PT_OK) return src;
         launch_permute_triangles(acc->dFlat, acc->dPerm, acc->dTris, (uint32_t)acc->total, t.stream);
         PPT_HIP(hipGetLastError());
     }
@@ -160,7 +201,10 @@ int upload_hierarchy(prosper_pt_ctx *ctx, GeometryTarget &t, const BvhBuildResul
         acc->refitCapacityNodes = capacity;
     }
     t.lap("  refit tables (host)");
-    PPT_HIP(hipMemcpyAsync(acc->dRefitOrder, order.data(), n * sizeof(uint32_t), hipMemcpyHostToDevice, t.stream));
+    {
+        const int src = staged_copy(ctx, t.stream, acc->dRefitOrder, order.data(), n * sizeof(uint32_t), hipMemcpyHostToDevice);
+        if (src != PROSPER_PT_OK) return src;
+    }
     if (!acc->dLeafPosition)
     {
         void *d = nullptr;
@@ -182,7 +226,8 @@ int upload_hierarchy(prosper_pt_ctx *ctx, GeometryTarget &t, const BvhBuildResul
     if (acc->total)
     {
         for (size_t leaf = 0; leaf < bvh.permutation.size(); ++leaf) position[bvh.permutation[leaf]] = (uint32_t)leaf;
-        PPT_HIP(hipMemcpyAsync(acc->dLeafPosition, position.data(), position.size() * sizeof(uint32_t), hipMemcpyHostToDevice, t.stream));
+        const int src = staged_copy(ctx, t.stream, acc->dLeafPosition, position.data(), position.size() * sizeof(uint32_t), hipMemcpyHostToDevice);
+        if (src != PROSPER_PT_OK) return src;
     }
     // one refit right away: the device encoder writes the bytes the emitter wrote (tested), and leaves the tree's
     // surface-area measure to compare later refits with
@@ -201,7 +246,8 @@ int upload_hierarchy(prosper_pt_ctx *ctx, GeometryTarget &t, const BvhBuildResul
         t.lap("  refit done");
         if (t.noUploadRefit)
         {
-            PPT_HIP(hipMemcpyAsync(acc->dNodes, bvh.nodes.data(), nodeBytes, hipMemcpyHostToDevice, t.stream));
+            const int src = staged_copy(ctx, t.stream, acc->dNodes, bvh.nodes.data(), nodeBytes, hipMemcpyHostToDevice);
+            if (src != PROSPER_PT_OK) return src;
         }
         const uint32_t slot = acc->cur % AccelState::kCostSlots;
         acc->costPending[slot] = false;
@@ -295,7 +341,7 @@ int begin_geometry(prosper_pt_ctx *ctx, GeometryTarget &t, GeometryLayout &layou
     launch_flatten_triangles(s, acc->dOffsets, drawInstanceCount, acc->dFlags, acc->dFlat, nullptr, nullptr, (uint32_t)total, t.stream);
     PPT_HIP(hipGetLastError());
     acc->flat.resize((size_t)total);
-    if (total) PPT_HIP(hipMemcpyAsync(acc->flat.data(), acc->dFlat, sizeof(WorldTriangle) * (size_t)total, hipMemcpyDeviceToHost, t.stream));
+    if (total && (rc = staged_copy(ctx, t.stream, acc->flat.data(), acc->dFlat, sizeof(WorldTriangle) * (size_t)total, hipMemcpyDeviceToHost))) return rc;
     PPT_HIP(hipStreamSynchronize(t.stream)); // (the layout's host arrays have been read, the world triangles are here)
     t.lap("flatten + read back");
     acc->triOffsets.swap(layout.triOffsets);
@@ -548,7 +594,10 @@ static int start_mesh_build_impl(prosper_pt_ctx *ctx, bool rebuild)
                     PPT_HIP(hipStreamSynchronize(t.stream)); // (newBuffers may move when it grows)
                 }
                 if (!a.bytes.empty())
-                    PPT_HIP(hipMemcpyAsync(static_cast<uint8_t *>(gs->buffers[a.bufferIndex]) + a.byteOffset, a.bytes.data(), a.bytes.size(), hipMemcpyHostToDevice, t.stream));
+                {
+                    const int src = staged_copy(ctx, t.stream, static_cast<uint8_t *>(gs->buffers[a.bufferIndex]) + a.byteOffset, a.bytes.data(), a.bytes.size(), hipMemcpyHostToDevice);
+                    if (src != PROSPER_PT_OK) return src;
+                }
                 PPT_HIP(hipMemcpyAsync(gs->dMetadatas + a.meshIndex, &a.metadata, sizeof(prosper_GeometryMetadata), hipMemcpyHostToDevice, t.stream));
             }
             PPT_HIP(hipMemcpyAsync(b->dAlphaSnapshot, snapshot->data(), alphaBytes, hipMemcpyHostToDevice, t.stream));

@@ -34,7 +34,7 @@ int validate_texture(const prosper_pt_texture_desc &t, uint32_t index)
     return PROSPER_PT_OK;
 }
 
-int create_device_texture(prosper_pt_ctx *ctx, const prosper_pt_texture_desc &t, void *staging, hipStream_t stream, DeviceTexture *out)
+int create_device_texture(prosper_pt_ctx *ctx, const prosper_pt_texture_desc &t, void *staging, hipStream_t stream, DeviceTexture *out, void *pinned)
 {
     const uint32_t tilesX = (t.width + kTexTileW - 1u) / kTexTileW, tilesY = (t.height + kTexTileH - 1u) / kTexTileH;
     const size_t tiledBytes = (size_t)tilesX * tilesY * (kTexTileW * kTexTileH) * 4u;
@@ -45,14 +45,26 @@ int create_device_texture(prosper_pt_ctx *ctx, const prosper_pt_texture_desc &t,
     {
         // the blocks go up as they are and a kernel decodes them into the tiles (pt_bc7.hpp)
         const size_t blockBytes = (size_t)(t.width / 4u) * (t.height / 4u) * 16u;
-        PPT_HIP(hipMemcpyAsync(staging, t.texels, blockBytes, hipMemcpyHostToDevice, stream));
+        const void *src = t.texels;
+        if (pinned)
+        {
+            std::memcpy(pinned, t.texels, blockBytes);
+            src = pinned;
+        }
+        PPT_HIP(hipMemcpyAsync(staging, src, blockBytes, hipMemcpyHostToDevice, stream));
         PPT_HIP(hipMemsetAsync(d, 0, tiledBytes, stream));
         launch_decode_bc7(staging, t.width, t.height, tilesX, d, stream);
     }
     else
     {
         // 8 x 4-texel tiles of one cache line each (pt_scene.hpp DeviceTexture), laid out by a kernel
-        PPT_HIP(hipMemcpyAsync(staging, t.texels, (size_t)t.width * t.height * 4u, hipMemcpyHostToDevice, stream));
+        const void *src = t.texels;
+        if (pinned)
+        {
+            std::memcpy(pinned, t.texels, (size_t)t.width * t.height * 4u);
+            src = pinned;
+        }
+        PPT_HIP(hipMemcpyAsync(staging, src, (size_t)t.width * t.height * 4u, hipMemcpyHostToDevice, stream));
         launch_retile_rgba8(staging, t.width, t.height, tilesX, d, stream);
     }
     PPT_HIP(hipGetLastError());
@@ -386,12 +398,23 @@ int prosper_pt_update_textures(prosper_pt_ctx *ctx, const prosper_pt_texture_des
         PPT_HIP(hipMalloc(&ms->linearStaging, stagingBytes));
         ms->linearStagingBytes = stagingBytes;
     }
+    if (stagingBytes > ms->pinnedStagingBytes)
+    {
+        // (the stream was synchronised at the end of the previous call: nothing reads the old area any more)
+        if (ms->pinnedStaging) PPT_HIP(hipHostFree(ms->pinnedStaging));
+        ms->pinnedStaging = nullptr;
+        ms->pinnedStagingBytes = 0;
+        PPT_HIP(hipHostMalloc(&ms->pinnedStaging, stagingBytes, hipHostMallocDefault));
+        ms->pinnedStagingBytes = stagingBytes;
+    }
     size_t offset = 0;
     std::vector<uint8_t> changed(ms->textures.size(), 0);
     for (uint32_t i = 0; i < count; ++i)
     {
         DeviceTexture dt;
-        if ((rc = create_device_texture(ctx, textures[i], static_cast<uint8_t *>(ms->linearStaging) + offset, ms->uploadStream, &dt)))
+        if ((rc = create_device_texture(
+                 ctx, textures[i], static_cast<uint8_t *>(ms->linearStaging) + offset, ms->uploadStream, &dt,
+                 static_cast<uint8_t *>(ms->pinnedStaging) + offset)))
         {
             (void)hipStreamSynchronize(ms->uploadStream);
             return rc;

@@ -10,10 +10,13 @@ namespace ppt
 // One entry of materialTextures[] on the device: the caller's level-0 texels (RGBA8 rows or BC7 blocks) go to a device
 // staging area, a kernel re-tiles / decodes them into a new scene allocation.  `staging` must hold
 // texture_staging_bytes(desc) bytes; everything is enqueued on `stream` (the host copy included: the caller's memory may
-// go once `stream` has been synchronised).
+// go once `stream` has been synchronised).  `pinned` (host, texture_staging_bytes(desc) bytes): the texels go through it - the
+// caller's memory has been read when the call returns, and the runtime never pins the caller's pages (which, freed soon
+// after, would stop every queue of the process for 20-30 ms while the driver unmaps them: prosper_pt_update_textures).
 size_t texture_staging_bytes(const prosper_pt_texture_desc &t);
 int validate_texture(const prosper_pt_texture_desc &t, uint32_t index);
-int create_device_texture(prosper_pt_ctx *ctx, const prosper_pt_texture_desc &t, void *staging, hipStream_t stream, DeviceTexture *out);
+int create_device_texture(
+    prosper_pt_ctx *ctx, const prosper_pt_texture_desc &t, void *staging, hipStream_t stream, DeviceTexture *out, void *pinned = nullptr);
 
 // The interleaved copy of a material's three textures (pt_scene.hpp MaterialPack) where they share extent and sampler;
 // texels == nullptr where the material is not packable.  `wide`: 16-byte texels also for opaque materials.
