@@ -389,6 +389,8 @@ int prosper_pt_update_textures(prosper_pt_ctx *ctx, const prosper_pt_texture_des
     int rc = ensure_update_state(ctx);
     if (rc == PROSPER_PT_OK) rc = collect_retired(ctx);
     if (rc != PROSPER_PT_OK) return rc;
+    // the previous update's copies out of the pinned staging area (a frame ago, as a rule: done long since)
+    if (ms->uploadedRecorded) PPT_HIP(hipEventSynchronize(ms->uploaded));
     if (stagingBytes > ms->linearStagingBytes)
     {
         // (the outgrown area joins the scene's allocations: kernels of an earlier update may still read it)
@@ -427,8 +429,8 @@ int prosper_pt_update_textures(prosper_pt_ctx *ctx, const prosper_pt_texture_des
         ms->textures[first + i] = dt;
         changed[first + i] = 1;
     }
-    // the caller's memory is only borrowed: every copy out of it must be done before the call returns
-    PPT_HIP(hipStreamSynchronize(ms->uploadStream));
+    // (the caller's memory has been read - into the pinned staging area - when create_device_texture returns: nothing to wait
+    //  for here.  The copies out of that area are waited for by the NEXT call, before it overwrites it.)
     // materials that sample a replaced texture: their packs and alpha bounds hold its texels
     for (uint32_t m = 0; m < ms->materials.size(); ++m)
     {
